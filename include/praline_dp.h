@@ -1,0 +1,181 @@
+/*
+ * praline_dp.h -- C ABI of libpraline_dp.so, the MI355X (gfx950) pairwise-DP hot path of PRALINE 2.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no Python / numpy / torch types.
+ * Section A replaces, one for one, the six functions the reference's native extension exports
+ * (praline/util/cext.c:506-520) and that praline/component/align.py:18-20,27-31,209,388 binds.
+ * Section B is the batched form of the same path (one submission per all-pairs stage instead of
+ * one Python call per pair): the seam the reference offers for it is Manager.execute_many
+ * (praline/core/manager.py:154-170), which receives the whole request list of
+ * GuideTreeBuilder (praline/component/tree.py:105-147), the master-slave aligners
+ * (praline/component/preprofile.py:127-154,227-267) and AdHoc re-scoring
+ * (praline/component/msa.py:488-558).
+ *
+ * All entry points return 0 on success and a negative PRALINE_ERR_* code otherwise;
+ * praline_last_error() gives the message of the calling thread's last failure.  The library
+ * owns its device memory and streams.  There is NO CPU fallback: without a usable HIP device
+ * every compute entry point fails with PRALINE_ERR_DEVICE.
+ *
+ * Threading: one host thread per device (praline_init binds the calling process to a device).
+ */
+#ifndef PRALINE_DP_H
+#define PRALINE_DP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRALINE_DP_ABI_VERSION 1
+
+#define PRALINE_OK 0
+#define PRALINE_ERR_ARG (-1)         /* bad argument (NULL, negative size, unknown mode ...) */
+#define PRALINE_ERR_DEVICE (-2)      /* no HIP device / HIP runtime error */
+#define PRALINE_ERR_NOMEM (-3)       /* host or device allocation failed */
+#define PRALINE_ERR_UNSUPPORTED (-4) /* valid request the batched kernels do not cover */
+
+/* Alignment modes: the five dispatch keys of _CEXT_ALIGN_FUNCTIONS
+ * (praline/component/align.py:27-31; praline/util/cext.c:27-31). */
+#define PRALINE_MODE_GLOBAL 0
+#define PRALINE_MODE_LOCAL 1
+#define PRALINE_MODE_SEMIGLOBAL_BOTH 2
+#define PRALINE_MODE_SEMIGLOBAL_ONE 3
+#define PRALINE_MODE_SEMIGLOBAL_TWO 4
+
+/* Traceback flag bits written to t (praline/util/cext.c:9-15, praline/util/align.py:15-21). */
+#define PRALINE_TB_MATCH_MATCH (1 << 1)
+#define PRALINE_TB_MATCH_INSERT_UP (1 << 2)
+#define PRALINE_TB_MATCH_INSERT_LEFT (1 << 3)
+#define PRALINE_TB_INSERT_UP_OPEN (1 << 4)
+#define PRALINE_TB_INSERT_UP_EXTEND (1 << 5)
+#define PRALINE_TB_INSERT_LEFT_OPEN (1 << 6)
+#define PRALINE_TB_INSERT_LEFT_EXTEND (1 << 7)
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int praline_abi_version(void);
+int praline_device_count(int *count);         /* number of visible HIP devices */
+int praline_init(int device);                 /* bind this process to `device` (lazy otherwise: 0) */
+int praline_shutdown(void);                   /* release streams and cached device buffers */
+int praline_synchronize(void);                /* wait for all work submitted by this library */
+const char *praline_last_error(void);         /* message of the last failure on this thread */
+void *praline_stream(void);                   /* the hipStream_t all kernels are launched on */
+
+/* ============================================================================================
+ * A. Parity-layout entry points: the reference's native functions on raw host buffers.
+ *    Ownership is the reference's: the caller allocates every buffer, outputs are written in
+ *    place (praline/util/cext.c:303-305,452-454).  Unlike the reference (no checks, UB on misuse,
+ *    praline/component/align.py:196-199) bad arguments return PRALINE_ERR_ARG.
+ *    Arrays are described by pointer + dims + BYTE strides, honouring arbitrary numpy strides as
+ *    the reference does (cext.c:109-129,356-377).
+ * ========================================================================================== */
+typedef struct praline_array {
+    void *data;
+    int64_t dim[3];     /* unused trailing dims = 1 */
+    int64_t stride[3];  /* bytes; unused trailing strides = 0 */
+} praline_array;
+
+/* Replaces cext_build_scores(i1s, i2s, i1nzs, i2nzs, ss, m)  (praline/util/cext.c:308-455).
+ *   i1s[n]: float32 [L1][A1_n] profile of sequence one for track set n; i2s[n]: [L2][A2_n];
+ *   ss[n] : float32 [A1_n][A2_n] score matrix; m: float32 [L1][L2] output, written in place.
+ *   i1nzs / i2nzs (the reference's -1 padded nonzero index lists, align.py:449-458) are accepted
+ *   for signature compatibility and may be NULL: the device evaluates the dense contraction
+ *   m = sum_n P1_n . S_n . P2_n^T with fp32 MFMA, which equals the reference's sparse loop
+ *   exactly when all terms are exactly representable (one-hot / integer scoring) and to fp32
+ *   rounding (<= 1e-5 relative) otherwise. */
+int praline_build_scores(int num_sets, const praline_array *i1s, const praline_array *i2s,
+                         const praline_array *i1nzs, const praline_array *i2nzs,
+                         const praline_array *ss, const praline_array *m);
+
+/* Replace cext_align_<mode>(m, g1, g2, o, t, z)  (praline/util/cext.c:99-306,457-485).
+ *   m float32 [L1][L2]; g1 float32 [L1][2], g2 float32 [L2][2] (open, extend per position);
+ *   o float32 [L1+1][L2+1][3] and t uint8 [L1+1][L2+1][3] in/out (caller pre-initialises the
+ *   boundaries as RawPairwiseAligner does, align.py:357-385); z uint8 [L1+1][L2+1] mask.
+ *   Results are bit-identical to the reference fill (all seven tie flags included). */
+int praline_align_global(const praline_array *m, const praline_array *g1, const praline_array *g2,
+                         const praline_array *o, const praline_array *t, const praline_array *z);
+int praline_align_local(const praline_array *m, const praline_array *g1, const praline_array *g2,
+                        const praline_array *o, const praline_array *t, const praline_array *z);
+int praline_align_semiglobal_both(const praline_array *m, const praline_array *g1,
+                                  const praline_array *g2, const praline_array *o,
+                                  const praline_array *t, const praline_array *z);
+int praline_align_semiglobal_one(const praline_array *m, const praline_array *g1,
+                                 const praline_array *g2, const praline_array *o,
+                                 const praline_array *t, const praline_array *z);
+int praline_align_semiglobal_two(const praline_array *m, const praline_array *g1,
+                                 const praline_array *g2, const praline_array *o,
+                                 const praline_array *t, const praline_array *z);
+/* Same, mode as an argument (PRALINE_MODE_*). */
+int praline_align(int mode, const praline_array *m, const praline_array *g1,
+                  const praline_array *g2, const praline_array *o, const praline_array *t,
+                  const praline_array *z);
+
+/* RawPairwiseAligner.execute in one call (praline/component/align.py:357-447): boundary init,
+ * fill, end-cell selection (align.py:401-431), traceback (praline/util/align.py:144-185) and
+ * semiglobal path extension (praline/util/align.py:268-297) on the device; only the score and the
+ * path travel back.  path: int32 [L1+L2+2][2] caller buffer, *path_rows receives the row count.
+ * z may be NULL. */
+int praline_raw_align(int mode, const praline_array *m, const praline_array *g1,
+                      const praline_array *g2, const praline_array *z, float *score,
+                      int32_t *path, int64_t *path_rows);
+
+/* ============================================================================================
+ * B. Batched entry points: a profile arena resident in HBM + pair lists.
+ * ========================================================================================== */
+typedef struct praline_arena praline_arena; /* profiles of N sequences, packed for the kernels */
+typedef struct praline_plan praline_plan;   /* a scheduled pair list (wave tasks) on the device */
+
+/* Uploads N sequences.  profiles: float32 [sum(lens)][A], sequence s occupying rows
+ * row_off(s) = lens[0]+...+lens[s-1]; this is PairwiseAligner's per-track fp32 profile
+ * (one-hot for PlainTrack, counts/rowsum for ProfileTrack, praline/component/align.py:163-177).
+ * Several track sets are passed concatenated along the alphabet axis (A = sum A_t) with
+ * S = blockdiag(S_t) (cext.c:389-420 sums the sets).  S: float32 [A][A], row = symbol of
+ * sequence one, column = symbol of sequence two (align.py:205).  Runs the profile x matrix
+ * pre-multiply (MFMA) on the device. */
+int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t A, const float *profiles,
+                         const float *S, praline_arena **out);
+int praline_arena_destroy(praline_arena *arena);
+/* Re-runs the device-side packing + pre-multiply from the resident raw profiles (the part of
+ * cext_build_scores that is per sequence, not per pair); asynchronous on praline_stream(). */
+int praline_arena_premultiply(praline_arena *arena);
+
+/* Schedules n_pairs alignments (pairs: int32 [n][2] = (sequence_one, sequence_two) arena
+ * indices, any order, duplicates allowed).  want_paths != 0 additionally reserves packed
+ * traceback storage.  rect_off (int32 [n+1]) / rects (int32 [rect_off[n]][4] = y0,y1,x0,x1
+ * inclusive DP coordinates) give per-pair zero rectangles (the Waterman-Eggert masks of
+ * praline/component/preprofile.py:247-255); both may be NULL. */
+int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pairs,
+                        int want_paths, const int32_t *rect_off, const int32_t *rects,
+                        praline_plan **out);
+int praline_plan_destroy(praline_plan *plan);
+int64_t praline_plan_cells(const praline_plan *plan);      /* sum L1*L2 over the pairs */
+int64_t praline_plan_path_capacity(const praline_plan *plan); /* rows: sum (L1+L2+2) */
+
+/* Launches the fused match-score + affine DP fill for every pair of the plan (asynchronous on
+ * praline_stream()).  gap_open/gap_extend: PairwiseAligner's gap_series [open, extend]
+ * (align.py:182-189,212-217; both <= 0).  d_scores: DEVICE pointer to n_pairs float32 in pair
+ * order, or NULL to use the plan's own buffer. */
+int praline_plan_run(praline_plan *plan, int mode, float gap_open, float gap_extend,
+                     void *d_scores);
+/* Copies the plan's score buffer (pair order) to the host; synchronises. */
+int praline_plan_scores(praline_plan *plan, float *scores);
+/* Device pointer of the plan's own score buffer. */
+void *praline_plan_device_scores(praline_plan *plan);
+/* want_paths plans: copies the alignment paths to the host; synchronises.  path_rows: int32 [n];
+ * path_off: int64 [n] row offset of pair p's first row inside `paths`
+ * (int32 [praline_plan_path_capacity][2], rows (y, x) in start->end order, semiglobal paths
+ * already extended to the corners, praline/util/align.py:268-297). */
+int praline_plan_paths(praline_plan *plan, int32_t *paths, int64_t *path_off, int32_t *path_rows);
+
+/* Convenience: arena-resident one-shot (plan + run + copy back). */
+int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float gap_extend,
+                         int64_t n_pairs, const int32_t *pairs, float *scores);
+
+/* Timing of the last praline_plan_run on this plan, measured with HIP events on the launch
+ * stream: kernel_ms = the DP kernel alone. */
+int praline_plan_last_timing(praline_plan *plan, float *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRALINE_DP_H */

@@ -1,0 +1,13 @@
+// dp_instance.hip -- one instantiation set of k_dp_batch; compiled with -DPRALINE_NSTEP_INST=N.
+#include "dp_launch.hip.h"
+
+#ifndef PRALINE_NSTEP_INST
+#error "compile with -DPRALINE_NSTEP_INST=<MFMA steps per tile>"
+#endif
+#define PRALINE_CAT2(a, b) a##b
+#define PRALINE_CAT(a, b) PRALINE_CAT2(a, b)
+
+int PRALINE_CAT(praline_launch_dp_, PRALINE_NSTEP_INST)(const LaunchArgs &la, int tp, bool local, int out, bool mask)
+{
+    return launch_nstep<PRALINE_NSTEP_INST>(la, tp, local, out, mask);
+}

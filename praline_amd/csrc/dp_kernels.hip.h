@@ -1,0 +1,840 @@
+// dp_kernels.hip.h -- gfx950 (MI355X / CDNA4) device code of libpraline_dp.so.
+//
+// Hot path restated for the device (reference lines relative to /root/reference):
+//   * match scores  m = sum_sets P1 . S . P2^T        praline/util/cext.c:308-455 (inner 33-97)
+//   * 3-state affine fill M/U/L + traceback flags     praline/util/cext.c:99-306
+//   * boundary init / end cell / traceback            praline/component/align.py:357-431,
+//                                                     praline/util/align.py:144-185,268-297
+//
+// Batched kernels (k_dp_batch): one wavefront owns up to 64 (TP=2) or 32 (TP=1) pairs.  The
+// pairs of a 32-lane half share their sequence TWO (the all-pairs and master-slave stages align
+// one sequence against many).  The DP matrix of every pair is swept in vertical strips of 32
+// columns of the shared sequence; for each DP row the wave issues NSTEP v_mfma_f32_32x32x2_f32:
+//     D[i][lane] = sum_k Q2[x0+i][k] * P1_lane[y][k]      (Q2 = P2 . S^T, the pre-multiply)
+// i.e. the 32 match scores m[y][x0..x0+31] of EVERY lane's own pair land in that lane's
+// accumulator registers (after a v_permlane32_swap exchange between the two 32-lane halves), so
+// the match-score matrix never exists in LDS or HBM.  The fp32 MFMA is an exact k-ordered fmaf
+// chain, so one-hot x integer scoring is bit-exact and float profiles differ from the
+// reference's summation order by fp32 rounding only.  The recurrence then runs on the VALU with
+// all per-column state in registers; only the strip-boundary column round-trips through HBM/L2.
+//
+// Raw kernels (k_raw_*): the reference's own buffer layout (m, g1, g2, o, t, z), one pair, a
+// single wavefront walking anti-diagonals: lane l owns column x0+l, computes row t-l at step t
+// and receives its left/diagonal neighbours from lane l-1 with __shfl_up.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PRALINE_NEG_INF (-__builtin_inff())
+#define PRALINE_MAX_RECTS 4
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// --------------------------------------------------------------------------------------------
+// Device-side views
+// --------------------------------------------------------------------------------------------
+struct ArenaDev {
+    const float *P;          // [rows_pad][KP]  parity-split profiles (B operand, sequence one)
+    const float *Q;          // [rows_pad][KP]  parity-split Q2 = P . S^T (A operand, sequence two)
+    const int32_t *row_off;  // [n_seqs] first padded row of each sequence
+    const int32_t *len;      // [n_seqs]
+    int KP;                  // floats per row  (2 * KS)
+    int KS;                  // floats per parity half (multiple of 4)
+};
+
+struct WaveTask {
+    int32_t two[2];   // shared sequence (arena index) of lanes 0-31 / 32-63, -1 = half unused
+    int32_t max_l1;   // longest sequence one among the lanes
+    int32_t nstrips;  // max over halves of ceil(len(two)/32)
+    int64_t bnd_off;  // element offset of the strip-boundary scratch [max_l1+1][64]
+    int64_t tb_off;   // uint4 offset of the packed traceback planes [nstrips][max_l1+1][64]
+    int64_t aux_off;  // float offset of the end-cell scratch: lastcol [max_l1+1][3][64] then
+                      // lastrow [nstrips*32][3][64]  (semiglobal paths only)
+};
+
+struct RunParams {
+    int mode;
+    float go1, ge1;  // gap open / extend of gap_score_model_one (state U, cext.c:155-158)
+    float go2, ge2;  // gap open / extend of gap_score_model_two (state L, cext.c:172-175)
+};
+
+struct RectList {
+    const int32_t *rect_off;  // [n_pairs + 1] or nullptr
+    const int32_t *rects;     // [.][4] y0,y1,x0,x1 inclusive DP coordinates
+};
+
+__device__ __forceinline__ bool mode_free_one(int mode) { return mode == 2 || mode == 3; }
+__device__ __forceinline__ bool mode_free_two(int mode) { return mode == 2 || mode == 4; }
+
+// Boundary value o[y,0,1] / o[0,x,2] for idx >= 1 (praline/component/align.py:375,383):
+// float64 arithmetic, one rounding to float32.
+__device__ __forceinline__ float boundary_value(int idx, float go, float ge, bool is_free)
+{
+    return is_free ? 0.0f : (float)((double)(idx - 1) * (double)ge + (double)go);
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);  // folds to v_max3_f32
+}
+
+#ifdef PRALINE_AUX_KERNELS  // non-template kernels: defined in praline_dp.hip's translation unit only
+// --------------------------------------------------------------------------------------------
+// Arena packing + the profile x matrix pre-multiply
+// --------------------------------------------------------------------------------------------
+// raw: [rows][A] fp32 (host layout, sequences concatenated); P: parity-split, compacted to the
+// active symbols: P[rowp][h][s] = raw[row][active[2s+h]], zero in padding rows / columns.
+__global__ void k_pack_profiles(const float *__restrict__ raw, const int32_t *__restrict__ seq_of_rowp,
+                                const int32_t *__restrict__ row_off_pad,
+                                const int32_t *__restrict__ row_off_raw,
+                                const int32_t *__restrict__ len, const int32_t *__restrict__ active,
+                                int n_active, int A, int KP, int KS, int64_t rows_pad, float *__restrict__ P)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows_pad * KP) return;
+    const int64_t rowp = idx / KP;
+    const int c = (int)(idx % KP);
+    const int h = c / KS, s = c % KS;
+    const int k = 2 * s + h;
+    float v = 0.0f;
+    const int seq = seq_of_rowp[rowp];
+    if (seq >= 0 && k < n_active) {
+        const int r = (int)(rowp - row_off_pad[seq]);
+        if (r < len[seq]) v = raw[(int64_t)(row_off_raw[seq] + r) * A + active[k]];
+    }
+    P[idx] = v;
+}
+
+// Q2[x][i] = sum_j S[i][j] * P2[x][j], an fp32 fmaf chain over j ascending, evaluated with
+// v_mfma_f32_32x32x2_f32: one wave computes 32 rows x 32 (compacted) symbols.
+//   A operand (lane l: row l&31, k = l>>5)  = raw[row0 + (l&31)][2s + (l>>5)]
+//   B operand (lane l: k = l>>5, col l&31)  = S[active[c0 + (l&31)]][2s + (l>>5)]
+// D[i][j]: lane holds column j = l&31 (symbol), rows i = (r&3) + 8(r>>2) + 4(l>>5).
+__global__ __launch_bounds__(64) void k_premultiply(const float *__restrict__ raw,
+                                                     const float *__restrict__ S,
+                                                     const int32_t *__restrict__ seq_of_rowp,
+                                                     const int32_t *__restrict__ row_off_pad,
+                                                     const int32_t *__restrict__ row_off_raw,
+                                                     const int32_t *__restrict__ len,
+                                                     const int32_t *__restrict__ active, int n_active,
+                                                     int A, int KP, int KS, int64_t rows_pad,
+                                                     float *__restrict__ Q)
+{
+    const int lane = threadIdx.x;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t rowp0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int64_t rowp = rowp0 + j;
+    const float *src = nullptr;
+    if (rowp < rows_pad) {
+        const int seq = seq_of_rowp[rowp];
+        if (seq >= 0) {
+            const int r = (int)(rowp - row_off_pad[seq]);
+            if (r < len[seq]) src = raw + (int64_t)(row_off_raw[seq] + r) * A;
+        }
+    }
+    const int sym = (c0 + j < n_active) ? active[c0 + j] : -1;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; 2 * s < A; ++s) {
+        const int k = 2 * s + h;
+        const float a = (src != nullptr && k < A) ? src[k] : 0.0f;
+        const float b = (sym >= 0 && k < A) ? S[(int64_t)sym * A + k] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    const int c = c0 + j;
+    if (c < KP) {
+        const int hh = c & 1, ss = c >> 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int64_t rp = rowp0 + i;
+            if (rp < rows_pad) Q[rp * KP + hh * KS + ss] = (c < n_active) ? acc[r] : 0.0f;
+        }
+    }
+}
+
+// m[y][x] = sum_k P1[y][k] * Q2[x][k] as a dense matrix in HBM (the cext_build_scores twin).
+// One wave per 32x32 tile: A operand = P rows of sequence `one`, B operand = Q rows of `two`;
+// lane holds column x0 + (l&31): coalesced 128-byte row segments on the store.
+__global__ __launch_bounds__(64) void k_scores_tile(ArenaDev ar, int one, int two, int nstep,
+                                                     float *__restrict__ m)
+{
+    const int lane = threadIdx.x;
+    const int j = lane & 31, h = lane >> 5;
+    const int L1 = ar.len[one], L2 = ar.len[two];
+    const int y0 = blockIdx.y * 32, x0 = blockIdx.x * 32;
+    const float *pa = ar.P + ((int64_t)ar.row_off[one] + y0 + j) * ar.KP + h * ar.KS;
+    const float *qb = ar.Q + ((int64_t)ar.row_off[two] + x0 + j) * ar.KP + h * ar.KS;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < nstep; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int x = x0 + j;
+        if (y < L1 && x < L2) m[(int64_t)y * L2 + x] = acc[r];
+    }
+}
+
+#endif  // PRALINE_AUX_KERNELS
+
+// --------------------------------------------------------------------------------------------
+// Fused match-score + DP fill, batched.
+//   OUT = 0: scores only.  Per column: H = max(M,U,L) of the previous row and U of the current
+//            row (computed one row ahead); boundary scratch float2 (H, L-input) per row.
+//   OUT = 1: + packed traceback.  Per column the three states of the previous row; boundary
+//            scratch float4 (M, U, L) per row; four bit planes per 32-cell row segment:
+//            .x/.y = match source (1 MM, 2 MU, 3 ML, 0 stop), .z = U from extend, .w = L from
+//            extend -- the first-set-flag choice get_paths makes (praline/util/align.py:161-174).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap_halves(float &a, float &b)
+{
+    // v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b.
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a),
+                                                    __builtin_bit_cast(unsigned, b), false, false);
+    a = __builtin_bit_cast(float, r[0]);
+    b = __builtin_bit_cast(float, r[1]);
+}
+
+// v[idx] for a per-lane idx in 0..31: 5-level v_cndmask tree (registers cannot be indexed per lane).
+__device__ __forceinline__ float select32(const float (&v)[32], int idx)
+{
+    float t16[16], t8[8], t4[4], t2[2];
+    const bool b0 = idx & 1, b1 = idx & 2, b2 = idx & 4, b3 = idx & 8, b4 = idx & 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t16[k] = b0 ? v[2 * k + 1] : v[2 * k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t8[k] = b1 ? t16[2 * k + 1] : t16[2 * k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t4[k] = b2 ? t8[2 * k + 1] : t8[2 * k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) t2[k] = b3 ? t4[2 * k + 1] : t4[2 * k];
+    return b4 ? t2[1] : t2[0];
+}
+
+template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK>
+__global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__restrict__ tasks,
+                                                 const int32_t *__restrict__ lane_one,
+                                                 const int32_t *__restrict__ lane_pair,
+                                                 void *__restrict__ bnd_raw, uint4 *__restrict__ tb,
+                                                 float *__restrict__ aux, RectList rl,
+                                                 float *__restrict__ scores,
+                                                 int32_t *__restrict__ end_cells, RunParams rp)
+{
+    constexpr int NQ = (NSTEP + 3) / 4;  // float4 loads per operand
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    const int j = lane & 31;
+    const int base = blockIdx.x * 64;
+
+    const WaveTask tk = tasks[blockIdx.x];
+    const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
+    const bool semiglobal = rp.mode >= 2;
+    const float go1 = rp.go1, ge1 = rp.ge1, go2 = rp.go2, ge2 = rp.ge2;
+
+    // ---- the pair this lane owns in the DP ----
+    const bool dp_lane = (TP == 2) || (half == 0);
+    const int my_one = dp_lane ? lane_one[base + lane] : -1;
+    const int my_two = tk.two[TP == 2 ? half : 0];
+    const bool have_pair = my_one >= 0 && my_two >= 0;
+    const int L1 = have_pair ? ar.len[my_one] : 0;
+    const int L2 = have_pair ? ar.len[my_two] : 0;
+    const int my_strips = (L2 + 31) >> 5;
+    const int clast = (L2 - 1) & 31;
+    const int my_pair = have_pair ? lane_pair[base + lane] : -1;
+
+    // ---- MFMA operand sources ----
+    // B operand: lane (j, half) feeds k = 2s + half of the profile row of the pair owned by DP
+    // lane j (tile A) and by DP lane 32 + j (tile B).
+    const int srcA = lane_one[base + j];
+    const float *pA = ar.P + (int64_t)(srcA >= 0 ? ar.row_off[srcA] : 0) * ar.KP + half * ar.KS;
+    const float *pB = pA;
+    if (TP == 2) {
+        const int srcB = lane_one[base + 32 + j];
+        pB = ar.P + (int64_t)(srcB >= 0 ? ar.row_off[srcB] : 0) * ar.KP + half * ar.KS;
+    }
+    // A operand: lane (i = j, half) feeds k = 2s + half of Q2 row x0 + i of the shared sequence.
+    const float *qA = ar.Q + ((int64_t)(tk.two[0] >= 0 ? ar.row_off[tk.two[0]] : 0) + j) * ar.KP + half * ar.KS;
+    const float *qB = qA;
+    if (TP == 2)
+        qB = ar.Q + ((int64_t)(tk.two[1] >= 0 ? ar.row_off[tk.two[1]] : 0) + j) * ar.KP + half * ar.KS;
+
+    // ---- zero rectangles (Waterman-Eggert masks, praline/component/preprofile.py:247-255) ----
+    int rect[PRALINE_MAX_RECTS][4];
+    if constexpr (MASK) {
+        int n_rects = 0, r0 = 0;
+        if (my_pair >= 0 && rl.rect_off != nullptr) {
+            r0 = rl.rect_off[my_pair];
+            n_rects = rl.rect_off[my_pair + 1] - r0;
+            if (n_rects > PRALINE_MAX_RECTS) n_rects = PRALINE_MAX_RECTS;
+        }
+#pragma unroll
+        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
+            const bool ok = r < n_rects;
+            rect[r][0] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 0] : (1 << 30);
+            rect[r][1] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 1] : -1;
+            rect[r][2] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 2] : (1 << 30);
+            rect[r][3] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 3] : -1;
+        }
+    }
+
+    float2 *bnd2 = reinterpret_cast<float2 *>(bnd_raw) + tk.bnd_off + lane;  // OUT==0: [y][64]
+    float4 *bnd4 = reinterpret_cast<float4 *>(bnd_raw) + tk.bnd_off + lane;  // OUT==1: [y][64]
+    uint4 *my_tb = tb + tk.tb_off + lane;                                     // [strip][y][64]
+    float *lastcol = aux + tk.aux_off + lane;                                 // [y][3][64]
+    float *lastrow = aux + tk.aux_off + (int64_t)(tk.max_l1 + 1) * 3 * 64 + lane;  // [x-1][3][64]
+
+    // ---- boundary cells (praline/component/align.py:367-385) ----
+    const float o001 = free_one ? 0.0f : (go1 - ge1);
+    const float o002 = free_two ? 0.0f : (go2 - ge2);
+    const float h00 = max3f(0.0f, o001, o002);
+
+    // ---- end-cell bookkeeping ----
+    // local: first flat argmax over o (align.py:402); among the boundary cells only o[0,0,:] can
+    // be >= 0 for gap scores <= 0 (the host rejects positive gap scores for batched local mode).
+    float best = 0.0f;
+    int best_y = 0, best_x = 0, best_k = 0;
+    if (LOCAL) {
+        if (o001 > best) { best = o001; best_k = 1; }
+        if (o002 > best) { best = o002; best_k = 2; }
+    }
+    float rowmax = have_pair ? boundary_value(L1, go1, ge1, free_one) : PRALINE_NEG_INF;  // o[L1,0,1]
+    float colmax = have_pair ? boundary_value(L2, go2, ge2, free_two) : PRALINE_NEG_INF;  // o[0,L2,2]
+    float corner_h = PRALINE_NEG_INF;
+    float corner_m = PRALINE_NEG_INF, corner_u = PRALINE_NEG_INF, corner_l = PRALINE_NEG_INF;
+
+    for (int s = 0; s < tk.nstrips; ++s) {
+        const int x0 = s * 32;  // this strip covers DP columns x0+1 .. x0+32
+        const bool strip_act = have_pair && s < my_strips;
+        const bool is_last = s == my_strips - 1;
+
+        // A operands of this strip (rows x0 + j of the shared sequences' Q2)
+        float aA[NSTEP], aB[NSTEP];
+        {
+            const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.KP);
+            const float4 *sb = reinterpret_cast<const float4 *>(qB + (int64_t)x0 * ar.KP);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float4 va = sa[q];
+                const float4 vb = (TP == 2) ? sb[q] : va;
+                const float ea[4] = {va.x, va.y, va.z, va.w};
+                const float eb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < NSTEP) { aA[4 * q + e] = ea[e]; aB[4 * q + e] = eb[e]; }
+            }
+        }
+
+        // per-column state carried down the strip (only the set of this OUT variant is live)
+        float Hp[32], Uc[32];          // OUT==0
+        float Mp[32], Up[32], Lp[32];  // OUT==1
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float bl = boundary_value(x0 + c + 1, go2, ge2, free_two);  // o[0,x,2]
+            Hp[c] = bl; Uc[c] = PRALINE_NEG_INF;
+            Mp[c] = PRALINE_NEG_INF; Up[c] = PRALINE_NEG_INF; Lp[c] = bl;
+        }
+        // states of the cell (y-1, x0), the diagonal input of column x0+1: row 0 first
+        float dM = (s == 0) ? 0.0f : PRALINE_NEG_INF;
+        float dU = (s == 0) ? o001 : PRALINE_NEG_INF;
+        float dL = (s == 0) ? o002 : boundary_value(x0, go2, ge2, free_two);
+        float dH = (s == 0) ? h00 : dL;
+
+        // B operands of row 1
+        float4 nA[NQ], nB[NQ];
+        {
+            const float4 *sa = reinterpret_cast<const float4 *>(pA);
+            const float4 *sb = reinterpret_cast<const float4 *>(pB);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { nA[q] = sa[q]; nB[q] = (TP == 2) ? sb[q] : nA[q]; }
+        }
+
+        for (int y = 1; y <= tk.max_l1; ++y) {
+            // ---- match scores of row y for all lanes: NSTEP MFMAs per tile ----
+            float bA[NSTEP], bB[NSTEP];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float ea[4] = {nA[q].x, nA[q].y, nA[q].z, nA[q].w};
+                const float eb[4] = {nB[q].x, nB[q].y, nB[q].z, nB[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < NSTEP) { bA[4 * q + e] = ea[e]; bB[4 * q + e] = eb[e]; }
+            }
+            // prefetch the next row's B operands (rows past a sequence's end read the arena's
+            // zeroed tail padding or the next sequence: finite values that only reach lanes whose
+            // DP is masked off)
+            {
+                const float4 *sa = reinterpret_cast<const float4 *>(pA + (int64_t)y * ar.KP);
+                const float4 *sb = reinterpret_cast<const float4 *>(pB + (int64_t)y * ar.KP);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { nA[q] = sa[q]; if (TP == 2) nB[q] = sb[q]; }
+            }
+            f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            f32x16 accB = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) {
+                accA = __builtin_amdgcn_mfma_f32_32x32x2f32(aA[k], bA[k], accA, 0, 0, 0);
+                if (TP == 2) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aB[k], bB[k], accB, 0, 0, 0);
+            }
+            // D[i][lane]: register r of half h holds i = (r&3) + 8(r>>2) + 4h.  Exchange halves so
+            // every DP lane holds all 32 columns of ITS pair: m[8q+r] = a[4q+r], m[8q+4+r] = b[4q+r].
+            float m[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = accA[r];
+                float b = (TP == 2) ? accB[r] : 0.0f;
+                swap_halves(a, b);
+                m[8 * (r >> 2) + (r & 3)] = a;
+                m[8 * (r >> 2) + 4 + (r & 3)] = b;
+            }
+
+            if (strip_act && y <= L1) {
+                bool row_in[PRALINE_MAX_RECTS];
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int r = 0; r < PRALINE_MAX_RECTS; ++r) row_in[r] = y >= rect[r][0] && y <= rect[r][1];
+                }
+                if constexpr (OUT == 0) {
+                    float hl, lin;  // H of cell (y, x0) and the L state of cell (y, x0+1)
+                    if (s == 0) { hl = boundary_value(y, go1, ge1, free_one); lin = PRALINE_NEG_INF; }
+                    else { const float2 bv = bnd2[(int64_t)y * 64]; hl = bv.x; lin = bv.y; }
+                    float hd = dH, lrun = lin;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) {
+                        float M = hd + m[c];                       // max_k(o[y-1,x-1,k]) + m  (cext.c:192-222)
+                        if (LOCAL) M = __builtin_fmaxf(M, 0.0f);   // cext.c:208-209
+                        float U = Uc[c];
+                        float Lc = lrun;
+                        if constexpr (MASK) {
+                            bool z = false;
+#pragma unroll
+                            for (int r = 0; r < PRALINE_MAX_RECTS; ++r)
+                                z = z || (row_in[r] && (x0 + c + 1) >= rect[r][2] && (x0 + c + 1) <= rect[r][3]);
+                            if (z) { M = 0.0f; U = 0.0f; Lc = 0.0f; }  // cext.c:141-149
+                        }
+                        const float H = max3f(M, U, Lc);
+                        if (LOCAL) best = __builtin_fmaxf(best, H);
+                        Uc[c] = __builtin_fmaxf(M + go1, U + ge1);   // U[y+1][x]   (cext.c:152-166,247-254)
+                        lrun = __builtin_fmaxf(M + go2, Lc + ge2);   // L[y][x+1]   (cext.c:169-183,276-283)
+                        hd = Hp[c];
+                        Hp[c] = H;
+                    }
+                    dH = hl;
+                    bnd2[(int64_t)y * 64] = make_float2(Hp[31], lrun);
+                    if (semiglobal && is_last) colmax = __builtin_fmaxf(colmax, select32(Hp, clast));
+                } else {
+                    float bm, bu, bl;  // states of the cell (y, x0)
+                    if (s == 0) { bm = PRALINE_NEG_INF; bu = boundary_value(y, go1, ge1, free_one); bl = PRALINE_NEG_INF; }
+                    else { const float4 bv = bnd4[(int64_t)y * 64]; bm = bv.x; bu = bv.y; bl = bv.z; }
+                    float md = dM, ud = dU, ld = dL;   // states of (y-1, x-1)
+                    float mleft = bm, lleft = bl;      // states of (y, x-1)
+                    unsigned w_mlo = 0, w_mhi = 0, w_u = 0, w_l = 0;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) {
+                        // exact candidate sums; first-match priority MM > MU > ML, UO > UE, LO > LE
+                        // (cext.c:185-295, praline/util/align.py:161-174)
+                        const float sMM = md + m[c], sMU = ud + m[c], sML = ld + m[c];
+                        float M = max3f(sMM, sMU, sML);
+                        if (LOCAL) M = __builtin_fmaxf(M, 0.0f);
+                        const float uo = Mp[c] + go1, ue = Up[c] + ge1;
+                        float U = __builtin_fmaxf(uo, ue);
+                        const float lo = mleft + go2, le = lleft + ge2;
+                        float Lc = __builtin_fmaxf(lo, le);
+                        bool isMM = sMM == M;
+                        bool isMU = !isMM && sMU == M;
+                        bool isML = !isMM && !isMU && sML == M;
+                        if constexpr (MASK) {
+                            bool z = false;
+#pragma unroll
+                            for (int r = 0; r < PRALINE_MAX_RECTS; ++r)
+                                z = z || (row_in[r] && (x0 + c + 1) >= rect[r][2] && (x0 + c + 1) <= rect[r][3]);
+                            if (z) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }
+                        }
+                        w_mlo |= (isMM || isML) ? (1u << c) : 0u;
+                        w_mhi |= (isMU || isML) ? (1u << c) : 0u;
+                        w_u |= (uo >= ue) ? 0u : (1u << c);
+                        w_l |= (lo >= le) ? 0u : (1u << c);
+                        if (LOCAL) {
+                            // first maximum in C order (y, x, k): rows ascend inside a strip and
+                            // later strips have larger x, so only a smaller y wins a tie.
+                            const float H = max3f(M, U, Lc);
+                            if (H > best || (H == best && y < best_y)) {
+                                best = H; best_y = y; best_x = x0 + c + 1;
+                                best_k = (M == H) ? 0 : ((U == H) ? 1 : 2);
+                            }
+                        }
+                        md = Mp[c]; ud = Up[c]; ld = Lp[c];
+                        Mp[c] = M; Up[c] = U; Lp[c] = Lc;
+                        mleft = M; lleft = Lc;
+                    }
+                    dM = bm; dU = bu; dL = bl;
+                    bnd4[(int64_t)y * 64] = make_float4(Mp[31], Up[31], Lp[31], 0.0f);
+                    my_tb[((int64_t)s * (tk.max_l1 + 1) + y) * 64] = make_uint4(w_mlo, w_mhi, w_u, w_l);
+                    if (semiglobal && is_last) {
+                        // o[y, L2, :] for the end-cell scan (align.py:408,418-422)
+                        float *lc = lastcol + (int64_t)y * 3 * 64;
+                        lc[0] = select32(Mp, clast);
+                        lc[64] = select32(Up, clast);
+                        lc[128] = select32(Lp, clast);
+                    }
+                }
+            }
+        }  // rows
+
+        // ---- strip epilogue: every lane's state is frozen at its own last row L1 ----
+        if (strip_act) {
+            if constexpr (OUT == 0) {
+                if (semiglobal) {
+                    const int cmax = is_last ? clast : 31;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c)
+                        rowmax = __builtin_fmaxf(rowmax, (c <= cmax) ? Hp[c] : PRALINE_NEG_INF);
+                }
+                if (is_last) corner_h = select32(Hp, clast);
+            } else {
+                if (is_last) {
+                    corner_m = select32(Mp, clast);
+                    corner_u = select32(Up, clast);
+                    corner_l = select32(Lp, clast);
+                }
+                if (semiglobal) {
+                    // o[L1, x, :] for x = x0+1 .. x0+32 (align.py:407,413-417)
+                    float *lr = lastrow + (int64_t)x0 * 3 * 64;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) {
+                        lr[(c * 3 + 0) * 64] = Mp[c];
+                        lr[(c * 3 + 1) * 64] = Up[c];
+                        lr[(c * 3 + 2) * 64] = Lp[c];
+                    }
+                }
+            }
+        }
+    }  // strips
+
+    if (have_pair) {
+        if constexpr (OUT == 0) {
+            float score;
+            if (LOCAL) score = best;
+            else if (semiglobal) score = (rowmax > colmax && free_two) ? rowmax : colmax;  // align.py:411-424
+            else score = corner_h;                                                        // align.py:428-430
+            scores[my_pair] = score;
+        } else {
+            int ey = L1, ex = L2, ek = 0;
+            float score = corner_m;
+            if (LOCAL) { ey = best_y; ex = best_x; ek = best_k; score = best; }
+            else {
+                if (corner_u > score) { score = corner_u; ek = 1; }  // np.argmax: first maximum
+                if (corner_l > score) { score = corner_l; ek = 2; }
+            }
+            // semiglobal end cells are resolved by k_traceback from lastrow / lastcol
+            end_cells[(int64_t)my_pair * 4 + 0] = ey;
+            end_cells[(int64_t)my_pair * 4 + 1] = ex;
+            end_cells[(int64_t)my_pair * 4 + 2] = ek;
+            end_cells[(int64_t)my_pair * 4 + 3] = 0;
+            scores[my_pair] = score;
+        }
+    }
+}
+
+#ifdef PRALINE_AUX_KERNELS
+// --------------------------------------------------------------------------------------------
+// Device traceback over the packed planes: one lane per pair.
+// get_paths (praline/util/align.py:144-185) + end-cell rules (praline/component/align.py:401-431)
+// + extend_path_semiglobal (praline/util/align.py:268-297).  Paths are written backwards from the
+// end of the pair's slot, so they come out in start->end order: rows [path_start, slot_end).
+// --------------------------------------------------------------------------------------------
+struct PairLoc { int32_t task; int32_t lane; };
+
+__global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
+                            const PairLoc *__restrict__ loc, const int32_t *__restrict__ pairs,
+                            const uint4 *__restrict__ tb, const float *__restrict__ aux, RectList rl,
+                            const int32_t *__restrict__ end_cells, float *__restrict__ scores,
+                            const int64_t *__restrict__ slot_off, int32_t *__restrict__ paths,
+                            int64_t *__restrict__ path_start, int32_t *__restrict__ path_rows,
+                            int64_t n_pairs, RunParams rp, int32_t task_lo, int32_t task_hi)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const PairLoc pl = loc[p];
+    if (pl.task < task_lo || pl.task >= task_hi) return;  // pair belongs to another launch chunk
+    const WaveTask tk = tasks[pl.task];
+    const int L1 = ar.len[pairs[2 * p]], L2 = ar.len[pairs[2 * p + 1]];
+    const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
+    const bool semiglobal = rp.mode >= 2;
+    const uint4 *my_tb = tb + tk.tb_off + pl.lane;
+
+    int y = end_cells[p * 4 + 0], x = end_cells[p * 4 + 1], k = end_cells[p * 4 + 2];
+    if (semiglobal) {
+        const float *lastcol = aux + tk.aux_off + pl.lane;
+        const float *lastrow = aux + tk.aux_off + (int64_t)(tk.max_l1 + 1) * 3 * 64 + pl.lane;
+        // o[L1, x, k] and o[y, L2, k] including the boundary cells (align.py:406-410)
+        auto row_at = [&](int xx, int kk) -> float {
+            if (xx == 0) return kk == 1 ? boundary_value(L1, rp.go1, rp.ge1, free_one) : PRALINE_NEG_INF;
+            return lastrow[((int64_t)(xx - 1) * 3 + kk) * 64];
+        };
+        auto col_at = [&](int yy, int kk) -> float {
+            if (yy == 0) return kk == 2 ? boundary_value(L2, rp.go2, rp.ge2, free_two) : PRALINE_NEG_INF;
+            return lastcol[((int64_t)yy * 3 + kk) * 64];
+        };
+        float rmax = PRALINE_NEG_INF, cmax = PRALINE_NEG_INF;
+        for (int xx = 0; xx <= L2; ++xx)
+            for (int kk = 0; kk < 3; ++kk) rmax = __builtin_fmaxf(rmax, row_at(xx, kk));
+        for (int yy = 0; yy <= L1; ++yy)
+            for (int kk = 0; kk < 3; ++kk) cmax = __builtin_fmaxf(cmax, col_at(yy, kk));
+        bool found = false;
+        if (rmax > cmax && free_two) {  // trace_from_row (align.py:411-417)
+            for (int xx = L2; xx >= 0 && !found; --xx)
+                for (int kk = 0; kk < 3; ++kk)
+                    if (row_at(xx, kk) == rmax) { y = L1; x = xx; k = kk; found = true; break; }
+            scores[p] = rmax;
+        } else {  // align.py:418-422
+            for (int yy = L1; yy >= 0 && !found; --yy)
+                for (int kk = 0; kk < 3; ++kk)
+                    if (col_at(yy, kk) == cmax) { y = yy; x = L2; k = kk; found = true; break; }
+            scores[p] = cmax;
+        }
+    }
+
+    int n_rects = 0, r0 = 0;
+    if (rl.rect_off != nullptr) { r0 = rl.rect_off[p]; n_rects = rl.rect_off[p + 1] - r0; }
+
+    const int64_t slot_end = slot_off[p] + (L1 + L2 + 2);
+    int64_t w = slot_end;  // next row is written at w-1
+    auto emit = [&](int yy, int xx) { --w; paths[2 * w] = yy; paths[2 * w + 1] = xx; };
+
+    // suffix extension (align.py:284-295)
+    if (semiglobal) {
+        if (y != L1) { for (int yy = L1; yy > y; --yy) emit(yy, x); }
+        else if (x != L2) { for (int xx = L2; xx > x; --xx) emit(y, xx); }
+    }
+    // traceback (praline/util/align.py:155-180)
+    emit(y, x);
+    for (int guard = 0; guard < L1 + L2 + 2; ++guard) {
+        int ny, nx, nk;
+        if (y == 0 || x == 0) {
+            // pre-initialised boundary flags (align.py:377,385): t[y>=1,0,1] = UE, t[0,x>=1,2] = LE
+            if (x == 0 && y >= 1 && k == 1 && !free_one) { ny = y - 1; nx = 0; nk = 1; }
+            else if (y == 0 && x >= 1 && k == 2 && !free_two) { ny = 0; nx = x - 1; nk = 2; }
+            else break;
+        } else {
+            bool masked = false;
+            for (int r = 0; r < n_rects; ++r) {
+                const int32_t *q = rl.rects + (int64_t)(r0 + r) * 4;
+                masked = masked || (y >= q[0] && y <= q[1] && x >= q[2] && x <= q[3]);
+            }
+            if (masked) break;  // t stays 0 in masked cells (cext.c:141-149)
+            const int s = (x - 1) >> 5, c = (x - 1) & 31;
+            const uint4 word = my_tb[((int64_t)s * (tk.max_l1 + 1) + y) * 64];
+            if (k == 0) {
+                const int code = ((word.x >> c) & 1) | (((word.y >> c) & 1) << 1);
+                if (code == 0) break;
+                ny = y - 1; nx = x - 1; nk = code - 1;     // 1 MM, 2 MU, 3 ML
+            } else if (k == 1) {
+                ny = y - 1; nx = x; nk = (word.z >> c) & 1;                 // 0 UO -> M, 1 UE -> U
+            } else {
+                ny = y; nx = x - 1; nk = ((word.w >> c) & 1) ? 2 : 0;       // 0 LO -> M, 1 LE -> L
+            }
+        }
+        y = ny; x = nx; k = nk;
+        emit(y, x);
+    }
+    // prefix extension (align.py:270-279): (y, x) is now the first path row
+    if (semiglobal) {
+        if (y != 0) { for (int yy = y - 1; yy >= 0; --yy) emit(yy, 0); }
+        else if (x != 0) { for (int xx = x - 1; xx >= 0; --xx) emit(0, xx); }
+    }
+    path_start[p] = w;
+    path_rows[p] = (int32_t)(slot_end - w);
+}
+
+// --------------------------------------------------------------------------------------------
+// Raw parity kernels: the reference's buffers (contiguous copies on the device).
+// --------------------------------------------------------------------------------------------
+// Boundary initialisation of RawPairwiseAligner (praline/component/align.py:357-385).
+__global__ void k_raw_init(int mode, const float *__restrict__ g1, const float *__restrict__ g2,
+                           float *__restrict__ o, uint8_t *__restrict__ t, int L1, int L2)
+{
+    const int64_t C = L2 + 1;
+    const int64_t n = (int64_t)(L1 + 1) * C;
+    const bool free_one = mode_free_one(mode), free_two = mode_free_two(mode);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t y = i / C, x = i % C;
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+        uint8_t t1 = 0, t2 = 0;
+        if (y == 0 || x == 0) { v0 = PRALINE_NEG_INF; v1 = PRALINE_NEG_INF; v2 = PRALINE_NEG_INF; }
+        if (y == 0 && x == 0) v0 = 0.0f;
+        if (x == 0) {
+            if (free_one) v1 = 0.0f;
+            else if (y == 0) v1 = g1[0] - g1[1];
+            else { v1 = (float)((double)(y - 1) * (double)g1[(y - 1) * 2 + 1] + (double)g1[0]); t1 = 32; }
+        }
+        if (y == 0) {
+            if (free_two) v2 = 0.0f;
+            else if (x == 0) v2 = g2[0] - g2[1];
+            else { v2 = (float)((double)(x - 1) * (double)g2[(x - 1) * 2 + 1] + (double)g2[0]); t2 = 128; }
+        }
+        o[i * 3 + 0] = v0; o[i * 3 + 1] = v1; o[i * 3 + 2] = v2;
+        t[i * 3 + 0] = 0; t[i * 3 + 1] = t1; t[i * 3 + 2] = t2;
+    }
+}
+
+// cext_align (praline/util/cext.c:99-306) on the reference's own buffers.  One wavefront; lane l
+// owns column x0 + l + 1 of a 64-column strip and computes row (step - l): the cells of one step
+// form an anti-diagonal.  Left / diagonal neighbours come from lane l-1 via __shfl_up; the up
+// neighbour is the lane's own previous step.  All seven tie flags are reproduced.
+__global__ __launch_bounds__(64) void k_raw_align(int local_mode, const float *__restrict__ m,
+                                                   const float *__restrict__ g1,
+                                                   const float *__restrict__ g2, float *o,
+                                                   uint8_t *t, const uint8_t *__restrict__ z, int L1,
+                                                   int L2)
+{
+    const int lane = threadIdx.x;
+    const int64_t C = L2 + 1;
+    const float base = local_mode ? 0.0f : PRALINE_NEG_INF;
+    for (int x0 = 0; x0 < L2; x0 += 64) {
+        const int x = x0 + lane + 1;
+        const bool col_ok = x <= L2;
+        // up neighbour (y-1, x): starts at the boundary row
+        float upM = PRALINE_NEG_INF, upU = PRALINE_NEG_INF, upL = PRALINE_NEG_INF;
+        // diagonal neighbour (y-1, x-1)
+        float dgM = PRALINE_NEG_INF, dgU = PRALINE_NEG_INF, dgL = PRALINE_NEG_INF;
+        float go2 = 0.0f, ge2 = 0.0f;
+        if (col_ok) {
+            upM = o[(int64_t)x * 3 + 0]; upU = o[(int64_t)x * 3 + 1]; upL = o[(int64_t)x * 3 + 2];
+            dgM = o[(int64_t)(x - 1) * 3 + 0]; dgU = o[(int64_t)(x - 1) * 3 + 1]; dgL = o[(int64_t)(x - 1) * 3 + 2];
+            go2 = g2[(x - 1) * 2]; ge2 = g2[(x - 1) * 2 + 1];
+        }
+        float curM = 0.0f, curU = 0.0f, curL = 0.0f;
+        for (int step = 1; step <= L1 + 63; ++step) {
+            const int y = step - lane;
+            // left neighbour (y, x-1): what lane-1 produced in the previous step
+            float lfM = __shfl_up(curM, 1), lfU = __shfl_up(curU, 1), lfL = __shfl_up(curL, 1);
+            const bool row_ok = y >= 1 && y <= L1;
+            if (lane == 0 && row_ok) {
+                const int64_t i = ((int64_t)y * C + x0) * 3;
+                lfM = o[i]; lfU = o[i + 1]; lfL = o[i + 2];
+            }
+            if (row_ok && col_ok) {
+                const int64_t cell = (int64_t)y * C + x;
+                if (z[cell]) {
+                    // masked: the cell keeps whatever the caller pre-initialised (cext.c:147-149)
+                    curM = o[cell * 3]; curU = o[cell * 3 + 1]; curL = o[cell * 3 + 2];
+                } else {
+                    const float go1 = g1[(y - 1) * 2], ge1 = g1[(y - 1) * 2 + 1];
+                    const float ms = m[(int64_t)(y - 1) * L2 + (x - 1)];
+                    const float up_open = upM + go1, up_ext = upU + ge1;
+                    const float lf_open = lfM + go2, lf_ext = lfL + ge2;
+                    const float mm = dgM + ms, mu = dgU + ms, ml = dgL + ms;
+                    float mmax = base;
+                    if (mm > mmax) mmax = mm;
+                    if (mu > mmax) mmax = mu;
+                    if (ml > mmax) mmax = ml;
+                    uint8_t tm = 0;
+                    if (mm == mmax) tm |= 2;
+                    if (mu == mmax) tm |= 4;
+                    if (ml == mmax) tm |= 8;
+                    float umax = PRALINE_NEG_INF;
+                    if (up_open > umax) umax = up_open;
+                    if (up_ext > umax) umax = up_ext;
+                    uint8_t tu = 0;
+                    if (up_open == umax) tu |= 16;
+                    if (up_ext == umax) tu |= 32;
+                    float lmax = PRALINE_NEG_INF;
+                    if (lf_open > lmax) lmax = lf_open;
+                    if (lf_ext > lmax) lmax = lf_ext;
+                    uint8_t tl = 0;
+                    if (lf_open == lmax) tl |= 64;
+                    if (lf_ext == lmax) tl |= 128;
+                    o[cell * 3] = mmax; o[cell * 3 + 1] = umax; o[cell * 3 + 2] = lmax;
+                    t[cell * 3] = tm; t[cell * 3 + 1] = tu; t[cell * 3 + 2] = tl;
+                    curM = mmax; curU = umax; curL = lmax;
+                }
+                upM = curM; upU = curU; upL = curL;
+            }
+            if (y >= 1) { dgM = lfM; dgU = lfU; dgL = lfL; }  // (y, x-1) is the diagonal of (y+1, x)
+        }
+        // the next strip's lane 0 reads this strip's last column back from o
+        __threadfence();
+    }
+}
+
+// End cell + traceback on the raw o / t buffers (align.py:401-431, util/align.py:144-185,268-297).
+// One workgroup: a parallel first-argmax / row-col maxima, then thread 0 walks the path.
+__global__ __launch_bounds__(256) void k_raw_trace(int mode, const float *__restrict__ o,
+                                                    const uint8_t *__restrict__ t, int L1, int L2,
+                                                    float *__restrict__ score_out,
+                                                    int32_t *__restrict__ path,
+                                                    int64_t *__restrict__ path_info)
+{
+    __shared__ float s_val[256];
+    __shared__ long long s_idx[256];
+    const int tid = threadIdx.x;
+    const int64_t C = L2 + 1, R = L1 + 1;
+    const bool semiglobal = mode >= 2;
+    const bool trace_from_row = mode_free_two(mode);
+    int64_t cy = L1, cx = L2, ck = 0;
+    if (mode == 1) {
+        // first flat argmax (align.py:402): per-thread contiguous chunks keep index order
+        const int64_t n = R * C * 3;
+        const int64_t chunk = (n + 255) / 256;
+        const int64_t lo = tid * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+        float bv = PRALINE_NEG_INF; long long bi = -1;
+        for (int64_t i = lo; i < hi; ++i) { const float v = o[i]; if (bi < 0 || v > bv) { bv = v; bi = i; } }
+        s_val[tid] = bv; s_idx[tid] = bi;
+        __syncthreads();
+        if (tid == 0) {
+            float v = s_val[0]; long long b = s_idx[0];
+            for (int q = 1; q < 256; ++q) if (s_idx[q] >= 0 && (b < 0 || s_val[q] > v)) { v = s_val[q]; b = s_idx[q]; }
+            cy = b / (C * 3); cx = (b / 3) % C; ck = b % 3;
+        }
+    }
+    if (tid != 0) return;
+    if (mode == 0) {
+        const float *q = o + ((int64_t)L1 * C + L2) * 3;
+        ck = 0;
+        if (q[1] > q[ck]) ck = 1;
+        if (q[2] > q[ck]) ck = 2;
+    } else if (semiglobal) {
+        float rmax = PRALINE_NEG_INF, cmax = PRALINE_NEG_INF;
+        for (int64_t x = 0; x < C; ++x) for (int k = 0; k < 3; ++k) rmax = __builtin_fmaxf(rmax, o[((int64_t)L1 * C + x) * 3 + k]);
+        for (int64_t y = 0; y < R; ++y) for (int k = 0; k < 3; ++k) cmax = __builtin_fmaxf(cmax, o[(y * C + L2) * 3 + k]);
+        bool found = false;
+        if (rmax > cmax && trace_from_row) {
+            for (int64_t x = C - 1; x >= 0 && !found; --x)
+                for (int k = 0; k < 3; ++k)
+                    if (o[((int64_t)L1 * C + x) * 3 + k] == rmax) { cy = L1; cx = x; ck = k; found = true; break; }
+        } else {
+            for (int64_t y = R - 1; y >= 0 && !found; --y)
+                for (int k = 0; k < 3; ++k)
+                    if (o[(y * C + L2) * 3 + k] == cmax) { cy = y; cx = L2; ck = k; found = true; break; }
+        }
+    }
+    *score_out = o[(cy * C + cx) * 3 + ck];
+    const int64_t cap = L1 + L2 + 2;
+    int64_t w = cap;
+    auto emit = [&](int64_t yy, int64_t xx) { --w; path[2 * w] = (int32_t)yy; path[2 * w + 1] = (int32_t)xx; };
+    int64_t y = cy, x = cx, k = ck;
+    if (semiglobal) {
+        if (y != L1) { for (int64_t yy = L1; yy > y; --yy) emit(yy, x); }
+        else if (x != L2) { for (int64_t xx = L2; xx > x; --xx) emit(y, xx); }
+    }
+    emit(y, x);
+    for (int64_t guard = 0; guard < cap; ++guard) {
+        const uint8_t f = t[(y * C + x) * 3 + k];
+        if (f & 2) { --y; --x; k = 0; }
+        else if (f & 4) { --y; --x; k = 1; }
+        else if (f & 8) { --y; --x; k = 2; }
+        else if (f & 16) { --y; k = 0; }
+        else if (f & 32) { --y; k = 1; }
+        else if (f & 64) { --x; k = 0; }
+        else if (f & 128) { --x; k = 2; }
+        else break;
+        emit(y, x);
+    }
+    if (semiglobal) {
+        if (y != 0) { for (int64_t yy = y - 1; yy >= 0; --yy) emit(yy, 0); }
+        else if (x != 0) { for (int64_t xx = x - 1; xx >= 0; --xx) emit(0, xx); }
+    }
+    path_info[0] = w;
+    path_info[1] = cap - w;
+}
+#endif  // PRALINE_AUX_KERNELS

@@ -1,0 +1,51 @@
+// dp_launch.hip.h -- launch glue for k_dp_batch.  The kernel is instantiated once per MFMA step
+// count in its own translation unit (dp_instance.hip, -DPRALINE_NSTEP_INST=N) so the instances
+// compile in parallel.
+#pragma once
+#include "dp_kernels.hip.h"
+#include "praline_dp.h"
+
+struct LaunchArgs {
+    ArenaDev ar;
+    const WaveTask *tasks;
+    const int32_t *lane_one, *lane_pair;
+    void *bnd;
+    uint4 *tb;
+    float *aux;
+    RectList rl;
+    float *scores;
+    int32_t *end_cells;
+    RunParams rp;
+    unsigned n_tasks;
+    hipStream_t stream;
+};
+
+int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, bool mask);
+int praline_launch_dp_8(const LaunchArgs &la, int tp, bool local, int out, bool mask);
+int praline_launch_dp_10(const LaunchArgs &la, int tp, bool local, int out, bool mask);
+int praline_launch_dp_12(const LaunchArgs &la, int tp, bool local, int out, bool mask);
+int praline_launch_dp_14(const LaunchArgs &la, int tp, bool local, int out, bool mask);
+int praline_launch_dp_16(const LaunchArgs &la, int tp, bool local, int out, bool mask);
+
+template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK> static void launch_one(const LaunchArgs &la)
+{
+    hipLaunchKernelGGL((k_dp_batch<NSTEP, TP, LOCAL, OUT, MASK>), dim3(la.n_tasks), dim3(64), 0, la.stream, la.ar,
+                       la.tasks, la.lane_one, la.lane_pair, la.bnd, la.tb, la.aux, la.rl, la.scores, la.end_cells, la.rp);
+}
+
+// Instantiated variants: scores-only (TP 1/2, local or not); traceback (TP 1, local or not, with or
+// without zero rectangles).
+template <int NSTEP> static int launch_nstep(const LaunchArgs &la, int tp, bool local, int out, bool mask)
+{
+    if (out == 0) {
+        if (mask) return PRALINE_ERR_UNSUPPORTED;
+        if (tp == 2) { if (local) launch_one<NSTEP, 2, true, 0, false>(la); else launch_one<NSTEP, 2, false, 0, false>(la); }
+        else if (tp == 1) { if (local) launch_one<NSTEP, 1, true, 0, false>(la); else launch_one<NSTEP, 1, false, 0, false>(la); }
+        else return PRALINE_ERR_UNSUPPORTED;
+    } else {
+        if (tp != 1) return PRALINE_ERR_UNSUPPORTED;
+        if (local) { if (mask) launch_one<NSTEP, 1, true, 1, true>(la); else launch_one<NSTEP, 1, true, 1, false>(la); }
+        else { if (mask) launch_one<NSTEP, 1, false, 1, true>(la); else launch_one<NSTEP, 1, false, 1, false>(la); }
+    }
+    return PRALINE_OK;
+}

@@ -1,0 +1,805 @@
+// praline_dp.hip -- host side + C ABI of libpraline_dp.so (see include/praline_dp.h).
+//
+// Host responsibilities (all plain C++, no Python/torch types):
+//   * runtime: device binding, one launch stream, error strings
+//   * arena:   packs profiles into the kernels' parity-split layout, finds the active symbols,
+//              runs the profile x matrix pre-multiply on the device
+//   * plan:    groups a pair list by its sequence TWO into 32-lane half tasks (length-sorted),
+//              builds wave tasks, sizes the strip-boundary / traceback scratch
+//   * parity entry points mirroring praline/util/cext.c:506-520 on raw (strided) host buffers
+//
+// There is deliberately NO CPU fallback here: every compute entry point needs a HIP device.
+#include "praline_dp.h"
+#define PRALINE_AUX_KERNELS 1
+#include "dp_kernels.hip.h"
+#include "dp_launch.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+// --------------------------------------------------------------------------------------------
+// errors + runtime
+// --------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(e_ == hipErrorOutOfMemory ? PRALINE_ERR_NOMEM : PRALINE_ERR_DEVICE,     \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+static Runtime g_rt;
+
+static int ensure_runtime(int device)
+{
+    if (g_rt.ready) {
+        if (device >= 0 && device != g_rt.device)
+            return fail(PRALINE_ERR_ARG, "already bound to device %d (requested %d)", g_rt.device, device);
+        return PRALINE_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PRALINE_ERR_DEVICE, "no HIP device available (%s): libpraline_dp has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0) device = 0;
+    if (device >= n) return fail(PRALINE_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&g_rt.stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&g_rt.ev0));
+    HIPCHK(hipEventCreate(&g_rt.ev1));
+    g_rt.device = device;
+    g_rt.ready = true;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_abi_version(void) { return PRALINE_DP_ABI_VERSION; }
+
+extern "C" int praline_device_count(int *count)
+{
+    if (!count) return fail(PRALINE_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(PRALINE_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_init(int device) { return ensure_runtime(device); }
+
+extern "C" int praline_shutdown(void)
+{
+    if (!g_rt.ready) return PRALINE_OK;
+    (void)hipStreamSynchronize(g_rt.stream);
+    (void)hipEventDestroy(g_rt.ev0);
+    (void)hipEventDestroy(g_rt.ev1);
+    (void)hipStreamDestroy(g_rt.stream);
+    g_rt = Runtime();
+    return PRALINE_OK;
+}
+
+extern "C" int praline_synchronize(void)
+{
+    if (!g_rt.ready) return PRALINE_OK;
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
+    return PRALINE_OK;
+}
+
+extern "C" const char *praline_last_error(void) { return g_err.c_str(); }
+extern "C" void *praline_stream(void) { return g_rt.ready ? (void *)g_rt.stream : nullptr; }
+
+// small RAII device buffer
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    int alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess)
+            return fail(PRALINE_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        n = count;
+        return PRALINE_OK;
+    }
+    int upload(const T *src, size_t count, hipStream_t st)
+    {
+        if (count == 0) return PRALINE_OK;
+        HIPCHK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+        return PRALINE_OK;
+    }
+    int upload(const std::vector<T> &v, hipStream_t st)
+    {
+        int rc = alloc(v.size());
+        if (rc) return rc;
+        return upload(v.data(), v.size(), st);
+    }
+};
+
+#define RC(expr) do { int rc_ = (expr); if (rc_ != PRALINE_OK) return rc_; } while (0)
+
+// --------------------------------------------------------------------------------------------
+// arena
+// --------------------------------------------------------------------------------------------
+static const int kNstepChoices[] = {2, 8, 10, 12, 14, 16};
+
+struct praline_arena {
+    int64_t n_seqs = 0;
+    int A = 0;               // alphabet size of the raw profiles
+    int n_active = 0;        // symbols that can contribute to a match score
+    int nstep = 0;           // MFMA steps per tile (template instance)
+    int KP = 0, KS = 0;
+    int64_t rows_raw = 0, rows_pad = 0;
+    int max_len = 0;
+    std::vector<int32_t> len, row_off_pad, row_off_raw, active;
+    DevBuf<float> d_raw, d_S, d_P, d_Q;
+    DevBuf<int32_t> d_len, d_row_off_pad, d_row_off_raw, d_seq_of_rowp, d_active;
+    ArenaDev view() const
+    {
+        ArenaDev v;
+        v.P = d_P.p; v.Q = d_Q.p; v.row_off = d_row_off_pad.p; v.len = d_len.p; v.KP = KP; v.KS = KS;
+        return v;
+    }
+};
+
+static int arena_launch_premultiply(praline_arena *a)
+{
+    const int64_t total = a->rows_pad * a->KP;
+    const int threads = 256;
+    const int64_t blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(k_pack_profiles, dim3((unsigned)blocks), dim3(threads), 0, g_rt.stream, a->d_raw.p,
+                       a->d_seq_of_rowp.p, a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p,
+                       a->d_active.p, a->n_active, a->A, a->KP, a->KS, a->rows_pad, a->d_P.p);
+    dim3 grid((unsigned)((a->rows_pad + 31) / 32), (unsigned)((a->KP + 31) / 32));
+    hipLaunchKernelGGL(k_premultiply, grid, dim3(64), 0, g_rt.stream, a->d_raw.p, a->d_S.p,
+                       a->d_seq_of_rowp.p, a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p,
+                       a->d_active.p, a->n_active, a->A, a->KP, a->KS, a->rows_pad, a->d_Q.p);
+    HIPCHK(hipGetLastError());
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t A, const float *profiles,
+                                    const float *S, praline_arena **out)
+{
+    if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_seqs <= 0 || !lens || !profiles || !S) return fail(PRALINE_ERR_ARG, "NULL or empty arena input");
+    if (A <= 0 || A > 32) return fail(PRALINE_ERR_ARG, "alphabet size %d not in 1..32 (concatenated track sets)", A);
+    RC(ensure_runtime(-1));
+    praline_arena *a = new praline_arena();
+    a->n_seqs = n_seqs;
+    a->A = A;
+    a->len.assign(lens, lens + n_seqs);
+    a->row_off_pad.resize(n_seqs);
+    a->row_off_raw.resize(n_seqs);
+    int64_t rr = 0, rp = 0;
+    for (int64_t s = 0; s < n_seqs; ++s) {
+        if (lens[s] <= 0) { delete a; return fail(PRALINE_ERR_ARG, "sequence %lld has length %d (must be >= 1)", (long long)s, lens[s]); }
+        a->row_off_raw[s] = (int32_t)rr;
+        a->row_off_pad[s] = (int32_t)rp;
+        rr += lens[s];
+        rp += (lens[s] + 31) / 32 * 32;
+        a->max_len = std::max(a->max_len, lens[s]);
+        if (rp > (int64_t)1 << 30) { delete a; return fail(PRALINE_ERR_ARG, "arena too large"); }
+    }
+    a->rows_raw = rr;
+    // tail padding: the kernels prefetch one row past the longest sequence and read whole strips
+    a->rows_pad = rp + (a->max_len + 31) / 32 * 32 + 64;
+
+    // active symbols: i contributes to m = sum_i P1[y,i] * Q2[x,i] only if some profile has mass on
+    // it and row i of S is not all zero; dropping the others is exact (their terms are +-0).
+    std::vector<char> has_mass(A, 0), has_score(A, 0);
+    for (int64_t r = 0; r < rr; ++r)
+        for (int i = 0; i < A; ++i)
+            if (profiles[r * A + i] != 0.0f) has_mass[i] = 1;
+    for (int i = 0; i < A; ++i)
+        for (int j = 0; j < A; ++j)
+            if (S[i * A + j] != 0.0f) has_score[i] = 1;
+    for (int i = 0; i < A; ++i)
+        if (has_mass[i] && has_score[i]) a->active.push_back(i);
+    a->n_active = (int)a->active.size();
+    if (const char *env = getenv("PRALINE_NO_COMPACT")) {
+        if (env[0] == '1') { a->active.resize(A); std::iota(a->active.begin(), a->active.end(), 0); a->n_active = A; }
+    }
+    const int need = std::max(1, (a->n_active + 1) / 2);
+    a->nstep = 0;
+    for (int c : kNstepChoices) if (c >= need) { a->nstep = c; break; }
+    if (!a->nstep) { delete a; return fail(PRALINE_ERR_ARG, "too many active symbols (%d)", a->n_active); }
+    a->KS = (a->nstep + 3) / 4 * 4;
+    a->KP = 2 * a->KS;
+
+    std::vector<int32_t> seq_of_rowp((size_t)a->rows_pad, -1);
+    for (int64_t s = 0; s < n_seqs; ++s)
+        for (int r = 0; r < (lens[s] + 31) / 32 * 32; ++r) seq_of_rowp[a->row_off_pad[s] + r] = (int32_t)s;
+
+    int rc = PRALINE_OK;
+    hipStream_t st = g_rt.stream;
+    if ((rc = a->d_raw.alloc((size_t)rr * A)) || (rc = a->d_raw.upload(profiles, (size_t)rr * A, st)) ||
+        (rc = a->d_S.alloc((size_t)A * A)) || (rc = a->d_S.upload(S, (size_t)A * A, st)) ||
+        (rc = a->d_len.upload(a->len, st)) || (rc = a->d_row_off_pad.upload(a->row_off_pad, st)) ||
+        (rc = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
+        (rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
+        (rc = a->d_P.alloc((size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc((size_t)a->rows_pad * a->KP)) ||
+        (rc = arena_launch_premultiply(a))) {
+        delete a;
+        return rc;
+    }
+    hipError_t e = hipStreamSynchronize(st);  // host vectors above go out of scope
+    if (e != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena upload: %s", hipGetErrorString(e)); }
+    *out = a;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_destroy(praline_arena *arena)
+{
+    if (!arena) return PRALINE_OK;
+    if (g_rt.ready) (void)hipStreamSynchronize(g_rt.stream);
+    delete arena;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_premultiply(praline_arena *arena)
+{
+    if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    return arena_launch_premultiply(arena);
+}
+
+// --------------------------------------------------------------------------------------------
+// plan
+// --------------------------------------------------------------------------------------------
+struct praline_plan {
+    praline_arena *arena = nullptr;
+    int64_t n_pairs = 0;
+    int64_t cells = 0;
+    int64_t path_cap = 0;
+    bool want_paths = false;
+    bool has_rects = false;
+    int tp = 1;
+    std::vector<WaveTask> tasks;
+    std::vector<int64_t> tb_elems;  // per task, uint4 elements
+    std::vector<int64_t> aux_elems; // per task, floats
+    int64_t bnd_elems = 0;
+    DevBuf<WaveTask> d_tasks;
+    DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
+    DevBuf<PairLoc> d_loc;
+    DevBuf<float> d_scores, d_aux;
+    DevBuf<char> d_bnd;
+    DevBuf<uint4> d_tb;
+    DevBuf<int64_t> d_slot_off, d_path_start;
+    std::vector<int64_t> slot_off;
+    float last_kernel_ms = 0.0f;
+    int last_mode = -1;
+};
+
+struct HalfTask {
+    int32_t two;
+    int32_t max_l1;
+    int32_t one[32];
+    int32_t pair[32];
+};
+
+// traceback scratch budget per launch chunk (bytes)
+static size_t tb_budget_bytes()
+{
+    if (const char *env = getenv("PRALINE_TB_BUDGET_MB")) return (size_t)atoll(env) << 20;
+    return (size_t)24 << 30;
+}
+
+extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, int want_paths,
+                                   const int32_t *rect_off, const int32_t *rects, praline_plan **out)
+{
+    if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!arena || n_pairs < 0 || (n_pairs > 0 && !pairs)) return fail(PRALINE_ERR_ARG, "bad plan arguments");
+    if ((rect_off != nullptr) != (rects != nullptr) && rect_off && rect_off[n_pairs] > 0)
+        return fail(PRALINE_ERR_ARG, "rect_off given without rects");
+    if (rect_off && !want_paths && rect_off[n_pairs] > 0)
+        return fail(PRALINE_ERR_UNSUPPORTED, "zero rectangles are only supported together with want_paths");
+    RC(ensure_runtime(-1));
+    const praline_arena &a = *arena;
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int32_t o = pairs[2 * p], t = pairs[2 * p + 1];
+        if (o < 0 || o >= a.n_seqs || t < 0 || t >= a.n_seqs)
+            return fail(PRALINE_ERR_ARG, "pair %lld = (%d, %d) out of range", (long long)p, o, t);
+        if (rect_off && rect_off[p + 1] - rect_off[p] > PRALINE_MAX_RECTS)
+            return fail(PRALINE_ERR_UNSUPPORTED, "pair %lld has more than %d zero rectangles", (long long)p, PRALINE_MAX_RECTS);
+    }
+    praline_plan *pl = new praline_plan();
+    pl->arena = arena;
+    pl->n_pairs = n_pairs;
+    pl->want_paths = want_paths != 0;
+    pl->has_rects = rect_off && rect_off[n_pairs] > 0;
+
+    // ---- group by sequence two, sort by len(one) descending, cut into 32-lane half tasks ----
+    std::vector<int64_t> order((size_t)n_pairs);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+        const int32_t tx = pairs[2 * x + 1], ty = pairs[2 * y + 1];
+        if (tx != ty) return tx < ty;
+        const int lx = a.len[pairs[2 * x]], ly = a.len[pairs[2 * y]];
+        if (lx != ly) return lx > ly;
+        return x < y;
+    });
+    std::vector<HalfTask> halves;
+    for (int64_t i = 0; i < n_pairs;) {
+        const int32_t two = pairs[2 * order[i] + 1];
+        HalfTask h;
+        h.two = two;
+        h.max_l1 = 0;
+        int n = 0;
+        for (int q = 0; q < 32; ++q) { h.one[q] = -1; h.pair[q] = -1; }
+        while (i < n_pairs && n < 32 && pairs[2 * order[i] + 1] == two) {
+            h.one[n] = pairs[2 * order[i]];
+            h.pair[n] = (int32_t)order[i];
+            h.max_l1 = std::max(h.max_l1, a.len[h.one[n]]);
+            ++n; ++i;
+        }
+        halves.push_back(h);
+    }
+    // longest work first; equal-shaped halves end up adjacent (paired into one wave when TP = 2)
+    std::stable_sort(halves.begin(), halves.end(), [&](const HalfTask &x, const HalfTask &y) {
+        const int sx = (a.len[x.two] + 31) / 32, sy = (a.len[y.two] + 31) / 32;
+        if (sx != sy) return sx > sy;
+        return x.max_l1 > y.max_l1;
+    });
+    int tp = halves.size() >= 4096 ? 2 : 1;
+    if (want_paths) tp = 1;  // the traceback variant keeps three states per column in registers
+    if (const char *env = getenv("PRALINE_TP")) { if (env[0] == '1') tp = 1; else if (env[0] == '2' && !want_paths) tp = 2; }
+    pl->tp = tp;
+
+    const size_t n_tasks = (halves.size() + tp - 1) / tp;
+    pl->tasks.resize(n_tasks);
+    std::vector<int32_t> lane_one(n_tasks * 64, -1), lane_pair(n_tasks * 64, -1);
+    std::vector<PairLoc> loc((size_t)n_pairs);
+    int64_t bnd = 0;
+    pl->tb_elems.resize(n_tasks);
+    pl->aux_elems.resize(n_tasks);
+    for (size_t t = 0; t < n_tasks; ++t) {
+        WaveTask &wt = pl->tasks[t];
+        wt.two[0] = wt.two[1] = -1;
+        wt.max_l1 = 0;
+        wt.nstrips = 0;
+        for (int hh = 0; hh < tp; ++hh) {
+            const size_t hi = t * tp + hh;
+            if (hi >= halves.size()) break;
+            const HalfTask &h = halves[hi];
+            wt.two[hh] = h.two;
+            wt.max_l1 = std::max(wt.max_l1, h.max_l1);
+            wt.nstrips = std::max(wt.nstrips, (a.len[h.two] + 31) / 32);
+            for (int q = 0; q < 32; ++q) {
+                lane_one[t * 64 + hh * 32 + q] = h.one[q];
+                lane_pair[t * 64 + hh * 32 + q] = h.pair[q];
+                if (h.pair[q] >= 0) { loc[h.pair[q]].task = (int32_t)t; loc[h.pair[q]].lane = hh * 32 + q; }
+            }
+        }
+        wt.bnd_off = bnd;
+        bnd += (int64_t)(wt.max_l1 + 1) * 64;
+        wt.tb_off = 0;
+        wt.aux_off = 0;
+        pl->tb_elems[t] = (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
+        pl->aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * 64;
+    }
+    pl->bnd_elems = bnd;
+
+    pl->slot_off.resize((size_t)n_pairs);
+    int64_t cap = 0, cells = 0;
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int64_t l1 = a.len[pairs[2 * p]], l2 = a.len[pairs[2 * p + 1]];
+        pl->slot_off[p] = cap;
+        cap += l1 + l2 + 2;
+        cells += l1 * l2;
+    }
+    pl->path_cap = cap;
+    pl->cells = cells;
+
+    hipStream_t st = g_rt.stream;
+    int rc = PRALINE_OK;
+    if ((rc = pl->d_lane_one.upload(lane_one, st)) || (rc = pl->d_lane_pair.upload(lane_pair, st)) ||
+        (rc = pl->d_scores.alloc((size_t)n_pairs)) ||
+        (rc = pl->d_bnd.alloc((size_t)bnd * (want_paths ? sizeof(float4) : sizeof(float2))))) {
+        delete pl;
+        return rc;
+    }
+    if (want_paths) {
+        std::vector<int32_t> pv(pairs, pairs + 2 * n_pairs);
+        if ((rc = pl->d_pairs.upload(pv, st)) || (rc = pl->d_loc.upload(loc, st)) ||
+            (rc = pl->d_end_cells.alloc((size_t)n_pairs * 4)) || (rc = pl->d_path_rows.alloc((size_t)n_pairs)) ||
+            (rc = pl->d_path_start.alloc((size_t)n_pairs)) || (rc = pl->d_paths.alloc((size_t)cap * 2)) ||
+            (rc = pl->d_slot_off.upload(pl->slot_off, st))) {
+            delete pl;
+            return rc;
+        }
+        if (pl->has_rects) {
+            std::vector<int32_t> ro(rect_off, rect_off + n_pairs + 1), rv(rects, rects + (size_t)rect_off[n_pairs] * 4);
+            if ((rc = pl->d_rect_off.upload(ro, st)) || (rc = pl->d_rects.upload(rv, st))) { delete pl; return rc; }
+        }
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { delete pl; return fail(PRALINE_ERR_DEVICE, "plan upload: %s", hipGetErrorString(e)); }
+    *out = pl;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_destroy(praline_plan *plan)
+{
+    if (!plan) return PRALINE_OK;
+    if (g_rt.ready) (void)hipStreamSynchronize(g_rt.stream);
+    delete plan;
+    return PRALINE_OK;
+}
+
+extern "C" int64_t praline_plan_cells(const praline_plan *plan) { return plan ? plan->cells : 0; }
+extern "C" int64_t praline_plan_path_capacity(const praline_plan *plan) { return plan ? plan->path_cap : 0; }
+extern "C" void *praline_plan_device_scores(praline_plan *plan) { return plan ? (void *)plan->d_scores.p : nullptr; }
+
+// --------------------------------------------------------------------------------------------
+// kernel dispatch: one translation unit per MFMA step count (dp_instance.hip), see dp_launch.hip.h
+// --------------------------------------------------------------------------------------------
+static int launch_dp(int nstep, const LaunchArgs &la, int tp, bool local, int out, bool mask)
+{
+    int rc = PRALINE_ERR_UNSUPPORTED;
+    switch (nstep) {
+        case 2: rc = praline_launch_dp_2(la, tp, local, out, mask); break;
+        case 8: rc = praline_launch_dp_8(la, tp, local, out, mask); break;
+        case 10: rc = praline_launch_dp_10(la, tp, local, out, mask); break;
+        case 12: rc = praline_launch_dp_12(la, tp, local, out, mask); break;
+        case 14: rc = praline_launch_dp_14(la, tp, local, out, mask); break;
+        case 16: rc = praline_launch_dp_16(la, tp, local, out, mask); break;
+    }
+    if (rc != PRALINE_OK)
+        return fail(rc, "no kernel instance for nstep=%d tp=%d local=%d out=%d mask=%d", nstep, tp, (int)local, out, (int)mask);
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, float gap_extend, void *d_scores)
+{
+    if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
+    if (mode < 0 || mode > 4) return fail(PRALINE_ERR_ARG, "unknown alignment mode %d", mode);
+    if (!(gap_open <= 0.0f) || !(gap_extend <= 0.0f))
+        return fail(PRALINE_ERR_UNSUPPORTED, "batched kernels need gap scores <= 0 (got %g, %g)", gap_open, gap_extend);
+    RC(ensure_runtime(-1));
+    praline_plan &pl = *plan;
+    if (pl.n_pairs == 0) return PRALINE_OK;
+    const praline_arena &a = *pl.arena;
+    LaunchArgs la;
+    la.ar = a.view();
+    la.lane_one = pl.d_lane_one.p;
+    la.lane_pair = pl.d_lane_pair.p;
+    la.bnd = pl.d_bnd.p;
+    la.rl.rect_off = pl.has_rects ? pl.d_rect_off.p : nullptr;
+    la.rl.rects = pl.has_rects ? pl.d_rects.p : nullptr;
+    la.scores = d_scores ? (float *)d_scores : pl.d_scores.p;
+    la.end_cells = pl.d_end_cells.p;
+    la.rp.mode = mode;
+    la.rp.go1 = la.rp.go2 = gap_open;
+    la.rp.ge1 = la.rp.ge2 = gap_extend;
+    la.stream = g_rt.stream;
+    const bool local = mode == PRALINE_MODE_LOCAL;
+    pl.last_mode = mode;
+    hipStream_t st = g_rt.stream;
+
+    if (!pl.want_paths) {
+        if (!pl.d_tasks.p) { RC(pl.d_tasks.upload(pl.tasks, st)); }
+        la.tasks = pl.d_tasks.p;
+        la.tb = nullptr;
+        la.aux = nullptr;
+        la.n_tasks = (unsigned)pl.tasks.size();
+        HIPCHK(hipEventRecord(g_rt.ev0, st));
+        RC(launch_dp(a.nstep, la, pl.tp, local, 0, false));
+        HIPCHK(hipEventRecord(g_rt.ev1, st));
+        HIPCHK(hipGetLastError());
+        return PRALINE_OK;
+    }
+
+    // ---- with paths: chunk the tasks so the packed traceback fits the scratch budget ----
+    const size_t budget = tb_budget_bytes();
+    const bool semiglobal = mode >= 2;
+    size_t t0 = 0;
+    const size_t nt = pl.tasks.size();
+    HIPCHK(hipEventRecord(g_rt.ev0, st));
+    while (t0 < nt) {
+        size_t t1 = t0;
+        int64_t tb_e = 0, aux_e = 0;
+        while (t1 < nt) {
+            const int64_t add = pl.tb_elems[t1];
+            if (t1 > t0 && (size_t)(tb_e + add) * sizeof(uint4) > budget) break;
+            pl.tasks[t1].tb_off = tb_e;
+            pl.tasks[t1].aux_off = aux_e;
+            tb_e += add;
+            aux_e += semiglobal ? pl.aux_elems[t1] : 0;
+            ++t1;
+        }
+        if (pl.d_tb.n < (size_t)tb_e) RC(pl.d_tb.alloc((size_t)tb_e));
+        if (pl.d_aux.n < (size_t)std::max<int64_t>(aux_e, 1)) RC(pl.d_aux.alloc((size_t)std::max<int64_t>(aux_e, 1)));
+        if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
+        HIPCHK(hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, st));
+        la.tasks = pl.d_tasks.p + t0;
+        la.lane_one = pl.d_lane_one.p + t0 * 64;
+        la.lane_pair = pl.d_lane_pair.p + t0 * 64;
+        la.tb = pl.d_tb.p;
+        la.aux = pl.d_aux.p;
+        la.n_tasks = (unsigned)(t1 - t0);
+        RC(launch_dp(a.nstep, la, 1, local, 1, pl.has_rects));
+        HIPCHK(hipGetLastError());
+        // traceback of the pairs of this chunk: every pair checks its task range
+        // (k_traceback is launched once per chunk over all pairs whose task is in [t0, t1))
+        {
+            // pairs are not contiguous per chunk; launch over all pairs with a task-range filter
+            const int threads = 64;
+            const int64_t blocks = (pl.n_pairs + threads - 1) / threads;
+            hipLaunchKernelGGL(k_traceback, dim3((unsigned)blocks), dim3(threads), 0, st, la.ar, pl.d_tasks.p,
+                               pl.d_loc.p, pl.d_pairs.p, pl.d_tb.p, pl.d_aux.p, la.rl, pl.d_end_cells.p, la.scores,
+                               pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs, la.rp,
+                               (int32_t)t0, (int32_t)t1);
+            HIPCHK(hipGetLastError());
+        }
+        t0 = t1;
+    }
+    HIPCHK(hipEventRecord(g_rt.ev1, st));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_last_timing(praline_plan *plan, float *kernel_ms)
+{
+    if (!plan || !kernel_ms) return fail(PRALINE_ERR_ARG, "NULL argument");
+    HIPCHK(hipEventSynchronize(g_rt.ev1));
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, g_rt.ev0, g_rt.ev1));
+    plan->last_kernel_ms = ms;
+    *kernel_ms = ms;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_scores(praline_plan *plan, float *scores)
+{
+    if (!plan || (!scores && plan->n_pairs)) return fail(PRALINE_ERR_ARG, "NULL argument");
+    if (plan->n_pairs == 0) return PRALINE_OK;
+    HIPCHK(hipMemcpyAsync(scores, plan->d_scores.p, (size_t)plan->n_pairs * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_paths(praline_plan *plan, int32_t *paths, int64_t *path_off, int32_t *path_rows)
+{
+    if (!plan || !paths || !path_off || !path_rows) return fail(PRALINE_ERR_ARG, "NULL argument");
+    if (!plan->want_paths) return fail(PRALINE_ERR_ARG, "plan was created without want_paths");
+    if (plan->n_pairs == 0) return PRALINE_OK;
+    hipStream_t st = g_rt.stream;
+    HIPCHK(hipMemcpyAsync(paths, plan->d_paths.p, (size_t)plan->path_cap * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(path_off, plan->d_path_start.p, (size_t)plan->n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(path_rows, plan->d_path_rows.p, (size_t)plan->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float gap_extend, int64_t n_pairs,
+                                    const int32_t *pairs, float *scores)
+{
+    praline_plan *pl = nullptr;
+    RC(praline_plan_create(arena, n_pairs, pairs, 0, nullptr, nullptr, &pl));
+    int rc = praline_plan_run(pl, mode, gap_open, gap_extend, nullptr);
+    if (rc == PRALINE_OK) rc = praline_plan_scores(pl, scores);
+    praline_plan_destroy(pl);
+    return rc;
+}
+
+// --------------------------------------------------------------------------------------------
+// parity-layout entry points (strided host buffers <-> contiguous device copies)
+// --------------------------------------------------------------------------------------------
+static bool arr_ok(const praline_array *a) { return a && a->data; }
+
+template <typename T> static void gather2(const praline_array &a, std::vector<T> &out)
+{
+    const int64_t R = a.dim[0], C = a.dim[1];
+    out.resize((size_t)(R * C));
+    const char *base = (const char *)a.data;
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t c = 0; c < C; ++c) out[(size_t)(r * C + c)] = *(const T *)(base + r * a.stride[0] + c * a.stride[1]);
+}
+
+template <typename T> static void gather3(const praline_array &a, std::vector<T> &out)
+{
+    const int64_t R = a.dim[0], C = a.dim[1], K = a.dim[2];
+    out.resize((size_t)(R * C * K));
+    const char *base = (const char *)a.data;
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t c = 0; c < C; ++c)
+            for (int64_t k = 0; k < K; ++k)
+                out[(size_t)((r * C + c) * K + k)] = *(const T *)(base + r * a.stride[0] + c * a.stride[1] + k * a.stride[2]);
+}
+
+template <typename T> static void scatter2(const std::vector<T> &in, const praline_array &a)
+{
+    const int64_t R = a.dim[0], C = a.dim[1];
+    char *base = (char *)a.data;
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t c = 0; c < C; ++c) *(T *)(base + r * a.stride[0] + c * a.stride[1]) = in[(size_t)(r * C + c)];
+}
+
+template <typename T> static void scatter3(const std::vector<T> &in, const praline_array &a)
+{
+    const int64_t R = a.dim[0], C = a.dim[1], K = a.dim[2];
+    char *base = (char *)a.data;
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t c = 0; c < C; ++c)
+            for (int64_t k = 0; k < K; ++k)
+                *(T *)(base + r * a.stride[0] + c * a.stride[1] + k * a.stride[2]) = in[(size_t)((r * C + c) * K + k)];
+}
+
+extern "C" int praline_build_scores(int num_sets, const praline_array *i1s, const praline_array *i2s,
+                                    const praline_array *i1nzs, const praline_array *i2nzs, const praline_array *ss,
+                                    const praline_array *m)
+{
+    (void)i1nzs; (void)i2nzs;  // dense contraction on the device; see praline_dp.h
+    if (num_sets <= 0 || !i1s || !i2s || !ss || !arr_ok(m)) return fail(PRALINE_ERR_ARG, "NULL / empty build_scores argument");
+    const int64_t L1 = i1s[0].dim[0], L2 = i2s[0].dim[0];
+    if (L1 <= 0 || L2 <= 0) return fail(PRALINE_ERR_ARG, "empty sequence");
+    if (m->dim[0] != L1 || m->dim[1] != L2) return fail(PRALINE_ERR_ARG, "m has shape %lldx%lld, expected %lldx%lld",
+                                                     (long long)m->dim[0], (long long)m->dim[1], (long long)L1, (long long)L2);
+    int64_t A = 0;
+    for (int n = 0; n < num_sets; ++n) {
+        if (!arr_ok(&i1s[n]) || !arr_ok(&i2s[n]) || !arr_ok(&ss[n])) return fail(PRALINE_ERR_ARG, "NULL array in set %d", n);
+        if (i1s[n].dim[0] != L1 || i2s[n].dim[0] != L2) return fail(PRALINE_ERR_ARG, "set %d: profile lengths differ", n);
+        if (ss[n].dim[0] != i1s[n].dim[1] || ss[n].dim[1] != i2s[n].dim[1])
+            return fail(PRALINE_ERR_ARG, "set %d: score matrix shape does not match the profiles", n);
+        A += std::max(i1s[n].dim[1], i2s[n].dim[1]);
+    }
+    if (A > 32) return fail(PRALINE_ERR_UNSUPPORTED, "concatenated alphabet size %lld > 32", (long long)A);
+    // concatenate the track sets along the alphabet axis: P = [P_1 | P_2 ...], S = blockdiag(S_n)
+    std::vector<float> prof((size_t)((L1 + L2) * A), 0.0f), S((size_t)(A * A), 0.0f), tmp;
+    int64_t off = 0;
+    for (int n = 0; n < num_sets; ++n) {
+        const int64_t A1 = i1s[n].dim[1], A2 = i2s[n].dim[1];
+        gather2<float>(i1s[n], tmp);
+        for (int64_t r = 0; r < L1; ++r) for (int64_t c = 0; c < A1; ++c) prof[(size_t)(r * A + off + c)] = tmp[(size_t)(r * A1 + c)];
+        gather2<float>(i2s[n], tmp);
+        for (int64_t r = 0; r < L2; ++r) for (int64_t c = 0; c < A2; ++c) prof[(size_t)((L1 + r) * A + off + c)] = tmp[(size_t)(r * A2 + c)];
+        gather2<float>(ss[n], tmp);
+        for (int64_t r = 0; r < A1; ++r) for (int64_t c = 0; c < A2; ++c) S[(size_t)((off + r) * A + off + c)] = tmp[(size_t)(r * A2 + c)];
+        off += std::max(A1, A2);
+    }
+    const int32_t lens[2] = {(int32_t)L1, (int32_t)L2};
+    praline_arena *ar = nullptr;
+    RC(praline_arena_create(2, lens, (int32_t)A, prof.data(), S.data(), &ar));
+    DevBuf<float> d_m;
+    int rc = d_m.alloc((size_t)(L1 * L2));
+    if (rc == PRALINE_OK) {
+        dim3 grid((unsigned)((L2 + 31) / 32), (unsigned)((L1 + 31) / 32));
+        hipLaunchKernelGGL(k_scores_tile, grid, dim3(64), 0, g_rt.stream, ar->view(), 0, 1, ar->nstep, d_m.p);
+        std::vector<float> hm((size_t)(L1 * L2));
+        hipError_t e = hipMemcpyAsync(hm.data(), d_m.p, hm.size() * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_rt.stream);
+        if (e != hipSuccess) rc = fail(PRALINE_ERR_DEVICE, "build_scores: %s", hipGetErrorString(e));
+        else scatter2<float>(hm, *m);
+    }
+    praline_arena_destroy(ar);
+    return rc;
+}
+
+struct RawDev {
+    DevBuf<float> m, g1, g2, o;
+    DevBuf<uint8_t> t, z;
+    int64_t L1 = 0, L2 = 0;
+};
+
+static int raw_upload(const praline_array *m, const praline_array *g1, const praline_array *g2, const praline_array *o,
+                      const praline_array *t, const praline_array *z, RawDev &d)
+{
+    if (!arr_ok(m) || !arr_ok(g1) || !arr_ok(g2)) return fail(PRALINE_ERR_ARG, "NULL m / g1 / g2");
+    const int64_t L1 = m->dim[0], L2 = m->dim[1];
+    if (L1 <= 0 || L2 <= 0) return fail(PRALINE_ERR_ARG, "empty match score matrix");
+    if (g1->dim[0] != L1 || g1->dim[1] != 2 || g2->dim[0] != L2 || g2->dim[1] != 2)
+        return fail(PRALINE_ERR_ARG, "gap score arrays must be [L1][2] and [L2][2]");
+    if (o && (o->dim[0] != L1 + 1 || o->dim[1] != L2 + 1 || o->dim[2] != 3)) return fail(PRALINE_ERR_ARG, "o must be [L1+1][L2+1][3]");
+    if (t && (t->dim[0] != L1 + 1 || t->dim[1] != L2 + 1 || t->dim[2] != 3)) return fail(PRALINE_ERR_ARG, "t must be [L1+1][L2+1][3]");
+    if (z && z->data && (z->dim[0] != L1 + 1 || z->dim[1] != L2 + 1)) return fail(PRALINE_ERR_ARG, "z must be [L1+1][L2+1]");
+    RC(ensure_runtime(-1));
+    d.L1 = L1; d.L2 = L2;
+    hipStream_t st = g_rt.stream;
+    std::vector<float> hm, hg1, hg2, ho;
+    std::vector<uint8_t> ht, hz;
+    gather2<float>(*m, hm); gather2<float>(*g1, hg1); gather2<float>(*g2, hg2);
+    RC(d.m.upload(hm, st)); RC(d.g1.upload(hg1, st)); RC(d.g2.upload(hg2, st));
+    const size_t cells = (size_t)((L1 + 1) * (L2 + 1));
+    if (o) { gather3<float>(*o, ho); RC(d.o.upload(ho, st)); } else RC(d.o.alloc(cells * 3));
+    if (t) { gather3<uint8_t>(*t, ht); RC(d.t.upload(ht, st)); } else RC(d.t.alloc(cells * 3));
+    if (z && z->data) { gather2<uint8_t>(*z, hz); RC(d.z.upload(hz, st)); }
+    else { RC(d.z.alloc(cells)); HIPCHK(hipMemsetAsync(d.z.p, 0, cells, st)); }
+    HIPCHK(hipStreamSynchronize(st));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_align(int mode, const praline_array *m, const praline_array *g1, const praline_array *g2,
+                             const praline_array *o, const praline_array *t, const praline_array *z)
+{
+    if (mode < 0 || mode > 4) return fail(PRALINE_ERR_ARG, "unknown alignment mode %d", mode);
+    if (!arr_ok(o) || !arr_ok(t) || !arr_ok(z)) return fail(PRALINE_ERR_ARG, "NULL o / t / z");
+    RawDev d;
+    RC(raw_upload(m, g1, g2, o, t, z, d));
+    hipLaunchKernelGGL(k_raw_align, dim3(1), dim3(64), 0, g_rt.stream, mode == PRALINE_MODE_LOCAL ? 1 : 0, d.m.p, d.g1.p,
+                       d.g2.p, d.o.p, d.t.p, d.z.p, (int)d.L1, (int)d.L2);
+    HIPCHK(hipGetLastError());
+    const size_t cells = (size_t)((d.L1 + 1) * (d.L2 + 1));
+    std::vector<float> ho(cells * 3);
+    std::vector<uint8_t> ht(cells * 3);
+    HIPCHK(hipMemcpyAsync(ho.data(), d.o.p, ho.size() * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
+    HIPCHK(hipMemcpyAsync(ht.data(), d.t.p, ht.size(), hipMemcpyDeviceToHost, g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
+    scatter3<float>(ho, *o);
+    scatter3<uint8_t>(ht, *t);
+    return PRALINE_OK;
+}
+
+extern "C" int praline_align_global(const praline_array *m, const praline_array *g1, const praline_array *g2,
+                                    const praline_array *o, const praline_array *t, const praline_array *z)
+{ return praline_align(PRALINE_MODE_GLOBAL, m, g1, g2, o, t, z); }
+extern "C" int praline_align_local(const praline_array *m, const praline_array *g1, const praline_array *g2,
+                                   const praline_array *o, const praline_array *t, const praline_array *z)
+{ return praline_align(PRALINE_MODE_LOCAL, m, g1, g2, o, t, z); }
+extern "C" int praline_align_semiglobal_both(const praline_array *m, const praline_array *g1, const praline_array *g2,
+                                             const praline_array *o, const praline_array *t, const praline_array *z)
+{ return praline_align(PRALINE_MODE_SEMIGLOBAL_BOTH, m, g1, g2, o, t, z); }
+extern "C" int praline_align_semiglobal_one(const praline_array *m, const praline_array *g1, const praline_array *g2,
+                                            const praline_array *o, const praline_array *t, const praline_array *z)
+{ return praline_align(PRALINE_MODE_SEMIGLOBAL_ONE, m, g1, g2, o, t, z); }
+extern "C" int praline_align_semiglobal_two(const praline_array *m, const praline_array *g1, const praline_array *g2,
+                                            const praline_array *o, const praline_array *t, const praline_array *z)
+{ return praline_align(PRALINE_MODE_SEMIGLOBAL_TWO, m, g1, g2, o, t, z); }
+
+extern "C" int praline_raw_align(int mode, const praline_array *m, const praline_array *g1, const praline_array *g2,
+                                 const praline_array *z, float *score, int32_t *path, int64_t *path_rows)
+{
+    if (mode < 0 || mode > 4) return fail(PRALINE_ERR_ARG, "unknown alignment mode %d", mode);
+    if (!score || !path || !path_rows) return fail(PRALINE_ERR_ARG, "NULL output");
+    RawDev d;
+    RC(raw_upload(m, g1, g2, nullptr, nullptr, z, d));
+    hipStream_t st = g_rt.stream;
+    const int L1 = (int)d.L1, L2 = (int)d.L2;
+    hipLaunchKernelGGL(k_raw_init, dim3(256), dim3(256), 0, st, mode, d.g1.p, d.g2.p, d.o.p, d.t.p, L1, L2);
+    hipLaunchKernelGGL(k_raw_align, dim3(1), dim3(64), 0, st, mode == PRALINE_MODE_LOCAL ? 1 : 0, d.m.p, d.g1.p, d.g2.p,
+                       d.o.p, d.t.p, d.z.p, L1, L2);
+    DevBuf<float> d_score;
+    DevBuf<int32_t> d_path;
+    DevBuf<int64_t> d_info;
+    const size_t cap = (size_t)(L1 + L2 + 2);
+    RC(d_score.alloc(1)); RC(d_path.alloc(cap * 2)); RC(d_info.alloc(2));
+    hipLaunchKernelGGL(k_raw_trace, dim3(1), dim3(256), 0, st, mode, d.o.p, d.t.p, L1, L2, d_score.p, d_path.p, d_info.p);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> hp(cap * 2);
+    int64_t info[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(score, d_score.p, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hp.data(), d_path.p, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(info, d_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (info[1] <= 0 || info[0] < 0 || (size_t)(info[0] + info[1]) > cap) return fail(PRALINE_ERR_DEVICE, "traceback produced an invalid path");
+    memcpy(path, hp.data() + 2 * info[0], (size_t)info[1] * 2 * sizeof(int32_t));
+    *path_rows = info[1];
+    return PRALINE_OK;
+}

@@ -1,0 +1,286 @@
+"""ctypes binding of libpraline_dp.so (include/praline_dp.h) - the only way Python reaches HIP.
+
+Nothing in here computes on the CPU: if the shared library is missing, or no HIP device is
+usable, the calls raise NativeError.  The numpy-level helpers mirror the call shapes of the
+reference's native module (praline/util/cext.c:506-520 as bound in
+praline/component/align.py:18-20) so the operator layer reads like the reference's.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpraline_dp.so")
+
+MODES = {"global": 0, "local": 1, "semiglobal_both": 2, "semiglobal_one": 3,
+         "semiglobal_two": 4}
+
+OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super(NativeError, self).__init__("libpraline_dp error %d: %s" % (code, message))
+        self.code = code
+
+
+class PralineArray(ctypes.Structure):
+    """struct praline_array (pointer + dims + byte strides)."""
+    _fields_ = [("data", ctypes.c_void_p), ("dim", ctypes.c_int64 * 3),
+                ("stride", ctypes.c_int64 * 3)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libpraline_dp.so (built by __graft_entry__.build / make -C praline_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(ERR_DEVICE, "%s not found - build it with `make -C praline_amd/csrc` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    pa = ctypes.POINTER(PralineArray)
+    L.praline_abi_version.restype = i32
+    L.praline_device_count.argtypes = [ctypes.POINTER(i32)]
+    L.praline_init.argtypes = [i32]
+    L.praline_last_error.restype = ctypes.c_char_p
+    L.praline_stream.restype = vp
+    L.praline_build_scores.argtypes = [i32, pa, pa, pa, pa, pa, pa]
+    for name in ("global", "local", "semiglobal_both", "semiglobal_one", "semiglobal_two"):
+        getattr(L, "praline_align_" + name).argtypes = [pa, pa, pa, pa, pa, pa]
+    L.praline_align.argtypes = [i32, pa, pa, pa, pa, pa, pa]
+    L.praline_raw_align.argtypes = [i32, pa, pa, pa, pa, ctypes.POINTER(f32), vp,
+                                    ctypes.POINTER(i64)]
+    L.praline_arena_create.argtypes = [i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
+    L.praline_arena_destroy.argtypes = [vp]
+    L.praline_arena_premultiply.argtypes = [vp]
+    L.praline_plan_create.argtypes = [vp, i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
+    L.praline_plan_destroy.argtypes = [vp]
+    L.praline_plan_cells.argtypes = [vp]
+    L.praline_plan_cells.restype = i64
+    L.praline_plan_path_capacity.argtypes = [vp]
+    L.praline_plan_path_capacity.restype = i64
+    L.praline_plan_run.argtypes = [vp, i32, f32, f32, vp]
+    L.praline_plan_scores.argtypes = [vp, vp]
+    L.praline_plan_device_scores.argtypes = [vp]
+    L.praline_plan_device_scores.restype = vp
+    L.praline_plan_paths.argtypes = [vp, vp, vp, vp]
+    L.praline_batch_scores.argtypes = [vp, i32, f32, f32, i64, vp, vp]
+    L.praline_plan_last_timing.argtypes = [vp, ctypes.POINTER(f32)]
+    if L.praline_abi_version() != 1:
+        raise NativeError(ERR_ARG, "ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise NativeError(rc, lib().praline_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = lib().praline_device_count(ctypes.byref(n))
+    return n.value if rc == OK else 0
+
+
+def init(device=0):
+    _check(lib().praline_init(int(device)))
+
+
+def synchronize():
+    _check(lib().praline_synchronize())
+
+
+def stream_handle():
+    return lib().praline_stream()
+
+
+def _arr(a):
+    """numpy array (any strides) -> praline_array."""
+    pa = PralineArray()
+    pa.data = a.ctypes.data
+    for k in range(3):
+        pa.dim[k] = a.shape[k] if k < a.ndim else 1
+        pa.stride[k] = a.strides[k] if k < a.ndim else 0
+    return pa
+
+
+def _arr_list(arrs):
+    return (PralineArray * len(arrs))(*[_arr(a) for a in arrs])
+
+
+def _need(a, dtype, name):
+    if not isinstance(a, np.ndarray) or a.dtype != dtype:
+        raise TypeError("%s must be a numpy array of dtype %s" % (name, np.dtype(dtype)))
+    return a
+
+
+# ---- drop-in twins of the reference's native functions -----------------------------------------
+def cext_build_scores(i1s, i2s, i1nzs, i2nzs, ss, m):
+    """cext_build_scores(i1s, i2s, i1nzs, i2nzs, ss, m) -> None   (praline/util/cext.c:308-455)
+
+    Writes the match-score matrix into m in place; arbitrary strides are honoured.  The nonzero
+    index lists are accepted but unused (dense MFMA contraction on the device)."""
+    n = len(i1s)
+    for k in range(n):
+        _need(i1s[k], np.float32, "i1s[%d]" % k)
+        _need(i2s[k], np.float32, "i2s[%d]" % k)
+        _need(ss[k], np.float32, "ss[%d]" % k)
+    _need(m, np.float32, "m")
+    pm = _arr(m)
+    _check(lib().praline_build_scores(n, _arr_list(i1s), _arr_list(i2s), None, None,
+                                      _arr_list(ss), ctypes.byref(pm)))
+
+
+def _cext_align(mode, m, g1, g2, o, t, z):
+    args = [_arr(_need(m, np.float32, "m")), _arr(_need(g1, np.float32, "g1")),
+            _arr(_need(g2, np.float32, "g2")), _arr(_need(o, np.float32, "o")),
+            _arr(_need(t, np.uint8, "t")), _arr(_need(z, np.uint8, "z"))]
+    fn = getattr(lib(), "praline_align_" + mode)
+    _check(fn(*[ctypes.byref(a) for a in args]))
+
+
+def cext_align_global(m, g1, g2, o, t, z):
+    _cext_align("global", m, g1, g2, o, t, z)
+
+
+def cext_align_local(m, g1, g2, o, t, z):
+    _cext_align("local", m, g1, g2, o, t, z)
+
+
+def cext_align_semiglobal_both(m, g1, g2, o, t, z):
+    _cext_align("semiglobal_both", m, g1, g2, o, t, z)
+
+
+def cext_align_semiglobal_one(m, g1, g2, o, t, z):
+    _cext_align("semiglobal_one", m, g1, g2, o, t, z)
+
+
+def cext_align_semiglobal_two(m, g1, g2, o, t, z):
+    _cext_align("semiglobal_two", m, g1, g2, o, t, z)
+
+
+def raw_align(mode, m, g1, g2, z=None):
+    """RawPairwiseAligner's numeric core on the device (praline/component/align.py:357-447):
+    returns (score, path int32 [rows, 2]) without moving o / t back to the host."""
+    m = _need(m, np.float32, "m")
+    g1 = _need(g1, np.float32, "g1")
+    g2 = _need(g2, np.float32, "g2")
+    L1, L2 = m.shape
+    path = np.zeros((L1 + L2 + 2, 2), dtype=np.int32)
+    score = ctypes.c_float(0.0)
+    rows = ctypes.c_int64(0)
+    am, ag1, ag2 = _arr(m), _arr(g1), _arr(g2)
+    az = _arr(_need(z, np.uint8, "z")) if z is not None else None
+    _check(lib().praline_raw_align(MODES[mode], ctypes.byref(am), ctypes.byref(ag1),
+                                   ctypes.byref(ag2), ctypes.byref(az) if az is not None else None,
+                                   ctypes.byref(score), path.ctypes.data, ctypes.byref(rows)))
+    return float(score.value), path[:rows.value].copy()
+
+
+# ---- batched path --------------------------------------------------------------------------------
+class Arena(object):
+    """Profiles of N sequences resident in HBM (praline_arena_create)."""
+
+    def __init__(self, profiles, score_matrix):
+        """profiles: list of float32 [L_s, A] arrays; score_matrix: float32 [A, A]."""
+        A = int(score_matrix.shape[0])
+        self.lens = np.array([p.shape[0] for p in profiles], dtype=np.int32)
+        cat = np.ascontiguousarray(np.concatenate(profiles, axis=0), dtype=np.float32)
+        if cat.shape[1] != A:
+            raise ValueError("profile width %d != score matrix size %d" % (cat.shape[1], A))
+        S = np.ascontiguousarray(score_matrix, dtype=np.float32)
+        self.n_seqs = len(profiles)
+        self.A = A
+        h = ctypes.c_void_p()
+        _check(lib().praline_arena_create(self.n_seqs, self.lens.ctypes.data, A, cat.ctypes.data,
+                                          S.ctypes.data, ctypes.byref(h)))
+        self._h = h
+
+    def premultiply(self):
+        _check(lib().praline_arena_premultiply(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().praline_arena_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan(object):
+    """A scheduled pair list (praline_plan_create)."""
+
+    def __init__(self, arena, pairs, want_paths=False, rects=None):
+        """pairs: int [n, 2] (sequence_one, sequence_two); rects: optional list (one entry per
+        pair) of lists of (y0, y1, x0, x1) inclusive zero rectangles."""
+        self.arena = arena
+        self.pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        self.n = self.pairs.shape[0]
+        self.want_paths = bool(want_paths)
+        ro = rv = None
+        if rects is not None:
+            ro = np.zeros(self.n + 1, dtype=np.int32)
+            flat = []
+            for p, rl in enumerate(rects):
+                flat.extend(rl)
+                ro[p + 1] = ro[p] + len(rl)
+            rv = np.ascontiguousarray(np.array(flat, dtype=np.int32).reshape(-1, 4))
+            if rv.shape[0] == 0:
+                rv = np.zeros((1, 4), dtype=np.int32)
+        self._keep = (ro, rv)
+        h = ctypes.c_void_p()
+        _check(lib().praline_plan_create(arena._h, self.n, self.pairs.ctypes.data, int(want_paths),
+                                         ro.ctypes.data if ro is not None else None,
+                                         rv.ctypes.data if rv is not None else None,
+                                         ctypes.byref(h)))
+        self._h = h
+        self.cells = int(lib().praline_plan_cells(h))
+
+    def run(self, mode, gap_open, gap_extend, d_scores=None):
+        """Asynchronous launch on the library stream.  d_scores: optional DEVICE pointer (int)."""
+        _check(lib().praline_plan_run(self._h, MODES[mode], float(gap_open), float(gap_extend),
+                                      ctypes.c_void_p(d_scores) if d_scores else None))
+
+    def scores(self):
+        out = np.zeros(self.n, dtype=np.float32)
+        _check(lib().praline_plan_scores(self._h, out.ctypes.data))
+        return out
+
+    def device_scores_ptr(self):
+        return lib().praline_plan_device_scores(self._h)
+
+    def kernel_ms(self):
+        ms = ctypes.c_float(0.0)
+        _check(lib().praline_plan_last_timing(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def paths(self):
+        """list of int32 [rows, 2] arrays in pair order."""
+        cap = int(lib().praline_plan_path_capacity(self._h))
+        buf = np.zeros((max(cap, 1), 2), dtype=np.int32)
+        off = np.zeros(max(self.n, 1), dtype=np.int64)
+        rows = np.zeros(max(self.n, 1), dtype=np.int32)
+        _check(lib().praline_plan_paths(self._h, buf.ctypes.data, off.ctypes.data, rows.ctypes.data))
+        return [buf[off[p]:off[p] + rows[p]].copy() for p in range(self.n)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().praline_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,263 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of
+libpraline_dp.so; the CPU oracle and the committed golden vectors are the checkers."""
+import numpy as np
+import pytest
+
+from conftest import MODES, load_golden, one_hot, synth_lengths, synth_profile
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GAPS = (-11.0, -1.0)
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from praline_amd import native
+    native.init(0)
+    return native
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else a.dtype)
+
+
+def oracle_dp_on_device_m(mode, p1, p2, S, gaps=GAPS, zero_idxs=None):
+    """Oracle DP fed with the match scores in the device's (fma-chain) evaluation order."""
+    m = orc.build_scores_fma([p1], [p2], [S])
+    g1, g2 = orc.gap_arrays(m.shape[0], m.shape[1], gaps)
+    return orc.raw_pairwise_align(mode, m, g1, g2, zero_idxs)
+
+
+# ------------------------------------------------------------------------------------------------
+# A. parity-layout entry points
+# ------------------------------------------------------------------------------------------------
+def test_build_scores_golden_and_order(nat, bba):
+    d = load_golden("fill_small.npz")
+    S = bba["S"]
+    for n in range(int(d["n_cases"])):
+        p = "c%03d_" % n
+        p1, p2, m_ref = d[p + "p1"], d[p + "p2"], d[p + "m"]
+        m = np.zeros_like(m_ref)
+        nat.cext_build_scores([p1], [p2], None, None, [S], m)
+        # bit-exact against the fma-order oracle; within 1e-5 relative of the reference order
+        assert np.array_equal(bits(m), bits(orc.build_scores_fma([p1], [p2], [S]))), n
+        if str(d[p + "kind"]).startswith("onehot") or str(d[p + "kind"]).startswith("mask"):
+            assert np.array_equal(m, m_ref), n  # integer scoring: exact
+        else:
+            assert np.abs(m - m_ref).max() <= 1e-5 * max(1.0, np.abs(m_ref).max()), n
+
+
+def test_build_scores_multiset_and_strides(nat, bba):
+    d = load_golden("multitrack.npz")
+    i, j = 0, 4
+    for nsets, key in ((2, "s2_0_4_global_m"), (3, "s3_0_4_global_m")):
+        i1 = [one_hot(bba["seqs"][i], 27), one_hot(bba["motif"][i], 2)]
+        i2 = [one_hot(bba["seqs"][j], 27), one_hot(bba["motif"][j], 2)]
+        ss = [bba["S"], bba["motif_matrix"]]
+        if nsets == 3:
+            i1.append(one_hot(bba["ss"][i], 3))
+            i2.append(one_hot(bba["ss"][j], 3))
+            ss.append(bba["ss_matrix"])
+        # non-contiguous views: transposed storage and a column-strided output
+        i1 = [np.asfortranarray(a) for a in i1]
+        big = np.zeros((i1[0].shape[0], 2 * i2[0].shape[0]), dtype=np.float32)
+        m = big[:, ::2]
+        nat.cext_build_scores(i1, i2, None, None, ss, m)
+        assert np.array_equal(m, d[key])
+        assert not big[:, 1::2].any()
+
+
+def test_align_fill_golden_bitexact(nat):
+    d = load_golden("fill_small.npz")
+    for n in range(int(d["n_cases"])):
+        p = "c%03d_" % n
+        mode = str(d[p + "mode"])
+        o, t = d[p + "o0"].copy(), d[p + "t0"].copy()
+        getattr(nat, "cext_align_" + mode)(d[p + "m"], d[p + "g1"], d[p + "g2"], o, t, d[p + "z"])
+        assert np.array_equal(bits(o), bits(d[p + "o"])), (n, mode)
+        assert np.array_equal(t, d[p + "t"]), (n, mode)
+        zi = d[p + "z"] if d[p + "z"].any() else None
+        score, path = nat.raw_align(mode, d[p + "m"], d[p + "g1"], d[p + "g2"], zi)
+        assert score == float(d[p + "score"]), (n, mode)
+        assert np.array_equal(path, d[p + "path"]), (n, mode)
+
+
+def test_align_fill_random_vs_oracle(nat):
+    rng = np.random.default_rng(11)
+    for trial in range(10):
+        L1, L2 = (int(v) for v in rng.integers(1, 200, 2))
+        m = (rng.normal(size=(L1, L2)) * 5).astype(np.float32)
+        if trial % 2:
+            m = np.rint(m)
+        g1 = rng.normal(-5, 2, (L1, 2)).astype(np.float32)
+        g2 = rng.normal(-5, 2, (L2, 2)).astype(np.float32)
+        zi = [(int(rng.integers(0, L1 + 1)), int(rng.integers(0, L2 + 1))) for _ in range(3 * trial)]
+        for mode in MODES:
+            o, t, z = orc.init_matrices(mode, g1, g2, zi)
+            o2, t2 = o.copy(), t.copy()
+            orc.CEXT_ALIGN_FUNCTIONS[mode](m, g1, g2, o, t, z)
+            getattr(nat, "cext_align_" + mode)(m, g1, g2, o2, t2, z)
+            assert np.array_equal(bits(o), bits(o2)) and np.array_equal(t, t2), (trial, mode)
+            score, path = nat.raw_align(mode, m, g1, g2, z)
+            s_ref, p_ref = orc.raw_pairwise_align(mode, m, g1, g2, zi)
+            assert score == s_ref and np.array_equal(path, p_ref), (trial, mode)
+
+
+# ------------------------------------------------------------------------------------------------
+# B. batched path
+# ------------------------------------------------------------------------------------------------
+def all_pairs(n):
+    return np.array([(i, j) for i in range(n) for j in range(i + 1, n)], dtype=np.int32)
+
+
+@pytest.mark.parametrize("name,A,n", [("synthetic_c1.npz", 27, 8), ("synthetic_dna.npz", 15, 6)])
+def test_batch_golden_scores_and_paths(nat, bba, name, A, n):
+    d = load_golden(name)
+    S = bba["S"] if A == 27 else d["matrix"]
+    profs = [one_hot(d["seq%d" % i], A) for i in range(n)]
+    arena = nat.Arena(profs, S)
+    pairs = all_pairs(n)
+    for mode in MODES:
+        plan = nat.Plan(arena, pairs)
+        plan.run(mode, *GAPS)
+        assert np.array_equal(plan.scores().astype(np.float64), d["scores_" + mode]), mode
+        plan.close()
+        plan = nat.Plan(arena, pairs, want_paths=True)
+        plan.run(mode, *GAPS)
+        assert np.array_equal(plan.scores().astype(np.float64), d["scores_" + mode]), mode
+        off = d["paths_off_" + mode]
+        for k, path in enumerate(plan.paths()):
+            assert np.array_equal(path, d["paths_" + mode][off[k]:off[k + 1]]), (mode, k)
+        plan.close()
+    arena.close()
+
+
+def test_batch_kat_appendix_b(nat, bba):
+    d = load_golden("kat_pairwise.npz")
+    profs = [one_hot(s, 27) for s in bba["seqs"]]
+    arena = nat.Arena(profs, bba["S"])
+    pairs = all_pairs(5)
+    for mode in MODES:
+        plan = nat.Plan(arena, pairs, want_paths=True)
+        plan.run(mode, *GAPS)
+        sc, paths = plan.scores(), plan.paths()
+        for k, (i, j) in enumerate(pairs):
+            assert sc[k] == float(d["score_%d_%d_%s" % (i, j, mode)]), (mode, i, j)
+            assert np.array_equal(paths[k], d["path_%d_%d_%s" % (i, j, mode)]), (mode, i, j)
+        plan.close()
+    arena.close()
+
+
+def test_batch_float_profiles(nat, bba):
+    """Float profile scoring: within 1e-5 relative of the reference (golden), and bit-identical to
+    the oracle DP fed with the device-order match scores."""
+    d = load_golden("profile_profile.npz")
+    profs = [d["profile%d" % i] for i in range(5)]
+    arena = nat.Arena(profs, bba["S"])
+    pairs = all_pairs(5)
+    for mode in MODES:
+        plan = nat.Plan(arena, pairs, want_paths=True)
+        plan.run(mode, *GAPS)
+        sc, paths = plan.scores(), plan.paths()
+        for k, (i, j) in enumerate(pairs):
+            ref = float(d["score_%d_%d_%s" % (i, j, mode)])
+            assert abs(sc[k] - ref) <= 1e-5 * max(1.0, abs(ref)), (mode, i, j, sc[k], ref)
+            s_or, p_or = oracle_dp_on_device_m(mode, profs[i], profs[j], bba["S"])
+            assert sc[k] == np.float32(s_or), (mode, i, j)
+            assert np.array_equal(paths[k], p_or), (mode, i, j)
+        plan.close()
+    arena.close()
+
+
+def test_batch_waterman_eggert_masks(nat, bba):
+    """LocalMasterSlaveAligner's inner calls (praline/component/preprofile.py:227-267)."""
+    d = load_golden("preprofile.npz")
+    profs = [one_hot(s, 27) for s in bba["seqs"]]
+    arena = nat.Arena(profs, bba["S"])
+    for key, master, iters in (("local_m0_", 0, 2), ("local_m4_", 4, 2), ("local_we3_m0_", 0, 3)):
+        slaves = [k for k in range(5) if k != master]
+        pairs = np.array([(master, s) for s in slaves], dtype=np.int32)
+        rects = [[] for _ in slaves]
+        for it in range(iters):
+            plan = nat.Plan(arena, pairs, want_paths=True, rects=rects)
+            plan.run("local", *GAPS)
+            sc, paths = plan.scores(), plan.paths()
+            plan.close()
+            for q in range(len(slaves)):
+                c = q * iters + it
+                assert sc[q] == float(d[key + "call%d_score" % c]), (key, c)
+                assert np.array_equal(paths[q], d[key + "call%d_path" % c]), (key, c)
+                p = paths[q]
+                rects[q] = rects[q] + [(int(p[:, 0].min()), int(p[:, 0].max()),
+                                        int(p[:, 1].min()), int(p[:, 1].max()))]
+    arena.close()
+
+
+@pytest.mark.parametrize("kind", ["onehot", "profile"])
+def test_batch_random_vs_oracle(nat, bba, kind):
+    rng = np.random.default_rng(3)
+    N = 40
+    lens = synth_lengths(rng, N, 90)
+    lens[0], lens[1], lens[2] = 1, 32, 33  # edge lengths: single residue, exact strip, strip + 1
+    if kind == "onehot":
+        profs = [one_hot(rng.integers(0, 20, L), 27) for L in lens]
+    else:
+        profs = [synth_profile(rng, int(L))[0] for L in lens]
+    S = bba["S"]
+    arena = nat.Arena(profs, S)
+    pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j and (i * 7 + j) % 5 == 0],
+                     dtype=np.int32)
+    for mode in MODES:
+        plan = nat.Plan(arena, pairs, want_paths=True)
+        plan.run(mode, *GAPS)
+        sc, paths = plan.scores(), plan.paths()
+        plan.close()
+        plan0 = nat.Plan(arena, pairs)
+        plan0.run(mode, *GAPS)
+        sc0 = plan0.scores()
+        plan0.close()
+        assert np.array_equal(bits(sc), bits(sc0)), mode  # both kernel variants agree
+        for k in range(0, len(pairs), 3):
+            i, j = pairs[k]
+            s_or, p_or = oracle_dp_on_device_m(mode, profs[i], profs[j], S)
+            assert sc[k] == np.float32(s_or), (mode, i, j)
+            assert np.array_equal(paths[k], p_or), (mode, i, j)
+    arena.close()
+
+
+def test_batch_c2_slice_properties(nat, bba):
+    """BASELINE config 1 shape (256 x ~400 aa profiles, all pairs, global): properties that do not
+    need the oracle at full size + oracle spot checks."""
+    rng = np.random.default_rng(2)
+    N = 256
+    lens = synth_lengths(rng, N, 400)
+    profs = [synth_profile(rng, int(L))[0] for L in lens]
+    S = bba["S"]
+    arena = nat.Arena(profs, S)
+    pairs = all_pairs(N)
+    plan = nat.Plan(arena, pairs)
+    plan.run("global", *GAPS)
+    sc = plan.scores()
+    plan.close()
+    assert np.isfinite(sc).all()
+    # symmetric matrix + equal gap models: score(i, j) == score(j, i) bit for bit
+    sub = pairs[::97]
+    plan = nat.Plan(arena, sub[:, ::-1].copy())
+    plan.run("global", *GAPS)
+    assert np.array_equal(bits(plan.scores()), bits(sc[::97]))
+    plan.close()
+    # self alignment of a one-hot sequence scores the sum of its diagonal entries (no gaps)
+    # local >= semiglobal_both >= global for every pair
+    plan = nat.Plan(arena, sub)
+    plan.run("local", *GAPS)
+    loc = plan.scores()
+    plan.run("semiglobal_both", *GAPS)
+    semi = plan.scores()
+    plan.close()
+    assert (loc >= semi).all() and (semi >= sc[::97]).all()
+    for k in range(0, len(pairs), 4001):
+        i, j = pairs[k]
+        s_or, _ = oracle_dp_on_device_m("global", profs[i], profs[j], S)
+        assert sc[k] == np.float32(s_or)
+    arena.close()
