@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py - GCUPS of the all-pairs profile-profile affine-gap DP hot path (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch: the per-sequence pre-multiply (P . S^T, MFMA)
+plus the fused match-score + DP kernel over every pair of the batch, inputs resident in HBM.
+Workload at N=1: BASELINE configs[1] - 256 sequences ~400 aa as float profiles (~7 nonzeros per
+column), all 32 640 pairs, global mode, gaps -11/-1, BLOSUM62.  For N>1 the number
+of sequences grows so that the pairs per GPU stay constant (weak scaling); every rank aligns its
+cell-balanced slice of the pair list and the score slices are all-gathered over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+A = 27
+GAP_OPEN, GAP_EXTEND = -11.0, -1.0
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+PAIRS_PER_GPU = 32640          # C2: 256 * 255 / 2
+
+
+def blosum62():
+    from praline_amd.matrices import blosum62_matrix
+    return blosum62_matrix()
+
+
+def synth_lengths(rng, n, mu):
+    return np.clip(np.rint(rng.normal(mu, 0.1 * mu, n)), 0.5 * mu, 1.5 * mu).astype(int)
+
+
+def synth_profile(rng, L):
+    """one-hot x5 counts + 6 random extra residues with counts 1-3, normalised as
+    ProfileTrack.profile does (praline/container/sequence.py:200-202)."""
+    counts = np.zeros((L, A), dtype=np.int64)
+    counts[np.arange(L), rng.integers(0, 20, L)] += 5
+    for _ in range(6):
+        counts[np.arange(L), rng.integers(0, 20, L)] += rng.integers(1, 4, L)
+    totals = np.array(counts.sum(axis=1), dtype=np.float32)
+    return np.array(counts / totals[:, np.newaxis], dtype=np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="global")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-per-thread", type=int, default=24)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+
+    import torch
+    from praline_amd import native
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    native.init(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic batch (identical on every rank) ----
+    n_seqs = int(round(0.5 + math.sqrt(0.25 + 2.0 * world * PAIRS_PER_GPU)))
+    rng = np.random.default_rng(2)
+    lens = synth_lengths(rng, n_seqs, 400)
+    profs = [synth_profile(rng, int(L)) for L in lens]
+    S = blosum62()
+    pairs = np.array([(i, j) for i in range(n_seqs) for j in range(i + 1, n_seqs)], dtype=np.int32)
+    cells = lens[pairs[:, 0]].astype(np.int64) * lens[pairs[:, 1]].astype(np.int64)
+    total_cells = int(cells.sum())
+
+    # contiguous, cell-balanced slice of the pair list for this rank
+    from praline_amd.allpairs import shard_bounds
+    bounds = shard_bounds(cells, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    my_pairs = pairs[lo:hi]
+    slice_len = int(max(bounds[r + 1] - bounds[r] for r in range(world)))
+
+    arena = native.Arena(profs, S)
+    plan = native.Plan(arena, my_pairs)
+    d_slice = torch.zeros(slice_len, dtype=torch.float32, device="cuda")
+    d_all = torch.zeros(slice_len * world, dtype=torch.float32, device="cuda") if world > 1 else None
+    lib_stream = torch.cuda.ExternalStream(native.stream_handle())
+
+    def step():
+        arena.premultiply()
+        plan.run(args.mode, GAP_OPEN, GAP_EXTEND, d_scores=d_slice.data_ptr())
+        if world > 1:
+            # the exchange step: all ranks obtain every score slice (RCCL all-gather over xGMI)
+            torch.cuda.current_stream().wait_stream(lib_stream)
+            dist.all_gather_into_tensor(d_all, d_slice)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        native.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if rank == 0 and len(kernel_ms) < 1:
+            pass
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernel_ms.append(plan.kernel_ms())  # HIP events around the last DP launch on its own stream
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # separate untimed pass: average DP-kernel duration over a few launches via HIP events
+    kms = []
+    for _ in range(5):
+        plan.run(args.mode, GAP_OPEN, GAP_EXTEND, d_scores=d_slice.data_ptr())
+        kms.append(plan.kernel_ms())
+    kernel_ms_avg = float(np.mean(kms))
+
+    ms_per_step = elapsed / args.steps * 1e3
+    gcups = total_cells / (elapsed / args.steps) / 1e9
+
+    # ---- roofline of the dominant kernel (k_dp_batch) on this rank's slice ----
+    my_cells = int(cells[lo:hi].sum())
+    lsum = int((lens[my_pairs[:, 0]] + lens[my_pairs[:, 1]]).sum())
+    alg_flops = 2.0 * A * my_cells                        # 2A flop / cell (MFMA step)
+    alg_bytes = 4.0 * A * lsum + 4.0 * len(my_pairs)      # 4A(L1+L2) + 4 per pair
+    ksec = kernel_ms_avg * 1e-3
+    roofline = {
+        "bound": "mfma", "achieved": alg_flops / ksec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+        "unit": "TFLOP/s", "frac": alg_flops / ksec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "traffic": None, "kernel": "k_dp_batch", "kernel_ms": kernel_ms_avg,
+        "kernel_gcups": my_cells / ksec / 1e9,
+        "hbm": {"achieved": alg_bytes / ksec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": alg_bytes / ksec / 1e9 / PEAK_HBM_GBS,
+                "bytes_per_cell": alg_bytes / my_cells},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(traffic_file):
+        try:
+            roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    out = {
+        "metric": "GCUPS (DP cell updates/s) all-pairs profile-profile affine align",
+        "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: %d seqs ~400 aa float profiles, all %d pairs, %s, BLOSUM62, "
+                               "gaps -11/-1, score-only" % (n_seqs, len(pairs), args.mode),
+                   "n_seqs": n_seqs, "pairs": int(len(pairs)), "cells": total_cells,
+                   "pairs_per_gpu": int(len(my_pairs)), "parallelism": "pairs sharded x%d" % world},
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the oracle (C restatement of the reference path) on the host cores ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        threads = os.cpu_count() or 1
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        n_sample = min(len(pairs), threads * args.cpu_sample_per_thread)
+        idx = np.linspace(0, len(pairs) - 1, n_sample).astype(np.int64)
+        sample = pairs[idx]
+        arena_cat = np.concatenate(profs, axis=0)
+        row_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        tc0 = time.perf_counter()
+        cpu_scores = orc.batch_scores(args.mode, arena_cat, row_off, lens.astype(np.int32), S,
+                                      sample, GAP_OPEN, GAP_EXTEND, threads=threads)
+        tc1 = time.perf_counter()
+        sample_cells = int(cells[idx].sum())
+        gpu_scores = d_slice.cpu().numpy()[idx] if world == 1 else None
+        max_rel = float(np.max(np.abs(gpu_scores - cpu_scores) / np.maximum(1.0, np.abs(cpu_scores))))
+        out["cpu_baseline"] = {
+            "value": sample_cells / (tc1 - tc0) / 1e9, "unit": "GCUPS", "cores": threads,
+            "kind": "port",
+            "sample": "%d of %d pairs (evenly spaced), %.1f s, oracle/praline_oracle.c "
+                      "(build_nonzero + build_scores + fill + end cell per pair, OpenMP)" % (
+                          n_sample, len(pairs), tc1 - tc0),
+            "max_rel_diff_vs_gpu": max_rel,
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -189,10 +189,15 @@ __global__ __launch_bounds__(64) void k_scores_tile(ArenaDev ar, int one, int tw
 __device__ __forceinline__ void swap_halves(float &a, float &b)
 {
     // v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b.
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a),
-                                                    __builtin_bit_cast(unsigned, b), false, false);
-    a = __builtin_bit_cast(float, r[0]);
-    b = __builtin_bit_cast(float, r[1]);
+    // NOTE: extract both results into scalars before any bit cast.  hipcc (ROCm 7.2) folds
+    // __builtin_bit_cast(float, r[1]) on the builtin's result vector into r[0] (checked in the
+    // ISA: both stores used the vdst register); this form lowers to one swap + two live outputs.
+    unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+    ua = r[0];
+    ub = r[1];
+    a = __builtin_bit_cast(float, ua);
+    b = __builtin_bit_cast(float, ub);
 }
 
 // v[idx] for a per-lane idx in 0..31: 5-level v_cndmask tree (registers cannot be indexed per lane).

@@ -803,3 +803,46 @@ extern "C" int praline_raw_align(int mode, const praline_array *m, const praline
     *path_rows = info[1];
     return PRALINE_OK;
 }
+
+// --------------------------------------------------------------------------------------------
+// debug: the per-lane match-score tile exactly as k_dp_batch forms it (NSTEP = arena.nstep via a
+// runtime loop).  out: [64][32] floats.  Not part of the public header.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_debug_tile(ArenaDev ar, const int32_t *lane_one, int two0, int two1, int x0,
+                                                    int y, int tp, int nstep, float *out)
+{
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const int srcA = lane_one[j], srcB = lane_one[32 + j];
+    const float *pA = ar.P + ((int64_t)(srcA >= 0 ? ar.row_off[srcA] : 0) + (y - 1)) * ar.KP + half * ar.KS;
+    const float *pB = ar.P + ((int64_t)(srcB >= 0 ? ar.row_off[srcB] : 0) + (y - 1)) * ar.KP + half * ar.KS;
+    const float *qA = ar.Q + ((int64_t)ar.row_off[two0] + x0 + j) * ar.KP + half * ar.KS;
+    const float *qB = ar.Q + ((int64_t)ar.row_off[two1] + x0 + j) * ar.KP + half * ar.KS;
+    f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
+    for (int k = 0; k < nstep; ++k) {
+        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(qA[k], pA[k], accA, 0, 0, 0);
+        if (tp == 2) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(qB[k], pB[k], accB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float a = accA[r], b = (tp == 2) ? accB[r] : 0.0f;
+        swap_halves(a, b);
+        out[lane * 32 + 8 * (r >> 2) + (r & 3)] = a;
+        out[lane * 32 + 8 * (r >> 2) + 4 + (r & 3)] = b;
+    }
+}
+
+extern "C" int praline_debug_tile(praline_arena *arena, const int32_t *lane_one, int two0, int two1, int x0, int y, int tp,
+                                  float *out)
+{
+    RC(ensure_runtime(-1));
+    DevBuf<int32_t> d_l;
+    DevBuf<float> d_o;
+    std::vector<int32_t> lv(lane_one, lane_one + 64);
+    RC(d_l.upload(lv, g_rt.stream));
+    RC(d_o.alloc(64 * 32));
+    hipLaunchKernelGGL(k_debug_tile, dim3(1), dim3(64), 0, g_rt.stream, arena->view(), d_l.p, two0, two1, x0, y, tp,
+                       arena->nstep, d_o.p);
+    HIPCHK(hipMemcpyAsync(out, d_o.p, 64 * 32 * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
+    return PRALINE_OK;
+}

@@ -241,11 +241,13 @@ def test_batch_c2_slice_properties(nat, bba):
     sc = plan.scores()
     plan.close()
     assert np.isfinite(sc).all()
-    # symmetric matrix + equal gap models: score(i, j) == score(j, i) bit for bit
+    # symmetric matrix + equal gap models: score(i, j) ~ score(j, i); the two orientations round
+    # the float match scores differently (P_i . Q_j vs P_j . Q_i), so 1e-5 relative, not bitwise
     sub = pairs[::97]
     plan = nat.Plan(arena, sub[:, ::-1].copy())
     plan.run("global", *GAPS)
-    assert np.array_equal(bits(plan.scores()), bits(sc[::97]))
+    rev = plan.scores()
+    assert np.abs(rev - sc[::97]).max() <= 1e-5 * np.abs(sc[::97]).max()
     plan.close()
     # self alignment of a one-hot sequence scores the sum of its diagonal entries (no gaps)
     # local >= semiglobal_both >= global for every pair
