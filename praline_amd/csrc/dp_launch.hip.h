@@ -3,6 +3,7 @@
 // compile in parallel.
 #pragma once
 #include "dp_kernels.hip.h"
+#include "dp_split.hip.h"
 #include "praline_dp.h"
 
 struct LaunchArgs {
@@ -18,6 +19,7 @@ struct LaunchArgs {
     RunParams rp;
     unsigned n_tasks;
     hipStream_t stream;
+    int split;  // 1: k_dp_split task layout (32 lane entries per task, float2 [max_l1+2][32] boundary)
 };
 
 int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, bool mask);
@@ -37,6 +39,16 @@ template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK> static void launch_
 // without zero rectangles).
 template <int NSTEP> static int launch_nstep(const LaunchArgs &la, int tp, bool local, int out, bool mask)
 {
+    if (la.split) {
+        if (out != 0 || mask) return PRALINE_ERR_UNSUPPORTED;
+        if (local)
+            hipLaunchKernelGGL((k_dp_split<NSTEP, true>), dim3(la.n_tasks), dim3(64), 0, la.stream, la.ar, la.tasks,
+                               la.lane_one, la.lane_pair, (float2 *)la.bnd, la.scores, la.rp);
+        else
+            hipLaunchKernelGGL((k_dp_split<NSTEP, false>), dim3(la.n_tasks), dim3(64), 0, la.stream, la.ar, la.tasks,
+                               la.lane_one, la.lane_pair, (float2 *)la.bnd, la.scores, la.rp);
+        return PRALINE_OK;
+    }
     if (out == 0) {
         if (mask) return PRALINE_ERR_UNSUPPORTED;
         if (tp == 2) { if (local) launch_one<NSTEP, 2, true, 0, false>(la); else launch_one<NSTEP, 2, false, 0, false>(la); }

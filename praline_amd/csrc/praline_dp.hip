@@ -282,6 +282,7 @@ struct praline_plan {
     bool want_paths = false;
     bool has_rects = false;
     int tp = 1;
+    bool split = false;  // k_dp_split task layout
     std::vector<WaveTask> tasks;
     std::vector<int64_t> tb_elems;  // per task, uint4 elements
     std::vector<int64_t> aux_elems; // per task, floats
@@ -372,11 +373,17 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     int tp = halves.size() >= 4096 ? 2 : 1;
     if (want_paths) tp = 1;  // the traceback variant keeps three states per column in registers
     if (const char *env = getenv("PRALINE_TP")) { if (env[0] == '1') tp = 1; else if (env[0] == '2' && !want_paths) tp = 2; }
+    // scores-only plans run on k_dp_split (both halves of the wave on the same 32 pairs)
+    bool split = !want_paths;
+    if (const char *env = getenv("PRALINE_KERNEL")) { if (!strcmp(env, "batch")) split = false; }
+    if (split) tp = 1;
     pl->tp = tp;
+    pl->split = split;
+    const int lanes_per_task = split ? 32 : 64;
 
     const size_t n_tasks = (halves.size() + tp - 1) / tp;
     pl->tasks.resize(n_tasks);
-    std::vector<int32_t> lane_one(n_tasks * 64, -1), lane_pair(n_tasks * 64, -1);
+    std::vector<int32_t> lane_one(n_tasks * lanes_per_task, -1), lane_pair(n_tasks * lanes_per_task, -1);
     std::vector<PairLoc> loc((size_t)n_pairs);
     int64_t bnd = 0;
     pl->tb_elems.resize(n_tasks);
@@ -394,13 +401,13 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             wt.max_l1 = std::max(wt.max_l1, h.max_l1);
             wt.nstrips = std::max(wt.nstrips, (a.len[h.two] + 31) / 32);
             for (int q = 0; q < 32; ++q) {
-                lane_one[t * 64 + hh * 32 + q] = h.one[q];
-                lane_pair[t * 64 + hh * 32 + q] = h.pair[q];
+                lane_one[t * lanes_per_task + hh * 32 + q] = h.one[q];
+                lane_pair[t * lanes_per_task + hh * 32 + q] = h.pair[q];
                 if (h.pair[q] >= 0) { loc[h.pair[q]].task = (int32_t)t; loc[h.pair[q]].lane = hh * 32 + q; }
             }
         }
         wt.bnd_off = bnd;
-        bnd += (int64_t)(wt.max_l1 + 1) * 64;
+        bnd += split ? (int64_t)(wt.max_l1 + 2) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
         wt.tb_off = 0;
         wt.aux_off = 0;
         pl->tb_elems[t] = (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
@@ -501,6 +508,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     la.rp.go1 = la.rp.go2 = gap_open;
     la.rp.ge1 = la.rp.ge2 = gap_extend;
     la.stream = g_rt.stream;
+    la.split = pl.split ? 1 : 0;
     const bool local = mode == PRALINE_MODE_LOCAL;
     pl.last_mode = mode;
     hipStream_t st = g_rt.stream;
