@@ -3,7 +3,6 @@
 // compile in parallel.
 #pragma once
 #include "dp_kernels.hip.h"
-#include "dp_split.hip.h"
 #include "praline_dp.h"
 
 struct LaunchArgs {
@@ -22,6 +21,14 @@ struct LaunchArgs {
     int split;  // 1: k_dp_split task layout (32 lane entries per task, float2 [max_l1+2][32] boundary)
 };
 
+// k_dp_split instances (dp_split_instance.hip, built with -mllvm -amdgpu-mfma-vgpr-form)
+int praline_launch_split_2(const LaunchArgs &la, bool local);
+int praline_launch_split_8(const LaunchArgs &la, bool local);
+int praline_launch_split_10(const LaunchArgs &la, bool local);
+int praline_launch_split_12(const LaunchArgs &la, bool local);
+int praline_launch_split_14(const LaunchArgs &la, bool local);
+int praline_launch_split_16(const LaunchArgs &la, bool local);
+// k_dp_batch instances (dp_instance.hip)
 int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, bool mask);
 int praline_launch_dp_8(const LaunchArgs &la, int tp, bool local, int out, bool mask);
 int praline_launch_dp_10(const LaunchArgs &la, int tp, bool local, int out, bool mask);
@@ -39,16 +46,7 @@ template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK> static void launch_
 // without zero rectangles).
 template <int NSTEP> static int launch_nstep(const LaunchArgs &la, int tp, bool local, int out, bool mask)
 {
-    if (la.split) {
-        if (out != 0 || mask) return PRALINE_ERR_UNSUPPORTED;
-        if (local)
-            hipLaunchKernelGGL((k_dp_split<NSTEP, true>), dim3(la.n_tasks), dim3(64), 0, la.stream, la.ar, la.tasks,
-                               la.lane_one, la.lane_pair, (float2 *)la.bnd, la.scores, la.rp);
-        else
-            hipLaunchKernelGGL((k_dp_split<NSTEP, false>), dim3(la.n_tasks), dim3(64), 0, la.stream, la.ar, la.tasks,
-                               la.lane_one, la.lane_pair, (float2 *)la.bnd, la.scores, la.rp);
-        return PRALINE_OK;
-    }
+    if (la.split) return PRALINE_ERR_UNSUPPORTED;  // handled by praline_launch_split_N
     if (out == 0) {
         if (mask) return PRALINE_ERR_UNSUPPORTED;
         if (tp == 2) { if (local) launch_one<NSTEP, 2, true, 0, false>(la); else launch_one<NSTEP, 2, false, 0, false>(la); }

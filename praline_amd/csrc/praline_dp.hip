@@ -407,7 +407,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             }
         }
         wt.bnd_off = bnd;
-        bnd += split ? (int64_t)(wt.max_l1 + 2) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
+        bnd += split ? (int64_t)(wt.max_l1 + 4) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
         wt.tb_off = 0;
         wt.aux_off = 0;
         pl->tb_elems[t] = (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
@@ -472,6 +472,18 @@ extern "C" void *praline_plan_device_scores(praline_plan *plan) { return plan ? 
 static int launch_dp(int nstep, const LaunchArgs &la, int tp, bool local, int out, bool mask)
 {
     int rc = PRALINE_ERR_UNSUPPORTED;
+    if (la.split) {
+        if (out != 0 || mask) return fail(PRALINE_ERR_UNSUPPORTED, "k_dp_split is scores-only");
+        switch (nstep) {
+            case 2: return praline_launch_split_2(la, local);
+            case 8: return praline_launch_split_8(la, local);
+            case 10: return praline_launch_split_10(la, local);
+            case 12: return praline_launch_split_12(la, local);
+            case 14: return praline_launch_split_14(la, local);
+            case 16: return praline_launch_split_16(la, local);
+        }
+        return fail(PRALINE_ERR_UNSUPPORTED, "no k_dp_split instance for nstep=%d", nstep);
+    }
     switch (nstep) {
         case 2: rc = praline_launch_dp_2(la, tp, local, out, mask); break;
         case 8: rc = praline_launch_dp_8(la, tp, local, out, mask); break;
