@@ -171,6 +171,17 @@ int praline_plan_paths(praline_plan *plan, int32_t *paths, int64_t *path_off, in
 int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float gap_extend,
                          int64_t n_pairs, const int32_t *pairs, float *scores);
 
+/* Diagnostics / audits.  praline_arena_match_scores writes the dense match-score matrix
+ * m (float32 [L1][L2], host) of the arena pair (one, two) exactly as the kernels evaluate it:
+ * kind 0 = fp32 MFMA chain (k-ordered fmaf chain, used by the traceback plans and
+ * praline_build_scores), kind 1 = f16 hi/lo split on the matrix pipe (used by scores-only plans;
+ * identical to kind 0 whenever all operands are f16-representable, e.g. one-hot x integer matrix).
+ * praline_plan_match_kind tells which of the two a plan's praline_plan_run uses. */
+int praline_arena_match_scores(praline_arena *arena, int32_t one, int32_t two, int kind, float *m);
+int praline_arena_info(const praline_arena *arena, int32_t *n_active, int32_t *mfma_steps_f32,
+                       int32_t *f16_ranges, int32_t *f16_terms);
+int praline_plan_match_kind(const praline_plan *plan);
+
 /* Timing of the last praline_plan_run on this plan, measured with HIP events on the launch
  * stream: kernel_ms = the DP kernel alone. */
 int praline_plan_last_timing(praline_plan *plan, float *kernel_ms);

@@ -1,0 +1,11 @@
+// dp_arena16.h -- device view of the f16 hi/lo operand arrays (see dp_split16.hip.h).
+#pragma once
+#include <stdint.h>
+struct Arena16Dev {
+    const char *P16;        // [rows_pad][2][slots][16 bytes]
+    const char *Q16;
+    const int32_t *row_off;
+    const int32_t *len;
+    int row_bytes;          // 2 * half_bytes
+    int half_bytes;         // 2 (pieces) * NR * 16
+};

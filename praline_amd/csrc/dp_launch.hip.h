@@ -3,6 +3,7 @@
 // compile in parallel.
 #pragma once
 #include "dp_kernels.hip.h"
+#include "dp_arena16.h"
 #include "praline_dp.h"
 
 struct LaunchArgs {
@@ -18,6 +19,8 @@ struct LaunchArgs {
     RunParams rp;
     unsigned n_tasks;
     hipStream_t stream;
+    const struct Arena16Dev *a16;  // non-null: run k_dp_split16 on these f16 operands
+    int nr16, nterm16;
     int split;  // 1: k_dp_split task layout (32 lane entries per task, float2 [max_l1+2][32] boundary)
 };
 
@@ -28,6 +31,12 @@ int praline_launch_split_10(const LaunchArgs &la, bool local);
 int praline_launch_split_12(const LaunchArgs &la, bool local);
 int praline_launch_split_14(const LaunchArgs &la, bool local);
 int praline_launch_split_16(const LaunchArgs &la, bool local);
+// k_dp_split16 and friends (dp_split16_instance.hip)
+int praline_launch_split16(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local);
+void praline_launch_split_f16(const float *src, int KP, int KS, int n_active, int NR, int64_t rows_pad, void *dst, int *flag,
+                              hipStream_t stream);
+int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int one, int two, int L1, int L2, float *m,
+                                 hipStream_t stream);
 // k_dp_batch instances (dp_instance.hip)
 int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, bool mask);
 int praline_launch_dp_8(const LaunchArgs &la, int tp, bool local, int out, bool mask);

@@ -1,0 +1,307 @@
+// dp_split16.hip.h -- k_dp_split16: the split-strip scores kernel with the match scores on the
+// MATRIX pipe (v_mfma_f32_32x32x16_f16) instead of the fp32 MFMA.
+//
+// Why: measured on MI355X (scripts/micro/mfma_valu.hip) the fp32-input MFMA occupies the vector
+// FP32 datapath - an fp32-MFMA wave and a VALU wave on one SIMD take the SUM of their times -
+// while f16/bf16 MFMAs run on the separate matrix pipe and overlap with the VALU recurrence.
+//
+// Arithmetic: every fp32 operand x is split exactly into two halves hi = f16(x), lo = f16(x - hi)
+// (22 significant bits), and the contraction m = sum_k Q2[x][k] * P1[y][k] is evaluated as
+//     sum_k ( qlo*phi + qhi*plo ) + sum_k qhi*phi          (the lo*lo term, <= 2^-22, is dropped)
+// in ONE fp32 accumulator, small terms first.  Products of f16 values are exact in fp32; the
+// result differs from the reference's fp32 evaluation by <~ 1e-6 relative (north_star allows
+// 1e-5).  EXACT mode (NTERM = 1): when every P and Q2 entry is exactly representable in f16 -
+// one-hot profiles x integer matrices, the reference's "integer scoring" - only the hi*hi term
+// is issued and every intermediate is an exactly representable integer: bit-identical results.
+//
+// Layout per arena row and k-parity half hh (lane >> 5): piece-major 16-byte slots
+//     [hi r0][hi r1]...[lo r0][lo r1]...   slot (piece, r) holds k = 16 r + 8 hh + 0..7
+// (lane l supplies A[row l&31][k = 8 (l>>5) + j] / B[k = 8 (l>>5) + j][col l&31], j = 0..7).
+//
+// Everything else (split-strip layout, two-lane wavefront, software pipeline, snapshots) is
+// dp_split.hip.h's; see there.
+#pragma once
+#include "dp_split.hip.h"
+#include "dp_arena16.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
+
+// NR: 16-wide k ranges (1: <= 16 active symbols, 2: <= 32); NTERM: 1 exact / 3 split.
+template <int NR, int NTERM, bool LOCAL>
+__device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
+                                             float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
+                                             const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR], const char *&b_next,
+                                             int b_stride, const char *&bnd_ld, char *&bnd_st, float2 &bnd_pref,
+                                             float (&Hp)[16], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
+                                             float &best_run, float &col_run, SplitOut &out, const SplitCtx &cx)
+{
+    constexpr int NP = (NTERM == 1) ? 1 : 2;   // pieces held per operand
+    constexpr int NM = NTERM * NR;             // MFMAs per step
+    // ---- match scores of this lane's row: lower half row t (CUR), upper half row t-1 (PREV) ----
+    float m[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) m[c] = h ? PREV[c] : CUR[c];
+
+    const float2 bv = bnd_pref;
+    bnd_pref = *reinterpret_cast<const float2 *>(bnd_ld);
+    bnd_ld += 32 * sizeof(float2);
+    float hd = h ? hd_x : dH;
+    float lrun = h ? l_x : bv.y;
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- MFMAs of row t+1 on the matrix pipe, interleaved with the recurrence of this row ----
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        // order: (qlo, phi) r.., (qhi, plo) r.., then (qhi, phi) r..   [small terms first]
+        const int term = (NTERM == 1) ? 2 : k / NR;
+        const int r = k % NR;
+        const int ia = (term == 0) ? NR + r : r;          // A piece: lo for term 0, hi otherwise
+        const int ib = (term == 1) ? NR + r : r;          // B piece: lo for term 1, hi otherwise
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+#pragma unroll
+        for (int c = (16 * k) / NM; c < (16 * (k + 1)) / NM; ++c) {
+            float M = hd + m[c];
+            if (LOCAL) M = __builtin_fmaxf(M, 0.0f);
+            const float U = Uc[c];
+            const float H = max3f(M, U, lrun);
+            if (LOCAL) best_run = __builtin_fmaxf(best_run, H);
+            const float Mo = M + cx.go;
+            Uc[c] = __builtin_fmaxf(Mo, U + cx.ge);
+            lrun = __builtin_fmaxf(Mo, lrun + cx.ge);
+            hd = Hp[c];
+            Hp[c] = H;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    PREV = acc;
+    {
+        const float4 *bsrc = reinterpret_cast<const float4 *>(b_next);
+#pragma unroll
+        for (int q = 0; q < NP * NR; ++q) BOPS[q] = bsrc[q];
+    }
+    b_next += b_stride;
+    dH = bv.x;
+    hd_x = from_lower_half(hd);
+    l_x = from_lower_half(lrun);
+
+    if (h) *reinterpret_cast<float2 *>(bnd_st) = make_float2(Hp[15], lrun);
+    bnd_st += 32 * sizeof(float2);
+    if (cx.semiglobal && cx.last_owner) col_run = __builtin_fmaxf(col_run, select16(Hp, cx.cidx));
+    if (have_pair && yy == L1) {
+        if (LOCAL) out.best = best_run;
+        if (cx.semiglobal) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                out.rowmax = __builtin_fmaxf(out.rowmax, (cx.xb + c + 1 <= cx.L2) ? Hp[c] : PRALINE_NEG_INF);
+            out.colmax = col_run;
+        }
+        if (cx.last_owner) out.corner = select16(Hp, cx.cidx);
+    }
+}
+
+
+template <int NR, int NTERM, bool LOCAL>
+__global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+                                                    const int32_t *__restrict__ lane_one,
+                                                    const int32_t *__restrict__ lane_pair, float2 *bnd,
+                                                    float *__restrict__ scores, RunParams rp, int n_tasks)
+{
+    constexpr int NP = (NTERM == 1) ? 1 : 2;
+    constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
+    const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const WaveTask tk = tasks[task];
+    const int base = task * 32;
+    const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
+    const float go = rp.go1, ge = rp.ge1;
+
+    const int my_one = lane_one[base + j];
+    const int two = tk.two[0];
+    const bool have_pair = my_one >= 0;
+    const int L1 = have_pair ? ar.len[my_one] : 0;
+    const int L2 = ar.len[two];
+    const int nstrips = (L2 + 31) >> 5;
+    const int clast = (L2 - 1) & 31;
+    const bool own_last = (clast >> 4) == h;
+    const int max_l1 = tk.max_l1;
+
+    const char *pB = ar.P16 + (int64_t)(have_pair ? ar.row_off[my_one] : 0) * ar.row_bytes + h * ar.half_bytes;
+    const int b_stride = ar.row_bytes;
+    const int acol = 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
+    const char *qA = ar.Q16 + ((int64_t)ar.row_off[two] + acol) * ar.row_bytes + h * ar.half_bytes;
+
+    char *my_bnd = reinterpret_cast<char *>(bnd + tk.bnd_off + j);  // float2 [y][32]
+    constexpr int BROW = 32 * (int)sizeof(float2);
+
+    const float o001 = free_one ? 0.0f : (go - ge);
+    const float o002 = free_two ? 0.0f : (go - ge);
+    const float h00 = max3f(0.0f, o001, o002);
+
+    if (h == 0)
+        for (int y = 1; y <= max_l1 + 2; ++y)
+            *reinterpret_cast<float2 *>(my_bnd + (int64_t)y * BROW) = make_float2(boundary_value(y, go, ge, free_one), PRALINE_NEG_INF);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+
+    SplitCtx cx;
+    cx.go = go; cx.ge = ge;
+    cx.semiglobal = rp.mode >= 2;
+    cx.cidx = clast & 15;
+    asm volatile("" : "+v"(cx.cidx));
+    cx.L2 = L2;
+
+    SplitOut out;
+    out.best = LOCAL ? h00 : 0.0f;
+    out.rowmax = (have_pair && h == 0) ? boundary_value(L1, go, ge, free_one) : PRALINE_NEG_INF;
+    out.colmax = (have_pair && own_last) ? boundary_value(L2, go, ge, free_two) : PRALINE_NEG_INF;
+    out.corner = PRALINE_NEG_INF;
+
+    for (int s = 0; s < nstrips; ++s) {
+        const int x0 = s * 32;
+        cx.xb = x0 + 16 * h;
+        cx.last_owner = (s == nstrips - 1) && own_last;
+
+        float4 aop[NOP];
+        {
+            const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.row_bytes);
+#pragma unroll
+            for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
+        }
+        float Hp[16], Uc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            Hp[c] = boundary_value(cx.xb + c + 1, go, ge, free_two);
+            Uc[c] = PRALINE_NEG_INF;
+        }
+        float dH = (s == 0) ? h00 : boundary_value(x0, go, ge, free_two);
+        float hd_x = PRALINE_NEG_INF, l_x = PRALINE_NEG_INF;
+        float best_run = out.best;
+        float col_run = out.colmax;
+
+        // pipeline prologue: B operands of rows 1..3, MFMAs of row 1, boundary of row 1
+        float4 bX[NOP], bY[NOP];
+        f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        f32x16 accB = accA;
+        {
+            float4 b1[NOP];
+            const float4 *s1 = reinterpret_cast<const float4 *>(pB);
+            const float4 *s2 = reinterpret_cast<const float4 *>(pB + b_stride);
+            const float4 *s3 = reinterpret_cast<const float4 *>(pB + 2 * b_stride);
+#pragma unroll
+            for (int q = 0; q < NOP; ++q) { b1[q] = s1[q]; bX[q] = s2[q]; bY[q] = s3[q]; }
+#pragma unroll
+            for (int k = 0; k < NTERM * NR; ++k) {
+                const int term = (NTERM == 1) ? 2 : k / NR;
+                const int r = k % NR;
+                const int ia = (term == 0) ? NR + r : r;
+                const int ib = (term == 1) ? NR + r : r;
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(b1[ib]), accA, 0, 0, 0);
+            }
+        }
+        const char *b_next = pB + 3 * b_stride;
+        const char *bnd_ld = my_bnd + 2 * BROW;
+        char *bnd_st = my_bnd;
+        float2 bnd_pref = *reinterpret_cast<const float2 *>(my_bnd + BROW);
+
+        {
+            float Hs[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Hs[c] = Hp[c];
+            const float best_s = best_run, col_s = col_run;
+            split16_step<NR, NTERM, LOCAL>(1 - h, L1, have_pair, h, accA, accB, bX, aop, b_next, b_stride, bnd_ld, bnd_st,
+                                           bnd_pref, Hp, Uc, dH, hd_x, l_x, best_run, col_run, out, cx);
+            if (h) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) { Hp[c] = Hs[c]; Uc[c] = PRALINE_NEG_INF; }
+                best_run = best_s;
+                col_run = col_s;
+            }
+        }
+        for (int t = 2; t <= max_l1 + 1; t += 2) {
+            split16_step<NR, NTERM, LOCAL>(t - h, L1, have_pair, h, accB, accA, bY, aop, b_next, b_stride, bnd_ld, bnd_st,
+                                           bnd_pref, Hp, Uc, dH, hd_x, l_x, best_run, col_run, out, cx);
+            split16_step<NR, NTERM, LOCAL>(t + 1 - h, L1, have_pair, h, accA, accB, bX, aop, b_next, b_stride, bnd_ld,
+                                           bnd_st, bnd_pref, Hp, Uc, dH, hd_x, l_x, best_run, col_run, out, cx);
+        }
+    }
+
+    const float corner_all = __builtin_fmaxf(out.corner, partner_value(out.corner, h));
+    const float rowmax_all = __builtin_fmaxf(out.rowmax, partner_value(out.rowmax, h));
+    const float colmax_all = __builtin_fmaxf(out.colmax, partner_value(out.colmax, h));
+    const float best_all = __builtin_fmaxf(out.best, partner_value(out.best, h));
+    if (have_pair && h == 0) {
+        float score;
+        if (LOCAL) score = best_all;
+        else if (cx.semiglobal) score = (rowmax_all > colmax_all && free_two) ? rowmax_all : colmax_all;
+        else score = corner_all;
+        scores[lane_pair[base + j]] = score;
+    }
+}
+
+// ---- arena side: split the fp32 parity-layout operands into f16 pieces ----------------------
+// src: P or Q in the fp32 layout [rowp][hh][KS] (k = 2 s + hh).  dst: [rowp][hh][piece][r][8 halves],
+// slot (piece, r) element jj holds k = 16 r + 8 hh + jj.  flag[0] is set when any value needs a
+// non-zero lo piece (i.e. the exact single-term mode is not applicable).
+__global__ void k_split_f16(const float *__restrict__ src, int KP, int KS, int n_active, int NR, int64_t rows_pad,
+                            _Float16 *__restrict__ dst, int *__restrict__ flag)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = 2 * NR * 8;  // (hh, r, jj) triples per row
+    if (idx >= rows_pad * per_row) return;  // (total is a multiple of 64: whole waves leave together)
+    const int64_t rowp = idx / per_row;
+    const int rem = (int)(idx % per_row);
+    const int hh = rem / (NR * 8), r = (rem / 8) % NR, jj = rem % 8;
+    const int k = 16 * r + 8 * hh + jj;
+    float v = 0.0f;
+    if (k < n_active) v = src[rowp * KP + (k & 1) * KS + (k >> 1)];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const int64_t half_elems = 2 * NR * 8;  // halves per (rowp, hh)
+    _Float16 *o = dst + (rowp * 2 + hh) * half_elems;
+    o[(0 * NR + r) * 8 + jj] = hi;
+    o[(1 * NR + r) * 8 + jj] = lo;
+    // flag == nullptr: the representability check was already done when the arena was created
+    if (flag != nullptr) {
+        const bool inexact = (float)lo != 0.0f || (float)hi + (float)lo != v;
+        if (__ballot(inexact) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    }
+}
+
+// Dense match-score matrix of one pair with EXACTLY the arithmetic of k_dp_split16 (diagnostics /
+// tests: the DP is verified bit-for-bit on these values).  One wave per 32x32 tile.
+template <int NR, int NTERM>
+__global__ __launch_bounds__(64) void k_scores_tile16(Arena16Dev ar, int one, int two, float *__restrict__ m)
+{
+    constexpr int NP = (NTERM == 1) ? 1 : 2;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int L1 = ar.len[one], L2 = ar.len[two];
+    const int y0 = blockIdx.y * 32, x0 = blockIdx.x * 32;
+    // B operand = profile rows of `one` (columns of the tile = rows y), A operand = Q rows of `two`
+    const float4 *pb = reinterpret_cast<const float4 *>(ar.P16 + ((int64_t)ar.row_off[one] + y0 + j) * ar.row_bytes + h * ar.half_bytes);
+    const float4 *qa = reinterpret_cast<const float4 *>(ar.Q16 + ((int64_t)ar.row_off[two] + x0 + j) * ar.row_bytes + h * ar.half_bytes);
+    float4 a[NP * NR], b[NP * NR];
+#pragma unroll
+    for (int q = 0; q < NP * NR; ++q) { a[q] = qa[q]; b[q] = pb[q]; }
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NTERM * NR; ++k) {
+        const int term = (NTERM == 1) ? 2 : k / NR;
+        const int r = k % NR;
+        const int ia = (term == 0) ? NR + r : r;
+        const int ib = (term == 1) ? NR + r : r;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(a[ia]), as_half8(b[ib]), acc, 0, 0, 0);
+    }
+    // D[i][jcol]: lane holds column jcol = j (row y0 + j of the DP), i = x within the strip
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int x = x0 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        const int y = y0 + j;
+        if (y < L1 && x < L2) m[(int64_t)y * L2 + x] = acc[rr];
+    }
+}

@@ -1,0 +1,49 @@
+// dp_split16_instance.hip -- k_dp_split16 / k_split_f16 / k_scores_tile16 instances; compiled with
+// -mllvm -amdgpu-mfma-vgpr-form.
+#include "dp_launch.hip.h"
+#include "dp_split16.hip.h"
+
+#include <cstdlib>
+
+template <int NR, int NTERM> static void launch16(const LaunchArgs &la, const Arena16Dev &a16, bool local, unsigned wpb)
+{
+    const dim3 grid((la.n_tasks + wpb - 1) / wpb), block(64 * wpb);
+    if (local)
+        hipLaunchKernelGGL((k_dp_split16<NR, NTERM, true>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,
+                           la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks);
+    else
+        hipLaunchKernelGGL((k_dp_split16<NR, NTERM, false>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,
+                           la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks);
+}
+
+int praline_launch_split16(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local)
+{
+    unsigned wpb = 1;  // wavefronts (= tasks) per workgroup
+    if (const char *env = getenv("PRALINE_WPB")) { const int v = atoi(env); if (v >= 1 && v <= 4) wpb = (unsigned)v; }
+    if (nr == 1 && nterm == 1) launch16<1, 1>(la, a16, local, wpb);
+    else if (nr == 1 && nterm == 3) launch16<1, 3>(la, a16, local, wpb);
+    else if (nr == 2 && nterm == 1) launch16<2, 1>(la, a16, local, wpb);
+    else if (nr == 2 && nterm == 3) launch16<2, 3>(la, a16, local, wpb);
+    else return PRALINE_ERR_UNSUPPORTED;
+    return PRALINE_OK;
+}
+
+void praline_launch_split_f16(const float *src, int KP, int KS, int n_active, int NR, int64_t rows_pad, void *dst, int *flag,
+                              hipStream_t stream)
+{
+    const int64_t total = rows_pad * 2 * NR * 8;
+    hipLaunchKernelGGL(k_split_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, KP, KS, n_active, NR,
+                       rows_pad, (_Float16 *)dst, flag);
+}
+
+int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int one, int two, int L1, int L2, float *m,
+                                 hipStream_t stream)
+{
+    const dim3 grid((unsigned)((L2 + 31) / 32), (unsigned)((L1 + 31) / 32));
+    if (nr == 1 && nterm == 1) hipLaunchKernelGGL((k_scores_tile16<1, 1>), grid, dim3(64), 0, stream, a16, one, two, m);
+    else if (nr == 1 && nterm == 3) hipLaunchKernelGGL((k_scores_tile16<1, 3>), grid, dim3(64), 0, stream, a16, one, two, m);
+    else if (nr == 2 && nterm == 1) hipLaunchKernelGGL((k_scores_tile16<2, 1>), grid, dim3(64), 0, stream, a16, one, two, m);
+    else if (nr == 2 && nterm == 3) hipLaunchKernelGGL((k_scores_tile16<2, 3>), grid, dim3(64), 0, stream, a16, one, two, m);
+    else return PRALINE_ERR_UNSUPPORTED;
+    return PRALINE_OK;
+}

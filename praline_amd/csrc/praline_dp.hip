@@ -13,6 +13,7 @@
 #define PRALINE_AUX_KERNELS 1
 #include "dp_kernels.hip.h"
 #include "dp_launch.hip.h"
+#include "dp_arena16.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -161,6 +162,18 @@ struct praline_arena {
     std::vector<int32_t> len, row_off_pad, row_off_raw, active;
     DevBuf<float> d_raw, d_S, d_P, d_Q;
     DevBuf<int32_t> d_len, d_row_off_pad, d_row_off_raw, d_seq_of_rowp, d_active;
+    // f16 split operands for k_dp_split16 (matrix-pipe MFMA)
+    int nr16 = 0;          // 16-wide k ranges (1 or 2); 0 = not available (> 32 active symbols)
+    int nterm16 = 3;       // 1: every operand is exactly representable in f16, 3: hi/lo split
+    DevBuf<char> d_P16, d_Q16;
+    DevBuf<int> d_flag16;
+    Arena16Dev view16() const
+    {
+        Arena16Dev v;
+        v.P16 = d_P16.p; v.Q16 = d_Q16.p; v.row_off = d_row_off_pad.p; v.len = d_len.p;
+        v.half_bytes = 2 * nr16 * 16; v.row_bytes = 2 * v.half_bytes;
+        return v;
+    }
     ArenaDev view() const
     {
         ArenaDev v;
@@ -169,7 +182,7 @@ struct praline_arena {
     }
 };
 
-static int arena_launch_premultiply(praline_arena *a)
+static int arena_launch_premultiply(praline_arena *a, bool check_f16 = false)
 {
     const int64_t total = a->rows_pad * a->KP;
     const int threads = 256;
@@ -181,6 +194,12 @@ static int arena_launch_premultiply(praline_arena *a)
     hipLaunchKernelGGL(k_premultiply, grid, dim3(64), 0, g_rt.stream, a->d_raw.p, a->d_S.p,
                        a->d_seq_of_rowp.p, a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p,
                        a->d_active.p, a->n_active, a->A, a->KP, a->KS, a->rows_pad, a->d_Q.p);
+    if (a->nr16 > 0) {
+        int *flag = check_f16 ? a->d_flag16.p : nullptr;
+        if (check_f16) HIPCHK(hipMemsetAsync(a->d_flag16.p, 0, sizeof(int), g_rt.stream));
+        praline_launch_split_f16(a->d_P.p, a->KP, a->KS, a->n_active, a->nr16, a->rows_pad, a->d_P16.p, flag, g_rt.stream);
+        praline_launch_split_f16(a->d_Q.p, a->KP, a->KS, a->n_active, a->nr16, a->rows_pad, a->d_Q16.p, flag, g_rt.stream);
+    }
     HIPCHK(hipGetLastError());
     return PRALINE_OK;
 }
@@ -234,6 +253,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     if (!a->nstep) { delete a; return fail(PRALINE_ERR_ARG, "too many active symbols (%d)", a->n_active); }
     a->KS = (a->nstep + 3) / 4 * 4;
     a->KP = 2 * a->KS;
+    a->nr16 = a->n_active <= 16 ? 1 : (a->n_active <= 32 ? 2 : 0);
 
     std::vector<int32_t> seq_of_rowp((size_t)a->rows_pad, -1);
     for (int64_t s = 0; s < n_seqs; ++s)
@@ -247,12 +267,21 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         (rc = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
         (rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
         (rc = a->d_P.alloc((size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc((size_t)a->rows_pad * a->KP)) ||
-        (rc = arena_launch_premultiply(a))) {
+        (rc = a->d_flag16.alloc(1)) ||
+        (a->nr16 > 0 && ((rc = a->d_P16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)) ||
+                         (rc = a->d_Q16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)))) ||
+        (rc = arena_launch_premultiply(a, true))) {
         delete a;
         return rc;
     }
     hipError_t e = hipStreamSynchronize(st);  // host vectors above go out of scope
     if (e != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena upload: %s", hipGetErrorString(e)); }
+    if (a->nr16 > 0) {
+        int flag = 1;
+        e = hipMemcpy(&flag, a->d_flag16.p, sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena flag: %s", hipGetErrorString(e)); }
+        a->nterm16 = flag ? 3 : 1;
+    }
     *out = a;
     return PRALINE_OK;
 }
@@ -474,6 +503,11 @@ static int launch_dp(int nstep, const LaunchArgs &la, int tp, bool local, int ou
     int rc = PRALINE_ERR_UNSUPPORTED;
     if (la.split) {
         if (out != 0 || mask) return fail(PRALINE_ERR_UNSUPPORTED, "k_dp_split is scores-only");
+        if (la.a16 != nullptr) {
+            rc = praline_launch_split16(la, *la.a16, la.nr16, la.nterm16, local);
+            if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16 instance for nr=%d nterm=%d", la.nr16, la.nterm16);
+            return PRALINE_OK;
+        }
         switch (nstep) {
             case 2: return praline_launch_split_2(la, local);
             case 8: return praline_launch_split_8(la, local);
@@ -521,6 +555,15 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     la.rp.ge1 = la.rp.ge2 = gap_extend;
     la.stream = g_rt.stream;
     la.split = pl.split ? 1 : 0;
+    // match scores on the matrix pipe (f16 hi/lo split) unless PRALINE_MM=f32 asks for the fp32 MFMA chain
+    Arena16Dev a16 = a.view16();
+    la.a16 = nullptr;
+    la.nr16 = a.nr16;
+    la.nterm16 = a.nterm16;
+    if (pl.split && a.nr16 > 0) {
+        const char *mm = getenv("PRALINE_MM");
+        if (!(mm && !strcmp(mm, "f32"))) la.a16 = &a16;
+    }
     const bool local = mode == PRALINE_MODE_LOCAL;
     pl.last_mode = mode;
     hipStream_t st = g_rt.stream;
@@ -865,4 +908,51 @@ extern "C" int praline_debug_tile(praline_arena *arena, const int32_t *lane_one,
     HIPCHK(hipMemcpyAsync(out, d_o.p, 64 * 32 * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
     HIPCHK(hipStreamSynchronize(g_rt.stream));
     return PRALINE_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// diagnostics: the dense match-score matrix of one arena pair exactly as the kernels evaluate it
+// --------------------------------------------------------------------------------------------
+extern "C" int praline_arena_match_scores(praline_arena *arena, int32_t one, int32_t two, int kind, float *m)
+{
+    if (!arena || !m) return fail(PRALINE_ERR_ARG, "NULL argument");
+    if (one < 0 || one >= arena->n_seqs || two < 0 || two >= arena->n_seqs) return fail(PRALINE_ERR_ARG, "index out of range");
+    RC(ensure_runtime(-1));
+    const int L1 = arena->len[one], L2 = arena->len[two];
+    DevBuf<float> d_m;
+    RC(d_m.alloc((size_t)L1 * L2));
+    if (kind == 0) {
+        dim3 grid((unsigned)((L2 + 31) / 32), (unsigned)((L1 + 31) / 32));
+        hipLaunchKernelGGL(k_scores_tile, grid, dim3(64), 0, g_rt.stream, arena->view(), one, two, arena->nstep, d_m.p);
+    } else if (kind == 1) {
+        if (arena->nr16 == 0) return fail(PRALINE_ERR_UNSUPPORTED, "no f16 operands for this arena");
+        int rc = praline_launch_scores_tile16(arena->view16(), arena->nr16, arena->nterm16, one, two, L1, L2, d_m.p, g_rt.stream);
+        if (rc != PRALINE_OK) return fail(rc, "no k_scores_tile16 instance");
+    } else return fail(PRALINE_ERR_ARG, "kind must be 0 (fp32 MFMA chain) or 1 (f16 split)");
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(m, d_m.p, (size_t)L1 * L2 * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_info(const praline_arena *arena, int32_t *n_active, int32_t *mfma_steps_f32, int32_t *f16_ranges,
+                                  int32_t *f16_terms)
+{
+    if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    if (n_active) *n_active = arena->n_active;
+    if (mfma_steps_f32) *mfma_steps_f32 = arena->nstep;
+    if (f16_ranges) *f16_ranges = arena->nr16;
+    if (f16_terms) *f16_terms = arena->nterm16;
+    return PRALINE_OK;
+}
+
+// Which match-score arithmetic praline_plan_run uses for this plan: 0 = fp32 MFMA chain, 1 = f16 split.
+extern "C" int praline_plan_match_kind(const praline_plan *plan)
+{
+    if (!plan) return -1;
+    if (plan->split && plan->arena->nr16 > 0) {
+        const char *mm = getenv("PRALINE_MM");
+        if (!(mm && !strcmp(mm, "f32"))) return 1;
+    }
+    return 0;
 }

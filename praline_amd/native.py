@@ -72,6 +72,10 @@ def lib():
     L.praline_plan_paths.argtypes = [vp, vp, vp, vp]
     L.praline_batch_scores.argtypes = [vp, i32, f32, f32, i64, vp, vp]
     L.praline_plan_last_timing.argtypes = [vp, ctypes.POINTER(f32)]
+    L.praline_arena_match_scores.argtypes = [vp, i32, i32, i32, vp]
+    L.praline_arena_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                     ctypes.POINTER(i32)]
+    L.praline_plan_match_kind.argtypes = [vp]
     if L.praline_abi_version() != 1:
         raise NativeError(ERR_ARG, "ABI version mismatch")
     _lib = L
@@ -206,6 +210,18 @@ class Arena(object):
     def premultiply(self):
         _check(lib().praline_arena_premultiply(self._h))
 
+    def match_scores(self, one, two, kind=0):
+        """Dense match-score matrix of a pair exactly as the kernels evaluate it (diagnostics):
+        kind 0 = fp32 MFMA chain, kind 1 = f16 hi/lo split on the matrix pipe."""
+        m = np.zeros((int(self.lens[one]), int(self.lens[two])), dtype=np.float32)
+        _check(lib().praline_arena_match_scores(self._h, int(one), int(two), int(kind), m.ctypes.data))
+        return m
+
+    def info(self):
+        vals = [ctypes.c_int(0) for _ in range(4)]
+        _check(lib().praline_arena_info(self._h, *[ctypes.byref(v) for v in vals]))
+        return dict(zip(("n_active", "mfma_steps_f32", "f16_ranges", "f16_terms"), [v.value for v in vals]))
+
     def close(self):
         if getattr(self, "_h", None):
             lib().praline_arena_destroy(self._h)
@@ -256,6 +272,10 @@ class Plan(object):
         out = np.zeros(self.n, dtype=np.float32)
         _check(lib().praline_plan_scores(self._h, out.ctypes.data))
         return out
+
+    def match_kind(self):
+        """0: this plan's run() evaluates match scores with the fp32 MFMA chain, 1: f16 split."""
+        return int(lib().praline_plan_match_kind(self._h))
 
     def device_scores_ptr(self):
         return lib().praline_plan_device_scores(self._h)

@@ -23,10 +23,16 @@ def bits(a):
 
 
 def oracle_dp_on_device_m(mode, p1, p2, S, gaps=GAPS, zero_idxs=None):
-    """Oracle DP fed with the match scores in the device's (fma-chain) evaluation order."""
+    """Oracle DP fed with the match scores in the fp32-MFMA (fma-chain) evaluation order."""
     m = orc.build_scores_fma([p1], [p2], [S])
     g1, g2 = orc.gap_arrays(m.shape[0], m.shape[1], gaps)
     return orc.raw_pairwise_align(mode, m, g1, g2, zero_idxs)
+
+
+def oracle_dp_on_m(mode, m, gaps=GAPS, zero_idxs=None):
+    """Oracle DP (fill, end cell, traceback) on a given match-score matrix."""
+    g1, g2 = orc.gap_arrays(m.shape[0], m.shape[1], gaps)
+    return orc.raw_pairwise_align(mode, np.ascontiguousarray(m), g1, g2, zero_idxs)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -167,6 +173,41 @@ def test_batch_float_profiles(nat, bba):
             assert sc[k] == np.float32(s_or), (mode, i, j)
             assert np.array_equal(paths[k], p_or), (mode, i, j)
         plan.close()
+        # scores-only plan: match scores on the matrix pipe (f16 hi/lo split); the DP must be
+        # bit-identical to the oracle DP on the device's own match scores, and the scores stay
+        # within 1e-5 relative of the reference
+        plan = nat.Plan(arena, pairs)
+        kind = plan.match_kind()
+        plan.run(mode, *GAPS)
+        sc = plan.scores()
+        plan.close()
+        for k, (i, j) in enumerate(pairs):
+            ref = float(d["score_%d_%d_%s" % (i, j, mode)])
+            assert abs(sc[k] - ref) <= 1e-5 * max(1.0, abs(ref)), (mode, i, j, sc[k], ref)
+            s_or, _ = oracle_dp_on_m(mode, arena.match_scores(i, j, kind))
+            assert sc[k] == np.float32(s_or), (mode, i, j, kind)
+    # the f16-split match scores against the reference's own evaluation order
+    assert arena.info()["f16_terms"] == 3
+    for (i, j) in ((0, 4), (2, 3)):
+        m_ref = d["m_%d_%d" % (i, j)]
+        for kind in (0, 1):
+            m_dev = arena.match_scores(i, j, kind)
+            assert np.abs(m_dev - m_ref).max() <= 2e-6 * np.abs(m_ref).max(), (i, j, kind)
+    arena.close()
+
+
+def test_exact_mode_for_integer_scoring(nat, bba):
+    """One-hot x integer matrix: every operand is f16-representable, the matrix-pipe path runs its
+    single-term exact mode and its match scores equal the fp32 chain's (and the reference's) bitwise."""
+    profs = [one_hot(s, 27) for s in bba["seqs"]]
+    arena = nat.Arena(profs, bba["S"])
+    assert arena.info()["f16_terms"] == 1
+    m0, m1 = arena.match_scores(0, 4, 0), arena.match_scores(0, 4, 1)
+    assert np.array_equal(bits(m0), bits(m1))
+    m_ref = np.zeros_like(m0)
+    orc.cext_build_scores([profs[0]], [profs[4]], [orc.build_nonzero_matrix(profs[0])],
+                          [orc.build_nonzero_matrix(profs[4])], [bba["S"]], m_ref)
+    assert np.array_equal(m0, m_ref)
     arena.close()
 
 
@@ -217,12 +258,18 @@ def test_batch_random_vs_oracle(nat, bba, kind):
         plan0.run(mode, *GAPS)
         sc0 = plan0.scores()
         plan0.close()
-        assert np.array_equal(bits(sc), bits(sc0)), mode  # both kernel variants agree
+        if kind == "onehot":
+            assert np.array_equal(bits(sc), bits(sc0)), mode  # integer scoring: all kernels agree bitwise
+        else:
+            assert np.abs(sc - sc0).max() <= 1e-5 * np.abs(sc).max(), mode
+        mk = 1 if arena.info()["f16_ranges"] > 0 else 0
         for k in range(0, len(pairs), 3):
             i, j = pairs[k]
             s_or, p_or = oracle_dp_on_device_m(mode, profs[i], profs[j], S)
             assert sc[k] == np.float32(s_or), (mode, i, j)
             assert np.array_equal(paths[k], p_or), (mode, i, j)
+            s16, _ = oracle_dp_on_m(mode, arena.match_scores(i, j, mk))
+            assert sc0[k] == np.float32(s16), (mode, i, j)
     arena.close()
 
 
@@ -260,6 +307,8 @@ def test_batch_c2_slice_properties(nat, bba):
     assert (loc >= semi).all() and (semi >= sc[::97]).all()
     for k in range(0, len(pairs), 4001):
         i, j = pairs[k]
-        s_or, _ = oracle_dp_on_device_m("global", profs[i], profs[j], S)
+        s_or, _ = oracle_dp_on_m("global", arena.match_scores(i, j, 1))
         assert sc[k] == np.float32(s_or)
+        s_ref = orc.pairwise_score_fast("global", profs[i], profs[j], S, *GAPS)
+        assert abs(sc[k] - s_ref) <= 1e-5 * abs(s_ref)   # vs the reference evaluation order
     arena.close()
