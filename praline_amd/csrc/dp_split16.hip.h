@@ -37,6 +37,9 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
                                              float (&Hp)[16], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
                                              float &best_run, float &col_run, SplitOut &out, const SplitCtx &cx)
 {
+    // bnd_pref: this step's boundary value on entry; refilled with the value 3 rows ahead.
+    // BOPS: B operands of row t+1 on entry; refilled with row t+4 (3-deep rings, the caller rotates
+    // the register names through a 6x unrolled loop).
     constexpr int NP = (NTERM == 1) ? 1 : 2;   // pieces held per operand
     constexpr int NM = NTERM * NR;             // MFMAs per step
     // ---- match scores of this lane's row: lower half row t (CUR), upper half row t-1 (PREV) ----
@@ -184,38 +187,44 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         float best_run = out.best;
         float col_run = out.colmax;
 
-        // pipeline prologue: B operands of rows 1..3, MFMAs of row 1, boundary of row 1
-        float4 bX[NOP], bY[NOP];
+        // pipeline prologue: B operands of rows 1..4, MFMAs of row 1, boundary column of rows 1..3
+        float4 b0[NOP], b1[NOP], b2[NOP];
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
         {
-            float4 b1[NOP];
+            float4 br1[NOP];
             const float4 *s1 = reinterpret_cast<const float4 *>(pB);
             const float4 *s2 = reinterpret_cast<const float4 *>(pB + b_stride);
             const float4 *s3 = reinterpret_cast<const float4 *>(pB + 2 * b_stride);
+            const float4 *s4 = reinterpret_cast<const float4 *>(pB + 3 * b_stride);
 #pragma unroll
-            for (int q = 0; q < NOP; ++q) { b1[q] = s1[q]; bX[q] = s2[q]; bY[q] = s3[q]; }
+            for (int q = 0; q < NOP; ++q) { br1[q] = s1[q]; b0[q] = s2[q]; b1[q] = s3[q]; b2[q] = s4[q]; }
 #pragma unroll
             for (int k = 0; k < NTERM * NR; ++k) {
                 const int term = (NTERM == 1) ? 2 : k / NR;
                 const int r = k % NR;
                 const int ia = (term == 0) ? NR + r : r;
                 const int ib = (term == 1) ? NR + r : r;
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(b1[ib]), accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(br1[ib]), accA, 0, 0, 0);
             }
         }
-        const char *b_next = pB + 3 * b_stride;
-        const char *bnd_ld = my_bnd + 2 * BROW;
-        char *bnd_st = my_bnd;
-        float2 bnd_pref = *reinterpret_cast<const float2 *>(my_bnd + BROW);
+        const char *b_next = pB + 4 * b_stride;                   // first refill: row 5
+        const char *bnd_ld = my_bnd + 4 * BROW;                   // first prefetch inside a step: row 4
+        char *bnd_st = my_bnd;                                    // upper half stores row yy = t - 1 (row 0: dummy)
+        float2 p0 = *reinterpret_cast<const float2 *>(my_bnd + BROW);      // row 1
+        float2 p1 = *reinterpret_cast<const float2 *>(my_bnd + 2 * BROW);  // row 2
+        float2 p2 = *reinterpret_cast<const float2 *>(my_bnd + 3 * BROW);  // row 3
 
+#define PRALINE_STEP16(T, CUR, PREV, BSET, PSLOT)                                                                     \
+        split16_step<NR, NTERM, LOCAL>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld, bnd_st, \
+                                       PSLOT, Hp, Uc, dH, hd_x, l_x, best_run, col_run, out, cx)
+        // step 1: only the lower half has a row; the upper half's garbage is undone right after
         {
             float Hs[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) Hs[c] = Hp[c];
             const float best_s = best_run, col_s = col_run;
-            split16_step<NR, NTERM, LOCAL>(1 - h, L1, have_pair, h, accA, accB, bX, aop, b_next, b_stride, bnd_ld, bnd_st,
-                                           bnd_pref, Hp, Uc, dH, hd_x, l_x, best_run, col_run, out, cx);
+            PRALINE_STEP16(1, accA, accB, b0, p0);
             if (h) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) { Hp[c] = Hs[c]; Uc[c] = PRALINE_NEG_INF; }
@@ -223,12 +232,18 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                 col_run = col_s;
             }
         }
-        for (int t = 2; t <= max_l1 + 1; t += 2) {
-            split16_step<NR, NTERM, LOCAL>(t - h, L1, have_pair, h, accB, accA, bY, aop, b_next, b_stride, bnd_ld, bnd_st,
-                                           bnd_pref, Hp, Uc, dH, hd_x, l_x, best_run, col_run, out, cx);
-            split16_step<NR, NTERM, LOCAL>(t + 1 - h, L1, have_pair, h, accA, accB, bX, aop, b_next, b_stride, bnd_ld,
-                                           bnd_st, bnd_pref, Hp, Uc, dH, hd_x, l_x, best_run, col_run, out, cx);
+        // steps 2 .. max_l1 + 1: six per iteration - the accumulators ping-pong (period 2), the B operand
+        // sets and the boundary prefetch slots rotate (period 3); steps past max_l1 + 1 compute rows that
+        // nobody reports
+        for (int t = 2; t <= max_l1 + 1; t += 6) {
+            PRALINE_STEP16(t, accB, accA, b1, p1);
+            PRALINE_STEP16(t + 1, accA, accB, b2, p2);
+            PRALINE_STEP16(t + 2, accB, accA, b0, p0);
+            PRALINE_STEP16(t + 3, accA, accB, b1, p1);
+            PRALINE_STEP16(t + 4, accB, accA, b2, p2);
+            PRALINE_STEP16(t + 5, accA, accB, b0, p0);
         }
+#undef PRALINE_STEP16
     }
 
     const float corner_all = __builtin_fmaxf(out.corner, partner_value(out.corner, h));

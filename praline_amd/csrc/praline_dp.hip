@@ -436,7 +436,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             }
         }
         wt.bnd_off = bnd;
-        bnd += split ? (int64_t)(wt.max_l1 + 4) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
+        bnd += split ? (int64_t)(wt.max_l1 + 12) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
         wt.tb_off = 0;
         wt.aux_off = 0;
         pl->tb_elems[t] = (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;

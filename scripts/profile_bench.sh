@@ -21,7 +21,7 @@ for row in csv.DictReader(open(f)):
     k = (row.get('Kernel_Name', '')[:40], row.get('Counter_Name'))
     agg[k][0] += float(row.get('Counter_Value', 0)); agg[k][1] += 1
 for (kn, cn), (v, n) in sorted(agg.items()):
-    if 'k_dp_batch' in kn or 'premult' in kn:
+    if "k_dp_" in kn:
         print("%-42s %-28s per-launch %.4g (n=%d)" % (kn, cn, v / n, n))
 PY
 done
