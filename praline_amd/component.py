@@ -1,0 +1,484 @@
+"""Operator (plugin) layer of the hot path: same type ids, ports, options, defaults and output keys
+as the reference components, with the numeric work on the MI355X through native.py.
+
+  PairwiseAligner       praline/component/align.py:37-251      -> fused device path (arena + plan)
+  RawPairwiseAligner    praline/component/align.py:254-447     -> raw device path (m, g1, g2, z given)
+  ProfileBuilder        praline/component/profile.py:15-74
+  Global/Local/DummyMasterSlaveAligner   praline/component/preprofile.py:19-269  (callers: one
+                        device submission per Waterman-Eggert iteration instead of one call per slave)
+  GuideTreeBuilder      praline/component/tree.py:18-170       (caller: ONE scores-only submission for
+                        all N(N-1)/2 pairs; clustering restated from praline/util/cluster.py:27-114)
+  BatchManager          the Manager.execute_many seam (praline/core/manager.py:154-170): a homogeneous
+                        list of PairwiseAligner requests becomes one device submission.
+
+There is no CPU arithmetic here: every alignment goes through libpraline_dp.so.
+"""
+import numpy as np
+
+from . import native
+from .container import (Alignment, GapScoreModel, MatchScoreModel, PlainTrack, ProfileTrack,
+                        ScoreMatrix, Sequence, SequenceTree, TRACK_ID_INPUT)
+from .core import (BeginMessage, CompleteMessage, Component, ComponentError, DataError, Environment,
+                   Execution, Manager, MESSAGE_KIND_COMPLETE, Port, ProgressMessage, T)
+from .util import (auto_align_mode, compress_path, extend_path_local, get_frequencies,
+                   zero_idxs_to_rectangles)
+
+MODES = ("global", "local", "semiglobal_both", "semiglobal_one", "semiglobal_two")
+
+
+# ---- profile preparation (praline/component/align.py:114-189) ------------------------------------
+def _track_profile(track):
+    """PlainTrack -> one-hot, ProfileTrack -> counts / rowsum, float32 [L, A] (align.py:163-177)."""
+    if track.tid == PlainTrack.tid:
+        profile = np.zeros((len(track), track.alphabet.size), dtype=np.float32)
+        profile[np.arange(len(track)), track.values] = 1.0
+        return profile
+    if track.tid == ProfileTrack.tid:
+        return track.profile.astype(np.float32)
+    raise DataError("unknown track type id for this aligner: '{0}'".format(track.tid))
+
+
+def _validate_track_sets(sequence_one, sequence_two, track_id_sets_one, track_id_sets_two, score_matrices):
+    if len(track_id_sets_one) != len(track_id_sets_two):
+        raise ComponentError("should have an identical number of track id sets for both sequences")
+    for n, (ids_one, ids_two) in enumerate(zip(track_id_sets_one, track_id_sets_two)):
+        sm = score_matrices[n]
+        if len(ids_one) != 1 or len(ids_two) != 1:
+            raise ComponentError("the fast aligner only supports single-track alignments at the moment")
+        if sm.matrix.ndim != len(ids_one) + len(ids_two):
+            raise ComponentError("the score matrix must consist of as many dimensions as there are "
+                                 "tracks to be aligned ({0}), but it contains {1}".format(
+                                     len(ids_one) + len(ids_two), sm.matrix.ndim))
+        t1 = sequence_one.get_track(ids_one[0])
+        t2 = sequence_two.get_track(ids_two[0])
+        if sm.alphabets[0].aid != t1.alphabet.aid:
+            raise DataError("track 0 for sequence one has alphabet '{0}' but the corresponding dimension "
+                            "in the score matrix has alphabet '{1}'".format(t1.alphabet.aid, sm.alphabets[0].aid))
+        if sm.alphabets[1].aid != t2.alphabet.aid:
+            raise DataError("track 0 for sequence two has alphabet '{0}' but the corresponding dimension "
+                            "in the score matrix has alphabet '{1}'".format(t2.alphabet.aid, sm.alphabets[1].aid))
+
+
+def _normalise_gap_series(gap_series):
+    gap_series = list(gap_series)
+    if len(gap_series) == 1:
+        return [gap_series[0], gap_series[0]]
+    if len(gap_series) == 2:
+        return gap_series
+    raise ComponentError("the fast aligner only supports linear and affine gap penalties at the moment")
+
+
+def _block_diagonal(score_matrices):
+    """Several track sets = one concatenated alphabet with a block-diagonal matrix: the reference sums
+    the per-set scores (praline/util/cext.c:389-420)."""
+    mats = [np.asarray(sm.matrix, dtype=np.float32) for sm in score_matrices]
+    sizes = [max(m.shape) for m in mats]
+    S = np.zeros((sum(sizes), sum(sizes)), dtype=np.float32)
+    off = 0
+    for m, sz in zip(mats, sizes):
+        S[off:off + m.shape[0], off:off + m.shape[1]] = m
+        off += sz
+    return S, sizes
+
+
+class PairwiseBatch(object):
+    """A homogeneous set of PairwiseAligner requests (same track sets, score matrices and gap series)
+    executed as ONE device submission per alignment mode."""
+
+    def __init__(self, track_id_sets_one, track_id_sets_two, score_matrices, gap_series):
+        self.ids_one = [ids[0] for ids in track_id_sets_one]
+        self.ids_two = [ids[0] for ids in track_id_sets_two]
+        self.score_matrices = score_matrices
+        self.gap_open, self.gap_extend = _normalise_gap_series(gap_series)
+        self.S, self.sizes = _block_diagonal(score_matrices)
+        self._index = {}      # (id(sequence), role) -> arena index
+        self._profiles = []
+        self.requests = []    # (mode, arena_one, arena_two, rects or None)
+
+    def _arena_index(self, sequence, role):
+        key = (id(sequence), role if self.ids_one != self.ids_two else 0)
+        if key not in self._index:
+            ids = self.ids_one if role == 0 else self.ids_two
+            parts = []
+            for tid_, sz in zip(ids, self.sizes):
+                p = _track_profile(sequence.get_track(tid_))
+                if p.shape[1] < sz:
+                    p = np.pad(p, ((0, 0), (0, sz - p.shape[1])))
+                parts.append(p)
+            self._index[key] = len(self._profiles)
+            self._profiles.append(np.concatenate(parts, axis=1) if len(parts) > 1 else parts[0])
+        return self._index[key]
+
+    def add(self, mode, sequence_one, sequence_two, rects=None):
+        if mode not in MODES:
+            raise ComponentError("unknown alignment mode: '{0}'".format(mode))
+        self.requests.append((mode, self._arena_index(sequence_one, 0), self._arena_index(sequence_two, 1), rects))
+        return len(self.requests) - 1
+
+    def run(self, want_paths=True):
+        """Returns (scores float list, paths list or None) in request order."""
+        n = len(self.requests)
+        scores = [None] * n
+        paths = [None] * n if want_paths else None
+        if n == 0:
+            return scores, paths
+        arena = native.Arena(self._profiles, self.S)
+        try:
+            for mode in MODES:
+                sel = [k for k, r in enumerate(self.requests) if r[0] == mode]
+                if not sel:
+                    continue
+                pairs = np.array([(self.requests[k][1], self.requests[k][2]) for k in sel], dtype=np.int32)
+                rects = None
+                if any(self.requests[k][3] for k in sel):
+                    rects = [list(self.requests[k][3] or []) for k in sel]
+                plan = native.Plan(arena, pairs, want_paths=want_paths or rects is not None, rects=rects)
+                try:
+                    plan.run(mode, self.gap_open, self.gap_extend)
+                    sc = plan.scores()
+                    pt = plan.paths() if want_paths else None
+                finally:
+                    plan.close()
+                for q, k in enumerate(sel):
+                    scores[k] = float(sc[q])
+                    if want_paths:
+                        paths[k] = pt[q]
+        finally:
+            arena.close()
+        return scores, paths
+
+
+def _path_for_output(mode, path):
+    """The reference hands back a list of (y, x) tuples for global / local alignments and an int array
+    for semiglobal ones (praline/component/align.py:401-433)."""
+    if mode.startswith("semiglobal"):
+        return np.asarray(path, dtype=int)
+    return [(int(y), int(x)) for y, x in path]
+
+
+class PairwiseAligner(Component):
+    """Profile-profile pairwise aligner (praline/component/align.py:37-251): same ports, options and
+    outputs.  Match scores (P1 . S . P2^T) and the three-state affine fill, end-cell selection and
+    traceback all run on the device; nothing but the score and the path comes back."""
+    tid = "praline.component.PairwiseAligner"
+    inputs = {'mode': Port(str),
+              'sequence_one': Port(Sequence.tid),
+              'sequence_two': Port(Sequence.tid),
+              'track_id_sets_one': Port([[str]]),
+              'track_id_sets_two': Port([[str]]),
+              'zero_idxs': Port([(int, int)], optional=True),
+              'score_matrices': Port([ScoreMatrix.tid])}
+    outputs = {'alignment': Port(Alignment.tid), 'score': Port(float)}
+    options = {'gap_series': [float], 'debug': int}
+    defaults = {'gap_series': [-11.0, -1.0], 'debug': 0}
+
+    def execute(self, mode, sequence_one, sequence_two, track_id_sets_one, track_id_sets_two, zero_idxs,
+                score_matrices):
+        _validate_track_sets(sequence_one, sequence_two, track_id_sets_one, track_id_sets_two, score_matrices)
+        gap_series = _normalise_gap_series(self.environment['gap_series'])
+        if mode not in MODES:
+            raise ComponentError("unknown alignment mode: '{0}'".format(mode))
+        rects = None
+        if zero_idxs:
+            rects = zero_idxs_to_rectangles(zero_idxs)
+        if zero_idxs and rects is None:
+            # arbitrary zero_idxs: dense mask through the raw path (match scores built on the device)
+            outputs = self._execute_raw(mode, sequence_one, sequence_two, track_id_sets_one,
+                                        track_id_sets_two, zero_idxs, score_matrices, gap_series)
+        else:
+            batch = PairwiseBatch(track_id_sets_one, track_id_sets_two, score_matrices, gap_series)
+            batch.add(mode, sequence_one, sequence_two, rects)
+            scores, paths = batch.run(want_paths=True)
+            outputs = {'alignment': Alignment([sequence_one, sequence_two], _path_for_output(mode, paths[0])),
+                       'score': scores[0]}
+        yield CompleteMessage(outputs=outputs)
+
+    def _execute_raw(self, mode, sequence_one, sequence_two, ids_one, ids_two, zero_idxs, score_matrices, gap_series):
+        i1 = [_track_profile(sequence_one.get_track(ids[0])) for ids in ids_one]
+        i2 = [_track_profile(sequence_two.get_track(ids[0])) for ids in ids_two]
+        s = [sm.matrix.astype(np.float32) for sm in score_matrices]
+        m = np.zeros((i1[0].shape[0], i2[0].shape[0]), dtype=np.float32)
+        native.cext_build_scores(i1, i2, None, None, s, m)
+        g1 = np.empty((m.shape[0], 2), dtype=np.float32)
+        g2 = np.empty((m.shape[1], 2), dtype=np.float32)
+        g1[:, 0], g1[:, 1] = gap_series
+        g2[:, 0], g2[:, 1] = gap_series
+        z = np.zeros((m.shape[0] + 1, m.shape[1] + 1), dtype=np.uint8)
+        for idx in zero_idxs:
+            z[idx] = 1
+        score, path = native.raw_align(mode, m, g1, g2, z)
+        return {'alignment': Alignment([sequence_one, sequence_two], _path_for_output(mode, path)),
+                'score': float(score)}
+
+
+class RawPairwiseAligner(Component):
+    """Raw pairwise aligner (praline/component/align.py:254-447): caller-supplied match and gap score
+    models; boundary init, fill, end cell, traceback and semiglobal extension on the device.  The
+    reference's `accelerate` option is accepted; there is no non-accelerated path here."""
+    tid = "praline.component.RawPairwiseAligner"
+    inputs = {'mode': Port(str),
+              'sequence_one': Port(Sequence.tid),
+              'sequence_two': Port(Sequence.tid),
+              'match_score_model': Port(MatchScoreModel.tid),
+              'gap_score_model_one': Port(GapScoreModel.tid),
+              'gap_score_model_two': Port(GapScoreModel.tid),
+              'zero_idxs': Port([(int, int)], optional=True)}
+    outputs = {'alignment': Port(Alignment.tid), 'score': Port(float)}
+    options = {'debug': int, 'accelerate': bool}
+    defaults = {'debug': 0, 'accelerate': True}
+
+    def execute(self, mode, sequence_one, sequence_two, match_score_model, gap_score_model_one,
+                gap_score_model_two, zero_idxs):
+        if mode not in MODES:
+            raise ComponentError("unknown alignment mode: '{0}'".format(mode))
+        m = np.ascontiguousarray(match_score_model.scores, dtype=np.float32)
+        g1 = np.ascontiguousarray(gap_score_model_one.scores, dtype=np.float32)
+        g2 = np.ascontiguousarray(gap_score_model_two.scores, dtype=np.float32)
+        z = None
+        if zero_idxs:
+            z = np.zeros((m.shape[0] + 1, m.shape[1] + 1), dtype=np.uint8)
+            for idx in zero_idxs:
+                z[idx] = 1
+        score, path = native.raw_align(mode, m, g1, g2, z)
+        alignment = Alignment([sequence_one, sequence_two], _path_for_output(mode, path))
+        yield CompleteMessage(outputs={'alignment': alignment, 'score': float(score)})
+
+
+class ProfileBuilder(Component):
+    """Alignment -> per-column symbol counts -> ProfileTrack (praline/component/profile.py:15-74)."""
+    tid = "praline.component.ProfileBuilder"
+    inputs = {'alignment': Port(Alignment.tid), 'track_id': Port(str)}
+    outputs = {'profile_track': Port(ProfileTrack.tid)}
+    options = {'debug': int}
+    defaults = {'debug': 0}
+
+    def execute(self, alignment, track_id):
+        freqs = get_frequencies(alignment, track_id)
+        track = alignment.items[0].get_track(track_id)
+        yield CompleteMessage(outputs={'profile_track': ProfileTrack(freqs, track.alphabet)})
+
+
+# ---- callers: master-slave (preprofile) stage ----------------------------------------------------
+def _identity_alignment(sequence):
+    return Alignment([sequence], np.arange(len(sequence) + 1).reshape(len(sequence) + 1, 1))
+
+
+def merge_master_slave(master_sequence, slave_sequences, results, threshold, local):
+    """Grow the master-slave alignment (praline/component/preprofile.py:146-152,258-265): per slave and
+    per (score, path) result that passes the threshold, drop the rows where the master does not
+    advance, pad local paths with -1 rows, and merge the slave in."""
+    alignment = _identity_alignment(master_sequence)
+    for slave, res in zip(slave_sequences, results):
+        for score, path in res:
+            if threshold is None or score >= threshold:
+                path = compress_path(np.array(path, dtype=int), 0)
+                if local:
+                    path = extend_path_local(path, len(master_sequence), 0)
+                alignment = alignment.merge(_identity_alignment(slave), path)
+    return alignment
+
+
+class DummyMasterSlaveAligner(Component):
+    """praline/component/preprofile.py:19-63"""
+    tid = "praline.component.DummyMasterSlaveAligner"
+    inputs = {'master_sequence': Port(Sequence.tid),
+              'slave_sequences': Port([Sequence.tid]),
+              'track_id_sets': Port([[str]]),
+              'score_matrices': Port([ScoreMatrix.tid], optional=True)}
+    outputs = {'alignment': Port(Alignment.tid)}
+    options = {}
+    defaults = {}
+
+    def execute(self, master_sequence, slave_sequences, track_id_sets, score_matrices):
+        yield CompleteMessage({'alignment': _identity_alignment(master_sequence)})
+
+
+class GlobalMasterSlaveAligner(Component):
+    """praline/component/preprofile.py:67-156: master vs every slave in global mode, compressed to the
+    master's columns and merged.  All slaves are aligned in one device submission."""
+    tid = "praline.component.GlobalMasterSlaveAligner"
+    inputs = {'master_sequence': Port(Sequence.tid),
+              'slave_sequences': Port([Sequence.tid]),
+              'track_id_sets': Port([[str]]),
+              'score_matrices': Port([ScoreMatrix.tid])}
+    outputs = {'alignment': Port(Alignment.tid)}
+    options = {'gap_series': [float], 'aligner': str, 'aligner_env': Environment.tid,
+               'score_threshold': T(float, nullable=True)}
+    defaults = {'gap_series': [-11.0, -1.0], 'aligner': PairwiseAligner.tid,
+                'score_threshold': None, 'aligner_env': Environment({})}
+
+    def execute(self, master_sequence, slave_sequences, track_id_sets, score_matrices):
+        threshold = self.environment['score_threshold']
+        for s in slave_sequences:
+            _validate_track_sets(master_sequence, s, track_id_sets, track_id_sets, score_matrices)
+        batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
+        for s in slave_sequences:
+            batch.add("global", master_sequence, s)
+        scores, paths = batch.run(want_paths=True)
+        alignment = merge_master_slave(master_sequence, slave_sequences,
+                                       [[(scores[j], paths[j])] for j in range(len(slave_sequences))],
+                                       threshold, local=False)
+        yield ProgressMessage(1.0)
+        yield CompleteMessage({'alignment': alignment})
+
+
+class LocalMasterSlaveAligner(Component):
+    """praline/component/preprofile.py:158-269: local alignments with Waterman-Eggert re-alignment; the
+    bounding rectangle of each path is masked for the next iteration (preprofile.py:247-255).  One
+    device submission per iteration covers all slaves."""
+    tid = "praline.component.LocalMasterSlaveAligner"
+    inputs = GlobalMasterSlaveAligner.inputs
+    outputs = {'alignment': Port(Alignment.tid)}
+    options = {'gap_series': [float], 'aligner': str, 'aligner_env': Environment.tid,
+               'waterman_eggert_iterations': int, 'score_threshold': T(float, nullable=True)}
+    defaults = {'gap_series': [-11.0, -1.0], 'aligner': PairwiseAligner.tid, 'score_threshold': None,
+                'aligner_env': Environment({}), 'waterman_eggert_iterations': 2}
+
+    def execute(self, master_sequence, slave_sequences, track_id_sets, score_matrices):
+        threshold = self.environment['score_threshold']
+        iterations = self.environment['waterman_eggert_iterations']
+        for s in slave_sequences:
+            _validate_track_sets(master_sequence, s, track_id_sets, track_id_sets, score_matrices)
+        rects = [[] for _ in slave_sequences]
+        results = [[] for _ in slave_sequences]   # per slave: (score, path) per iteration
+        for _ in range(iterations):
+            batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
+            for j, s in enumerate(slave_sequences):
+                batch.add("local", master_sequence, s, list(rects[j]))
+            scores, paths = batch.run(want_paths=True)
+            for j in range(len(slave_sequences)):
+                p = np.array(paths[j], dtype=int)
+                results[j].append((scores[j], p))
+                rects[j].append((int(p[:, 0].min()), int(p[:, 0].max()), int(p[:, 1].min()), int(p[:, 1].max())))
+        alignment = merge_master_slave(master_sequence, slave_sequences, results, threshold, local=True)
+        yield ProgressMessage(1.0)
+        yield CompleteMessage({'alignment': alignment})
+
+
+# ---- callers: guide tree (all-pairs distance stage) ----------------------------------------------
+def merge_order(distance_matrix, linkage):
+    """Agglomerative clustering merge order (praline/util/cluster.py:27-114): repeatedly merge the two
+    clusters with the smallest linkage distance (first minimum in cluster-id order), the merged
+    cluster keeps the id of the first."""
+    d = np.asarray(distance_matrix, dtype=float)
+    reduce_fn = {'single': np.min, 'complete': np.max, 'average': np.mean}[linkage]
+    clusters = {i: [i] for i in range(d.shape[0])}
+    order = []
+    while len(clusters) > 1:
+        ids = list(clusters.keys())
+        a = np.full((len(ids), len(ids)), np.inf)
+        for i, ci in enumerate(ids):
+            for j, cj in enumerate(ids):
+                if ci != cj:
+                    a[i, j] = reduce_fn(d[np.ix_(clusters[ci], clusters[cj])])
+        i, j = np.unravel_index(a.argmin(), a.shape)
+        one, two = ids[i], ids[j]
+        clusters[one] = clusters[one] + clusters[two]
+        del clusters[two]
+        order.append((one, two))
+    return order
+
+
+class GuideTreeBuilder(Component):
+    """praline/component/tree.py:18-170.  Only the scores of the N(N-1)/2 alignments are consumed
+    (tree.py:142-145), so the whole stage is one scores-only submission (k_dp_split16)."""
+    tid = "praline.component.GuideTreeBuilder"
+    inputs = {'sequences': Port([Sequence.tid]),
+              'track_id_sets': Port([[str]]),
+              'score_matrices': Port([ScoreMatrix.tid])}
+    outputs = {'guide_tree': Port(SequenceTree.tid)}
+    options = {'gap_series': [float], 'aligner': str, 'aligner_env': Environment.tid,
+               'linkage_method': str, 'squash_profiles': bool, 'dist_mode': str, 'debug': int}
+    defaults = {'gap_series': [-11.0, -1.0], 'aligner': PairwiseAligner.tid, 'aligner_env': Environment({}),
+                'linkage_method': 'average', 'squash_profiles': False, 'dist_mode': 'global', 'debug': 0}
+
+    def execute(self, sequences, track_id_sets, score_matrices):
+        linkage = self.environment['linkage_method']
+        dist_mode = self.environment['dist_mode']
+        if linkage not in ('single', 'complete', 'average'):
+            raise ComponentError("unknown linkage method '{0}'".format(linkage))
+        if dist_mode not in ('semiglobal', 'global', 'semiglobal_auto'):
+            raise ComponentError("unknown alignment mode '{0}'".format(dist_mode))
+        n = len(sequences)
+        batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
+        idxs = []
+        for i in range(n):
+            for j in range(i + 1, n):  # tree.py:105-129: each unordered pair once, i outer
+                _validate_track_sets(sequences[i], sequences[j], track_id_sets, track_id_sets, score_matrices)
+                if dist_mode == "semiglobal":
+                    mode = "semiglobal_both"
+                elif dist_mode == "global":
+                    mode = "global"
+                else:
+                    mode = auto_align_mode(sequences[i], sequences[j])
+                batch.add(mode, sequences[i], sequences[j])
+                idxs.append((i, j))
+        scores, _ = batch.run(want_paths=False)
+        d = np.zeros((n, n), dtype=np.float32)  # tree.py:99-100,131: diagonal 0
+        for (i, j), sc in zip(idxs, scores):
+            d[i, j] = d[j, i] = sc
+        self.score_matrix = d
+        dist = (-d) + d.max()  # tree.py:147
+        tree = SequenceTree(sequences, merge_order(dist, linkage))
+        yield CompleteMessage({'guide_tree': tree})
+
+
+COMPONENTS = [PairwiseAligner, RawPairwiseAligner, ProfileBuilder, DummyMasterSlaveAligner,
+              GlobalMasterSlaveAligner, LocalMasterSlaveAligner, GuideTreeBuilder]
+
+
+# ---- the batching seam -----------------------------------------------------------------------------
+class BatchManager(Manager):
+    """Manager whose execute_many recognises a homogeneous list of PairwiseAligner requests (what
+    Execution.run hands over for the reference's all-pairs fan-outs, praline/core/execution.py:158-188)
+    and runs it as one device submission per mode; anything else falls back to the serial loop."""
+
+    def execute_many(self, requests, parent_tag):
+        self._require_open()
+        requests = list(requests)
+        if len(requests) < 2 or any(tid != PairwiseAligner.tid for tid, _, _, _ in requests):
+            for message in Manager.execute_many(self, requests, parent_tag):
+                yield message
+            return
+        groups = {}
+        for k, (tid, inputs, tag, env) in enumerate(requests):
+            component = PairwiseAligner(self, env, tag)
+            self._check_request(component, inputs, env)
+            _validate_track_sets(inputs['sequence_one'], inputs['sequence_two'], inputs['track_id_sets_one'],
+                                 inputs['track_id_sets_two'], inputs['score_matrices'])
+            rects = None
+            if inputs.get('zero_idxs'):
+                rects = zero_idxs_to_rectangles(inputs['zero_idxs'])
+                if rects is None:
+                    groups.setdefault(('serial', k), []).append(k)
+                    continue
+            key = (tuple(map(tuple, inputs['track_id_sets_one'])), tuple(map(tuple, inputs['track_id_sets_two'])),
+                   tuple(id(sm) for sm in inputs['score_matrices']), tuple(env['gap_series']))
+            groups.setdefault(key, []).append((k, rects))
+        results = [None] * len(requests)
+        for key, members in groups.items():
+            if key[0] == 'serial':
+                continue
+            first = requests[members[0][0]]
+            batch = PairwiseBatch(first[1]['track_id_sets_one'], first[1]['track_id_sets_two'],
+                                  first[1]['score_matrices'], first[3]['gap_series'])
+            for k, rects in members:
+                inputs = requests[k][1]
+                batch.add(inputs['mode'], inputs['sequence_one'], inputs['sequence_two'], rects)
+            scores, paths = batch.run(want_paths=True)
+            for (k, _), sc, pt in zip(members, scores, paths):
+                inputs = requests[k][1]
+                results[k] = {'alignment': Alignment([inputs['sequence_one'], inputs['sequence_two']],
+                                                     _path_for_output(inputs['mode'], pt)),
+                              'score': sc}
+        for k, (tid, inputs, tag, env) in enumerate(requests):
+            if results[k] is None:
+                for message in self._invoke(tid, inputs, tag, env, parent_tag=parent_tag):
+                    yield message
+                continue
+            begin = BeginMessage(parent_tag)
+            begin.tag = tag
+            yield begin
+            done = CompleteMessage(outputs=results[k])
+            done.tag = tag
+            yield done

@@ -1,0 +1,177 @@
+"""GPU tests of the operator layer: the reference's plugin API (type ids, ports, Execution) driving
+the HIP path, checked against golden vectors from the real reference."""
+import numpy as np
+import pytest
+
+from conftest import MODES, load_golden
+from oracle import oracle as orc
+from praline_amd import component as comp
+from praline_amd import container as ct
+from praline_amd import core
+
+pytestmark = pytest.mark.gpu
+T_IN = [[ct.TRACK_ID_INPUT]]
+
+
+@pytest.fixture(scope="module")
+def env():
+    from praline_amd import native
+    native.init(0)
+    idx = core.TypeIndex()
+    idx.autoregister()
+    return {"index": idx, "serial": core.Manager(idx), "batch": comp.BatchManager(idx), "blosum": ct.blosum62()}
+
+
+@pytest.fixture(scope="module")
+def seqs(bba):
+    return [ct.Sequence("seq%03d" % (i + 1), [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=v))])
+            for i, v in enumerate(bba["seqs"])]
+
+
+def run_one(manager, component, env_keys=None, **inputs):
+    ex = core.Execution(manager, "root")
+    ex.add_task(component).environment(core.Environment({}), core.Environment(dict(env_keys or {}))).inputs(**inputs)
+    return core.run(ex)[0]
+
+
+def test_pairwise_aligner_kats(env, seqs):
+    d = load_golden("kat_pairwise.npz")
+    for (i, j) in ((0, 1), (0, 4), (2, 3)):
+        for mode in MODES:
+            out = run_one(env["serial"], comp.PairwiseAligner, mode=mode, sequence_one=seqs[i], sequence_two=seqs[j],
+                          track_id_sets_one=T_IN, track_id_sets_two=T_IN, score_matrices=[env["blosum"]])
+            assert isinstance(out['score'], float) and out['score'] == float(d["score_%d_%d_%s" % (i, j, mode)])
+            path = out['alignment'].path
+            if mode.startswith("semiglobal"):
+                assert isinstance(path, np.ndarray)
+            else:
+                assert isinstance(path, list) and isinstance(path[0], tuple)
+            assert np.array_equal(np.array(path), d["path_%d_%d_%s" % (i, j, mode)])
+            assert out['alignment'].items == [seqs[i], seqs[j]]
+
+
+def test_batch_manager_is_equivalent(env, seqs):
+    d = load_golden("kat_pairwise.npz")
+    ex = core.Execution(env["batch"], "root")
+    keys = []
+    for i in range(5):
+        for j in range(i + 1, 5):
+            for mode in MODES:
+                ex.add_task(comp.PairwiseAligner).environment(core.Environment({}), core.Environment({})).inputs(
+                    mode=mode, sequence_one=seqs[i], sequence_two=seqs[j], track_id_sets_one=T_IN,
+                    track_id_sets_two=T_IN, score_matrices=[env["blosum"]])
+                keys.append((i, j, mode))
+    kinds = [m.kind for m in ex.run()]
+    assert kinds.count("begin") == len(keys) and kinds.count("complete") == len(keys)
+    for (i, j, mode), out in zip(keys, ex.outputs):
+        assert out['score'] == float(d["score_%d_%d_%s" % (i, j, mode)])
+        assert np.array_equal(np.array(out['alignment'].path), d["path_%d_%d_%s" % (i, j, mode)])
+
+
+def test_master_slave_aligners_and_profile_builder(env, seqs):
+    d = load_golden("preprofile.npz")
+    for key, component, master, keys in (("global_m0_", comp.GlobalMasterSlaveAligner, 0, {}),
+                                         ("global_m2_", comp.GlobalMasterSlaveAligner, 2, {}),
+                                         ("local_m0_", comp.LocalMasterSlaveAligner, 0, {}),
+                                         ("local_m4_", comp.LocalMasterSlaveAligner, 4, {}),
+                                         ("local_thr_m0_", comp.LocalMasterSlaveAligner, 0, {"score_threshold": 100.0}),
+                                         ("local_we3_m0_", comp.LocalMasterSlaveAligner, 0, {"waterman_eggert_iterations": 3})):
+        slaves = [s for k, s in enumerate(seqs) if k != master]
+        out = run_one(env["serial"], component, keys, master_sequence=seqs[master], slave_sequences=slaves,
+                      track_id_sets=T_IN, score_matrices=[env["blosum"]])
+        assert np.array_equal(np.asarray(out['alignment'].path), d[key + "msa_path"]), key
+        prof = run_one(env["serial"], comp.ProfileBuilder, alignment=out['alignment'], track_id=ct.TRACK_ID_INPUT)
+        assert np.array_equal(prof['profile_track'].counts, d[key + "profile_counts"]), key
+        assert np.array_equal(prof['profile_track'].profile, d[key + "profile_f32"]), key
+
+
+def test_guide_tree_on_preprofiles(env, seqs):
+    d = load_golden("profile_profile.npz")
+    pre = [ct.Sequence(s.name, [(ct.TRACK_ID_INPUT, s.get_track(ct.TRACK_ID_INPUT)),
+                                (ct.TRACK_ID_PREPROFILE, ct.ProfileTrack(d["counts%d" % i], ct.ALPHABET_AA))])
+           for i, s in enumerate(seqs)]
+    ex = core.Execution(env["serial"], "root")
+    ex.add_task(comp.GuideTreeBuilder).environment(core.Environment({}), core.Environment({})).inputs(
+        sequences=pre, track_id_sets=[[ct.TRACK_ID_PREPROFILE]], score_matrices=[env["blosum"]])
+    tree = core.run(ex)[0]['guide_tree']
+    assert [tuple(x) for x in tree.merge_orders] == [tuple(x) for x in d["merge_order"]]
+    # profile-profile alignments through the operator API: float scoring within 1e-5 of the reference
+    for (i, j) in ((0, 4), (1, 3)):
+        for mode in ("global", "local", "semiglobal_both"):
+            out = run_one(env["serial"], comp.PairwiseAligner, mode=mode, sequence_one=pre[i], sequence_two=pre[j],
+                          track_id_sets_one=[[ct.TRACK_ID_PREPROFILE]], track_id_sets_two=[[ct.TRACK_ID_PREPROFILE]],
+                          score_matrices=[env["blosum"]])
+            ref = float(d["score_%d_%d_%s" % (i, j, mode)])
+            assert abs(out['score'] - ref) <= 1e-5 * max(1.0, abs(ref))
+            assert np.array_equal(np.array(out['alignment'].path), d["path_%d_%d_%s" % (i, j, mode)])
+
+
+def test_multitrack_sets(env, seqs, bba):
+    d = load_golden("multitrack.npz")
+    motif_alpha = ct.Alphabet("golden.motif", [("*", 0), ("M", 1)])
+    ss_alpha = ct.Alphabet("golden.ss", [("C", 0), ("H", 1), ("E", 2)])
+    motif_sm = ct.ScoreMatrix(None, [motif_alpha, motif_alpha], matrix=bba["motif_matrix"])
+    ss_sm = ct.ScoreMatrix(None, [ss_alpha, ss_alpha], matrix=bba["ss_matrix"])
+    ms = [ct.Sequence(s.name, [(ct.TRACK_ID_INPUT, s.get_track(ct.TRACK_ID_INPUT)),
+                               ("golden.motif", ct.PlainTrack(None, motif_alpha, raw_indices=bba["motif"][i])),
+                               ("golden.ss", ct.PlainTrack(None, ss_alpha, raw_indices=bba["ss"][i]))])
+          for i, s in enumerate(seqs)]
+    for nsets, tracks, sms in ((2, [[ct.TRACK_ID_INPUT], ["golden.motif"]], [env["blosum"], motif_sm]),
+                               (3, [[ct.TRACK_ID_INPUT], ["golden.motif"], ["golden.ss"]], [env["blosum"], motif_sm, ss_sm])):
+        for (i, j) in ((0, 1), (0, 4), (2, 3)):
+            for mode in ("global", "local", "semiglobal_both"):
+                out = run_one(env["serial"], comp.PairwiseAligner, mode=mode, sequence_one=ms[i], sequence_two=ms[j],
+                              track_id_sets_one=tracks, track_id_sets_two=tracks, score_matrices=sms)
+                k = "s%d_%d_%d_%s_" % (nsets, i, j, mode)
+                assert out['score'] == float(d[k + "score"]), k
+                assert np.array_equal(np.array(out['alignment'].path), d[k + "path"]), k
+
+
+def test_raw_pairwise_aligner_and_arbitrary_zero_idxs(env, seqs):
+    d = load_golden("fill_small.npz")
+    for n in range(int(d["n_cases"])):
+        p = "c%03d_" % n
+        mode = str(d[p + "mode"])
+        m = d[p + "m"]
+        a = ct.Sequence("a", [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=np.zeros(m.shape[0], int)))])
+        b = ct.Sequence("b", [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=np.zeros(m.shape[1], int)))])
+        zi = [tuple(int(v) for v in r) for r in d[p + "zero_idxs"]] if (p + "zero_idxs") in d.files else None
+        out = run_one(env["serial"], comp.RawPairwiseAligner, mode=mode, sequence_one=a, sequence_two=b,
+                      match_score_model=ct.MatchScoreModel(a, b, m), gap_score_model_one=ct.GapScoreModel(a, d[p + "g1"]),
+                      gap_score_model_two=ct.GapScoreModel(b, d[p + "g2"]), zero_idxs=zi)
+        assert out['score'] == float(d[p + "score"]) and np.array_equal(np.array(out['alignment'].path), d[p + "path"]), n
+    # PairwiseAligner with a scattered (non-rectangular) mask goes through the dense-mask path
+    rng = np.random.default_rng(4)
+    zi = [(int(rng.integers(1, 100)), int(rng.integers(1, 100))) for _ in range(60)]
+    out = run_one(env["serial"], comp.PairwiseAligner, mode="local", sequence_one=seqs[4], sequence_two=seqs[3],
+                  track_id_sets_one=T_IN, track_id_sets_two=T_IN, score_matrices=[env["blosum"]], zero_idxs=zi)
+    from conftest import one_hot
+    s_ref, p_ref = orc.pairwise_align("local", [one_hot(seqs[4].get_track(ct.TRACK_ID_INPUT).values, 27)],
+                                      [one_hot(seqs[3].get_track(ct.TRACK_ID_INPUT).values, 27)], [env["blosum"].matrix],
+                                      zero_idxs=zi)
+    assert out['score'] == s_ref and np.array_equal(np.array(out['alignment'].path), p_ref)
+
+
+def test_error_behaviour(env, seqs):
+    base = dict(sequence_one=seqs[0], sequence_two=seqs[1], track_id_sets_one=T_IN, track_id_sets_two=T_IN,
+                score_matrices=[env["blosum"]])
+    with pytest.raises(core.ComponentError):
+        run_one(env["serial"], comp.PairwiseAligner, mode="banana", **base)
+    with pytest.raises(core.ComponentError):
+        run_one(env["serial"], comp.PairwiseAligner, {"gap_series": [-1.0, -2.0, -3.0]}, mode="global", **base)
+    with pytest.raises(core.ComponentError):
+        run_one(env["serial"], comp.PairwiseAligner, mode="global", **dict(base, track_id_sets_two=[]))
+    with pytest.raises(core.ComponentError):
+        run_one(env["serial"], comp.PairwiseAligner, mode="global",
+                **dict(base, track_id_sets_one=[[ct.TRACK_ID_INPUT, ct.TRACK_ID_INPUT]]))
+    with pytest.raises(core.DataError):
+        run_one(env["serial"], comp.PairwiseAligner, mode="global", **dict(base, score_matrices=[ct.nucleotide_matrix()]))
+    with pytest.raises(core.DataError):
+        run_one(env["serial"], comp.PairwiseAligner, mode=3, **base)
+    # single gap value = linear gaps (align.py:182-183)
+    out = run_one(env["serial"], comp.PairwiseAligner, {"gap_series": [-4.0]}, mode="global", **base)
+    from conftest import one_hot
+    s_ref, p_ref = orc.pairwise_align("global", [one_hot(seqs[0].get_track(ct.TRACK_ID_INPUT).values, 27)],
+                                      [one_hot(seqs[1].get_track(ct.TRACK_ID_INPUT).values, 27)], [env["blosum"].matrix],
+                                      gap_series=[-4.0])
+    assert out['score'] == s_ref and np.array_equal(np.array(out['alignment'].path), p_ref)

@@ -1,0 +1,209 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no native compute):
+core runtime semantics, containers, path utilities and the master-slave merge logic, checked against
+the golden vectors generated from the real reference."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from praline_amd import component as comp
+from praline_amd import container as ct
+from praline_amd import core, util
+
+
+def make_seqs(bba):
+    return [ct.Sequence("seq%03d" % (i + 1), [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=v))])
+            for i, v in enumerate(bba["seqs"])]
+
+
+def test_alphabets_and_matrices(bba):
+    assert ct.ALPHABET_AA.size == 27 and ct.ALPHABET_DNA.size == 15 and ct.ALPHABET_RNA.size == 4
+    assert [ct.ALPHABET_AA.symbol_to_index(c) for c in "ARNDCEQ*"] == [0, 1, 2, 3, 4, 5, 6, 26]
+    assert np.array_equal(ct.blosum62().matrix, bba["S"])
+    assert np.array_equal(ct.nucleotide_matrix().matrix, load_golden("synthetic_dna.npz")["matrix"])
+    with pytest.raises(core.AlphabetError):
+        ct.ALPHABET_AA.symbol_to_index("?")
+    t = ct.PlainTrack("ARN*", ct.ALPHABET_AA)
+    assert t.values.dtype == np.int32 and list(t.values) == [0, 1, 2, 26]
+
+
+def test_sequence_track_rules():
+    a = ct.PlainTrack("ARND", ct.ALPHABET_AA)
+    s = ct.Sequence("s", [(ct.TRACK_ID_INPUT, a)])
+    assert len(s) == 4
+    with pytest.raises(core.DataError):
+        s.add_track(ct.TRACK_ID_INPUT, a)
+    with pytest.raises(core.DataError):
+        s.add_track("other", ct.PlainTrack("AR", ct.ALPHABET_AA))
+    with pytest.raises(core.DataError):
+        s.get_track("missing")
+    s.replace_track(ct.TRACK_ID_INPUT, ct.PlainTrack("AR", ct.ALPHABET_AA))
+    assert len(s) == 2
+
+
+def test_profile_track_normalisation_and_merge():
+    d = load_golden("profile_profile.npz")
+    for i in range(5):
+        tr = ct.ProfileTrack(d["counts%d" % i], ct.ALPHABET_AA)
+        assert np.array_equal(tr.profile, d["profile%d" % i])  # sequence.py:200-202
+    a = ct.ProfileTrack([[1, 0, 2], [0, 3, 0]], ct.Alphabet("x", [("a", 0), ("b", 1), ("c", 2)]))
+    b = ct.ProfileTrack([[0, 1, 0]], a.alphabet)
+    merged = a.merge(b, np.array([[0, 0], [1, 0], [2, 1]]))
+    assert np.array_equal(merged.counts, [[1, 0, 2], [0, 4, 0]])
+
+
+def test_environment_inheritance():
+    class C(core.Component):
+        options = {'x': int, 'sub': core.Environment.tid}
+        defaults = {'x': 1, 'y': 5, 'sub': core.Environment({'a': 1})}
+
+    parent = core.Environment({'x': 2, 'sub': core.Environment({'b': 2})})
+    env = parent.collapse(C, core.Environment({'z': 3, 'sub': core.Environment({'c': 3})}))
+    assert env['x'] == 2 and env['y'] == 5 and env['z'] == 3
+    assert env['sub'].keys == {'a': 1, 'b': 2, 'c': 3}
+
+
+def test_manager_checks_ports_and_options():
+    class Echo(core.Component):
+        tid = "test.Echo"
+        inputs = {'value': core.Port(int), 'opt': core.Port(str, optional=True)}
+        outputs = {'value': core.Port(int)}
+        options = {'k': int}
+        defaults = {'k': 1}
+
+        def execute(self, value, opt):
+            yield core.ProgressMessage(0.5)
+            yield core.CompleteMessage({'value': value + self.environment['k']})
+
+    idx = core.TypeIndex()
+    idx.register(Echo)
+    man = core.Manager(idx)
+    ex = core.Execution(man, "root")
+    ex.add_task(Echo).environment(core.Environment({}), core.Environment({'k': 4})).inputs(value=3)
+    kinds = [m.kind for m in ex.run()]
+    assert kinds == ["begin", "progress", "complete"] and ex.outputs[0]['value'] == 7
+    ex = core.Execution(man, "root")
+    ex.add_task(Echo).inputs(value="no")
+    with pytest.raises(core.DataError):
+        list(ex.run())
+    ex = core.Execution(man, "root")
+    ex.add_task(Echo).inputs()
+    with pytest.raises(core.DataError):
+        list(ex.run())
+    with pytest.raises(core.ComponentError):
+        idx.resolve("nope")
+    with pytest.raises(core.ComponentError):
+        core.Execution(man).outputs
+    with pytest.raises(core.SignatureError):
+        core.check_signature([int, str])
+    man.close()
+    with pytest.raises(core.PralineError):
+        list(man.execute_many([], None))
+
+
+def test_component_declarations_match_reference():
+    """Type ids, ports, options and defaults of the hot-path components (align.py:75-86,289-300;
+    profile.py:32-39)."""
+    pa = comp.PairwiseAligner
+    assert pa.tid == "praline.component.PairwiseAligner"
+    assert set(pa.inputs) == {'mode', 'sequence_one', 'sequence_two', 'track_id_sets_one',
+                              'track_id_sets_two', 'zero_idxs', 'score_matrices'}
+    assert pa.inputs['zero_idxs'].optional and not pa.inputs['mode'].optional
+    assert set(pa.outputs) == {'alignment', 'score'}
+    assert pa.defaults == {'gap_series': [-11.0, -1.0], 'debug': 0}
+    raw = comp.RawPairwiseAligner
+    assert raw.tid == "praline.component.RawPairwiseAligner"
+    assert set(raw.inputs) == {'mode', 'sequence_one', 'sequence_two', 'match_score_model',
+                               'gap_score_model_one', 'gap_score_model_two', 'zero_idxs'}
+    assert raw.defaults == {'debug': 0, 'accelerate': True}
+    pb = comp.ProfileBuilder
+    assert pb.tid == "praline.component.ProfileBuilder" and set(pb.inputs) == {'alignment', 'track_id'}
+    idx = core.TypeIndex()
+    idx.autoregister()
+    for cls in comp.COMPONENTS:
+        assert idx.resolve(cls.tid) is cls
+
+
+def test_path_utilities_and_master_slave_merge(bba):
+    """compress_path / extend_path_local / Alignment.merge / get_frequencies (util/align.py:187-266,
+    container/align.py:30-61): feed the reference's own inner alignment results (golden) through the
+    host logic and compare the merged master-slave alignment and the ProfileBuilder counts."""
+    d = load_golden("preprofile.npz")
+    seqs = make_seqs(bba)
+    for key, master, local, iters, thr in (("global_m0_", 0, False, 1, None), ("global_m2_", 2, False, 1, None),
+                                           ("global_m4_", 4, False, 1, None), ("local_m0_", 0, True, 2, None),
+                                           ("local_m4_", 4, True, 2, None), ("local_thr_m0_", 0, True, 2, 100.0),
+                                           ("local_we3_m0_", 0, True, 3, None)):
+        slaves = [k for k in range(5) if k != master]
+        results, c = [], 0
+        for _ in slaves:
+            res = []
+            for _ in range(iters):
+                res.append((float(d[key + "call%d_score" % c]), d[key + "call%d_path" % c]))
+                c += 1
+            results.append(res)
+        assert c == int(d[key + "n_calls"])
+        aln = comp.merge_master_slave(seqs[master], [seqs[k] for k in slaves], results, thr, local)
+        assert np.array_equal(np.asarray(aln.path), d[key + "msa_path"]), key
+        assert [s.name for s in aln.items] == [str(x) for x in d[key + "msa_names"]]
+        freqs = util.get_frequencies(aln, ct.TRACK_ID_INPUT)
+        assert np.array_equal(freqs, d[key + "profile_counts"]), key
+        out = list(comp.ProfileBuilder(None, core.Environment({'debug': 0}), "t").execute(aln, ct.TRACK_ID_INPUT))[-1].outputs
+        assert np.array_equal(out['profile_track'].profile, d[key + "profile_f32"]), key
+
+
+def test_extend_path_semiglobal_matches_oracle():
+    from oracle import oracle as orc
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        n, m = (int(v) for v in rng.integers(2, 30, 2))
+        y0, x0 = (int(rng.integers(0, n)), 0) if rng.random() < 0.5 else (0, int(rng.integers(0, m)))
+        path = [(y0, x0)]
+        while path[-1][0] < n - 1 and path[-1][1] < m - 1 and rng.random() < 0.9:
+            y, x = path[-1]
+            step = rng.integers(0, 3)
+            path.append((y + (step != 2), x + (step != 1)))
+        path = np.array(path)
+        assert np.array_equal(util.extend_path_semiglobal(path, (n, m)), orc.extend_path_semiglobal(path, (n, m)))
+
+
+def test_zero_idxs_rectangles():
+    zi = [(y, x) for y in range(3, 7) for x in range(10, 15)] + [(y, x) for y in range(1, 3) for x in range(2, 4)]
+    assert util.zero_idxs_to_rectangles(zi) == [(3, 6, 10, 14), (1, 2, 2, 3)]
+    assert util.zero_idxs_to_rectangles([(1, 1), (3, 3), (5, 5), (7, 7), (9, 9), (11, 11)]) is None
+    assert util.zero_idxs_to_rectangles([]) == []
+    # a parsed rectangle list always reproduces the same mask
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        rects = []
+        for _ in range(int(rng.integers(1, 4))):
+            y0, x0 = (int(v) for v in rng.integers(0, 20, 2))
+            rects.append((y0, y0 + int(rng.integers(0, 6)), x0, x0 + int(rng.integers(0, 6))))
+        zi = [(y, x) for (a, b, c, e) in rects for y in range(a, b + 1) for x in range(c, e + 1)]
+        parsed = util.zero_idxs_to_rectangles(zi)
+        z1 = np.zeros((40, 40), bool)
+        z2 = np.zeros((40, 40), bool)
+        for idx in zi:
+            z1[idx] = True
+        for (a, b, c, e) in parsed:
+            z2[a:b + 1, c:e + 1] = True
+        assert np.array_equal(z1, z2)
+
+
+def test_merge_order_matches_reference(bba):
+    d = load_golden("profile_profile.npz")
+    assert [tuple(x) for x in d["merge_order"]] == comp.merge_order(d["dist"], "average")
+    dist = np.array([[0, 2, 6, 10], [2, 0, 5, 9], [6, 5, 0, 4], [10, 9, 4, 0]], float)
+    assert comp.merge_order(dist, "single") == [(0, 1), (2, 3), (0, 2)]
+    assert comp.merge_order(dist, "complete") == [(0, 1), (2, 3), (0, 2)]
+
+
+def test_all_pairs_sharding_helpers():
+    from praline_amd import allpairs
+    pairs = allpairs.enumerate_pairs(5)
+    assert [tuple(p) for p in pairs][:5] == [(0, 1), (0, 2), (0, 3), (0, 4), (1, 2)] and len(pairs) == 10
+    cells = np.array([5, 1, 1, 1, 1, 1, 5, 5, 1, 1])
+    for world in (1, 2, 3, 8, 16):
+        b = allpairs.shard_bounds(cells, world)
+        assert b[0] == 0 and b[-1] == len(cells) and all(b[i] <= b[i + 1] for i in range(world))
+    d, dist = allpairs.scores_to_distance(3, [(0, 1), (0, 2), (1, 2)], np.array([5.0, -2.0, 1.0], np.float32))
+    assert d[0, 1] == d[1, 0] == 5.0 and d[1, 1] == 0.0 and np.array_equal(dist, (-d) + 5.0)
