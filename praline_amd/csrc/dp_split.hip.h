@@ -232,8 +232,9 @@ __global__ __launch_bounds__(256) void k_dp_split(ArenaDev ar, const WaveTask *_
     SplitCtx cx;
     cx.go = go; cx.ge = ge;
     cx.semiglobal = rp.mode >= 2;
-    cx.cidx = clast & 15;
-    asm volatile("" : "+v"(cx.cidx));  // keep it a per-lane value: see SplitCtx
+    int cidx_v = clast & 15;
+    asm volatile("" : "+v"(cidx_v));  // keep it a per-lane value (see select16); launder a LOCAL, not a struct member
+    cx.cidx = cidx_v;  // keep it a per-lane value: see SplitCtx
     cx.L2 = L2;
 
     SplitOut out;

@@ -28,14 +28,37 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Measured: forcing v_pk_add_f32 for the three per-column adds made the kernel 13 % SLOWER (packed fp32
+// VALU beside MFMAs is an anti-lever on gfx950); plain scalar adds are used.
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b)
+{
+    f2 d;
+    d.x = a.x + b.x;
+    d.y = a.y + b.y;
+    return d;
+}
+
+// v[idx + 1] of the shifted H array (Hs[c + 1] = H of this lane's column c)
+__device__ __forceinline__ float select16s(const float (&v)[17], int idx)
+{
+    float w[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) w[c] = v[c + 1];
+    return select16(w, idx);
+}
+
 // NR: 16-wide k ranges (1: <= 16 active symbols, 2: <= 32); NTERM: 1 exact / 3 split.
 template <int NR, int NTERM, bool LOCAL>
 __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                              float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
                                              const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR], const char *&b_next,
                                              int b_stride, const char *&bnd_ld, char *&bnd_st, float2 &bnd_pref,
-                                             float (&Hp)[16], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
-                                             float &best_run, float &col_run, SplitOut &out, const SplitCtx &cx)
+                                             float (&Hs)[17], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
+                                             float &best_run, float &col_run, float &out_best, float &out_rowmax, float &out_colmax,
+                                             float &out_corner, float go, float ge, bool semiglobal, bool last_owner, int cidx,
+                                             int xb, int L2)
 {
     // bnd_pref: this step's boundary value on entry; refilled with the value 3 rows ahead.
     // BOPS: B operands of row t+1 on entry; refilled with row t+4 (3-deep rings, the caller rotates
@@ -43,15 +66,20 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     constexpr int NP = (NTERM == 1) ? 1 : 2;   // pieces held per operand
     constexpr int NM = NTERM * NR;             // MFMAs per step
     // ---- match scores of this lane's row: lower half row t (CUR), upper half row t-1 (PREV) ----
-    float m[16];
+    f2 m2[8];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) m[c] = h ? PREV[c] : CUR[c];
+    for (int c = 0; c < 8; ++c) { m2[c].x = h ? PREV[2 * c] : CUR[2 * c]; m2[c].y = h ? PREV[2 * c + 1] : CUR[2 * c + 1]; }
 
     const float2 bv = bnd_pref;
     bnd_pref = *reinterpret_cast<const float2 *>(bnd_ld);
     bnd_ld += 32 * sizeof(float2);
-    float hd = h ? hd_x : dH;
+    // Hs[c] = H[y-1] of the column LEFT of column c (Hs[0]: handed in), so the diagonal inputs of two
+    // adjacent columns sit in one aligned register pair and the adds below are v_pk_add_f32.
+    Hs[0] = h ? hd_x : dH;
     float lrun = h ? l_x : bv.y;
+    const float hd_out = Hs[16];  // H[y-1] of this lane's last column: diagonal input of the next lane / strip
+    const f2 go2 = {go, go}, ge2 = {ge, ge};
+    f2 hs = {Hs[0], Hs[1]};  // previous-row H left of the next column pair (read BEFORE that pair's slots are rewritten)
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- MFMAs of row t+1 on the matrix pipe, interleaved with the recurrence of this row ----
@@ -64,18 +92,26 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         const int ia = (term == 0) ? NR + r : r;          // A piece: lo for term 0, hi otherwise
         const int ib = (term == 1) ? NR + r : r;          // B piece: lo for term 1, hi otherwise
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+        // this MFMA's share of the 8 column pairs
 #pragma unroll
-        for (int c = (16 * k) / NM; c < (16 * (k + 1)) / NM; ++c) {
-            float M = hd + m[c];
-            if (LOCAL) M = __builtin_fmaxf(M, 0.0f);
-            const float U = Uc[c];
-            const float H = max3f(M, U, lrun);
-            if (LOCAL) best_run = __builtin_fmaxf(best_run, H);
-            const float Mo = M + cx.go;
-            Uc[c] = __builtin_fmaxf(Mo, U + cx.ge);
-            lrun = __builtin_fmaxf(Mo, lrun + cx.ge);
-            hd = Hp[c];
-            Hp[c] = H;
+        for (int cp = (8 * k) / NM; cp < (8 * (k + 1)) / NM; ++cp) {
+            f2 M = pk_add(hs, m2[cp]);                            // max_k o[y-1,x-1,k] + m      (cext.c:192-222)
+            if (LOCAL) { M.x = __builtin_fmaxf(M.x, 0.0f); M.y = __builtin_fmaxf(M.y, 0.0f); }  // cext.c:208-209
+            const f2 Mo = pk_add(M, go2);                       // gap opened from these cells
+            const f2 U = {Uc[2 * cp], Uc[2 * cp + 1]};
+            const f2 Ug = pk_add(U, ge2);
+            // column 2cp
+            const float H0 = max3f(M.x, U.x, lrun);
+            lrun = __builtin_fmaxf(Mo.x, lrun + ge);      // L[y][x+1]   (cext.c:169-183,276-283)
+            // column 2cp + 1
+            const float H1 = max3f(M.y, U.y, lrun);
+            lrun = __builtin_fmaxf(Mo.y, lrun + ge);
+            if (LOCAL) best_run = max3f(best_run, H0, H1);
+            Uc[2 * cp] = __builtin_fmaxf(Mo.x, Ug.x);        // U[y+1][x]   (cext.c:152-166,247-254)
+            Uc[2 * cp + 1] = __builtin_fmaxf(Mo.y, Ug.y);
+            if (cp < 7) { hs.x = Hs[2 * cp + 2]; hs.y = Hs[2 * cp + 3]; }  // still the previous row's values
+            Hs[2 * cp + 1] = H0;
+            Hs[2 * cp + 2] = H1;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -87,21 +123,21 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     }
     b_next += b_stride;
     dH = bv.x;
-    hd_x = from_lower_half(hd);
+    hd_x = from_lower_half(hd_out);
     l_x = from_lower_half(lrun);
 
-    if (h) *reinterpret_cast<float2 *>(bnd_st) = make_float2(Hp[15], lrun);
+    if (h) *reinterpret_cast<float2 *>(bnd_st) = make_float2(Hs[16], lrun);  // H[yy][x0+32], L[yy][x0+33]
     bnd_st += 32 * sizeof(float2);
-    if (cx.semiglobal && cx.last_owner) col_run = __builtin_fmaxf(col_run, select16(Hp, cx.cidx));
+    if (semiglobal && last_owner) col_run = __builtin_fmaxf(col_run, select16s(Hs, cidx));
     if (have_pair && yy == L1) {
-        if (LOCAL) out.best = best_run;
-        if (cx.semiglobal) {
+        if (LOCAL) out_best = best_run;
+        if (semiglobal) {
 #pragma unroll
             for (int c = 0; c < 16; ++c)
-                out.rowmax = __builtin_fmaxf(out.rowmax, (cx.xb + c + 1 <= cx.L2) ? Hp[c] : PRALINE_NEG_INF);
-            out.colmax = col_run;
+                out_rowmax = __builtin_fmaxf(out_rowmax, (xb + c + 1 <= L2) ? Hs[c + 1] : PRALINE_NEG_INF);
+            out_colmax = col_run;
         }
-        if (cx.last_owner) out.corner = select16(Hp, cx.cidx);
+        if (last_owner) out_corner = select16s(Hs, cidx);
     }
 }
 
@@ -152,23 +188,20 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
 
-    SplitCtx cx;
-    cx.go = go; cx.ge = ge;
-    cx.semiglobal = rp.mode >= 2;
-    cx.cidx = clast & 15;
-    asm volatile("" : "+v"(cx.cidx));
-    cx.L2 = L2;
+    const bool semiglobal = rp.mode >= 2;
+    int cidx = clast & 15;
+    asm volatile("" : "+v"(cidx));  // keep it a per-lane value so select16 stays a register select tree
 
-    SplitOut out;
-    out.best = LOCAL ? h00 : 0.0f;
-    out.rowmax = (have_pair && h == 0) ? boundary_value(L1, go, ge, free_one) : PRALINE_NEG_INF;
-    out.colmax = (have_pair && own_last) ? boundary_value(L2, go, ge, free_two) : PRALINE_NEG_INF;
-    out.corner = PRALINE_NEG_INF;
+    // per-pair results, snapshotted when the lane is at its last row
+    float out_best = LOCAL ? h00 : 0.0f;
+    float out_rowmax = (have_pair && h == 0) ? boundary_value(L1, go, ge, free_one) : PRALINE_NEG_INF;
+    float out_colmax = (have_pair && own_last) ? boundary_value(L2, go, ge, free_two) : PRALINE_NEG_INF;
+    float out_corner = PRALINE_NEG_INF;
 
     for (int s = 0; s < nstrips; ++s) {
         const int x0 = s * 32;
-        cx.xb = x0 + 16 * h;
-        cx.last_owner = (s == nstrips - 1) && own_last;
+        const int xb = x0 + 16 * h;
+        const bool last_owner = (s == nstrips - 1) && own_last;
 
         float4 aop[NOP];
         {
@@ -176,16 +209,17 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 #pragma unroll
             for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
         }
-        float Hp[16], Uc[16];
+        float Hs[17], Uc[16];  // Hs[c + 1] = H[y-1] of this lane's column c; Hs[0] is handed in per row
+        Hs[0] = PRALINE_NEG_INF;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            Hp[c] = boundary_value(cx.xb + c + 1, go, ge, free_two);
-            Uc[c] = PRALINE_NEG_INF;
+            Hs[c + 1] = boundary_value(xb + c + 1, go, ge, free_two);   // H[0][x] = o[0,x,2]
+            Uc[c] = PRALINE_NEG_INF;                                       // U[1][x]
         }
         float dH = (s == 0) ? h00 : boundary_value(x0, go, ge, free_two);
         float hd_x = PRALINE_NEG_INF, l_x = PRALINE_NEG_INF;
-        float best_run = out.best;
-        float col_run = out.colmax;
+        float best_run = out_best;
+        float col_run = out_colmax;
 
         // pipeline prologue: B operands of rows 1..4, MFMAs of row 1, boundary column of rows 1..3
         float4 b0[NOP], b1[NOP], b2[NOP];
@@ -217,17 +251,20 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 
 #define PRALINE_STEP16(T, CUR, PREV, BSET, PSLOT)                                                                     \
         split16_step<NR, NTERM, LOCAL>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld, bnd_st, \
-                                       PSLOT, Hp, Uc, dH, hd_x, l_x, best_run, col_run, out, cx)
+                                       PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax, out_colmax, out_corner, \
+                                       go, ge, semiglobal, last_owner, cidx, xb, L2)
         // step 1: only the lower half has a row; the upper half's garbage is undone right after
         {
-            float Hs[16];
+            float Hsave[17];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) Hs[c] = Hp[c];
+            for (int c = 0; c < 17; ++c) Hsave[c] = Hs[c];
             const float best_s = best_run, col_s = col_run;
             PRALINE_STEP16(1, accA, accB, b0, p0);
             if (h) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { Hp[c] = Hs[c]; Uc[c] = PRALINE_NEG_INF; }
+                for (int c = 0; c < 17; ++c) Hs[c] = Hsave[c];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) Uc[c] = PRALINE_NEG_INF;
                 best_run = best_s;
                 col_run = col_s;
             }
@@ -246,14 +283,14 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 #undef PRALINE_STEP16
     }
 
-    const float corner_all = __builtin_fmaxf(out.corner, partner_value(out.corner, h));
-    const float rowmax_all = __builtin_fmaxf(out.rowmax, partner_value(out.rowmax, h));
-    const float colmax_all = __builtin_fmaxf(out.colmax, partner_value(out.colmax, h));
-    const float best_all = __builtin_fmaxf(out.best, partner_value(out.best, h));
+    const float corner_all = __builtin_fmaxf(out_corner, partner_value(out_corner, h));
+    const float rowmax_all = __builtin_fmaxf(out_rowmax, partner_value(out_rowmax, h));
+    const float colmax_all = __builtin_fmaxf(out_colmax, partner_value(out_colmax, h));
+    const float best_all = __builtin_fmaxf(out_best, partner_value(out_best, h));
     if (have_pair && h == 0) {
         float score;
         if (LOCAL) score = best_all;
-        else if (cx.semiglobal) score = (rowmax_all > colmax_all && free_two) ? rowmax_all : colmax_all;
+        else if (semiglobal) score = (rowmax_all > colmax_all && free_two) ? rowmax_all : colmax_all;
         else score = corner_all;
         scores[lane_pair[base + j]] = score;
     }
