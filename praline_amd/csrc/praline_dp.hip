@@ -331,6 +331,7 @@ struct praline_plan {
 struct HalfTask {
     int32_t two;
     int32_t max_l1;
+    int32_t chunk;   // ordinal of this 32-pair chunk inside its sequence-two group (length class of its partners)
     int32_t one[32];
     int32_t pair[32];
 };
@@ -383,6 +384,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         HalfTask h;
         h.two = two;
         h.max_l1 = 0;
+        h.chunk = (!halves.empty() && halves.back().two == two) ? halves.back().chunk + 1 : 0;
         int n = 0;
         for (int q = 0; q < 32; ++q) { h.one[q] = -1; h.pair[q] = -1; }
         while (i < n_pairs && n < 32 && pairs[2 * order[i] + 1] == two) {
@@ -399,6 +401,35 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         if (sx != sy) return sx > sy;
         return x.max_l1 > y.max_l1;
     });
+    // XCD-aware placement (scores-only plans): workgroups are dealt round-robin to the 8 XCDs
+    // (block b -> XCD b % 8, each with a private 4 MB L2).  A task's operand stream is the profile rows
+    // of its 32 sequences one; chunk c of every group holds the c-th length class of partners, i.e.
+    // largely the SAME sequences across groups.  Order the tasks class-major and give every XCD a
+    // contiguous range of that order, so one XCD's L2 only has to hold a few length classes.
+    // (Placement is a speed matter only; results do not depend on it.)
+    // MEASURED (C2 and N=512): 30-40 % SLOWER than plain longest-first order - the class-major ranges put
+    // all expensive tasks on the same XCD, which then queues them behind each other (one resident wave per
+    // SIMD).  Kept opt-in (PRALINE_XCD=1) for kernels with more resident waves.
+    if (!want_paths && halves.size() >= 64 && getenv("PRALINE_XCD") && getenv("PRALINE_XCD")[0] == '1') {
+        std::stable_sort(halves.begin(), halves.end(), [&](const HalfTask &x, const HalfTask &y) { return x.chunk < y.chunk; });
+        const size_t n = halves.size(), per = (n + 7) / 8;
+        // inside each XCD's range: longest first again (late long tasks would stretch the makespan)
+        for (size_t x = 0; x < 8; ++x) {
+            const size_t b = std::min(n, x * per), e = std::min(n, (x + 1) * per);
+            std::stable_sort(halves.begin() + b, halves.begin() + e, [&](const HalfTask &u, const HalfTask &v) {
+                const int64_t cu = (int64_t)((a.len[u.two] + 31) / 32) * u.max_l1, cv = (int64_t)((a.len[v.two] + 31) / 32) * v.max_l1;
+                return cu > cv;
+            });
+        }
+        std::vector<HalfTask> placed;
+        placed.reserve(n);
+        for (size_t q = 0; q < per; ++q)
+            for (size_t x = 0; x < 8; ++x) {
+                const size_t src = x * per + q;
+                if (src < n) placed.push_back(halves[src]);
+            }
+        halves.swap(placed);
+    }
     int tp = halves.size() >= 4096 ? 2 : 1;
     if (want_paths) tp = 1;  // the traceback variant keeps three states per column in registers
     if (const char *env = getenv("PRALINE_TP")) { if (env[0] == '1') tp = 1; else if (env[0] == '2' && !want_paths) tp = 2; }
