@@ -555,7 +555,7 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
                             const int32_t *__restrict__ end_cells, float *__restrict__ scores,
                             const int64_t *__restrict__ slot_off, int32_t *__restrict__ paths,
                             int64_t *__restrict__ path_start, int32_t *__restrict__ path_rows,
-                            int64_t n_pairs, RunParams rp, int32_t task_lo, int32_t task_hi)
+                            int64_t n_pairs, RunParams rp, int32_t task_lo, int32_t task_hi, int layout)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
@@ -565,7 +565,10 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
     const int L1 = ar.len[pairs[2 * p]], L2 = ar.len[pairs[2 * p + 1]];
     const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
     const bool semiglobal = rp.mode >= 2;
+    // layout 0: k_dp_batch planes (uint4 per 32 cells, rows max_l1 + 1); layout 1: k_dp_split16_tb planes
+    // (uint2 per 16 cells, lane j = strip columns 1..16, lane j + 32 = columns 17..32, rows max_l1 + 8)
     const uint4 *my_tb = tb + tk.tb_off + pl.lane;
+    const uint2 *my_tb2 = reinterpret_cast<const uint2 *>(tb) + tk.tb_off + pl.lane;
 
     int y = end_cells[p * 4 + 0], x = end_cells[p * 4 + 1], k = end_cells[p * 4 + 2];
     if (semiglobal) {
@@ -628,15 +631,24 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
             }
             if (masked) break;  // t stays 0 in masked cells (cext.c:141-149)
             const int s = (x - 1) >> 5, c = (x - 1) & 31;
-            const uint4 word = my_tb[((int64_t)s * (tk.max_l1 + 1) + y) * 64];
+            unsigned p_mlo, p_mhi, p_u, p_l;
+            int bit = c;
+            if (layout == 0) {
+                const uint4 word = my_tb[((int64_t)s * (tk.max_l1 + 1) + y) * 64];
+                p_mlo = word.x; p_mhi = word.y; p_u = word.z; p_l = word.w;
+            } else {
+                const uint2 word = my_tb2[((int64_t)s * (tk.max_l1 + 8) + y) * 64 + 32 * (c >> 4)];
+                p_mlo = word.x & 0xffffu; p_mhi = word.x >> 16; p_u = word.y & 0xffffu; p_l = word.y >> 16;
+                bit = c & 15;
+            }
             if (k == 0) {
-                const int code = ((word.x >> c) & 1) | (((word.y >> c) & 1) << 1);
+                const int code = ((p_mlo >> bit) & 1) | (((p_mhi >> bit) & 1) << 1);
                 if (code == 0) break;
                 ny = y - 1; nx = x - 1; nk = code - 1;     // 1 MM, 2 MU, 3 ML
             } else if (k == 1) {
-                ny = y - 1; nx = x; nk = (word.z >> c) & 1;                 // 0 UO -> M, 1 UE -> U
+                ny = y - 1; nx = x; nk = (p_u >> bit) & 1;                 // 0 UO -> M, 1 UE -> U
             } else {
-                ny = y; nx = x - 1; nk = ((word.w >> c) & 1) ? 2 : 0;       // 0 LO -> M, 1 LE -> L
+                ny = y; nx = x - 1; nk = ((p_l >> bit) & 1) ? 2 : 0;       // 0 LO -> M, 1 LE -> L
             }
         }
         y = ny; x = nx; k = nk;

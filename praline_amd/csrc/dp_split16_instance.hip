@@ -2,6 +2,7 @@
 // -mllvm -amdgpu-mfma-vgpr-form.
 #include "dp_launch.hip.h"
 #include "dp_split16.hip.h"
+#include "dp_split16_tb.hip.h"
 
 #include <cstdlib>
 
@@ -44,6 +45,30 @@ int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int o
     else if (nr == 1 && nterm == 3) hipLaunchKernelGGL((k_scores_tile16<1, 3>), grid, dim3(64), 0, stream, a16, one, two, m);
     else if (nr == 2 && nterm == 1) hipLaunchKernelGGL((k_scores_tile16<2, 1>), grid, dim3(64), 0, stream, a16, one, two, m);
     else if (nr == 2 && nterm == 3) hipLaunchKernelGGL((k_scores_tile16<2, 3>), grid, dim3(64), 0, stream, a16, one, two, m);
+    else return PRALINE_ERR_UNSUPPORTED;
+    return PRALINE_OK;
+}
+
+template <int NR, int NTERM> static void launch16_tb(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask, unsigned wpb)
+{
+    const dim3 grid((la.n_tasks + wpb - 1) / wpb), block(64 * wpb);
+#define PRALINE_TB_LAUNCH(LOC, MSK)                                                                                      \
+    hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, LOC, MSK>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,      \
+                       la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells, la.rp,      \
+                       (int)la.n_tasks)
+    if (local) { if (mask) PRALINE_TB_LAUNCH(true, true); else PRALINE_TB_LAUNCH(true, false); }
+    else { if (mask) PRALINE_TB_LAUNCH(false, true); else PRALINE_TB_LAUNCH(false, false); }
+#undef PRALINE_TB_LAUNCH
+}
+
+int praline_launch_split16_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, bool mask)
+{
+    unsigned wpb = 1;
+    if (const char *env = getenv("PRALINE_WPB")) { const int v = atoi(env); if (v >= 1 && v <= 4) wpb = (unsigned)v; }
+    if (nr == 1 && nterm == 1) launch16_tb<1, 1>(la, a16, local, mask, wpb);
+    else if (nr == 1 && nterm == 3) launch16_tb<1, 3>(la, a16, local, mask, wpb);
+    else if (nr == 2 && nterm == 1) launch16_tb<2, 1>(la, a16, local, mask, wpb);
+    else if (nr == 2 && nterm == 3) launch16_tb<2, 3>(la, a16, local, mask, wpb);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }

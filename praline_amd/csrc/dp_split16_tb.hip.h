@@ -1,0 +1,337 @@
+// dp_split16_tb.hip.h -- k_dp_split16_tb: fill WITH packed traceback in the split-strip layout, match
+// scores on the matrix pipe (see dp_split.hip.h / dp_split16.hip.h for the layout and the pipeline).
+//
+// The three states are carried separately so ties resolve exactly as get_paths does
+// (praline/util/align.py:161-174: first set flag in the order MM, MU, ML / UO, UE / LO, LE): the
+// candidate sums are formed individually and compared with == as in praline/util/cext.c:224-295.
+// Per lane and DP row four 16-bit planes are stored (2-bit match source 1 MM / 2 MU / 3 ML / 0 stop,
+// 1 bit "U from extend", 1 bit "L from extend") = 8 bytes per 16 cells:
+//     tb2[(strip * tb_rows + y) * 64 + lane] = { mlo | mhi << 16,  ubit | lbit << 16 }
+// lane j holds strip columns 1..16, lane j + 32 columns 17..32 of pair j.
+// Zero rectangles (Waterman-Eggert, praline/component/preprofile.py:247-255) force M = U = L = 0 and
+// stop codes (cext.c:141-149).  End cells: the global corner triple, the local first argmax and the
+// semiglobal last row / last column triples (praline/component/align.py:401-431) are written to
+// end_cells / aux in the layout k_traceback reads.
+#pragma once
+#include "dp_split16.hip.h"
+
+struct TbCarry {
+    float xm, xu, xl;     // upper half: states of the cell left of its first column, same row (handed over)
+    float pxm, pxu, pxl;  // upper half: the same for the previous row (= its diagonal input)
+    float dM, dU, dL;     // lower half: states of the boundary cell (y-1, x0)
+};
+
+template <int NR, int NTERM, bool LOCAL, bool MASK>
+__device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
+                                                float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
+                                                const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR], const char *&b_next,
+                                                int b_stride, const char *&bnd_ld, char *&bnd_st, float4 &bnd_pref,
+                                                uint2 *&tb_st, float (&Mp)[16], float (&Up)[16], float (&Lp)[16],
+                                                float &cxm, float &cxu, float &cxl, float &cpxm, float &cpxu, float &cpxl,
+                                                float &cdM, float &cdU, float &cdL, float &best_run, int &best_y,
+                                                int &best_x, int &best_k, float go, float ge, int xb,
+                                                const int (&rect)[PRALINE_MAX_RECTS][4])
+{
+    constexpr int NP = (NTERM == 1) ? 1 : 2;
+    constexpr int NM = NTERM * NR;
+    float m[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) m[c] = h ? PREV[c] : CUR[c];
+
+    const float4 bv = bnd_pref;  // states (M, U, L) of the boundary cell (yy, x0)
+    bnd_pref = *reinterpret_cast<const float4 *>(bnd_ld);
+    bnd_ld += 32 * sizeof(float4);
+    float md = h ? cpxm : cdM, ud = h ? cpxu : cdU, ld = h ? cpxl : cdL;  // states of (yy-1, x-1)
+    float mleft = h ? cxm : bv.x, lleft = h ? cxl : bv.z;                 // states of (yy, x-1)
+    bool row_in[PRALINE_MAX_RECTS];
+    if constexpr (MASK) {
+#pragma unroll
+        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) row_in[r] = yy >= rect[r][0] && yy <= rect[r][1];
+    }
+    unsigned w_mlo = 0, w_mhi = 0, w_u = 0, w_l = 0;
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        const int term = (NTERM == 1) ? 2 : k / NR;
+        const int r = k % NR;
+        const int ia = (term == 0) ? NR + r : r;
+        const int ib = (term == 1) ? NR + r : r;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+#pragma unroll
+        for (int c = (16 * k) / NM; c < (16 * (k + 1)) / NM; ++c) {
+            // exact candidate sums (cext.c:185-201), maxima and first-match flags (cext.c:207-295)
+            const float sMM = md + m[c], sMU = ud + m[c], sML = ld + m[c];
+            float M = max3f(sMM, sMU, sML);
+            if (LOCAL) M = __builtin_fmaxf(M, 0.0f);
+            const float uo = Mp[c] + go, ue = Up[c] + ge;
+            float U = __builtin_fmaxf(uo, ue);
+            const float lo = mleft + go, le = lleft + ge;
+            float Lc = __builtin_fmaxf(lo, le);
+            bool isMM = sMM == M;
+            bool isMU = !isMM && sMU == M;
+            bool isML = !isMM && !isMU && sML == M;
+            if constexpr (MASK) {
+                bool z = false;
+#pragma unroll
+                for (int q = 0; q < PRALINE_MAX_RECTS; ++q)
+                    z = z || (row_in[q] && (xb + c + 1) >= rect[q][2] && (xb + c + 1) <= rect[q][3]);
+                if (z) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }
+            }
+            w_mlo |= (isMM || isML) ? (1u << c) : 0u;
+            w_mhi |= (isMU || isML) ? (1u << c) : 0u;
+            w_u |= (uo >= ue) ? 0u : (1u << c);
+            w_l |= (lo >= le) ? 0u : (1u << c);
+            if (LOCAL) {
+                // first maximum in C order (y, x, k): inside one strip rows and columns ascend, so a tie only
+                // wins with a smaller row (a later strip); ties between the two halves are resolved at the end
+                const float H = max3f(M, U, Lc);
+                if (H > best_run || (H == best_run && yy < best_y)) {
+                    best_run = H; best_y = yy; best_x = xb + c + 1;
+                    best_k = (M == H) ? 0 : ((U == H) ? 1 : 2);
+                }
+            }
+            md = Mp[c]; ud = Up[c]; ld = Lp[c];
+            Mp[c] = M; Up[c] = U; Lp[c] = Lc;
+            mleft = M; lleft = Lc;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    PREV = acc;
+    {
+        const float4 *bsrc = reinterpret_cast<const float4 *>(b_next);
+#pragma unroll
+        for (int q = 0; q < NP * NR; ++q) BOPS[q] = bsrc[q];
+    }
+    b_next += b_stride;
+    // lower half: this row's boundary states are the next row's diagonal input
+    cdM = bv.x; cdU = bv.y; cdL = bv.z;
+    // upper half: shift the hand-over generations, then receive the lower half's last column of this row
+    cpxm = cxm; cpxu = cxu; cpxl = cxl;
+    cxm = from_lower_half(Mp[15]);
+    cxu = from_lower_half(Up[15]);
+    cxl = from_lower_half(Lp[15]);
+
+    if (h) *reinterpret_cast<float4 *>(bnd_st) = make_float4(Mp[15], Up[15], Lp[15], 0.0f);
+    bnd_st += 32 * sizeof(float4);
+    *tb_st = make_uint2(w_mlo | (w_mhi << 16), w_u | (w_l << 16));
+    tb_st += 64;
+}
+
+template <int NR, int NTERM, bool LOCAL, bool MASK>
+__global__ __launch_bounds__(256) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+                                                       const int32_t *__restrict__ lane_one,
+                                                       const int32_t *__restrict__ lane_pair, float4 *bnd,
+                                                       uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,
+                                                       float *__restrict__ scores, int32_t *__restrict__ end_cells,
+                                                       RunParams rp, int n_tasks)
+{
+    constexpr int NP = (NTERM == 1) ? 1 : 2;
+    constexpr int NOP = NP * NR;
+    const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const WaveTask tk = tasks[task];
+    const int base = task * 32;
+    const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
+    const bool semiglobal = rp.mode >= 2;
+    const float go = rp.go1, ge = rp.ge1;
+
+    const int my_one = lane_one[base + j];
+    const int two = tk.two[0];
+    const bool have_pair = my_one >= 0;
+    const int my_pair = have_pair ? lane_pair[base + j] : -1;
+    const int L1 = have_pair ? ar.len[my_one] : 0;
+    const int L2 = ar.len[two];
+    const int nstrips = (L2 + 31) >> 5;
+    const int clast = (L2 - 1) & 31;
+    const bool own_last = (clast >> 4) == h;
+    int cidx = clast & 15;
+    asm volatile("" : "+v"(cidx));
+    const int max_l1 = tk.max_l1;
+    const int tb_rows = max_l1 + 8;  // rows per strip in the traceback planes (the pipeline overshoots)
+
+    const char *pB = ar.P16 + (int64_t)(have_pair ? ar.row_off[my_one] : 0) * ar.row_bytes + h * ar.half_bytes;
+    const int b_stride = ar.row_bytes;
+    const int acol = 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
+    const char *qA = ar.Q16 + ((int64_t)ar.row_off[two] + acol) * ar.row_bytes + h * ar.half_bytes;
+
+    char *my_bnd = reinterpret_cast<char *>(bnd + tk.bnd_off + j);  // float4 [y][32]
+    constexpr int BROW = 32 * (int)sizeof(float4);
+    uint2 *my_tb = tb + tk.tb_off + lane;                            // [strip][y][64]
+    float *lastcol = aux + tk.aux_off + j;                           // [y][3][64]   (lane slot j of 64)
+    float *lastrow = aux + tk.aux_off + (int64_t)(max_l1 + 1) * 3 * 64 + j;  // [x-1][3][64]
+
+    int rect[PRALINE_MAX_RECTS][4];
+    if constexpr (MASK) {
+        int n_rects = 0, r0 = 0;
+        if (my_pair >= 0 && rl.rect_off != nullptr) {
+            r0 = rl.rect_off[my_pair];
+            n_rects = rl.rect_off[my_pair + 1] - r0;
+            if (n_rects > PRALINE_MAX_RECTS) n_rects = PRALINE_MAX_RECTS;
+        }
+#pragma unroll
+        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
+            const bool ok = r < n_rects;
+            rect[r][0] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 0] : (1 << 30);
+            rect[r][1] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 1] : -1;
+            rect[r][2] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 2] : (1 << 30);
+            rect[r][3] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 3] : -1;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) { rect[r][0] = 1 << 30; rect[r][1] = -1; rect[r][2] = 1 << 30; rect[r][3] = -1; }
+    }
+
+    // boundary cells (praline/component/align.py:367-385)
+    const float o001 = free_one ? 0.0f : (go - ge);
+    const float o002 = free_two ? 0.0f : (go - ge);
+
+    // strip 0 reads its boundary column like every other strip: states of (y, 0) = (-inf, o[y,0,1], -inf)
+    if (h == 0)
+        for (int y = 1; y <= max_l1 + 4; ++y)
+            *reinterpret_cast<float4 *>(my_bnd + (int64_t)y * BROW) =
+                make_float4(PRALINE_NEG_INF, boundary_value(y, go, ge, free_one), PRALINE_NEG_INF, 0.0f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+
+    // local: first flat argmax over o (align.py:402); o[0,0,:] are the only boundary cells that can be >= 0
+    float out_best = 0.0f;
+    int out_y = 0, out_x = 0, out_k = 0;
+    if (LOCAL) {
+        if (o001 > out_best) { out_best = o001; out_k = 1; }
+        if (o002 > out_best) { out_best = o002; out_k = 2; }
+    }
+    float corner_m = PRALINE_NEG_INF, corner_u = PRALINE_NEG_INF, corner_l = PRALINE_NEG_INF;
+
+    for (int s = 0; s < nstrips; ++s) {
+        const int x0 = s * 32;
+        const int xb = x0 + 16 * h;
+        const bool last_owner = (s == nstrips - 1) && own_last;
+
+        float4 aop[NOP];
+        {
+            const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.row_bytes);
+#pragma unroll
+            for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
+        }
+        float Mp[16], Up[16], Lp[16];  // states of the previous row, per column (o[0,x,:] to start with)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            Mp[c] = PRALINE_NEG_INF;
+            Up[c] = PRALINE_NEG_INF;
+            Lp[c] = boundary_value(xb + c + 1, go, ge, free_two);
+        }
+        // lower half: states of the cell (0, x0); upper half: states of (0, x0 + 16), which after the first
+        // step's generation shift are the diagonal input of its row 1
+        float cdM = (s == 0) ? 0.0f : PRALINE_NEG_INF;
+        float cdU = (s == 0) ? o001 : PRALINE_NEG_INF;
+        float cdL = (s == 0) ? o002 : boundary_value(x0, go, ge, free_two);
+        float cxm = PRALINE_NEG_INF, cxu = PRALINE_NEG_INF, cxl = boundary_value(x0 + 16, go, ge, free_two);
+        float cpxm = PRALINE_NEG_INF, cpxu = PRALINE_NEG_INF, cpxl = PRALINE_NEG_INF;
+        float best_run = out_best;
+        int best_y = out_y, best_x = out_x, best_k = out_k;
+
+        float4 bX[NOP], bY[NOP];
+        f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        f32x16 accB = accA;
+        {
+            float4 b1[NOP];
+            const float4 *s1 = reinterpret_cast<const float4 *>(pB);
+            const float4 *s2 = reinterpret_cast<const float4 *>(pB + b_stride);
+            const float4 *s3 = reinterpret_cast<const float4 *>(pB + 2 * b_stride);
+#pragma unroll
+            for (int q = 0; q < NOP; ++q) { b1[q] = s1[q]; bX[q] = s2[q]; bY[q] = s3[q]; }
+#pragma unroll
+            for (int k = 0; k < NTERM * NR; ++k) {
+                const int term = (NTERM == 1) ? 2 : k / NR;
+                const int r = k % NR;
+                const int ia = (term == 0) ? NR + r : r;
+                const int ib = (term == 1) ? NR + r : r;
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(b1[ib]), accA, 0, 0, 0);
+            }
+        }
+        const char *b_next = pB + 3 * b_stride;
+        const char *bnd_ld = my_bnd + 2 * BROW;
+        char *bnd_st = my_bnd;                                               // upper half stores row yy = t - 1 (row 0: dummy)
+        float4 bnd_pref = *reinterpret_cast<const float4 *>(my_bnd + BROW);  // row 1
+        uint2 *tb_st = my_tb + (int64_t)s * tb_rows * 64 + (h ? 0 : 64);     // row yy = t - h of step t = 1
+
+#define PRALINE_TB_STEP(T, CUR, PREV, BSET)                                                                          \
+        split16_tb_step<NR, NTERM, LOCAL, MASK>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld,  \
+                                                bnd_st, bnd_pref, tb_st, Mp, Up, Lp, cxm, cxu, cxl, cpxm, cpxu, cpxl, cdM,  \
+                                                cdU, cdL, best_run, best_y, best_x, best_k, go, ge, xb, rect)
+#define PRALINE_TB_TAILS(T)                                                                                          \
+        {                                                                                                            \
+            const int yy_ = (T) - h;                                                                                 \
+            if (semiglobal && last_owner && have_pair && yy_ >= 1 && yy_ <= L1) {                                    \
+                float *lc = lastcol + (int64_t)yy_ * 3 * 64;            /* o[y, L2, :]  (align.py:408,418-422) */    \
+                lc[0] = select16(Mp, cidx); lc[64] = select16(Up, cidx); lc[128] = select16(Lp, cidx);               \
+            }                                                                                                        \
+            if (have_pair && yy_ == L1) {                                                                            \
+                if (LOCAL) { out_best = best_run; out_y = best_y; out_x = best_x; out_k = best_k; }                  \
+                if (last_owner) { corner_m = select16(Mp, cidx); corner_u = select16(Up, cidx); corner_l = select16(Lp, cidx); } \
+                if (semiglobal) {                                       /* o[L1, x, :]  (align.py:407,413-417) */    \
+                    float *lr = lastrow + (int64_t)xb * 3 * 64;                                                      \
+                    _Pragma("unroll") for (int c = 0; c < 16; ++c) {                                                 \
+                        lr[(c * 3 + 0) * 64] = Mp[c]; lr[(c * 3 + 1) * 64] = Up[c]; lr[(c * 3 + 2) * 64] = Lp[c];    \
+                    }                                                                                                \
+                }                                                                                                    \
+            }                                                                                                        \
+        }
+        // step 1: only the lower half has a row; the upper half's garbage is undone right after
+        {
+            const float best_s = best_run;
+            const int by = best_y, bx = best_x, bk = best_k;
+            PRALINE_TB_STEP(1, accA, accB, bX);
+            if (h) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    Mp[c] = PRALINE_NEG_INF; Up[c] = PRALINE_NEG_INF; Lp[c] = boundary_value(xb + c + 1, go, ge, free_two);
+                }
+                best_run = best_s; best_y = by; best_x = bx; best_k = bk;
+            }
+            PRALINE_TB_TAILS(1)
+        }
+        for (int t = 2; t <= max_l1 + 1; t += 2) {
+            PRALINE_TB_STEP(t, accB, accA, bY);
+            PRALINE_TB_TAILS(t)
+            PRALINE_TB_STEP(t + 1, accA, accB, bX);
+            PRALINE_TB_TAILS(t + 1)
+        }
+#undef PRALINE_TB_STEP
+#undef PRALINE_TB_TAILS
+    }
+
+    // ---- combine the halves: end cell (y, x, k) and score (align.py:401-431) ----
+    if (LOCAL) {
+        // first flat argmax: larger value wins; on ties the smaller (y, x)
+        const float pv = partner_value(out_best, h);
+        const int py = __builtin_bit_cast(int, partner_value(__builtin_bit_cast(float, out_y), h));
+        const int px = __builtin_bit_cast(int, partner_value(__builtin_bit_cast(float, out_x), h));
+        const int pk = __builtin_bit_cast(int, partner_value(__builtin_bit_cast(float, out_k), h));
+        if (pv > out_best || (pv == out_best && (py < out_y || (py == out_y && px < out_x)))) {
+            out_best = pv; out_y = py; out_x = px; out_k = pk;
+        }
+    }
+    const float cm = __builtin_fmaxf(corner_m, partner_value(corner_m, h));  // only the owner half holds finite values
+    const float cu = __builtin_fmaxf(corner_u, partner_value(corner_u, h));
+    const float cl = __builtin_fmaxf(corner_l, partner_value(corner_l, h));
+    if (have_pair && h == 0) {
+        int ey = L1, ex = L2, ek = 0;
+        float score = cm;
+        if (LOCAL) { ey = out_y; ex = out_x; ek = out_k; score = out_best; }
+        else {
+            if (cu > score) { score = cu; ek = 1; }  // np.argmax: first maximum
+            if (cl > score) { score = cl; ek = 2; }
+        }
+        end_cells[(int64_t)my_pair * 4 + 0] = ey;
+        end_cells[(int64_t)my_pair * 4 + 1] = ex;
+        end_cells[(int64_t)my_pair * 4 + 2] = ek;
+        end_cells[(int64_t)my_pair * 4 + 3] = 0;
+        scores[my_pair] = score;  // semiglobal: k_traceback overwrites it with the row / column rule
+    }
+}

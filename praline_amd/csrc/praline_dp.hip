@@ -321,7 +321,7 @@ struct praline_plan {
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
     DevBuf<char> d_bnd;
-    DevBuf<uint4> d_tb;
+    DevBuf<char> d_tb;
     DevBuf<int64_t> d_slot_off, d_path_start;
     std::vector<int64_t> slot_off;
     float last_kernel_ms = 0.0f;
@@ -434,7 +434,9 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     if (want_paths) tp = 1;  // the traceback variant keeps three states per column in registers
     if (const char *env = getenv("PRALINE_TP")) { if (env[0] == '1') tp = 1; else if (env[0] == '2' && !want_paths) tp = 2; }
     // scores-only plans run on k_dp_split (both halves of the wave on the same 32 pairs)
-    bool split = !want_paths;
+    // every plan runs on the split-strip kernels (32 pairs per wave, both halves on the same pairs);
+    // PRALINE_KERNEL=batch selects the older k_dp_batch layout for A/B comparisons
+    bool split = a.nr16 > 0 || !want_paths;
     if (const char *env = getenv("PRALINE_KERNEL")) { if (!strcmp(env, "batch")) split = false; }
     if (split) tp = 1;
     pl->tp = tp;
@@ -470,7 +472,8 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         bnd += split ? (int64_t)(wt.max_l1 + 12) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
         wt.tb_off = 0;
         wt.aux_off = 0;
-        pl->tb_elems[t] = (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
+        // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]
+        pl->tb_elems[t] = split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
         pl->aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * 64;
     }
     pl->bnd_elems = bnd;
@@ -615,6 +618,8 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     // ---- with paths: chunk the tasks so the packed traceback fits the scratch budget ----
     const size_t budget = tb_budget_bytes();
     const bool semiglobal = mode >= 2;
+    const size_t tb_elem_bytes = pl.split ? sizeof(uint2) : sizeof(uint4);
+    const int lanes_per_task = pl.split ? 32 : 64;
     size_t t0 = 0;
     const size_t nt = pl.tasks.size();
     HIPCHK(hipEventRecord(g_rt.ev0, st));
@@ -623,35 +628,39 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         int64_t tb_e = 0, aux_e = 0;
         while (t1 < nt) {
             const int64_t add = pl.tb_elems[t1];
-            if (t1 > t0 && (size_t)(tb_e + add) * sizeof(uint4) > budget) break;
+            if (t1 > t0 && (size_t)(tb_e + add) * tb_elem_bytes > budget) break;
             pl.tasks[t1].tb_off = tb_e;
             pl.tasks[t1].aux_off = aux_e;
             tb_e += add;
             aux_e += semiglobal ? pl.aux_elems[t1] : 0;
             ++t1;
         }
-        if (pl.d_tb.n < (size_t)tb_e) RC(pl.d_tb.alloc((size_t)tb_e));
+        if (pl.d_tb.n < (size_t)tb_e * tb_elem_bytes) RC(pl.d_tb.alloc((size_t)tb_e * tb_elem_bytes));
         if (pl.d_aux.n < (size_t)std::max<int64_t>(aux_e, 1)) RC(pl.d_aux.alloc((size_t)std::max<int64_t>(aux_e, 1)));
         if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
         HIPCHK(hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, st));
         la.tasks = pl.d_tasks.p + t0;
-        la.lane_one = pl.d_lane_one.p + t0 * 64;
-        la.lane_pair = pl.d_lane_pair.p + t0 * 64;
-        la.tb = pl.d_tb.p;
+        la.lane_one = pl.d_lane_one.p + t0 * lanes_per_task;
+        la.lane_pair = pl.d_lane_pair.p + t0 * lanes_per_task;
+        la.tb = (uint4 *)pl.d_tb.p;
         la.aux = pl.d_aux.p;
         la.n_tasks = (unsigned)(t1 - t0);
-        RC(launch_dp(a.nstep, la, 1, local, 1, pl.has_rects));
+        if (pl.split) {
+            int rc = praline_launch_split16_tb(la, a16, a.nr16, a.nterm16, local, pl.has_rects);
+            if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16_tb instance for nr=%d nterm=%d", a.nr16, a.nterm16);
+        } else {
+            la.split = 0;
+            RC(launch_dp(a.nstep, la, 1, local, 1, pl.has_rects));
+        }
         HIPCHK(hipGetLastError());
-        // traceback of the pairs of this chunk: every pair checks its task range
-        // (k_traceback is launched once per chunk over all pairs whose task is in [t0, t1))
         {
-            // pairs are not contiguous per chunk; launch over all pairs with a task-range filter
+            // k_traceback runs over all pairs and skips those whose task is outside [t0, t1)
             const int threads = 64;
             const int64_t blocks = (pl.n_pairs + threads - 1) / threads;
             hipLaunchKernelGGL(k_traceback, dim3((unsigned)blocks), dim3(threads), 0, st, la.ar, pl.d_tasks.p,
-                               pl.d_loc.p, pl.d_pairs.p, pl.d_tb.p, pl.d_aux.p, la.rl, pl.d_end_cells.p, la.scores,
-                               pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs, la.rp,
-                               (int32_t)t0, (int32_t)t1);
+                               pl.d_loc.p, pl.d_pairs.p, (const uint4 *)pl.d_tb.p, pl.d_aux.p, la.rl, pl.d_end_cells.p,
+                               la.scores, pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs,
+                               la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
             HIPCHK(hipGetLastError());
         }
         t0 = t1;
@@ -982,6 +991,7 @@ extern "C" int praline_plan_match_kind(const praline_plan *plan)
 {
     if (!plan) return -1;
     if (plan->split && plan->arena->nr16 > 0) {
+        if (plan->want_paths) return 1;  // k_dp_split16_tb
         const char *mm = getenv("PRALINE_MM");
         if (!(mm && !strcmp(mm, "f32"))) return 1;
     }

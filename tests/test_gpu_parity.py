@@ -164,14 +164,18 @@ def test_batch_float_profiles(nat, bba):
     pairs = all_pairs(5)
     for mode in MODES:
         plan = nat.Plan(arena, pairs, want_paths=True)
+        kind = plan.match_kind()
         plan.run(mode, *GAPS)
         sc, paths = plan.scores(), plan.paths()
         for k, (i, j) in enumerate(pairs):
             ref = float(d["score_%d_%d_%s" % (i, j, mode)])
             assert abs(sc[k] - ref) <= 1e-5 * max(1.0, abs(ref)), (mode, i, j, sc[k], ref)
-            s_or, p_or = oracle_dp_on_device_m(mode, profs[i], profs[j], bba["S"])
+            # bit-identical to the oracle DP (fill, end cell, traceback) on the device's own match scores
+            s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(i, j, kind))
             assert sc[k] == np.float32(s_or), (mode, i, j)
             assert np.array_equal(paths[k], p_or), (mode, i, j)
+            # and the path equals the reference's on these inputs
+            assert np.array_equal(paths[k], d["path_%d_%d_%s" % (i, j, mode)]), (mode, i, j)
         plan.close()
         # scores-only plan: match scores on the matrix pipe (f16 hi/lo split); the DP must be
         # bit-identical to the oracle DP on the device's own match scores, and the scores stay
@@ -251,6 +255,7 @@ def test_batch_random_vs_oracle(nat, bba, kind):
                      dtype=np.int32)
     for mode in MODES:
         plan = nat.Plan(arena, pairs, want_paths=True)
+        pk = plan.match_kind()
         plan.run(mode, *GAPS)
         sc, paths = plan.scores(), plan.paths()
         plan.close()
@@ -265,7 +270,7 @@ def test_batch_random_vs_oracle(nat, bba, kind):
         mk = 1 if arena.info()["f16_ranges"] > 0 else 0
         for k in range(0, len(pairs), 3):
             i, j = pairs[k]
-            s_or, p_or = oracle_dp_on_device_m(mode, profs[i], profs[j], S)
+            s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(i, j, pk))
             assert sc[k] == np.float32(s_or), (mode, i, j)
             assert np.array_equal(paths[k], p_or), (mode, i, j)
             s16, _ = oracle_dp_on_m(mode, arena.match_scores(i, j, mk))
