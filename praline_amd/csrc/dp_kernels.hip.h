@@ -572,16 +572,17 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
 
     int y = end_cells[p * 4 + 0], x = end_cells[p * 4 + 1], k = end_cells[p * 4 + 2];
     if (semiglobal) {
+        const int ls = layout ? 32 : 64;  // lane stride of the end-cell scratch
         const float *lastcol = aux + tk.aux_off + pl.lane;
-        const float *lastrow = aux + tk.aux_off + (int64_t)(tk.max_l1 + 1) * 3 * 64 + pl.lane;
+        const float *lastrow = aux + tk.aux_off + (int64_t)(tk.max_l1 + 1) * 3 * ls + pl.lane;
         // o[L1, x, k] and o[y, L2, k] including the boundary cells (align.py:406-410)
         auto row_at = [&](int xx, int kk) -> float {
             if (xx == 0) return kk == 1 ? boundary_value(L1, rp.go1, rp.ge1, free_one) : PRALINE_NEG_INF;
-            return lastrow[((int64_t)(xx - 1) * 3 + kk) * 64];
+            return lastrow[((int64_t)(xx - 1) * 3 + kk) * ls];
         };
         auto col_at = [&](int yy, int kk) -> float {
             if (yy == 0) return kk == 2 ? boundary_value(L2, rp.go2, rp.ge2, free_two) : PRALINE_NEG_INF;
-            return lastcol[((int64_t)yy * 3 + kk) * 64];
+            return lastcol[((int64_t)yy * 3 + kk) * ls];
         };
         float rmax = PRALINE_NEG_INF, cmax = PRALINE_NEG_INF;
         for (int xx = 0; xx <= L2; ++xx)

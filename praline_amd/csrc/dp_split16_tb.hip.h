@@ -43,10 +43,15 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     bnd_ld += 32 * sizeof(float4);
     float md = h ? cpxm : cdM, ud = h ? cpxu : cdU, ld = h ? cpxl : cdL;  // states of (yy-1, x-1)
     float mleft = h ? cxm : bv.x, lleft = h ? cxl : bv.z;                 // states of (yy, x-1)
-    bool row_in[PRALINE_MAX_RECTS];
+    // zero mask of this lane's 16 cells in this row: one bit per column, built once per row
+    unsigned zmask = 0;
     if constexpr (MASK) {
 #pragma unroll
-        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) row_in[r] = yy >= rect[r][0] && yy <= rect[r][1];
+        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
+            const int lo = max(rect[r][2] - (xb + 1), 0), hi = min(rect[r][3] - (xb + 1), 15);
+            const bool in = yy >= rect[r][0] && yy <= rect[r][1] && lo <= hi;
+            zmask |= in ? ((0xffffu >> (15 - hi)) & (0xffffu << lo)) : 0u;
+        }
     }
     unsigned w_mlo = 0, w_mhi = 0, w_u = 0, w_l = 0;
     __builtin_amdgcn_sched_barrier(0);
@@ -73,25 +78,12 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             bool isMU = !isMM && sMU == M;
             bool isML = !isMM && !isMU && sML == M;
             if constexpr (MASK) {
-                bool z = false;
-#pragma unroll
-                for (int q = 0; q < PRALINE_MAX_RECTS; ++q)
-                    z = z || (row_in[q] && (xb + c + 1) >= rect[q][2] && (xb + c + 1) <= rect[q][3]);
-                if (z) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }
+                if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }  // cext.c:141-149
             }
             w_mlo |= (isMM || isML) ? (1u << c) : 0u;
             w_mhi |= (isMU || isML) ? (1u << c) : 0u;
             w_u |= (uo >= ue) ? 0u : (1u << c);
             w_l |= (lo >= le) ? 0u : (1u << c);
-            if (LOCAL) {
-                // first maximum in C order (y, x, k): inside one strip rows and columns ascend, so a tie only
-                // wins with a smaller row (a later strip); ties between the two halves are resolved at the end
-                const float H = max3f(M, U, Lc);
-                if (H > best_run || (H == best_run && yy < best_y)) {
-                    best_run = H; best_y = yy; best_x = xb + c + 1;
-                    best_k = (M == H) ? 0 : ((U == H) ? 1 : 2);
-                }
-            }
             md = Mp[c]; ud = Up[c]; ld = Lp[c];
             Mp[c] = M; Up[c] = U; Lp[c] = Lc;
             mleft = M; lleft = Lc;
@@ -105,6 +97,29 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         for (int q = 0; q < NP * NR; ++q) BOPS[q] = bsrc[q];
     }
     b_next += b_stride;
+    if (LOCAL) {
+        // local end cell = first maximum of o in C order (y, x, k) (align.py:402).  The state arrays now hold
+        // this row's values: take the row maximum (2 ops per cell) and compare ONCE per row; the column and
+        // state are located only inside the update block, which a wave-level vote skips almost always.
+        // Inside one strip rows ascend, so a tie only wins with a smaller row (a later strip); ties between
+        // the two halves of a pair are resolved when their results are combined.
+        float rowH = max3f(Mp[0], Up[0], Lp[0]);
+#pragma unroll
+        for (int c = 1; c < 16; ++c) rowH = __builtin_fmaxf(rowH, max3f(Mp[c], Up[c], Lp[c]));
+        const bool better = rowH > best_run || (rowH == best_run && yy < best_y);
+        if (__ballot(better) != 0ull) {
+            if (better) {
+                best_run = rowH;
+                best_y = yy;
+#pragma unroll
+                for (int c = 15; c >= 0; --c)   // descending: the smallest column with the maximum wins
+                    if (max3f(Mp[c], Up[c], Lp[c]) == rowH) {
+                        best_x = xb + c + 1;
+                        best_k = (Mp[c] == rowH) ? 0 : ((Up[c] == rowH) ? 1 : 2);
+                    }
+            }
+        }
+    }
     // lower half: this row's boundary states are the next row's diagonal input
     cdM = bv.x; cdU = bv.y; cdL = bv.z;
     // upper half: shift the hand-over generations, then receive the lower half's last column of this row
@@ -162,8 +177,8 @@ __global__ __launch_bounds__(256) void k_dp_split16_tb(Arena16Dev ar, const Wave
     char *my_bnd = reinterpret_cast<char *>(bnd + tk.bnd_off + j);  // float4 [y][32]
     constexpr int BROW = 32 * (int)sizeof(float4);
     uint2 *my_tb = tb + tk.tb_off + lane;                            // [strip][y][64]
-    float *lastcol = aux + tk.aux_off + j;                           // [y][3][64]   (lane slot j of 64)
-    float *lastrow = aux + tk.aux_off + (int64_t)(max_l1 + 1) * 3 * 64 + j;  // [x-1][3][64]
+    float *lastcol = aux + tk.aux_off + j;                                   // [y][3][32]
+    float *lastrow = aux + tk.aux_off + (int64_t)(max_l1 + 1) * 3 * 32 + j;  // [x-1][3][32]
 
     int rect[PRALINE_MAX_RECTS][4];
     if constexpr (MASK) {
@@ -268,16 +283,16 @@ __global__ __launch_bounds__(256) void k_dp_split16_tb(Arena16Dev ar, const Wave
         {                                                                                                            \
             const int yy_ = (T) - h;                                                                                 \
             if (semiglobal && last_owner && have_pair && yy_ >= 1 && yy_ <= L1) {                                    \
-                float *lc = lastcol + (int64_t)yy_ * 3 * 64;            /* o[y, L2, :]  (align.py:408,418-422) */    \
-                lc[0] = select16(Mp, cidx); lc[64] = select16(Up, cidx); lc[128] = select16(Lp, cidx);               \
+                float *lc = lastcol + (int64_t)yy_ * 3 * 32;            /* o[y, L2, :]  (align.py:408,418-422) */    \
+                lc[0] = select16(Mp, cidx); lc[32] = select16(Up, cidx); lc[64] = select16(Lp, cidx);                \
             }                                                                                                        \
             if (have_pair && yy_ == L1) {                                                                            \
                 if (LOCAL) { out_best = best_run; out_y = best_y; out_x = best_x; out_k = best_k; }                  \
                 if (last_owner) { corner_m = select16(Mp, cidx); corner_u = select16(Up, cidx); corner_l = select16(Lp, cidx); } \
                 if (semiglobal) {                                       /* o[L1, x, :]  (align.py:407,413-417) */    \
-                    float *lr = lastrow + (int64_t)xb * 3 * 64;                                                      \
+                    float *lr = lastrow + (int64_t)xb * 3 * 32;                                                      \
                     _Pragma("unroll") for (int c = 0; c < 16; ++c) {                                                 \
-                        lr[(c * 3 + 0) * 64] = Mp[c]; lr[(c * 3 + 1) * 64] = Up[c]; lr[(c * 3 + 2) * 64] = Lp[c];    \
+                        lr[(c * 3 + 0) * 32] = Mp[c]; lr[(c * 3 + 1) * 32] = Up[c]; lr[(c * 3 + 2) * 32] = Lp[c];    \
                     }                                                                                                \
                 }                                                                                                    \
             }                                                                                                        \

@@ -79,6 +79,8 @@ static int ensure_runtime(int device)
     return PRALINE_OK;
 }
 
+static void pool_clear();
+
 extern "C" int praline_abi_version(void) { return PRALINE_DP_ABI_VERSION; }
 
 extern "C" int praline_device_count(int *count)
@@ -97,6 +99,7 @@ extern "C" int praline_shutdown(void)
 {
     if (!g_rt.ready) return PRALINE_OK;
     (void)hipStreamSynchronize(g_rt.stream);
+    pool_clear();
     (void)hipEventDestroy(g_rt.ev0);
     (void)hipEventDestroy(g_rt.ev1);
     (void)hipStreamDestroy(g_rt.stream);
@@ -114,20 +117,72 @@ extern "C" int praline_synchronize(void)
 extern "C" const char *praline_last_error(void) { return g_err.c_str(); }
 extern "C" void *praline_stream(void) { return g_rt.ready ? (void *)g_rt.stream : nullptr; }
 
+// Device buffers come from a small pool: plans allocate multi-GB scratch (strip boundaries, packed
+// traceback, paths) and hipMalloc / hipFree of such blocks costs 100s of ms.  Released blocks are kept
+// and handed out again when a request fits (block <= 2x request); praline_shutdown frees them.
+struct PoolBlock { void *p; size_t bytes; };
+static std::vector<PoolBlock> g_pool;
+static size_t g_pool_bytes = 0;
+static const size_t kPoolKeepBytes = (size_t)96 << 30;
+
+static void *pool_alloc(size_t bytes, size_t *got)
+{
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < g_pool.size(); ++i)
+        if (g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + (1 << 20) &&
+            (best == (size_t)-1 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+    if (best != (size_t)-1) {
+        PoolBlock b = g_pool[best];
+        g_pool.erase(g_pool.begin() + best);
+        g_pool_bytes -= b.bytes;
+        *got = b.bytes;
+        return b.p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // give cached blocks back to the driver and retry once
+        for (auto &b : g_pool) (void)hipFree(b.p);
+        g_pool.clear();
+        g_pool_bytes = 0;
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return nullptr;
+    }
+    *got = bytes;
+    return p;
+}
+
+static void pool_release(void *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes < ((size_t)1 << 20) || g_pool_bytes + bytes > kPoolKeepBytes) { (void)hipFree(p); return; }
+    g_pool.push_back({p, bytes});
+    g_pool_bytes += bytes;
+}
+
+static void pool_clear()
+{
+    for (auto &b : g_pool) (void)hipFree(b.p);
+    g_pool.clear();
+    g_pool_bytes = 0;
+}
+
 // small RAII device buffer
 template <typename T> struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0;          // elements requested
+    size_t cap_bytes = 0;  // bytes of the underlying block
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void release() { if (p) { pool_release(p, cap_bytes); p = nullptr; n = 0; cap_bytes = 0; } }
     int alloc(size_t count)
     {
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e != hipSuccess)
-            return fail(PRALINE_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        size_t got = 0;
+        p = (T *)pool_alloc(count * sizeof(T), &got);
+        if (!p) return fail(PRALINE_ERR_NOMEM, "device allocation of %zu bytes failed", count * sizeof(T));
         n = count;
+        cap_bytes = got;
         return PRALINE_OK;
     }
     int upload(const T *src, size_t count, hipStream_t st)
@@ -474,7 +529,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         wt.aux_off = 0;
         // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]
         pl->tb_elems[t] = split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
-        pl->aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * 64;
+        pl->aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * (split ? 32 : 64);
     }
     pl->bnd_elems = bnd;
 
