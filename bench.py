@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--mode", default="global")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-per-thread", type=int, default=24)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -197,15 +198,23 @@ def main():
             pass
         # the GPU box gives one GPU a share of 16 host cores; do not oversubscribe it
         threads = int(os.environ.get("BENCH_CPU_THREADS", min(threads, 16)))
-        n_sample = min(len(pairs), threads * args.cpu_sample_per_thread)
-        idx = np.linspace(0, len(pairs) - 1, n_sample).astype(np.int64)
-        sample = pairs[idx]
         arena_cat = np.concatenate(profs, axis=0)
         row_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
-        tc0 = time.perf_counter()
-        cpu_scores = orc.batch_scores(args.mode, arena_cat, row_off, lens.astype(np.int32), S,
-                                      sample, GAP_OPEN, GAP_EXTEND, threads=threads)
-        tc1 = time.perf_counter()
+
+        def run_sample(n):
+            idx_ = np.linspace(0, len(pairs) - 1, n).astype(np.int64)
+            t_a = time.perf_counter()
+            sc_ = orc.batch_scores(args.mode, arena_cat, row_off, lens.astype(np.int32), S, pairs[idx_],
+                                   GAP_OPEN, GAP_EXTEND, threads=threads)
+            return idx_, sc_, time.perf_counter() - t_a
+
+        # pilot to size the sample: about args.cpu_seconds of CPU work (bounded by the whole pair list)
+        n_pilot = min(len(pairs), threads * args.cpu_sample_per_thread)
+        idx, cpu_scores, dt = run_sample(n_pilot)
+        n_sample = int(min(len(pairs), max(n_pilot, n_pilot * args.cpu_seconds / max(dt, 1e-3))))
+        if n_sample > n_pilot:
+            idx, cpu_scores, dt = run_sample(n_sample)
+        tc0, tc1 = 0.0, dt
         sample_cells = int(cells[idx].sum())
         gpu_scores = d_slice.cpu().numpy()[idx] if world == 1 else None
         max_rel = float(np.max(np.abs(gpu_scores - cpu_scores) / np.maximum(1.0, np.abs(cpu_scores))))
