@@ -6,6 +6,9 @@ struct Arena16Dev {
     const char *Q16;
     const int32_t *row_off;
     const int32_t *len;
+    const unsigned char *sym8;  // [rows_pad + 64] active-symbol index of each (one-hot) profile row, 16 NR = none;
+                                // NULL unless every profile of the arena is one-hot
+    int stage;              // 1: use the LDS-staged operand stream (k_dp_split16 BSRC = 2)
     int row_bytes;          // 2 * half_bytes
     int half_bytes;         // 2 (pieces) * NR * 16
 };

@@ -24,11 +24,21 @@
 #include "dp_split.hip.h"
 #include "dp_arena16.h"
 
+#ifndef PRALINE_S16_ABLATE
+#define PRALINE_S16_ABLATE 0   // experiments only: 1 no operand refills, 2 no boundary column traffic, 4 no MFMAs
+#endif
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+
+// One-hot operand table (LDS): row `sym` holds the B operand slots of a profile row with all its mass
+// on active symbol sym, [hh][r][8 halves]; row 16 NR is the all-zero row (padding rows, symbols that
+// cannot score).  The odd 16-byte row stride spreads the rows over the LDS banks.
+__host__ __device__ constexpr int onehot_stride(int NR) { return 32 * NR + 16; }
+__host__ __device__ constexpr int onehot_bytes(int NR) { return (16 * NR + 1) * onehot_stride(NR); }
 
 // Measured: forcing v_pk_add_f32 for the three per-column adds made the kernel 13 % SLOWER (packed fp32
 // VALU beside MFMAs is an anti-lever on gfx950); plain scalar adds are used.
@@ -49,8 +59,118 @@ __device__ __forceinline__ float select16s(const float (&v)[17], int idx)
     return select16(w, idx);
 }
 
+
+// ---- LDS-staged operand stream (BSRC = 2) ------------------------------------------------------
+// Measured (scripts/exp_step.py): a wave-wide load whose 64 lanes touch 64 different rows costs the CU's
+// L1 about one tag cycle per lane; with 4 such loads per step and wave the four SIMDs of a CU saturate
+// that path (0.49 us per step whatever the occupancy).  The staged stream fetches the same bytes in
+// pieces of whole rows - C = row_bytes / 16 consecutive lanes read one row (128 contiguous bytes in the
+// 3-term, <= 32 symbol case), one piece = 64 / C pairs - by LDS-DMA (global_load_lds_dwordx4: no VGPR
+// destination, so the look-ahead costs LDS instead of registers), and every lane picks its operand
+// slots up from LDS with ds_read_b128.  The DMA destination is lane-linear, so the swizzle that makes
+// those reads bank-conflict free is applied to the SOURCE chunk and to the read address (the same XOR).
+// The strip-boundary column takes the same road (global_load_lds_dword, one 256-byte row per step) so
+// that no compiler-counted load is in flight inside the loop: the waits are counted by hand.
+//
+// LDS per wave: [4 x 256 B boundary rows][4 x SLOT operand rows], SLOT = 32 pairs x row_bytes.
+// Row r of either kind lives in ring slot r % 4.
+__host__ __device__ constexpr int stage_slot_bytes(int NOPB) { return 32 * 32 * NOPB; }  // 32 pairs x (2 halves x NOPB x 16 B)
+__host__ __device__ constexpr int stage_lds_bytes(int NOPB) { return 1024 + 4 * stage_slot_bytes(NOPB); }
+// swizzle of pair p's row: chunk c is kept at chunk position c ^ stage_swz(p)
+template <int C> __device__ __forceinline__ unsigned stage_swz(unsigned p) { return (p / (16 / C)) & (C - 1); }
+
+// One step's DMA: NOPB pieces of operand rows (wave-uniform row cursor curB, per-lane byte offsets gofs,
+// LDS slot address ldsB) and one boundary row (cursor curN, lane offset gofs_n, LDS address ldsN).
+// The instruction offset moves source AND destination (checked: scripts/micro/glds_test.hip); gofs[i]
+// carries the matching -1024 i (and a +4096 bias that the cursor takes back) so only the LDS side moves.
+template <int NOPB>
+__device__ __forceinline__ void stage_issue(unsigned long long curB, const unsigned (&gofs)[4], unsigned ldsB,
+                                            unsigned long long curN, unsigned gofs_n, unsigned ldsN)
+{
+    unsigned keep;
+    if constexpr (NOPB == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %5\n\t"
+                     "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %4, %5 offset:3072\n\t"
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %7, %8\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gofs[0]), "v"(gofs[1]), "v"(gofs[2]), "v"(gofs[3]), "s"(curB), "s"(ldsB), "v"(gofs_n), "s"(curN), "s"(ldsN)
+                     : "memory");
+    else if constexpr (NOPB == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %5, %6\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gofs[0]), "v"(gofs[1]), "s"(curB), "s"(ldsB), "v"(gofs_n), "s"(curN), "s"(ldsN)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %4, %5\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gofs[0]), "s"(curB), "s"(ldsB), "v"(gofs_n), "s"(curN), "s"(ldsN)
+                     : "memory");
+}
+// operand rows only (prologue)
+template <int NOPB>
+__device__ __forceinline__ void stage_issue_rows(unsigned long long curB, const unsigned (&gofs)[4], unsigned ldsB)
+{
+    unsigned keep;
+    if constexpr (NOPB == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %5\n\t"
+                     "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %4, %5 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gofs[0]), "v"(gofs[1]), "v"(gofs[2]), "v"(gofs[3]), "s"(curB), "s"(ldsB)
+                     : "memory");
+    else if constexpr (NOPB == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gofs[0]), "v"(gofs[1]), "s"(curB), "s"(ldsB)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gofs[0]), "s"(curB), "s"(ldsB)
+                     : "memory");
+}
+// boundary row only (prologue)
+__device__ __forceinline__ void stage_issue_bnd(unsigned long long curN, unsigned gofs_n, unsigned ldsN)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gofs_n), "s"(curN), "s"(ldsN)
+                 : "memory");
+}
+#define PRALINE_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
 // NR: 16-wide k ranges (1: <= 16 active symbols, 2: <= 32); NTERM: 1 exact / 3 split.
-template <int NR, int NTERM, bool LOCAL>
+// BSRC: where the B operands (profile rows of the sequences ONE) come from.
+//   0  per-lane global loads, 3-deep register ring (BOPS: row t+1 on entry, refilled with row t+4)
+//   1  one-hot arenas: looked up in the one-hot operand table in LDS by the row's symbol (byte SB of symw)
+//   2  LDS-staged stream (see above): SB = t % 4 selects the ring slots; BOPS holds row t+1, BFILL
+//      receives row t+2 from LDS; the boundary value of the next step is read from LDS into bnd_pref
+template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int SB = 0>
 __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                              float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
                                              const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR], const char *&b_next,
@@ -58,8 +178,13 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
                                              float (&Hs)[17], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
                                              float &best_run, float &col_run, float &out_best, float &out_rowmax, float &out_colmax,
                                              float &out_corner, float go, float ge, bool semiglobal, bool last_owner, int cidx,
-                                             int xb, int L2)
+                                             int xb, int L2, const char *onehot_lane = nullptr, unsigned symw = 0,
+                                             float4 *BFILL = nullptr, const char *stage_lds = nullptr,
+                                             const unsigned *stage_rd = nullptr, unsigned stage_rd_bnd = 0,
+                                             const unsigned (*stage_gofs)[4] = nullptr, unsigned long long *stage_cur = nullptr,
+                                             unsigned stage_lds_addr = 0, unsigned stage_gofs_n = 0)
 {
+    constexpr bool ONEHOT = BSRC == 1;
     // bnd_pref: this step's boundary value on entry; refilled with the value 3 rows ahead.
     // BOPS: B operands of row t+1 on entry; refilled with row t+4 (3-deep rings, the caller rotates
     // the register names through a 6x unrolled loop).
@@ -71,8 +196,21 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     for (int c = 0; c < 8; ++c) { m2[c].x = h ? PREV[2 * c] : CUR[2 * c]; m2[c].y = h ? PREV[2 * c + 1] : CUR[2 * c + 1]; }
 
     const float2 bv = bnd_pref;
-    bnd_pref = *reinterpret_cast<const float2 *>(bnd_ld);
-    bnd_ld += 32 * sizeof(float2);
+    if constexpr (BSRC == 2) {
+        constexpr int NOPB = ((NTERM == 1) ? 1 : 2) * NR;
+        // the DMA of operand row t+2 and boundary row t+1 was issued three steps ago: everything but the
+        // last two steps' pieces has landed
+        PRALINE_VMCNT(2 * (NOPB + 1));
+        bnd_pref = *reinterpret_cast<const float2 *>(stage_lds + ((SB + 1) & 3) * 256 + stage_rd_bnd);
+#pragma unroll
+        for (int q = 0; q < NOPB; ++q)
+            BFILL[q] = *reinterpret_cast<const float4 *>(stage_lds + 1024 + ((SB + 2) & 3) * stage_slot_bytes(NOPB) + stage_rd[q]);
+    } else {
+#if !(PRALINE_S16_ABLATE & 2)
+        bnd_pref = *reinterpret_cast<const float2 *>(bnd_ld);
+#endif
+        bnd_ld += 32 * sizeof(float2);
+    }
     // Hs[c] = H[y-1] of the column LEFT of column c (Hs[0]: handed in), so the diagonal inputs of two
     // adjacent columns sit in one aligned register pair and the adds below are v_pk_add_f32.
     Hs[0] = h ? hd_x : dH;
@@ -91,7 +229,11 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         const int r = k % NR;
         const int ia = (term == 0) ? NR + r : r;          // A piece: lo for term 0, hi otherwise
         const int ib = (term == 1) ? NR + r : r;          // B piece: lo for term 1, hi otherwise
+#if !(PRALINE_S16_ABLATE & 4)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+#else
+        acc[k] += BOPS[ib].x * aop[ia].x;
+#endif
         // this MFMA's share of the 8 column pairs
 #pragma unroll
         for (int cp = (8 * k) / NM; cp < (8 * (k + 1)) / NM; ++cp) {
@@ -116,17 +258,33 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         __builtin_amdgcn_sched_barrier(0);
     }
     PREV = acc;
-    {
+    if constexpr (BSRC == 2) {
+        // rows t+5 / t+4 go where rows t+1 / t lived (both consumed: their reads were waited for)
+        constexpr int NOPB = ((NTERM == 1) ? 1 : 2) * NR;
+        stage_issue<NOPB>(stage_cur[0], *stage_gofs, stage_lds_addr + 1024 + ((SB + 1) & 3) * stage_slot_bytes(NOPB),
+                          stage_cur[1], stage_gofs_n, stage_lds_addr + (SB & 3) * 256);
+        stage_cur[0] += 64 * NR;  // one arena row
+        stage_cur[1] += 256;
+    } else if constexpr (ONEHOT) {
+        const unsigned sym = (symw >> (8 * SB)) & 0xffu;
+        const float4 *bsrc = reinterpret_cast<const float4 *>(onehot_lane + sym * onehot_stride(NR));
+#pragma unroll
+        for (int q = 0; q < NR; ++q) BOPS[q] = bsrc[q];
+    } else {
+#if !(PRALINE_S16_ABLATE & 1)
         const float4 *bsrc = reinterpret_cast<const float4 *>(b_next);
 #pragma unroll
         for (int q = 0; q < NP * NR; ++q) BOPS[q] = bsrc[q];
+#endif
+        b_next += b_stride;
     }
-    b_next += b_stride;
     dH = bv.x;
     hd_x = from_lower_half(hd_out);
     l_x = from_lower_half(lrun);
 
+#if !(PRALINE_S16_ABLATE & 2)
     if (h) *reinterpret_cast<float2 *>(bnd_st) = make_float2(Hs[16], lrun);  // H[yy][x0+32], L[yy][x0+33]
+#endif
     bnd_st += 32 * sizeof(float2);
     if (semiglobal && last_owner) col_run = __builtin_fmaxf(col_run, select16s(Hs, cidx));
     if (have_pair && yy == L1) {
@@ -142,7 +300,13 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
 }
 
 
-template <int NR, int NTERM, bool LOCAL>
+// ONEHOT (exact mode only): every sequence ONE of the arena is one-hot (an ordinary sequence).  Its
+// operand rows are then not streamed from HBM - 64 lanes reading 64 different rows per step is what
+// saturates the CU's texture-address path (measured: scripts/exp_step.py, 0.47 -> 0.32 us per step and
+// SIMD without these loads) - but looked up in a one-hot table in LDS by the row's symbol; the symbols
+// arrive as one dword per lane and four rows.
+// BSRC = 2: the LDS-staged operand stream described above (one wave per workgroup).
+template <int NR, int NTERM, bool LOCAL, int BSRC = 0>
 __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ lane_one,
                                                     const int32_t *__restrict__ lane_pair, float2 *bnd,
@@ -150,6 +314,27 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
+    constexpr bool ONEHOT = BSRC == 1;
+    constexpr bool STAGED = BSRC == 2;
+    static_assert(!ONEHOT || NTERM == 1, "the one-hot table path is an exact-mode path");
+    __shared__ __attribute__((aligned(16))) char onehot_tab[ONEHOT ? onehot_bytes(NR) : 16];
+    __shared__ __attribute__((aligned(16))) char stage_lds[STAGED ? stage_lds_bytes(NP * NR) : 16];
+    if constexpr (STAGED) {
+        // defined contents before the first DMA (the compiler does not see the DMA's writes)
+        for (int i = threadIdx.x * 16; i < stage_lds_bytes(NP * NR); i += blockDim.x * 16)
+            *reinterpret_cast<float4 *>(stage_lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    if constexpr (ONEHOT) {
+        _Float16 *tab = reinterpret_cast<_Float16 *>(onehot_tab);
+        constexpr int per_row = onehot_stride(NR) / 2;  // halves per table row (the last 8 are padding)
+        for (int i = threadIdx.x; i < (16 * NR + 1) * per_row; i += blockDim.x) {
+            const int sym = i / per_row, e = i % per_row;
+            const int hh = e / (8 * NR), r = (e / 8) % NR, jj = e % 8;
+            tab[i] = (e < 16 * NR && 16 * r + 8 * hh + jj == sym) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
+        __syncthreads();
+    }
     const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (task >= n_tasks) return;
     const int lane = threadIdx.x & 63;
@@ -172,6 +357,36 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 
     const char *pB = ar.P16 + (int64_t)(have_pair ? ar.row_off[my_one] : 0) * ar.row_bytes + h * ar.half_bytes;
     const int b_stride = ar.row_bytes;
+    const unsigned *pSym = reinterpret_cast<const unsigned *>(ar.sym8 + (have_pair ? ar.row_off[my_one] : 0));
+    const char *onehot_lane = onehot_tab + h * (16 * NR);
+    // STAGED: per-lane source offsets of the DMA pieces and LDS read addresses (see the comment above)
+    unsigned stage_gofs[4] = {0, 0, 0, 0}, stage_rd[4] = {0, 0, 0, 0};
+    const unsigned stage_rd_bnd = (unsigned)j * 8u;
+    const unsigned stage_gofs_n = (unsigned)lane * 4u;
+    const unsigned stage_lds_addr = (unsigned)(uintptr_t)stage_lds;
+    unsigned long long stage_cur[2] = {0, 0};
+    unsigned long long stage_bnd_base = 0;
+    if constexpr (STAGED) {
+        constexpr int C = 2 * NOP;          // 16-byte chunks per row
+        constexpr int PP = 64 / C;          // pairs per DMA piece
+#pragma unroll
+        for (int i = 0; i < NOP; ++i) {
+            const int p = i * PP + lane / C;
+            const int one_p = lane_one[base + p];
+            const unsigned row0 = one_p >= 0 ? (unsigned)ar.row_off[one_p] : 0u;
+            const unsigned chunk = ((unsigned)lane % C) ^ stage_swz<C>((unsigned)p);  // = hh * NOP + slot
+            // arena rows always hold hi and lo pieces ([hh][2 NR slots]); exact mode fetches the hi slots only
+            const unsigned mem_chunk = (chunk / NOP) * (2 * NR) + chunk % NOP;
+            stage_gofs[i] = row0 * (unsigned)(64 * NR) + mem_chunk * 16u + 4096u - 1024u * i;
+        }
+#pragma unroll
+        for (int q = 0; q < NOP; ++q)
+            stage_rd[q] = (unsigned)j * (unsigned)(32 * NOP) + (((unsigned)(h * NOP + q)) ^ stage_swz<C>((unsigned)j)) * 16u;
+        const unsigned long long bb = reinterpret_cast<unsigned long long>(bnd) + (unsigned long long)tk.bnd_off * sizeof(float2);
+        // (readfirstlane returns int: widen through unsigned)
+        stage_bnd_base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bb >> 32)) << 32) |
+                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb);
+    }
     const int acol = 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
     const char *qA = ar.Q16 + ((int64_t)ar.row_off[two] + acol) * ar.row_bytes + h * ar.half_bytes;
 
@@ -225,12 +440,62 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         float4 b0[NOP], b1[NOP], b2[NOP];
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
-        {
+        unsigned d1 = 0, d2 = 0, d3 = 0, d4 = 0;  // ONEHOT: symbols of the rows the next 12 steps refill
+        float2 p0, p1, p2;
+        const char *b_next = pB + 4 * b_stride;                   // first refill: row 5
+        const char *bnd_ld = my_bnd + 4 * BROW;                   // first prefetch inside a step: row 4
+        char *bnd_st = my_bnd;                                    // upper half stores row yy = t - 1 (row 0: dummy)
+        if constexpr (STAGED) {
+            constexpr int SLOT = stage_slot_bytes(NOP);
+            PRALINE_VMCNT(0);  // the previous strip's look-ahead
+            // operand row r is arena row r - 1 of each sequence; rows 1..4 -> ring slots 1, 2, 3, 0
+            unsigned long long cb = reinterpret_cast<unsigned long long>(ar.P16) - 4096ull;
+            unsigned long long cn = stage_bnd_base + 256;
+#pragma unroll
+            for (int r = 1; r <= 4; ++r) {
+                stage_issue_rows<NOP>(cb, stage_gofs, stage_lds_addr + 1024 + (r & 3) * SLOT);
+                stage_issue_bnd(cn, stage_gofs_n, stage_lds_addr + (r & 3) * 256);
+                cb += 64 * NR;
+                cn += 256;
+            }
+            PRALINE_VMCNT(0);
             float4 br1[NOP];
-            const float4 *s1 = reinterpret_cast<const float4 *>(pB);
-            const float4 *s2 = reinterpret_cast<const float4 *>(pB + b_stride);
-            const float4 *s3 = reinterpret_cast<const float4 *>(pB + 2 * b_stride);
-            const float4 *s4 = reinterpret_cast<const float4 *>(pB + 3 * b_stride);
+#pragma unroll
+            for (int q = 0; q < NOP; ++q) {
+                br1[q] = *reinterpret_cast<const float4 *>(stage_lds + 1024 + 1 * SLOT + stage_rd[q]);
+                b0[q] = *reinterpret_cast<const float4 *>(stage_lds + 1024 + 2 * SLOT + stage_rd[q]);
+            }
+            p0 = *reinterpret_cast<const float2 *>(stage_lds + 1 * 256 + stage_rd_bnd);
+#pragma unroll
+            for (int k = 0; k < NTERM * NR; ++k) {
+                const int term = (NTERM == 1) ? 2 : k / NR;
+                const int r = k % NR;
+                const int ia = (term == 0) ? NR + r : r;
+                const int ib = (term == 1) ? NR + r : r;
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(br1[ib]), accA, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // row 5 takes row 1's slot (its operands are in the accumulator now)
+            stage_issue_rows<NOP>(cb, stage_gofs, stage_lds_addr + 1024 + 1 * SLOT);
+            cb += 64 * NR;
+            stage_cur[0] = cb;  // next: operand row 6 (step 1)
+            stage_cur[1] = cn;  // next: boundary row 5 (step 1)
+        } else {
+            float4 br1[NOP];
+            const float4 *s1, *s2, *s3, *s4;
+            if constexpr (ONEHOT) {
+                const unsigned w0 = pSym[0];
+                d1 = pSym[1]; d2 = pSym[2]; d3 = pSym[3]; d4 = pSym[4];
+                s1 = reinterpret_cast<const float4 *>(onehot_lane + (w0 & 0xffu) * onehot_stride(NR));
+                s2 = reinterpret_cast<const float4 *>(onehot_lane + ((w0 >> 8) & 0xffu) * onehot_stride(NR));
+                s3 = reinterpret_cast<const float4 *>(onehot_lane + ((w0 >> 16) & 0xffu) * onehot_stride(NR));
+                s4 = reinterpret_cast<const float4 *>(onehot_lane + (w0 >> 24) * onehot_stride(NR));
+            } else {
+                s1 = reinterpret_cast<const float4 *>(pB);
+                s2 = reinterpret_cast<const float4 *>(pB + b_stride);
+                s3 = reinterpret_cast<const float4 *>(pB + 2 * b_stride);
+                s4 = reinterpret_cast<const float4 *>(pB + 3 * b_stride);
+            }
 #pragma unroll
             for (int q = 0; q < NOP; ++q) { br1[q] = s1[q]; b0[q] = s2[q]; b1[q] = s3[q]; b2[q] = s4[q]; }
 #pragma unroll
@@ -241,25 +506,30 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                 const int ib = (term == 1) ? NR + r : r;
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(br1[ib]), accA, 0, 0, 0);
             }
+            p0 = *reinterpret_cast<const float2 *>(my_bnd + BROW);      // row 1
+            p1 = *reinterpret_cast<const float2 *>(my_bnd + 2 * BROW);  // row 2
+            p2 = *reinterpret_cast<const float2 *>(my_bnd + 3 * BROW);  // row 3
         }
-        const char *b_next = pB + 4 * b_stride;                   // first refill: row 5
-        const char *bnd_ld = my_bnd + 4 * BROW;                   // first prefetch inside a step: row 4
-        char *bnd_st = my_bnd;                                    // upper half stores row yy = t - 1 (row 0: dummy)
-        float2 p0 = *reinterpret_cast<const float2 *>(my_bnd + BROW);      // row 1
-        float2 p1 = *reinterpret_cast<const float2 *>(my_bnd + 2 * BROW);  // row 2
-        float2 p2 = *reinterpret_cast<const float2 *>(my_bnd + 3 * BROW);  // row 3
 
-#define PRALINE_STEP16(T, CUR, PREV, BSET, PSLOT)                                                                     \
-        split16_step<NR, NTERM, LOCAL>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld, bnd_st, \
-                                       PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax, out_colmax, out_corner, \
-                                       go, ge, semiglobal, last_owner, cidx, xb, L2)
+#define PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, SYMW, SB)                                                          \
+        split16_step<NR, NTERM, LOCAL, BSRC, SB>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld, \
+                                       bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
+                                       out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYMW)
+#define PRALINE_STEP16(T, CUR, PREV, BSET, PSLOT) PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, d1, 0)
+        // staged stream: BUSE holds row T+1, BFILL receives row T+2, PH = T % 4
+#define PRALINE_STEP16S(T, CUR, PREV, BUSE, BFILL, PH)                                                                \
+        split16_step<NR, NTERM, LOCAL, 2, PH>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, b_next, b_stride, bnd_ld,  \
+                                       bnd_st, p0, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,     \
+                                       out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, 0u, \
+                                       BFILL, stage_lds, stage_rd, stage_rd_bnd, &stage_gofs, stage_cur, stage_lds_addr, stage_gofs_n)
         // step 1: only the lower half has a row; the upper half's garbage is undone right after
         {
             float Hsave[17];
 #pragma unroll
             for (int c = 0; c < 17; ++c) Hsave[c] = Hs[c];
             const float best_s = best_run, col_s = col_run;
-            PRALINE_STEP16(1, accA, accB, b0, p0);
+            if constexpr (STAGED) PRALINE_STEP16S(1, accA, accB, b0, b1, 1);
+            else PRALINE_STEP16(1, accA, accB, b0, p0);
             if (h) {
 #pragma unroll
                 for (int c = 0; c < 17; ++c) Hs[c] = Hsave[c];
@@ -269,19 +539,62 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                 col_run = col_s;
             }
         }
-        // steps 2 .. max_l1 + 1: six per iteration - the accumulators ping-pong (period 2), the B operand
-        // sets and the boundary prefetch slots rotate (period 3); steps past max_l1 + 1 compute rows that
-        // nobody reports
-        for (int t = 2; t <= max_l1 + 1; t += 6) {
-            PRALINE_STEP16(t, accB, accA, b1, p1);
-            PRALINE_STEP16(t + 1, accA, accB, b2, p2);
-            PRALINE_STEP16(t + 2, accB, accA, b0, p0);
-            PRALINE_STEP16(t + 3, accA, accB, b1, p1);
-            PRALINE_STEP16(t + 4, accB, accA, b2, p2);
-            PRALINE_STEP16(t + 5, accA, accB, b0, p0);
+        // steps 2 .. max_l1 + 1: the accumulators ping-pong (period 2), the B operand sets and the boundary
+        // prefetch slots rotate (period 3; staged stream: operand sets period 2, ring slots period 4);
+        // steps past max_l1 + 1 compute rows that nobody reports
+        if constexpr (STAGED) {
+            for (int t = 2; t <= max_l1 + 1; t += 12) {
+                PRALINE_STEP16S(t, accB, accA, b1, b0, 2);
+                PRALINE_STEP16S(t + 1, accA, accB, b0, b1, 3);
+                PRALINE_STEP16S(t + 2, accB, accA, b1, b0, 0);
+                PRALINE_STEP16S(t + 3, accA, accB, b0, b1, 1);
+                PRALINE_STEP16S(t + 4, accB, accA, b1, b0, 2);
+                PRALINE_STEP16S(t + 5, accA, accB, b0, b1, 3);
+                PRALINE_STEP16S(t + 6, accB, accA, b1, b0, 0);
+                PRALINE_STEP16S(t + 7, accA, accB, b0, b1, 1);
+                PRALINE_STEP16S(t + 8, accB, accA, b1, b0, 2);
+                PRALINE_STEP16S(t + 9, accA, accB, b0, b1, 3);
+                PRALINE_STEP16S(t + 10, accB, accA, b1, b0, 0);
+                PRALINE_STEP16S(t + 11, accA, accB, b0, b1, 1);
+            }
+        } else if constexpr (ONEHOT) {
+            // twelve per iteration: the step at t refills the operands of row t + 4, i.e. symbol t + 3 of
+            // the sequence; t = 2 (mod 12), so the twelve symbols are bytes 1..3 of d1, d2, d3 and byte 0
+            // of d4 - d4 becomes the next iteration's d1, three new dwords arrive per iteration.
+            const unsigned *pn = pSym + 5;
+            for (int t = 2; t <= max_l1 + 1; t += 12) {
+                const unsigned n2 = pn[0], n3 = pn[1], n4 = pn[2];
+                pn += 3;
+                PRALINE_STEP16X(t, accB, accA, b1, p1, d1, 1);
+                PRALINE_STEP16X(t + 1, accA, accB, b2, p2, d1, 2);
+                PRALINE_STEP16X(t + 2, accB, accA, b0, p0, d1, 3);
+                PRALINE_STEP16X(t + 3, accA, accB, b1, p1, d2, 0);
+                PRALINE_STEP16X(t + 4, accB, accA, b2, p2, d2, 1);
+                PRALINE_STEP16X(t + 5, accA, accB, b0, p0, d2, 2);
+                PRALINE_STEP16X(t + 6, accB, accA, b1, p1, d2, 3);
+                PRALINE_STEP16X(t + 7, accA, accB, b2, p2, d3, 0);
+                PRALINE_STEP16X(t + 8, accB, accA, b0, p0, d3, 1);
+                PRALINE_STEP16X(t + 9, accA, accB, b1, p1, d3, 2);
+                PRALINE_STEP16X(t + 10, accB, accA, b2, p2, d3, 3);
+                PRALINE_STEP16X(t + 11, accA, accB, b0, p0, d4, 0);
+                d1 = d4; d2 = n2; d3 = n3; d4 = n4;
+            }
+        } else {
+            for (int t = 2; t <= max_l1 + 1; t += 6) {
+                PRALINE_STEP16(t, accB, accA, b1, p1);
+                PRALINE_STEP16(t + 1, accA, accB, b2, p2);
+                PRALINE_STEP16(t + 2, accB, accA, b0, p0);
+                PRALINE_STEP16(t + 3, accA, accB, b1, p1);
+                PRALINE_STEP16(t + 4, accB, accA, b2, p2);
+                PRALINE_STEP16(t + 5, accA, accB, b0, p0);
+            }
         }
 #undef PRALINE_STEP16
+#undef PRALINE_STEP16S
+#undef PRALINE_STEP16X
     }
+
+    if constexpr (STAGED) PRALINE_VMCNT(0);  // no DMA may be in flight when the wave ends
 
     const float corner_all = __builtin_fmaxf(out_corner, partner_value(out_corner, h));
     const float rowmax_all = __builtin_fmaxf(out_rowmax, partner_value(out_rowmax, h));

@@ -9,12 +9,22 @@
 template <int NR, int NTERM> static void launch16(const LaunchArgs &la, const Arena16Dev &a16, bool local, unsigned wpb)
 {
     const dim3 grid((la.n_tasks + wpb - 1) / wpb), block(64 * wpb);
-    if (local)
-        hipLaunchKernelGGL((k_dp_split16<NR, NTERM, true>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,
-                           la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks);
-    else
-        hipLaunchKernelGGL((k_dp_split16<NR, NTERM, false>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,
-                           la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks);
+#define PRALINE_LAUNCH16(LOC, BSRC, GRID, BLOCK)                                                                         \
+    hipLaunchKernelGGL((k_dp_split16<NR, NTERM, LOC, BSRC>), GRID, BLOCK, 0, la.stream, a16, la.tasks, la.lane_one,       \
+                       la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks)
+    if constexpr (NTERM == 1) {
+        if (a16.sym8 != nullptr) {  // one-hot arena: operand table in LDS
+            if (local) PRALINE_LAUNCH16(true, 1, grid, block); else PRALINE_LAUNCH16(false, 1, grid, block);
+            return;
+        }
+    }
+    if (a16.stage) {  // LDS-staged operand stream: one wave (= its own LDS rings) per workgroup
+        const dim3 g1((unsigned)la.n_tasks), b1(64);
+        if (local) PRALINE_LAUNCH16(true, 2, g1, b1); else PRALINE_LAUNCH16(false, 2, g1, b1);
+        return;
+    }
+    if (local) PRALINE_LAUNCH16(true, 0, grid, block); else PRALINE_LAUNCH16(false, 0, grid, block);
+#undef PRALINE_LAUNCH16
 }
 
 int praline_launch_split16(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local)

@@ -222,9 +222,16 @@ struct praline_arena {
     int nterm16 = 3;       // 1: every operand is exactly representable in f16, 3: hi/lo split
     DevBuf<char> d_P16, d_Q16;
     DevBuf<int> d_flag16;
+    // one-hot arenas (ordinary sequences): active-symbol index per padded row; see k_dp_split16<.., ONEHOT>
+    bool onehot = false;
+    DevBuf<unsigned char> d_sym8;
     Arena16Dev view16() const
     {
         Arena16Dev v;
+        v.sym8 = (onehot && nterm16 == 1) ? d_sym8.p : nullptr;
+        // the staged stream addresses the arena with 32-bit lane offsets
+        const char *ns = getenv("PRALINE_NO_STAGE");
+        v.stage = (!(ns && ns[0] == '1') && (uint64_t)rows_pad * 64 * nr16 < 0xffff0000ull) ? 1 : 0;
         v.P16 = d_P16.p; v.Q16 = d_Q16.p; v.row_off = d_row_off_pad.p; v.len = d_len.p;
         v.half_bytes = 2 * nr16 * 16; v.row_bytes = 2 * v.half_bytes;
         return v;
@@ -310,6 +317,27 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     a->KP = 2 * a->KS;
     a->nr16 = a->n_active <= 16 ? 1 : (a->n_active <= 32 ? 2 : 0);
 
+    // one-hot profiles (every row: a single 1, zeros elsewhere) are streamed as symbol bytes
+    std::vector<unsigned char> sym8;
+    if (a->nr16 > 0 && !(getenv("PRALINE_NO_ONEHOT") && getenv("PRALINE_NO_ONEHOT")[0] == '1')) {
+        const unsigned char none = (unsigned char)(16 * a->nr16);
+        std::vector<int> slot_of(A, -1);
+        for (int k = 0; k < a->n_active; ++k) slot_of[a->active[k]] = k;
+        sym8.assign((size_t)a->rows_pad + 64, none);
+        bool all = true;
+        for (int64_t s = 0; s < n_seqs && all; ++s)
+            for (int y = 0; y < lens[s] && all; ++y) {
+                const float *row = profiles + (a->row_off_raw[s] + y) * (int64_t)A;
+                int hot = -1, nz = 0;
+                for (int i = 0; i < A; ++i)
+                    if (row[i] != 0.0f) { ++nz; hot = i; }
+                if (nz != 1 || row[hot] != 1.0f) all = false;
+                else sym8[a->row_off_pad[s] + y] = slot_of[hot] >= 0 ? (unsigned char)slot_of[hot] : none;
+            }
+        a->onehot = all;
+        if (!all) sym8.clear();
+    }
+
     std::vector<int32_t> seq_of_rowp((size_t)a->rows_pad, -1);
     for (int64_t s = 0; s < n_seqs; ++s)
         for (int r = 0; r < (lens[s] + 31) / 32 * 32; ++r) seq_of_rowp[a->row_off_pad[s] + r] = (int32_t)s;
@@ -322,7 +350,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         (rc = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
         (rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
         (rc = a->d_P.alloc((size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc((size_t)a->rows_pad * a->KP)) ||
-        (rc = a->d_flag16.alloc(1)) ||
+        (rc = a->d_flag16.alloc(1)) || (a->onehot && (rc = a->d_sym8.upload(sym8, st))) ||
         (a->nr16 > 0 && ((rc = a->d_P16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)) ||
                          (rc = a->d_Q16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)))) ||
         (rc = arena_launch_premultiply(a, true))) {
@@ -456,34 +484,34 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         if (sx != sy) return sx > sy;
         return x.max_l1 > y.max_l1;
     });
-    // XCD-aware placement (scores-only plans): workgroups are dealt round-robin to the 8 XCDs
-    // (block b -> XCD b % 8, each with a private 4 MB L2).  A task's operand stream is the profile rows
-    // of its 32 sequences one; chunk c of every group holds the c-th length class of partners, i.e.
-    // largely the SAME sequences across groups.  Order the tasks class-major and give every XCD a
-    // contiguous range of that order, so one XCD's L2 only has to hold a few length classes.
-    // (Placement is a speed matter only; results do not depend on it.)
-    // MEASURED (C2 and N=512): 30-40 % SLOWER than plain longest-first order - the class-major ranges put
-    // all expensive tasks on the same XCD, which then queues them behind each other (one resident wave per
-    // SIMD).  Kept opt-in (PRALINE_XCD=1) for kernels with more resident waves.
-    if (!want_paths && halves.size() >= 64 && getenv("PRALINE_XCD") && getenv("PRALINE_XCD")[0] == '1') {
-        std::stable_sort(halves.begin(), halves.end(), [&](const HalfTask &x, const HalfTask &y) { return x.chunk < y.chunk; });
-        const size_t n = halves.size(), per = (n + 7) / 8;
-        // inside each XCD's range: longest first again (late long tasks would stretch the makespan)
-        for (size_t x = 0; x < 8; ++x) {
-            const size_t b = std::min(n, x * per), e = std::min(n, (x + 1) * per);
-            std::stable_sort(halves.begin() + b, halves.begin() + e, [&](const HalfTask &u, const HalfTask &v) {
-                const int64_t cu = (int64_t)((a.len[u.two] + 31) / 32) * u.max_l1, cv = (int64_t)((a.len[v.two] + 31) / 32) * v.max_l1;
-                return cu > cv;
-            });
-        }
-        std::vector<HalfTask> placed;
-        placed.reserve(n);
-        for (size_t q = 0; q < per; ++q)
-            for (size_t x = 0; x < 8; ++x) {
-                const size_t src = x * per + q;
-                if (src < n) placed.push_back(halves[src]);
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with
+    // a private 4 MB L2).  A task streams the profile rows of its 32 sequences one; neighbours in the
+    // longest-first order are mostly the same length class of partners of different sequences two, i.e.
+    // largely the SAME rows.  Groups of G consecutive tasks are therefore placed on one XCD (they run at
+    // the same time and share those rows in its L2), and the groups rotate over the XCDs so that every
+    // XCD still gets the same cost mix.  (Placement only affects speed, never results.)
+    //   order index i -> group g = i / G, XCD x = g % 8, position q = (g / 8) * G + i % G -> block 8 q + x
+    // The list is padded with empty tasks to a multiple of 8 G.
+    // (A first attempt - whole length classes per XCD - was 30-40 % slower: it put all expensive tasks on
+    // one XCD.)
+    {
+        int G = 16;
+        if (const char *env = getenv("PRALINE_XCD_GROUP")) G = atoi(env);
+        if (G > 1 && halves.size() >= (size_t)(16 * G)) {
+            const size_t n0 = halves.size();
+            const size_t n = (n0 + 8 * G - 1) / (8 * G) * (8 * G);
+            HalfTask empty;
+            empty.two = halves.back().two;
+            empty.max_l1 = 0;
+            empty.chunk = 0;
+            for (int q = 0; q < 32; ++q) { empty.one[q] = -1; empty.pair[q] = -1; }
+            std::vector<HalfTask> placed(n, empty);
+            for (size_t i = 0; i < n; ++i) {
+                const size_t g = i / G, x = g % 8, q = (g / 8) * G + i % G;
+                placed[8 * q + x] = i < n0 ? halves[i] : empty;
             }
-        halves.swap(placed);
+            halves.swap(placed);
+        }
     }
     int tp = halves.size() >= 4096 ? 2 : 1;
     if (want_paths) tp = 1;  // the traceback variant keeps three states per column in registers
@@ -524,7 +552,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             }
         }
         wt.bnd_off = bnd;
-        bnd += split ? (int64_t)(wt.max_l1 + 12) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
+        bnd += split ? (int64_t)(wt.max_l1 + 24) * 32 : (int64_t)(wt.max_l1 + 1) * 64;  // (the 12x unrolled loops read ahead)
         wt.tb_off = 0;
         wt.aux_off = 0;
         // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpraline_dp.so")
+LIB_PATH = os.environ.get("PRALINE_LIB") or os.path.join(_HERE, "libpraline_dp.so")
 
 MODES = {"global": 0, "local": 1, "semiglobal_both": 2, "semiglobal_one": 3,
          "semiglobal_two": 4}

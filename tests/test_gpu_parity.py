@@ -278,6 +278,47 @@ def test_batch_random_vs_oracle(nat, bba, kind):
     arena.close()
 
 
+@pytest.mark.parametrize("kind", ["onehot", "profile", "dna"])
+def test_operand_stream_variants_agree_bitwise(nat, bba, kind, monkeypatch):
+    """k_dp_split16 has three sources for the sequence-one operands (LDS one-hot table, LDS-staged
+    DMA stream, per-lane global loads): same arithmetic, so the scores must agree bit for bit."""
+    rng = np.random.default_rng(11)
+    if kind == "dna":
+        N, mu, A = 24, 700, 15
+        S = load_golden("synthetic_dna.npz")["matrix"]
+        lens = synth_lengths(rng, N, mu)
+        profs = [one_hot(rng.integers(0, 4, L), A) for L in lens]
+    else:
+        N, mu, A = 70, 150, 27
+        S = bba["S"]
+        lens = synth_lengths(rng, N, mu)
+        lens[0], lens[1], lens[2], lens[3] = 1, 5, 32, 33
+        if kind == "onehot":
+            profs = [one_hot(rng.integers(0, 20, L), A) for L in lens]
+        else:
+            profs = [synth_profile(rng, int(L))[0] for L in lens]
+    pairs = all_pairs(N)
+    results = {}
+    for variant, env in (("default", {}), ("staged", {"PRALINE_NO_ONEHOT": "1"}),
+                         ("lanes", {"PRALINE_NO_ONEHOT": "1", "PRALINE_NO_STAGE": "1"})):
+        for k in ("PRALINE_NO_ONEHOT", "PRALINE_NO_STAGE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        arena = nat.Arena(profs, S)
+        plan = nat.Plan(arena, pairs)
+        for mode in MODES:
+            plan.run(mode, *GAPS)
+            results[(variant, mode)] = plan.scores().copy()
+        plan.close()
+        arena.close()
+    for mode in MODES:
+        ref = results[("lanes", mode)]
+        assert np.isfinite(ref).all()
+        for variant in ("default", "staged"):
+            assert np.array_equal(bits(results[(variant, mode)]), bits(ref)), (kind, variant, mode)
+
+
 def test_batch_c2_slice_properties(nat, bba):
     """BASELINE config 1 shape (256 x ~400 aa profiles, all pairs, global): properties that do not
     need the oracle at full size + oracle spot checks."""
