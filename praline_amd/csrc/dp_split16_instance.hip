@@ -18,6 +18,16 @@ template <int NR, int NTERM> static void launch16(const LaunchArgs &la, const Ar
             return;
         }
     }
+    if (a16.stage && la.wg != nullptr) {  // small batch: two-wave workgroups (see k_dp_split16 W2)
+        const dim3 g2(la.n_wg), b2(128);
+        if (local)
+            hipLaunchKernelGGL((k_dp_split16<NR, NTERM, true, 2, true>), g2, b2, 0, la.stream, a16, la.tasks, la.lane_one,
+                               la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
+        else
+            hipLaunchKernelGGL((k_dp_split16<NR, NTERM, false, 2, true>), g2, b2, 0, la.stream, a16, la.tasks, la.lane_one,
+                               la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
+        return;
+    }
     if (a16.stage) {  // LDS-staged operand stream: one wave (= its own LDS rings) per workgroup
         const dim3 g1((unsigned)la.n_tasks), b1(64);
         if (local) PRALINE_LAUNCH16(true, 2, g1, b1); else PRALINE_LAUNCH16(false, 2, g1, b1);

@@ -400,6 +400,9 @@ struct praline_plan {
     std::vector<int64_t> aux_elems; // per task, floats
     int64_t bnd_elems = 0;
     DevBuf<WaveTask> d_tasks;
+    // small batches: two-wave workgroups (k_dp_split16 W2): (task a, task b | -1 | -2 = both waves on a)
+    std::vector<int2> wg;
+    DevBuf<int2> d_wg;
     DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
@@ -424,6 +427,19 @@ static size_t tb_budget_bytes()
 {
     if (const char *env = getenv("PRALINE_TB_BUDGET_MB")) return (size_t)atoll(env) << 20;
     return (size_t)24 << 30;
+}
+
+// Launch order for an ordered list of n work items: groups of G consecutive items on one XCD (block b runs
+// on XCD b % 8), groups dealt round-robin over the XCDs.  Returns, per block, the item it runs (-1: padding).
+static std::vector<int64_t> xcd_group_order(int64_t n0, int G)
+{
+    const int64_t n = (n0 + 8 * G - 1) / (8 * G) * (8 * G);
+    std::vector<int64_t> src((size_t)n, -1);
+    for (int64_t i = 0; i < n0; ++i) {
+        const int64_t g = i / G, x = g % 8, q = (g / 8) * G + i % G;
+        src[(size_t)(8 * q + x)] = i;
+    }
+    return src;
 }
 
 extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, int want_paths,
@@ -495,21 +511,18 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     // (A first attempt - whole length classes per XCD - was 30-40 % slower: it put all expensive tasks on
     // one XCD.)
     {
-        int G = 16;
+        int G = 16;  // measured (N = 512, staged stream): none 1984, G = 4 2115, G = 16 2393 GCUPS
         if (const char *env = getenv("PRALINE_XCD_GROUP")) G = atoi(env);
         if (G > 1 && halves.size() >= (size_t)(16 * G)) {
-            const size_t n0 = halves.size();
-            const size_t n = (n0 + 8 * G - 1) / (8 * G) * (8 * G);
             HalfTask empty;
             empty.two = halves.back().two;
             empty.max_l1 = 0;
             empty.chunk = 0;
             for (int q = 0; q < 32; ++q) { empty.one[q] = -1; empty.pair[q] = -1; }
-            std::vector<HalfTask> placed(n, empty);
-            for (size_t i = 0; i < n; ++i) {
-                const size_t g = i / G, x = g % 8, q = (g / 8) * G + i % G;
-                placed[8 * q + x] = i < n0 ? halves[i] : empty;
-            }
+            const std::vector<int64_t> src = xcd_group_order((int64_t)halves.size(), G);
+            std::vector<HalfTask> placed(src.size(), empty);
+            for (size_t b = 0; b < src.size(); ++b)
+                if (src[b] >= 0) placed[b] = halves[(size_t)src[b]];
             halves.swap(placed);
         }
     }
@@ -560,6 +573,55 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         pl->aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * (split ? 32 : 64);
     }
     pl->bnd_elems = bnd;
+
+    // Two-wave workgroups for batches that cannot fill the chip's 2048 wave slots (2 per SIMD) with one wave
+    // per task: the longest tasks - the launch's critical path - are each pipelined by two waves.  A task is
+    // shared when its cost exceeds `frac` x the longest half cost and its strips are long enough for the
+    // half-strip hand-off distance (>= 6 iterations of 12 rows); the others run two to a workgroup.
+    if (split && !want_paths && !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')) {
+        const int64_t slots = 2048;
+        std::vector<std::pair<int64_t, int>> by_cost;
+        for (size_t t = 0; t < n_tasks; ++t) {
+            const WaveTask &wt = pl->tasks[t];
+            if (wt.max_l1 <= 0) continue;  // placement padding
+            by_cost.push_back({(int64_t)wt.nstrips * (wt.max_l1 + 17), (int)t});
+        }
+        std::sort(by_cost.begin(), by_cost.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) {
+            return x.first != y.first ? x.first > y.first : x.second < y.second;
+        });
+        const int64_t n_real = (int64_t)by_cost.size();
+        double frac = 0.3;   // measured (scripts/exp_w2.py): 0 .. 0.3 best for N = 128 .. 300, 0.7 clearly worse
+        if (const char *env = getenv("PRALINE_W2_FRAC")) frac = atof(env);
+        if (n_real > 0 && n_real < slots) {
+            const int64_t k_max = slots - n_real;
+            const double thr = frac * (double)by_cost[0].first;
+            std::vector<int> shared, single;
+            for (const auto &ct : by_cost) {
+                const WaveTask &wt = pl->tasks[ct.second];
+                const bool ok = wt.nstrips >= 2 && (wt.max_l1 - 1) / 12 + 1 >= 6;
+                if (ok && (int64_t)shared.size() < k_max && (double)ct.first > thr) shared.push_back(ct.second);
+                else single.push_back(ct.second);
+            }
+            if (!shared.empty()) {
+                // launch order: by descending wave cost (shared: half the task; singles: longest with shortest)
+                for (int t : shared) pl->wg.push_back(make_int2(t, -2));
+                for (size_t lo = 0, hi = single.size(); lo < hi;) {
+                    --hi;
+                    if (lo < hi) { pl->wg.push_back(make_int2(single[lo], single[hi])); ++lo; }
+                    else pl->wg.push_back(make_int2(single[lo], -1));
+                }
+                int G = 0;
+                if (const char *env = getenv("PRALINE_XCD_GROUP_W2")) G = atoi(env);
+                if (G > 1 && pl->wg.size() >= (size_t)(16 * G)) {
+                    const std::vector<int64_t> src = xcd_group_order((int64_t)pl->wg.size(), G);
+                    std::vector<int2> placed(src.size(), make_int2(-1, -1));
+                    for (size_t b = 0; b < src.size(); ++b)
+                        if (src[b] >= 0) placed[b] = pl->wg[(size_t)src[b]];
+                    pl->wg.swap(placed);
+                }
+            }
+        }
+    }
 
     pl->slot_off.resize((size_t)n_pairs);
     int64_t cap = 0, cells = 0;
@@ -659,6 +721,8 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     if (pl.n_pairs == 0) return PRALINE_OK;
     const praline_arena &a = *pl.arena;
     LaunchArgs la;
+    la.wg = nullptr;
+    la.n_wg = 0;
     la.ar = a.view();
     la.lane_one = pl.d_lane_one.p;
     la.lane_pair = pl.d_lane_pair.p;
@@ -691,6 +755,11 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         la.tb = nullptr;
         la.aux = nullptr;
         la.n_tasks = (unsigned)pl.tasks.size();
+        if (!pl.wg.empty() && la.a16 != nullptr && a16.stage && a16.sym8 == nullptr) {
+            if (!pl.d_wg.p) { RC(pl.d_wg.upload(pl.wg, st)); }
+            la.wg = pl.d_wg.p;
+            la.n_wg = (unsigned)pl.wg.size();
+        }
         HIPCHK(hipEventRecord(g_rt.ev0, st));
         RC(launch_dp(a.nstep, la, pl.tp, local, 0, false));
         HIPCHK(hipEventRecord(g_rt.ev1, st));
