@@ -21,7 +21,7 @@ struct LaunchArgs {
     hipStream_t stream;
     const struct Arena16Dev *a16;  // non-null: run k_dp_split16 on these f16 operands
     int nr16, nterm16;
-    const int2 *wg;  // non-null: two-wave workgroups (k_dp_split16 W2), n_wg of them
+    const struct WgDesc *wg;  // non-null: four-wave workgroups (k_dp_split16 WPG = 4), n_wg of them
     unsigned n_wg;
     int split;  // 1: k_dp_split task layout (32 lane entries per task, float2 [max_l1+2][32] boundary)
 };

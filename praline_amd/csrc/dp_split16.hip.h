@@ -307,37 +307,38 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
 // arrive as one dword per lane and four rows.
 // BSRC = 2: the LDS-staged operand stream described above (one wave per workgroup).
 //
-// W2 (staged stream only): workgroups of TWO waves, described by wg[blockIdx.x] = (task a, task b).
-//   b == -2: both waves work on task a - wave 0 takes the even strips, wave 1 the odd ones, half a strip
-//            behind: a task's strips form a chain (strip s+1 needs the boundary column of strip s row by
-//            row), so two waves pipeline it and the task's critical path halves.  That is what small
-//            batches need: with about one task per SIMD (BASELINE C2: 1144 tasks, 1024 SIMDs) the launch
-//            lasts as long as its longest task while most SIMDs idle.  The waves stay in lock step through
-//            one s_barrier per 12 rows; the hand-off is the ordinary boundary buffer in global memory
-//            (producer and consumer are half a strip = hundreds of rows apart in both directions, and
-//            the per-step counted vmcnt retires every store older than three steps before a barrier).
-//   else:    wave 0 runs task a, wave 1 task b (or nothing when b < 0), independently, no barriers.
-template <int NR, int NTERM, bool LOCAL, int BSRC = 0, bool W2 = false>
+// WPG = 4 (staged stream only): workgroups of FOUR waves described by wg[blockIdx.x] (WgDesc): `share`
+// consecutive waves work on ONE task - the wave of rank r takes the strips r, r + share, ... and runs
+// r / share of a strip behind rank 0.  A task's strips form a chain (strip s+1 needs the boundary column
+// of strip s row by row), so the waves pipeline it and the task's critical path shrinks by ~share.  That
+// is what small batches need: with about one task per SIMD (BASELINE C2: 1144 tasks, 1024 SIMDs) a launch
+// lasts as long as its longest task while most SIMDs idle.  The waves of a workgroup stay in lock step
+// through one s_barrier per 12 rows; the hand-off is the ordinary boundary buffer in global memory
+// (producer and consumer are >= 3 iterations = 36 rows apart in every direction, and the per-step
+// counted vmcnt retires every store older than three steps before a barrier).  share == 1: four
+// independent tasks, no barriers.
+template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int WPG = 1>
 __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ lane_one,
                                                     const int32_t *__restrict__ lane_pair, float2 *bnd,
                                                     float *__restrict__ scores, RunParams rp, int n_tasks,
-                                                    const int2 *__restrict__ wg = nullptr)
+                                                    const WgDesc *__restrict__ wg = nullptr)
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
-    static_assert(!W2 || BSRC == 2, "two-wave workgroups use the staged stream");
+    static_assert(WPG == 1 || (WPG == 4 && BSRC == 2), "four-wave workgroups use the staged stream");
+    constexpr bool MW = WPG > 1;
     constexpr bool ONEHOT = BSRC == 1;
     constexpr bool STAGED = BSRC == 2;
     static_assert(!ONEHOT || NTERM == 1, "the one-hot table path is an exact-mode path");
     __shared__ __attribute__((aligned(16))) char onehot_tab[ONEHOT ? onehot_bytes(NR) : 16];
-    __shared__ __attribute__((aligned(16))) char stage_lds_all[STAGED ? (W2 ? 2 : 1) * stage_lds_bytes(NP * NR) : 16];
-    __shared__ float w2_out[W2 ? 4 * 32 : 1];  // wave 1's partial results of a shared task
-    const int wv = W2 ? (int)(threadIdx.x >> 6) : 0;
+    __shared__ __attribute__((aligned(16))) char stage_lds_all[STAGED ? WPG * stage_lds_bytes(NP * NR) : 16];
+    __shared__ float mw_out[MW ? WPG * 4 * 32 : 1];  // partial results of the waves sharing a task
+    const int wv = MW ? (int)(threadIdx.x >> 6) : 0;
     char *stage_lds = stage_lds_all + (STAGED ? wv * stage_lds_bytes(NP * NR) : 0);
     if constexpr (STAGED) {
         // defined contents before the first DMA (the compiler does not see the DMA's writes)
-        for (int i = threadIdx.x * 16; i < (W2 ? 2 : 1) * stage_lds_bytes(NP * NR); i += blockDim.x * 16)
+        for (int i = threadIdx.x * 16; i < WPG * stage_lds_bytes(NP * NR); i += blockDim.x * 16)
             *reinterpret_cast<float4 *>(stage_lds_all + i) = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
@@ -352,12 +353,19 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         __syncthreads();
     }
     int task;
-    bool shared_task = false;  // W2: both waves of the workgroup pipeline one task
-    if constexpr (W2) {
-        const int2 d = wg[blockIdx.x];
-        shared_task = d.y == -2;
-        task = (shared_task || wv == 0) ? d.x : d.y;
-        if (task < 0) return;  // (never in a shared task: both waves meet at its barriers)
+    int share = 1, rank = 0;   // MW: `share` waves pipeline this task, this wave is number `rank` of them
+    int mw_left = 0;           // MW: barriers this wave still owes its workgroup
+    if constexpr (MW) {
+        const WgDesc *d = wg + blockIdx.x;
+        share = d->share;
+        rank = wv & (share - 1);
+        task = d->task[wv - rank];
+        mw_left = d->barriers;
+        if (task < 0) {  // idle wave: keep the workgroup's barrier count
+            for (; mw_left > 0; --mw_left) __builtin_amdgcn_s_barrier();
+            if (share > 1) __syncthreads();
+            return;
+        }
     } else {
         task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (task >= n_tasks) return;
@@ -422,25 +430,17 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     const float o002 = free_two ? 0.0f : (go - ge);
     const float h00 = max3f(0.0f, o001, o002);
 
-    if (h == 0 && !(shared_task && wv == 1))
+    if (h == 0 && rank == 0)
         for (int y = 1; y <= max_l1 + 2; ++y)
             *reinterpret_cast<float2 *>(my_bnd + (int64_t)y * BROW) = make_float2(boundary_value(y, go, ge, free_one), PRALINE_NEG_INF);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
 
-    // W2 shared task: lock-step bookkeeping.  One barrier per 12-row iteration; wave 1 starts w2_delay
-    // iterations late (half a strip) and the wave that runs out of strips first keeps meeting the other
-    // at the remaining barriers.
-    const int w2_iter = (max_l1 - 1) / 12 + 1;         // iterations (barriers) per strip
-    const int w2_delay = w2_iter / 2;
-    int w2_left = 0;                                    // barriers still owed by this wave
-    if constexpr (W2) {
-        if (shared_task) {
-            const int n0 = (nstrips + 1) / 2, n1 = nstrips / 2;
-            const int total = max(n0 * w2_iter, w2_delay + n1 * w2_iter);
-            w2_left = total;
-            if (wv == 1)
-                for (int i = 0; i < w2_delay; ++i) { __builtin_amdgcn_s_barrier(); --w2_left; }
+    // shared task: rank r starts r / share of a strip (in 12-row iterations) behind rank 0
+    if constexpr (MW) {
+        if (share > 1) {
+            const int delay = rank * (((max_l1 - 1) / 12 + 1) / share);
+            for (int i = 0; i < delay; ++i) { __builtin_amdgcn_s_barrier(); --mw_left; }
         }
     }
 
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     float out_colmax = (have_pair && own_last) ? boundary_value(L2, go, ge, free_two) : PRALINE_NEG_INF;
     float out_corner = PRALINE_NEG_INF;
 
-    for (int s = (W2 && shared_task) ? wv : 0; s < nstrips; s += (W2 && shared_task) ? 2 : 1) {
+    for (int s = rank; s < nstrips; s += share) {
         const int x0 = s * 32;
         const int xb = x0 + 16 * h;
         const bool last_owner = (s == nstrips - 1) && own_last;
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         // steps past max_l1 + 1 compute rows that nobody reports
         if constexpr (STAGED) {
             for (int t = 2; t <= max_l1 + 1; t += 12) {
-                if constexpr (W2) {
-                    if (shared_task) { __builtin_amdgcn_s_barrier(); --w2_left; }
+                if constexpr (MW) {
+                    if (share > 1) { __builtin_amdgcn_s_barrier(); --mw_left; }
                 }
                 PRALINE_STEP16S(t, accB, accA, b1, b0, 2);
                 PRALINE_STEP16S(t + 1, accA, accB, b0, b1, 3);
@@ -644,19 +644,23 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     float rowmax_all = __builtin_fmaxf(out_rowmax, partner_value(out_rowmax, h));
     float colmax_all = __builtin_fmaxf(out_colmax, partner_value(out_colmax, h));
     float best_all = __builtin_fmaxf(out_best, partner_value(out_best, h));
-    if constexpr (W2) {
-        if (shared_task) {
-            for (; w2_left > 0; --w2_left) __builtin_amdgcn_s_barrier();
-            // every result is a maximum over strips: wave 0 folds wave 1's share in
-            if (wv == 1 && h == 0) {
-                w2_out[j] = corner_all; w2_out[32 + j] = rowmax_all; w2_out[64 + j] = colmax_all; w2_out[96 + j] = best_all;
+    if constexpr (MW) {
+        if (share > 1) {
+            for (; mw_left > 0; --mw_left) __builtin_amdgcn_s_barrier();
+            // every result is a maximum over strips: rank 0 folds the other ranks' shares in
+            if (rank > 0 && h == 0) {
+                float *o = mw_out + wv * 128;
+                o[j] = corner_all; o[32 + j] = rowmax_all; o[64 + j] = colmax_all; o[96 + j] = best_all;
             }
             __syncthreads();
-            if (wv == 1) return;
-            corner_all = __builtin_fmaxf(corner_all, w2_out[j]);
-            rowmax_all = __builtin_fmaxf(rowmax_all, w2_out[32 + j]);
-            colmax_all = __builtin_fmaxf(colmax_all, w2_out[64 + j]);
-            best_all = __builtin_fmaxf(best_all, w2_out[96 + j]);
+            if (rank > 0) return;
+            for (int r = 1; r < share; ++r) {
+                const float *o = mw_out + (wv + r) * 128;
+                corner_all = __builtin_fmaxf(corner_all, o[j]);
+                rowmax_all = __builtin_fmaxf(rowmax_all, o[32 + j]);
+                colmax_all = __builtin_fmaxf(colmax_all, o[64 + j]);
+                best_all = __builtin_fmaxf(best_all, o[96 + j]);
+            }
         }
     }
     if (have_pair && h == 0) {

@@ -18,13 +18,13 @@ template <int NR, int NTERM> static void launch16(const LaunchArgs &la, const Ar
             return;
         }
     }
-    if (a16.stage && la.wg != nullptr) {  // small batch: two-wave workgroups (see k_dp_split16 W2)
-        const dim3 g2(la.n_wg), b2(128);
+    if (a16.stage && la.wg != nullptr) {  // small batch: four-wave workgroups (see k_dp_split16 WPG)
+        const dim3 g4(la.n_wg), b4(256);
         if (local)
-            hipLaunchKernelGGL((k_dp_split16<NR, NTERM, true, 2, true>), g2, b2, 0, la.stream, a16, la.tasks, la.lane_one,
+            hipLaunchKernelGGL((k_dp_split16<NR, NTERM, true, 2, 4>), g4, b4, 0, la.stream, a16, la.tasks, la.lane_one,
                                la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
         else
-            hipLaunchKernelGGL((k_dp_split16<NR, NTERM, false, 2, true>), g2, b2, 0, la.stream, a16, la.tasks, la.lane_one,
+            hipLaunchKernelGGL((k_dp_split16<NR, NTERM, false, 2, 4>), g4, b4, 0, la.stream, a16, la.tasks, la.lane_one,
                                la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
         return;
     }

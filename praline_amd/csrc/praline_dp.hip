@@ -400,9 +400,9 @@ struct praline_plan {
     std::vector<int64_t> aux_elems; // per task, floats
     int64_t bnd_elems = 0;
     DevBuf<WaveTask> d_tasks;
-    // small batches: two-wave workgroups (k_dp_split16 W2): (task a, task b | -1 | -2 = both waves on a)
-    std::vector<int2> wg;
-    DevBuf<int2> d_wg;
+    // small batches: four-wave workgroups whose waves share long tasks (k_dp_split16 WPG = 4, WgDesc)
+    std::vector<WgDesc> wg;
+    DevBuf<WgDesc> d_wg;
     DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
@@ -574,50 +574,97 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     }
     pl->bnd_elems = bnd;
 
-    // Two-wave workgroups for batches that cannot fill the chip's 2048 wave slots (2 per SIMD) with one wave
-    // per task: the longest tasks - the launch's critical path - are each pipelined by two waves.  A task is
-    // shared when its cost exceeds `frac` x the longest half cost and its strips are long enough for the
-    // half-strip hand-off distance (>= 6 iterations of 12 rows); the others run two to a workgroup.
+    // Small batches (fewer tasks than the chip's 2048 wave slots, 2 per SIMD): the waves of a workgroup
+    // share long tasks (k_dp_split16 WPG = 4).  Every task gets W = 1, 2 or 4 waves - the smallest W that
+    // brings its per-wave cost under c*, c* the smallest value for which all waves fit the slots.
     if (split && !want_paths && !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')) {
-        const int64_t slots = 2048;
-        std::vector<std::pair<int64_t, int>> by_cost;
+        int64_t slots = 2048;
+        if (const char *env = getenv("PRALINE_W_SLOTS")) slots = atoll(env);
+        struct Cand { int64_t cost; int task; int iter, nstrips, wmax; };
+        std::vector<Cand> cand;
         for (size_t t = 0; t < n_tasks; ++t) {
             const WaveTask &wt = pl->tasks[t];
             if (wt.max_l1 <= 0) continue;  // placement padding
-            by_cost.push_back({(int64_t)wt.nstrips * (wt.max_l1 + 17), (int)t});
+            Cand c;
+            c.task = (int)t;
+            c.iter = (wt.max_l1 - 1) / 12 + 1;
+            c.nstrips = wt.nstrips;
+            c.cost = (int64_t)wt.nstrips * (12 * c.iter + 1);
+            // the hand-off distance between consecutive ranks must stay >= 3 iterations
+            c.wmax = (c.nstrips >= 4 && c.iter / 4 >= 3) ? 4 : (c.nstrips >= 2 && c.iter / 2 >= 3) ? 2 : 1;
+            cand.push_back(c);
         }
-        std::sort(by_cost.begin(), by_cost.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) {
-            return x.first != y.first ? x.first > y.first : x.second < y.second;
-        });
-        const int64_t n_real = (int64_t)by_cost.size();
-        double frac = 0.3;   // measured (scripts/exp_w2.py): 0 .. 0.3 best for N = 128 .. 300, 0.7 clearly worse
-        if (const char *env = getenv("PRALINE_W2_FRAC")) frac = atof(env);
-        if (n_real > 0 && n_real < slots) {
-            const int64_t k_max = slots - n_real;
-            const double thr = frac * (double)by_cost[0].first;
-            std::vector<int> shared, single;
-            for (const auto &ct : by_cost) {
-                const WaveTask &wt = pl->tasks[ct.second];
-                const bool ok = wt.nstrips >= 2 && (wt.max_l1 - 1) / 12 + 1 >= 6;
-                if (ok && (int64_t)shared.size() < k_max && (double)ct.first > thr) shared.push_back(ct.second);
-                else single.push_back(ct.second);
+        std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.cost != y.cost ? x.cost > y.cost : x.task < y.task; });
+        // per-wave cost of a task run by W waves: rank 0's strips plus the last rank's start delay
+        auto wave_cost = [](const Cand &c, int W) {
+            const int n0 = (c.nstrips + W - 1) / W;
+            return (int64_t)(n0 * c.iter + (W - 1) * (c.iter / W)) * 12;
+        };
+        auto choose = [&](const Cand &c, int64_t cstar) {
+            int W = 1;
+            while (W < c.wmax && wave_cost(c, W) > cstar) W *= 2;
+            return W;
+        };
+        auto slots_for = [&](int64_t cstar) {
+            int64_t n1 = 0, n2 = 0, n4 = 0;
+            for (const Cand &c : cand) { const int W = choose(c, cstar); (W == 1 ? n1 : W == 2 ? n2 : n4)++; }
+            return 4 * (n4 + (n2 + 1) / 2 + (n1 + 3) / 4);
+        };
+        if (!cand.empty() && (int64_t)cand.size() < slots) {
+            int64_t lo = 1, hi = cand[0].cost;  // smallest c* whose workgroups fit
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) / 2;
+                if (slots_for(mid) <= slots) hi = mid; else lo = mid + 1;
             }
-            if (!shared.empty()) {
-                // launch order: by descending wave cost (shared: half the task; singles: longest with shortest)
-                for (int t : shared) pl->wg.push_back(make_int2(t, -2));
-                for (size_t lo = 0, hi = single.size(); lo < hi;) {
-                    --hi;
-                    if (lo < hi) { pl->wg.push_back(make_int2(single[lo], single[hi])); ++lo; }
-                    else pl->wg.push_back(make_int2(single[lo], -1));
+            std::vector<const Cand *> by_w[5];
+            for (const Cand &c : cand) by_w[choose(c, lo)].push_back(&c);
+            if (!by_w[2].empty() || !by_w[4].empty()) {
+                auto barriers = [](const Cand &c, int W) {
+                    int total = 0;
+                    for (int r = 0; r < W; ++r) {
+                        const int nr = c.nstrips > r ? (c.nstrips - r + W - 1) / W : 0;
+                        total = std::max(total, r * (c.iter / W) + nr * c.iter);
+                    }
+                    return total;
+                };
+                struct Built { int64_t cost; WgDesc d; };
+                std::vector<Built> built;
+                for (const Cand *c : by_w[4]) {
+                    Built b; b.cost = wave_cost(*c, 4);
+                    b.d.task[0] = c->task; b.d.task[1] = b.d.task[2] = b.d.task[3] = -1;
+                    b.d.share = 4; b.d.barriers = barriers(*c, 4); b.d.pad[0] = b.d.pad[1] = 0;
+                    built.push_back(b);
                 }
-                int G = 0;
-                if (const char *env = getenv("PRALINE_XCD_GROUP_W2")) G = atoi(env);
-                if (G > 1 && pl->wg.size() >= (size_t)(16 * G)) {
-                    const std::vector<int64_t> src = xcd_group_order((int64_t)pl->wg.size(), G);
-                    std::vector<int2> placed(src.size(), make_int2(-1, -1));
-                    for (size_t b = 0; b < src.size(); ++b)
-                        if (src[b] >= 0) placed[b] = pl->wg[(size_t)src[b]];
-                    pl->wg.swap(placed);
+                for (size_t i = 0; i < by_w[2].size(); i += 2) {
+                    const Cand *c0 = by_w[2][i], *c1 = i + 1 < by_w[2].size() ? by_w[2][i + 1] : nullptr;
+                    Built b; b.cost = wave_cost(*c0, 2);
+                    b.d.task[0] = c0->task; b.d.task[1] = -1; b.d.task[2] = c1 ? c1->task : -1; b.d.task[3] = -1;
+                    b.d.share = 2; b.d.barriers = std::max(barriers(*c0, 2), c1 ? barriers(*c1, 2) : 0); b.d.pad[0] = b.d.pad[1] = 0;
+                    built.push_back(b);
+                }
+                for (size_t i = 0; i < by_w[1].size(); i += 4) {
+                    Built b; b.cost = by_w[1][i]->cost;
+                    for (int q = 0; q < 4; ++q) b.d.task[q] = i + q < by_w[1].size() ? by_w[1][i + q]->task : -1;
+                    b.d.share = 1; b.d.barriers = 0; b.d.pad[0] = b.d.pad[1] = 0;
+                    built.push_back(b);
+                }
+                std::stable_sort(built.begin(), built.end(), [](const Built &x, const Built &y) { return x.cost > y.cost; });
+                // Launch order.  A CU holds two of these workgroups and the dispatcher deals them round-robin,
+                // so blocks b and b + 256 end up on the same CU (same SIMDs): the 256 longest go first in
+                // descending order, then the SHORTEST 256 in ascending order (the longest shares its SIMDs
+                // with the shortest), then whatever is left in the middle.
+                const size_t nb = built.size();
+                int snake = 1;
+                if (const char *env = getenv("PRALINE_W_SNAKE")) snake = atoi(env);
+                if (snake && nb > 256) {
+                    std::vector<size_t> order;
+                    for (size_t i = 0; i < 256; ++i) order.push_back(i);
+                    const size_t tail = std::min<size_t>(256, nb - 256);
+                    for (size_t i = 0; i < tail; ++i) order.push_back(nb - 1 - i);
+                    for (size_t i = 256; i < nb - tail; ++i) order.push_back(i);
+                    for (size_t i : order) pl->wg.push_back(built[i].d);
+                } else {
+                    for (const Built &b : built) pl->wg.push_back(b.d);
                 }
             }
         }

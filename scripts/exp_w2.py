@@ -9,7 +9,7 @@ from bench import synth_lengths, synth_profile
 nat.init(0)
 S = blosum62_matrix()
 def run(N, env):
-    for k in ("PRALINE_W2_FRAC", "PRALINE_NO_W2", "PRALINE_XCD_GROUP", "PRALINE_XCD_GROUP_W2"):
+    for k in ("PRALINE_W_SNAKE", "PRALINE_W_SLOTS", "PRALINE_W2_FRAC", "PRALINE_NO_W2", "PRALINE_XCD_GROUP", "PRALINE_XCD_GROUP_W2"):
         os.environ.pop(k, None)
     os.environ.update(env)
     rng = np.random.default_rng(2)
@@ -24,8 +24,10 @@ def run(N, env):
         pl.run("global", -11, -1); ms.append(pl.kernel_ms())
     print("N=%d %s kernel_ms=%.3f GCUPS=%.0f" % (N, env, np.median(ms), cells / np.median(ms) / 1e6), flush=True)
     pl.close(); ar.close()
-for N in (200, 256, 300):
-    for g in ("0", "2", "4", "8", "16"):
-        run(N, {"PRALINE_XCD_GROUP_W2": g})
-for G in ("16", "32", "64"):
+for N in (200, 230, 256, 280, 300, 320):
+    for g in ("0",):
+        run(N, {"PRALINE_W_SNAKE": "0"})
+        run(N, {})
+        run(N, {"PRALINE_W_SLOTS": "2560"})
+for G in ():
     run(512, {"PRALINE_XCD_GROUP": G})
