@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", default="global")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the one-hot / with-path side measurements")
     ap.add_argument("--cpu-sample-per-thread", type=int, default=24)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -187,6 +188,40 @@ def main():
                    "pairs_per_gpu": int(len(my_pairs)), "parallelism": "pairs sharded x%d" % world},
         "roofline": roofline,
     }
+
+    # ---- side measurements on the same batch shape (one-hot variant, with-path run); N=1 only,
+    # not part of `value`.  Same timing rule: inputs and results stay in HBM.
+    if rank == 0 and world == 1 and not args.no_variants:
+        def timed(fn, reps=5):
+            fn(); fence()
+            t_a = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            fence()
+            return (time.perf_counter() - t_a) / reps
+
+        variants = {}
+        dt_paths = None
+        plan_p = native.Plan(arena, my_pairs, want_paths=True)
+        dt_paths = timed(lambda: plan_p.run(args.mode, GAP_OPEN, GAP_EXTEND))
+        plan_p.close()
+        variants["float_profiles_with_paths_gcups"] = total_cells / dt_paths / 1e9
+        rng1 = np.random.default_rng(2)
+        profs_1h = [np.eye(A, dtype=np.float32)[rng1.integers(0, 20, int(L))] for L in lens]
+        arena_1h = native.Arena(profs_1h, S)
+        plan_1h = native.Plan(arena_1h, my_pairs)
+        dt_1h = timed(lambda: (arena_1h.premultiply(), plan_1h.run(args.mode, GAP_OPEN, GAP_EXTEND)))
+        variants["onehot_score_only_gcups"] = total_cells / dt_1h / 1e9
+        variants["onehot_f16_terms"] = arena_1h.info()["f16_terms"]
+        plan_1h.close()
+        plan_1hp = native.Plan(arena_1h, my_pairs, want_paths=True)
+        dt_1hp = timed(lambda: plan_1hp.run(args.mode, GAP_OPEN, GAP_EXTEND))
+        plan_1hp.close()
+        arena_1h.close()
+        variants["onehot_with_paths_gcups"] = total_cells / dt_1hp / 1e9
+        variants["note"] = ("same 32640 pairs; with_paths = fill with packed traceback + end cells + device traceback, "
+                            "paths left in HBM; onehot = integer scoring (bit-exact mode)")
+        out["variants"] = variants
 
     # ---- CPU baseline: the oracle (C restatement of the reference path) on the host cores ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

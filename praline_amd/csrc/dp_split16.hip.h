@@ -162,6 +162,7 @@ __device__ __forceinline__ void stage_issue_bnd(unsigned long long curN, unsigne
                  : "v"(gofs_n), "s"(curN), "s"(ldsN)
                  : "memory");
 }
+#define PRALINE_MW_LAG 2   // iterations between consecutive ranks of a shared task (host: praline_dp.hip)
 #define PRALINE_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // NR: 16-wide k ranges (1: <= 16 active symbols, 2: <= 32); NTERM: 1 exact / 3 split.
@@ -309,13 +310,13 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
 //
 // WPG = 4 (staged stream only): workgroups of FOUR waves described by wg[blockIdx.x] (WgDesc): `share`
 // consecutive waves work on ONE task - the wave of rank r takes the strips r, r + share, ... and runs
-// r / share of a strip behind rank 0.  A task's strips form a chain (strip s+1 needs the boundary column
+// two 12-row iterations behind rank r - 1.  A task's strips form a chain (strip s+1 needs the boundary column
 // of strip s row by row), so the waves pipeline it and the task's critical path shrinks by ~share.  That
 // is what small batches need: with about one task per SIMD (BASELINE C2: 1144 tasks, 1024 SIMDs) a launch
 // lasts as long as its longest task while most SIMDs idle.  The waves of a workgroup stay in lock step
 // through one s_barrier per 12 rows; the hand-off is the ordinary boundary buffer in global memory
-// (producer and consumer are >= 3 iterations = 36 rows apart in every direction, and the per-step
-// counted vmcnt retires every store older than three steps before a barrier).  share == 1: four
+// (producer and consumer are >= 2 iterations = 24 rows apart in every direction, and the per-step
+// counted vmcnt retires every store older than three steps).  share == 1: four
 // independent tasks, no barriers.
 template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int WPG = 1>
 __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
@@ -436,10 +437,13 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
 
-    // shared task: rank r starts r / share of a strip (in 12-row iterations) behind rank 0
+    // shared task: rank r starts PRALINE_MW_LAG 12-row iterations behind rank r - 1.  Two iterations are
+    // enough: the waves meet at every iteration start, so a consumer is at most at step 12 i + 13 while its
+    // producer is at least at step 12 (i + 2) + 2; it prefetches boundary row t + 4, stored at the
+    // producer's step t + 5 and retired by the counted vmcnt three steps later.
     if constexpr (MW) {
         if (share > 1) {
-            const int delay = rank * (((max_l1 - 1) / 12 + 1) / share);
+            const int delay = rank * PRALINE_MW_LAG;
             for (int i = 0; i < delay; ++i) { __builtin_amdgcn_s_barrier(); --mw_left; }
         }
     }

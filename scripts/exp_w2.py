@@ -24,10 +24,5 @@ def run(N, env):
         pl.run("global", -11, -1); ms.append(pl.kernel_ms())
     print("N=%d %s kernel_ms=%.3f GCUPS=%.0f" % (N, env, np.median(ms), cells / np.median(ms) / 1e6), flush=True)
     pl.close(); ar.close()
-for N in (200, 230, 256, 280, 300, 320):
-    for g in ("0",):
-        run(N, {"PRALINE_W_SNAKE": "0"})
-        run(N, {})
-        run(N, {"PRALINE_W_SLOTS": "2560"})
-for G in ():
-    run(512, {"PRALINE_XCD_GROUP": G})
+for N in (32, 64, 128, 200, 256, 300, 340):
+    run(N, {})
