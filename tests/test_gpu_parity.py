@@ -319,6 +319,41 @@ def test_operand_stream_variants_agree_bitwise(nat, bba, kind, monkeypatch):
             assert np.array_equal(bits(results[(variant, mode)]), bits(ref)), (kind, variant, mode)
 
 
+@pytest.mark.parametrize("kind", ["onehot", "profile"])
+def test_shared_wave_boundaries_vs_oracle(nat, bba, kind):
+    """Small batches run on four-wave workgroups whose waves share tasks (1, 2 or 4 waves per task,
+    chosen from the number of 12-row iterations and of 32-column strips).  Lengths sit on both sides
+    of every threshold; every score is checked against the oracle DP on the device's match scores
+    (integer scoring: against the reference order too)."""
+    rng = np.random.default_rng(17)
+    S = bba["S"]
+    # sequence two: 1..5 strips (+- 1 column around the strip edges); sequence one: 2..9 iterations
+    lens_two = [31, 32, 33, 63, 64, 65, 96, 97, 127, 128, 129, 160]
+    lens_one = [23, 24, 25, 36, 37, 47, 48, 49, 60, 61, 84, 85, 96, 97, 108]
+    lens = lens_one + lens_two
+    if kind == "onehot":
+        profs = [one_hot(rng.integers(0, 20, L), 27) for L in lens]
+    else:
+        profs = [synth_profile(rng, int(L))[0] for L in lens]
+    n1 = len(lens_one)
+    pairs = np.array([(i, n1 + j) for j in range(len(lens_two)) for i in range(n1)], dtype=np.int32)
+    arena = nat.Arena(profs, S)
+    plan = nat.Plan(arena, pairs)
+    mk = plan.match_kind()
+    for mode in MODES:
+        plan.run(mode, *GAPS)
+        sc = plan.scores()
+        for k in range(len(pairs)):
+            i, j = pairs[k]
+            s_or, _ = oracle_dp_on_m(mode, arena.match_scores(i, j, mk))
+            assert sc[k] == np.float32(s_or), (kind, mode, lens[i], lens[j])
+            if kind == "onehot" and k % 7 == 0:
+                s_ref = orc.pairwise_score_fast(mode, profs[i], profs[j], S, *GAPS)
+                assert sc[k] == np.float32(s_ref), (mode, lens[i], lens[j])
+    plan.close()
+    arena.close()
+
+
 def test_batch_c2_slice_properties(nat, bba):
     """BASELINE config 1 shape (256 x ~400 aa profiles, all pairs, global): properties that do not
     need the oracle at full size + oracle spot checks."""
