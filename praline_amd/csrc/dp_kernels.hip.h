@@ -639,8 +639,10 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
                 p_mlo = word.x; p_mhi = word.y; p_u = word.z; p_l = word.w;
             } else {
                 const uint2 word = my_tb2[((int64_t)s * (tk.max_l1 + 8) + y) * 64 + 32 * (c >> 4)];
-                p_mlo = word.x & 0xffffu; p_mhi = word.x >> 16; p_u = word.y & 0xffffu; p_l = word.y >> 16;
+                // word.x: 16 two-bit match sources; word.y: U-extend bits | L-extend bits << 16
                 bit = c & 15;
+                const unsigned code2 = (word.x >> (2 * bit)) & 3u;
+                p_mlo = (code2 & 1u) << bit; p_mhi = (code2 >> 1) << bit; p_u = word.y & 0xffffu; p_l = word.y >> 16;
             }
             if (k == 0) {
                 const int code = ((p_mlo >> bit) & 1) | (((p_mhi >> bit) & 1) << 1);

@@ -4,9 +4,9 @@
 // The three states are carried separately so ties resolve exactly as get_paths does
 // (praline/util/align.py:161-174: first set flag in the order MM, MU, ML / UO, UE / LO, LE): the
 // candidate sums are formed individually and compared with == as in praline/util/cext.c:224-295.
-// Per lane and DP row four 16-bit planes are stored (2-bit match source 1 MM / 2 MU / 3 ML / 0 stop,
-// 1 bit "U from extend", 1 bit "L from extend") = 8 bytes per 16 cells:
-//     tb2[(strip * tb_rows + y) * 64 + lane] = { mlo | mhi << 16,  ubit | lbit << 16 }
+// Per lane and DP row two words are stored (16 x 2-bit match source 1 MM / 2 MU / 3 ML / 0 stop; 16 bits
+// "U from extend" | 16 bits "L from extend" << 16) = 8 bytes per 16 cells:
+//     tb2[(strip * tb_rows + y) * 64 + lane] = { code_c << 2c,  ubit_c << c | lbit_c << (16 + c) }
 // lane j holds strip columns 1..16, lane j + 32 columns 17..32 of pair j.
 // Zero rectangles (Waterman-Eggert, praline/component/preprofile.py:247-255) force M = U = L = 0 and
 // stop codes (cext.c:141-149).  End cells: the global corner triple, the local first argmax and the
@@ -53,7 +53,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             zmask |= in ? ((0xffffu >> (15 - hi)) & (0xffffu << lo)) : 0u;
         }
     }
-    unsigned w_mlo = 0, w_mhi = 0, w_u = 0, w_l = 0;
+    unsigned w_code = 0, w_ul = 0;  // 16 x 2-bit match sources; 16 U-extend bits | 16 L-extend bits << 16
     __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -74,16 +74,17 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             float U = __builtin_fmaxf(uo, ue);
             const float lo = mleft + go, le = lleft + ge;
             float Lc = __builtin_fmaxf(lo, le);
-            bool isMM = sMM == M;
-            bool isMU = !isMM && sMU == M;
-            bool isML = !isMM && !isMU && sML == M;
+            // 2-bit match source, first match in the order MM, MU, ML (1 / 2 / 3; 0 = stop), by nested selects:
+            // no scalar mask logic.  Without the local clamp one of the three sums IS the maximum, so ML needs
+            // no compare of its own.
+            unsigned code = LOCAL ? ((sML == M) ? 3u : 0u) : 3u;
+            code = (sMU == M) ? 2u : code;
+            code = (sMM == M) ? 1u : code;
             if constexpr (MASK) {
-                if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }  // cext.c:141-149
+                if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; code = 0u; }  // cext.c:141-149
             }
-            w_mlo |= (isMM || isML) ? (1u << c) : 0u;
-            w_mhi |= (isMU || isML) ? (1u << c) : 0u;
-            w_u |= (uo >= ue) ? 0u : (1u << c);
-            w_l |= (lo >= le) ? 0u : (1u << c);
+            w_code |= code << (2 * c);
+            w_ul |= ((uo >= ue) ? 0u : (1u << c)) | ((lo >= le) ? 0u : (0x10000u << c));
             md = Mp[c]; ud = Up[c]; ld = Lp[c];
             Mp[c] = M; Up[c] = U; Lp[c] = Lc;
             mleft = M; lleft = Lc;
@@ -130,7 +131,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 
     if (h) *reinterpret_cast<float4 *>(bnd_st) = make_float4(Mp[15], Up[15], Lp[15], 0.0f);
     bnd_st += 32 * sizeof(float4);
-    *tb_st = make_uint2(w_mlo | (w_mhi << 16), w_u | (w_l << 16));
+    *tb_st = make_uint2(w_code, w_ul);
     tb_st += 64;
 }
 
