@@ -40,6 +40,10 @@ def synth_lengths(rng, n, mu):
     return np.clip(np.rint(rng.normal(mu, 0.1 * mu, n)), 0.5 * mu, 1.5 * mu).astype(int)
 
 
+VALU_PER_STEP = 143.0                      # k_dp_split16, 3-term, global: profiles/r01_g_shared_waves_pmc_summary.txt
+PEAK_VALU_GINSTR = 256 * 4 * 2.4 / 4.0     # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+
+
 def synth_profile(rng, L):
     """one-hot x5 counts + 6 random extra residues with counts 1-3, normalised as
     ProfileTrack.profile does (praline/container/sequence.py:200-202)."""
@@ -96,17 +100,24 @@ def main():
     cells = lens[pairs[:, 0]].astype(np.int64) * lens[pairs[:, 1]].astype(np.int64)
     total_cells = int(cells.sum())
 
-    # contiguous, cell-balanced slice of the pair list for this rank
-    from praline_amd.allpairs import shard_bounds
-    bounds = shard_bounds(cells, world)
-    lo, hi = bounds[rank], bounds[rank + 1]
-    my_pairs = pairs[lo:hi]
-    slice_len = int(max(bounds[r + 1] - bounds[r] for r in range(world)))
+    # this rank's shard of the pair list: whole columns (pairs sharing sequence two), balanced by cells
+    from praline_amd.allpairs import shard_columns
+    shards = shard_columns(lens, pairs, world)
+    my_idx = shards[rank]
+    my_pairs = pairs[my_idx]
+    slice_len = int(max(len(ix) for ix in shards))
 
     arena = native.Arena(profs, S)
     plan = native.Plan(arena, my_pairs)
     d_slice = torch.zeros(slice_len, dtype=torch.float32, device="cuda")
     d_all = torch.zeros(slice_len * world, dtype=torch.float32, device="cuda") if dist is not None else None
+    # gathered shard slot -> position in the reference's row-major pair order
+    if dist is not None:
+        src = np.concatenate([r * slice_len + np.arange(len(shards[r])) for r in range(world)])
+        dst = np.concatenate(shards)
+        d_src = torch.as_tensor(src, device="cuda")
+        d_dst = torch.as_tensor(dst, device="cuda")
+        d_ordered = torch.zeros(len(pairs), dtype=torch.float32, device="cuda")
     lib_stream = torch.cuda.ExternalStream(native.stream_handle())
 
     def step():
@@ -116,6 +127,7 @@ def main():
             # the exchange step: all ranks obtain every score slice (RCCL all-gather over xGMI)
             torch.cuda.current_stream().wait_stream(lib_stream)
             dist.all_gather_into_tensor(d_all, d_slice)
+            d_ordered[d_dst] = d_all[d_src]   # back into the reference's pair order (tree.py:142-145)
 
     def fence():
         if dist is not None:
@@ -152,7 +164,7 @@ def main():
     gcups = total_cells / (elapsed / args.steps) / 1e9
 
     # ---- roofline of the dominant kernel (k_dp_split16) on this rank's slice ----
-    my_cells = int(cells[lo:hi].sum())
+    my_cells = int(cells[my_idx].sum())
     lsum = int((lens[my_pairs[:, 0]] + lens[my_pairs[:, 1]]).sum())
     alg_bytes = 4.0 * A * lsum + 4.0 * len(my_pairs)      # 4A(L1+L2) + 4 per pair
     alg_flops = 2.0 * A * my_cells                        # 2A flop / cell (MFMA step)
@@ -176,6 +188,11 @@ def main():
                  "frac": alg_flops / ksec / 1e12 / PEAK_F16_MFMA_TFLOPS, "dtype": "f16 hi/lo split (3 terms)",
                  "frac_of_fp32_mfma_peak": alg_flops / ksec / 1e12 / PEAK_F32_MFMA_TFLOPS,
                  "f16_terms": info["f16_terms"], "f16_ranges": info["f16_ranges"]},
+        # what actually bounds the recurrence: VALU issue.  VALU_PER_STEP is the PMC-measured dynamic count
+        # (profiles/r01_g_*: SQ_INSTS_VALU / steps); peak = 1024 SIMDs x one wave64 instruction per 4 cycles.
+        "valu": {"achieved": plan.steps * VALU_PER_STEP / ksec / 1e9, "peak": PEAK_VALU_GINSTR,
+                 "unit": "G wave-instr/s", "frac": plan.steps * VALU_PER_STEP / ksec / 1e9 / PEAK_VALU_GINSTR,
+                 "valu_per_step": VALU_PER_STEP, "steps": plan.steps, "tasks": plan.tasks},
     }
     out = {
         "metric": "GCUPS (DP cell updates/s) all-pairs profile-profile affine align",

@@ -149,6 +149,10 @@ int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pa
                         praline_plan **out);
 int praline_plan_destroy(praline_plan *plan);
 int64_t praline_plan_cells(const praline_plan *plan);      /* sum L1*L2 over the pairs */
+/* Diagnostics: wavefront steps one praline_plan_run executes (one step = one DP row of a 32-pair x 32-column
+ * strip = 1024 cells incl. padding) and the number of 32-pair tasks; bench.py prices VALU issue with them. */
+int64_t praline_plan_steps(const praline_plan *plan);
+int64_t praline_plan_tasks(const praline_plan *plan);
 int64_t praline_plan_path_capacity(const praline_plan *plan); /* rows: sum (L1+L2+2) */
 
 /* Launches the fused match-score + affine DP fill for every pair of the plan (asynchronous on

@@ -135,8 +135,11 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     tb_st += 64;
 }
 
+#ifndef PRALINE_TB_WAVES_PER_SIMD
+#define PRALINE_TB_WAVES_PER_SIMD 1
+#endif
 template <int NR, int NTERM, bool LOCAL, bool MASK>
-__global__ __launch_bounds__(256) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one,
                                                        const int32_t *__restrict__ lane_pair, float4 *bnd,
                                                        uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,

@@ -721,6 +721,21 @@ extern "C" int praline_plan_destroy(praline_plan *plan)
 }
 
 extern "C" int64_t praline_plan_cells(const praline_plan *plan) { return plan ? plan->cells : 0; }
+extern "C" int64_t praline_plan_steps(const praline_plan *plan)
+{
+    if (!plan) return 0;
+    int64_t steps = 0;
+    for (const WaveTask &wt : plan->tasks)
+        if (wt.max_l1 > 0) steps += (int64_t)wt.nstrips * (wt.max_l1 + 1);
+    return steps;
+}
+extern "C" int64_t praline_plan_tasks(const praline_plan *plan)
+{
+    if (!plan) return 0;
+    int64_t n = 0;
+    for (const WaveTask &wt : plan->tasks) n += wt.max_l1 > 0;
+    return n;
+}
 extern "C" int64_t praline_plan_path_capacity(const praline_plan *plan) { return plan ? plan->path_cap : 0; }
 extern "C" void *praline_plan_device_scores(praline_plan *plan) { return plan ? (void *)plan->d_scores.p : nullptr; }
 

@@ -63,6 +63,9 @@ def lib():
     L.praline_plan_destroy.argtypes = [vp]
     L.praline_plan_cells.argtypes = [vp]
     L.praline_plan_cells.restype = i64
+    for name in ("praline_plan_steps", "praline_plan_tasks"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = i64
     L.praline_plan_path_capacity.argtypes = [vp]
     L.praline_plan_path_capacity.restype = i64
     L.praline_plan_run.argtypes = [vp, i32, f32, f32, vp]
@@ -262,6 +265,8 @@ class Plan(object):
                                          ctypes.byref(h)))
         self._h = h
         self.cells = int(lib().praline_plan_cells(h))
+        self.steps = int(lib().praline_plan_steps(h))   # wavefront steps per run (1024 cells each, incl. padding)
+        self.tasks = int(lib().praline_plan_tasks(h))   # 32-pair tasks
 
     def run(self, mode, gap_open, gap_extend, d_scores=None):
         """Asynchronous launch on the library stream.  d_scores: optional DEVICE pointer (int)."""

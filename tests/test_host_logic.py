@@ -205,5 +205,22 @@ def test_all_pairs_sharding_helpers():
     for world in (1, 2, 3, 8, 16):
         b = allpairs.shard_bounds(cells, world)
         assert b[0] == 0 and b[-1] == len(cells) and all(b[i] <= b[i + 1] for i in range(world))
+    # column shards: a partition of the pair list, whole columns per rank, balanced by cells
+    rng = np.random.default_rng(4)
+    lens = rng.integers(50, 500, 40)
+    pairs40 = allpairs.enumerate_pairs(40)
+    cells40 = lens[pairs40[:, 0]].astype(np.int64) * lens[pairs40[:, 1]]
+    for world in (1, 2, 3, 8):
+        shards = allpairs.shard_columns(lens, pairs40, world)
+        assert len(shards) == world
+        allidx = np.concatenate(shards)
+        assert np.array_equal(np.sort(allidx), np.arange(len(pairs40)))
+        owner_of_col = {}
+        for r, ix in enumerate(shards):
+            assert np.all(np.diff(ix) > 0)
+            for j in np.unique(pairs40[ix, 1]):
+                assert owner_of_col.setdefault(int(j), r) == r
+        loads = np.array([cells40[ix].sum() for ix in shards], dtype=np.float64)
+        assert loads.max() <= 1.15 * loads.mean()
     d, dist = allpairs.scores_to_distance(3, [(0, 1), (0, 2), (1, 2)], np.array([5.0, -2.0, 1.0], np.float32))
     assert d[0, 1] == d[1, 0] == 5.0 and d[1, 1] == 0.0 and np.array_equal(dist, (-d) + 5.0)
