@@ -290,14 +290,21 @@ class Plan(object):
         _check(lib().praline_plan_last_timing(self._h, ctypes.byref(ms)))
         return float(ms.value)
 
-    def paths(self):
-        """list of int32 [rows, 2] arrays in pair order."""
+    def paths_packed(self):
+        """(buf int32 [capacity, 2], off int64 [n], rows int32 [n]): path p is buf[off[p]:off[p] + rows[p]]."""
         cap = int(lib().praline_plan_path_capacity(self._h))
-        buf = np.zeros((max(cap, 1), 2), dtype=np.int32)
+        buf = np.empty((max(cap, 1), 2), dtype=np.int32)
         off = np.zeros(max(self.n, 1), dtype=np.int64)
         rows = np.zeros(max(self.n, 1), dtype=np.int32)
         _check(lib().praline_plan_paths(self._h, buf.ctypes.data, off.ctypes.data, rows.ctypes.data))
-        return [buf[off[p]:off[p] + rows[p]].copy() for p in range(self.n)]
+        return buf, off, rows
+
+    def paths(self):
+        """list of int32 [rows, 2] arrays in pair order (views into one buffer)."""
+        buf, off, rows = self.paths_packed()
+        off = off.tolist()
+        rows = rows.tolist()
+        return [buf[off[p]:off[p] + rows[p]] for p in range(self.n)]
 
     def close(self):
         if getattr(self, "_h", None):
