@@ -171,6 +171,19 @@ void *praline_plan_device_scores(praline_plan *plan);
  * already extended to the corners, praline/util/align.py:268-297). */
 int praline_plan_paths(praline_plan *plan, int32_t *paths, int64_t *path_off, int32_t *path_rows);
 
+/* Preprofile stage on the device.  For plans whose pairs are (master, slave) alignments with paths,
+ * praline_plan_add_counts adds, for every pair whose score passes the threshold, the slave's share of the
+ * master's profile counts - what the reference obtains on the host with compress_path + extend_path_local
+ * (local != 0) + Alignment.merge + ProfileBuilder.get_frequencies (praline/component/preprofile.py:145-152,
+ * 258-265, praline/util/align.py:187-266, praline/component/profile.py:41-74) - into the arena's count buffer
+ * int32 [sum of lengths][A].  Requires one-hot profiles (plain sequences) for the slaves.  The masters' own
+ * symbols are not added.  praline_plan_path_bounds returns (y0, y1, x0, x1) per pair: the bounding box the next
+ * Waterman-Eggert iteration masks (preprofile.py:247-255). */
+int praline_arena_counts_reset(praline_arena *arena);
+int praline_plan_add_counts(praline_plan *plan, int use_threshold, float threshold, int local);
+int praline_arena_counts_read(praline_arena *arena, int32_t *counts);
+int praline_plan_path_bounds(praline_plan *plan, int32_t *bounds);
+
 /* Convenience: arena-resident one-shot (plan + run + copy back). */
 int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float gap_extend,
                          int64_t n_pairs, const int32_t *pairs, float *scores);

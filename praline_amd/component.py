@@ -355,6 +355,57 @@ class LocalMasterSlaveAligner(Component):
         yield CompleteMessage({'alignment': alignment})
 
 
+def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_series=(-11.0, -1.0),
+                      score_threshold=None, waterman_eggert_iterations=2):
+    """The whole preprofile stage in a few device submissions: for EVERY sequence as master,
+    what the reference computes with one Global/LocalMasterSlaveAligner execution (preprofile.py:114-156,
+    213-269) followed by ProfileBuilder (profile.py:41-74) - N(N-1) alignments with paths, the master-slave
+    merge and the symbol counting - without the N(N-1) paths ever leaving the GPU: the counting runs on the
+    device paths (native.Plan.add_counts), only the bounding boxes for the Waterman-Eggert masks
+    (preprofile.py:247-255) and the count matrix come back.
+
+    sequences: Sequences with a PlainTrack under track_id; mode "global" or "local".
+    Returns one ProfileTrack per sequence (identical to the component chain's)."""
+    if mode not in ("global", "local"):
+        raise ComponentError("the preprofile stage aligns in 'global' or 'local' mode, not '{0}'".format(mode))
+    tracks = [seq.get_track(track_id) for seq in sequences]
+    for t in tracks:
+        if t.tid != PlainTrack.tid:
+            raise DataError("build_preprofiles needs plain tracks (got {0})".format(t.tid))
+    alphabet = tracks[0].alphabet
+    gap_open, gap_extend = _normalise_gap_series(list(gap_series))
+    S = np.ascontiguousarray(score_matrix.matrix if hasattr(score_matrix, "matrix") else score_matrix, dtype=np.float32)
+    n = len(sequences)
+    profiles = [_track_profile(t) for t in tracks]
+    lens = np.array([len(t.values) for t in tracks], dtype=np.int64)
+    row_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32).reshape(-1, 2)
+    arena = native.Arena(profiles, S)
+    try:
+        arena.counts_reset()
+        iterations = waterman_eggert_iterations if mode == "local" else 1
+        rects = None
+        for it in range(iterations if len(pairs) else 0):
+            plan = native.Plan(arena, pairs, want_paths=True, rects=rects)
+            try:
+                plan.run(mode, gap_open, gap_extend)
+                plan.add_counts(score_threshold, local=(mode == "local"))
+                if it + 1 < iterations:
+                    b = plan.path_bounds().reshape(-1, 1, 4)
+                    rects = b if rects is None else np.concatenate([rects, b], axis=1)
+            finally:
+                plan.close()
+        counts = arena.counts().astype(int)
+    finally:
+        arena.close()
+    out = []
+    for i, t in enumerate(tracks):
+        c = counts[row_off[i]:row_off[i] + lens[i]].copy()
+        c[np.arange(lens[i]), np.asarray(t.values)] += 1      # the master advances in every column
+        out.append(ProfileTrack(c, alphabet))
+    return out
+
+
 # ---- callers: guide tree (all-pairs distance stage) ----------------------------------------------
 def merge_order(distance_matrix, linkage):
     """Agglomerative clustering merge order (praline/util/cluster.py:27-114): repeatedly merge the two

@@ -666,6 +666,64 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
     path_rows[p] = (int32_t)(slot_end - w);
 }
 
+// ---- preprofile stage on the device ------------------------------------------------------------
+// Fuses, per pair (sequence one = master, two = slave) of a path plan, what the reference does on the host after a
+// master-slave alignment: compress_path(path, 0) (praline/util/align.py:215-232: keep the rows in which the master
+// advances), extend_path_local for local mode (align.py:234-266: -1 outside the local path), Alignment.merge
+// (container/align.py:30-61: the slave column of the merged path IS that compressed path) and the slave's share
+// of ProfileBuilder / get_frequencies (align.py:187-213): with X_r the slave index of row r = master index r,
+//     X_{r+1} > X_r  ->  counts[master row r][ sym_slave[X_{r+1} - 1] ] += 1
+// including the reference's own corner case: a local path that starts at slave index 0 comes after -1 padding,
+// 0 - (-1) > 0 counts as an advance and values[0 - 1] wraps to the slave's LAST symbol.
+// One lane per pair walks its path start -> end; the masters' own symbols are added by the host.
+__global__ void k_path_counts(const int32_t *__restrict__ pairs, const float *__restrict__ scores,
+                              const int32_t *__restrict__ paths, const int64_t *__restrict__ path_start,
+                              const int32_t *__restrict__ path_rows, int64_t n_pairs, int use_threshold, float threshold,
+                              int local, const int32_t *__restrict__ row_off_raw, const int32_t *__restrict__ len,
+                              const unsigned char *__restrict__ sym_raw, int A, int32_t *__restrict__ counts)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    if (use_threshold && !(scores[p] >= threshold)) return;   // preprofile.py:145,258
+    const int master = pairs[2 * p], slave = pairs[2 * p + 1];
+    const int rows = path_rows[p];
+    if (rows <= 0) return;
+    const int32_t *path = paths + path_start[p] * 2;
+    const unsigned char *ss = sym_raw + row_off_raw[slave];
+    const int ls = len[slave];
+    int32_t *mc = counts + (int64_t)row_off_raw[master] * A;
+    int y = path[0], xk = path[1];   // last kept row: (master index, slave index)
+    if (local && y > 0) {
+        // row y - 1 of the extended path holds -1: xk - (-1) > 0 always
+        const int sx = xk >= 1 ? xk - 1 : ls - 1;
+        atomicAdd(mc + (int64_t)(y - 1) * A + ss[sx], 1);
+    }
+    for (int r = 1; r < rows; ++r) {
+        const int y1 = path[2 * r], x1 = path[2 * r + 1];
+        if (y1 > y) {   // the master advances: a kept row
+            if (x1 > xk) atomicAdd(mc + (int64_t)(y1 - 1) * A + ss[x1 - 1], 1);
+            xk = x1;
+            y = y1;
+        }
+    }
+}
+
+// first and last row of every path = its bounding box (paths are monotone): (y0, y1, x0, x1), the rectangle the
+// next Waterman-Eggert iteration masks (praline/component/preprofile.py:247-255)
+__global__ void k_path_bounds(const int32_t *__restrict__ paths, const int64_t *__restrict__ path_start,
+                              const int32_t *__restrict__ path_rows, int64_t n_pairs, int32_t *__restrict__ bounds)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int rows = path_rows[p];
+    const int32_t *path = paths + path_start[p] * 2;
+    bounds[4 * p + 0] = rows > 0 ? path[0] : 0;
+    bounds[4 * p + 1] = rows > 0 ? path[2 * (rows - 1)] : -1;
+    bounds[4 * p + 2] = rows > 0 ? path[1] : 0;
+    bounds[4 * p + 3] = rows > 0 ? path[2 * (rows - 1) + 1] : -1;
+}
+
+
 // --------------------------------------------------------------------------------------------
 // Raw parity kernels: the reference's buffers (contiguous copies on the device).
 // --------------------------------------------------------------------------------------------

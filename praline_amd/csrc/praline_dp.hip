@@ -225,6 +225,9 @@ struct praline_arena {
     // one-hot arenas (ordinary sequences): active-symbol index per padded row; see k_dp_split16<.., ONEHOT>
     bool onehot = false;
     DevBuf<unsigned char> d_sym8;
+    // preprofile stage (k_path_counts): raw symbol of every one-hot row (255: not one-hot), int32 counts [rows_raw][A]
+    DevBuf<unsigned char> d_sym_raw;
+    DevBuf<int32_t> d_counts;
     Arena16Dev view16() const
     {
         Arena16Dev v;
@@ -317,25 +320,28 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     a->KP = 2 * a->KS;
     a->nr16 = a->n_active <= 16 ? 1 : (a->n_active <= 32 ? 2 : 0);
 
-    // one-hot profiles (every row: a single 1, zeros elsewhere) are streamed as symbol bytes
-    std::vector<unsigned char> sym8;
-    if (a->nr16 > 0 && !(getenv("PRALINE_NO_ONEHOT") && getenv("PRALINE_NO_ONEHOT")[0] == '1')) {
-        const unsigned char none = (unsigned char)(16 * a->nr16);
+    // one-hot profiles (every row: a single 1, zeros elsewhere): raw symbol per row (preprofile counting) and,
+    // when ALL rows are one-hot, active-symbol bytes for the one-hot operand table
+    std::vector<unsigned char> sym8, sym_raw((size_t)rr, 255);
+    {
+        const unsigned char none = (unsigned char)(16 * std::max(a->nr16, 1));
         std::vector<int> slot_of(A, -1);
         for (int k = 0; k < a->n_active; ++k) slot_of[a->active[k]] = k;
         sym8.assign((size_t)a->rows_pad + 64, none);
         bool all = true;
-        for (int64_t s = 0; s < n_seqs && all; ++s)
-            for (int y = 0; y < lens[s] && all; ++y) {
+        for (int64_t s = 0; s < n_seqs; ++s)
+            for (int y = 0; y < lens[s]; ++y) {
                 const float *row = profiles + (a->row_off_raw[s] + y) * (int64_t)A;
                 int hot = -1, nz = 0;
                 for (int i = 0; i < A; ++i)
                     if (row[i] != 0.0f) { ++nz; hot = i; }
-                if (nz != 1 || row[hot] != 1.0f) all = false;
-                else sym8[a->row_off_pad[s] + y] = slot_of[hot] >= 0 ? (unsigned char)slot_of[hot] : none;
+                if (nz != 1 || row[hot] != 1.0f) { all = false; continue; }
+                sym_raw[(size_t)(a->row_off_raw[s] + y)] = (unsigned char)hot;
+                sym8[a->row_off_pad[s] + y] = slot_of[hot] >= 0 ? (unsigned char)slot_of[hot] : none;
             }
-        a->onehot = all;
-        if (!all) sym8.clear();
+        const bool want_table = a->nr16 > 0 && !(getenv("PRALINE_NO_ONEHOT") && getenv("PRALINE_NO_ONEHOT")[0] == '1');
+        a->onehot = all && want_table;
+        if (!a->onehot) sym8.clear();
     }
 
     std::vector<int32_t> seq_of_rowp((size_t)a->rows_pad, -1);
@@ -350,7 +356,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         (rc = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
         (rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
         (rc = a->d_P.alloc((size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc((size_t)a->rows_pad * a->KP)) ||
-        (rc = a->d_flag16.alloc(1)) || (a->onehot && (rc = a->d_sym8.upload(sym8, st))) ||
+        (rc = a->d_flag16.alloc(1)) || (a->onehot && (rc = a->d_sym8.upload(sym8, st))) || (rc = a->d_sym_raw.upload(sym_raw, st)) ||
         (a->nr16 > 0 && ((rc = a->d_P16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)) ||
                          (rc = a->d_Q16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)))) ||
         (rc = arena_launch_premultiply(a, true))) {
@@ -919,6 +925,59 @@ extern "C" int praline_plan_paths(praline_plan *plan, int32_t *paths, int64_t *p
     HIPCHK(hipMemcpyAsync(path_off, plan->d_path_start.p, (size_t)plan->n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(path_rows, plan->d_path_rows.p, (size_t)plan->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return PRALINE_OK;
+}
+
+// ---- preprofile stage on the device: counts and path bounding boxes (k_path_counts / k_path_bounds) ----------
+extern "C" int praline_arena_counts_reset(praline_arena *arena)
+{
+    if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    if (!arena->d_counts.p) RC(arena->d_counts.alloc((size_t)arena->rows_raw * arena->A));
+    HIPCHK(hipMemsetAsync(arena->d_counts.p, 0, (size_t)arena->rows_raw * arena->A * sizeof(int32_t), g_rt.stream));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_add_counts(praline_plan *plan, int use_threshold, float threshold, int local)
+{
+    if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
+    if (!plan->want_paths) return fail(PRALINE_ERR_ARG, "plan was created without want_paths");
+    if (plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "praline_plan_run has not been called");
+    praline_arena &a = *plan->arena;
+    if (!a.d_counts.p) return fail(PRALINE_ERR_ARG, "praline_arena_counts_reset has not been called");
+    if (plan->n_pairs == 0) return PRALINE_OK;
+    const int threads = 64;
+    const int64_t blocks = (plan->n_pairs + threads - 1) / threads;
+    hipLaunchKernelGGL(k_path_counts, dim3((unsigned)blocks), dim3(threads), 0, g_rt.stream, plan->d_pairs.p,
+                       plan->d_scores.p, plan->d_paths.p, plan->d_path_start.p, plan->d_path_rows.p, plan->n_pairs,
+                       use_threshold, threshold, local, a.d_row_off_raw.p, a.d_len.p, a.d_sym_raw.p, a.A, a.d_counts.p);
+    HIPCHK(hipGetLastError());
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_counts_read(praline_arena *arena, int32_t *counts)
+{
+    if (!arena || !counts) return fail(PRALINE_ERR_ARG, "NULL argument");
+    if (!arena->d_counts.p) return fail(PRALINE_ERR_ARG, "praline_arena_counts_reset has not been called");
+    HIPCHK(hipMemcpyAsync(counts, arena->d_counts.p, (size_t)arena->rows_raw * arena->A * sizeof(int32_t),
+                          hipMemcpyDeviceToHost, g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_path_bounds(praline_plan *plan, int32_t *bounds)
+{
+    if (!plan || !bounds) return fail(PRALINE_ERR_ARG, "NULL argument");
+    if (!plan->want_paths) return fail(PRALINE_ERR_ARG, "plan was created without want_paths");
+    if (plan->n_pairs == 0) return PRALINE_OK;
+    DevBuf<int32_t> d_bounds;
+    RC(d_bounds.alloc((size_t)plan->n_pairs * 4));
+    const int threads = 256;
+    const int64_t blocks = (plan->n_pairs + threads - 1) / threads;
+    hipLaunchKernelGGL(k_path_bounds, dim3((unsigned)blocks), dim3(threads), 0, g_rt.stream, plan->d_paths.p,
+                       plan->d_path_start.p, plan->d_path_rows.p, plan->n_pairs, d_bounds.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(bounds, d_bounds.p, (size_t)plan->n_pairs * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
     return PRALINE_OK;
 }
 

@@ -63,6 +63,13 @@ def lib():
     L.praline_plan_destroy.argtypes = [vp]
     L.praline_plan_cells.argtypes = [vp]
     L.praline_plan_cells.restype = i64
+    L.praline_arena_counts_reset.argtypes = [vp]
+    L.praline_plan_add_counts.argtypes = [vp, ctypes.c_int, f32, ctypes.c_int]
+    L.praline_arena_counts_read.argtypes = [vp, vp]
+    L.praline_plan_path_bounds.argtypes = [vp, vp]
+    for name in ("praline_arena_counts_reset", "praline_plan_add_counts", "praline_arena_counts_read",
+                 "praline_plan_path_bounds"):
+        getattr(L, name).restype = ctypes.c_int
     for name in ("praline_plan_steps", "praline_plan_tasks"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i64
@@ -220,6 +227,16 @@ class Arena(object):
         _check(lib().praline_arena_match_scores(self._h, int(one), int(two), int(kind), m.ctypes.data))
         return m
 
+    def counts_reset(self):
+        """Zero the preprofile count buffer int32 [sum L, A] (praline_arena_counts_reset)."""
+        _check(lib().praline_arena_counts_reset(self._h))
+
+    def counts(self):
+        """The preprofile counts accumulated by Plan.add_counts, int32 [sum L, A] on the host."""
+        out = np.empty((int(self.lens.sum()), self.A), dtype=np.int32)
+        _check(lib().praline_arena_counts_read(self._h, out.ctypes.data))
+        return out
+
     def info(self):
         vals = [ctypes.c_int(0) for _ in range(4)]
         _check(lib().praline_arena_info(self._h, *[ctypes.byref(v) for v in vals]))
@@ -242,13 +259,20 @@ class Plan(object):
 
     def __init__(self, arena, pairs, want_paths=False, rects=None):
         """pairs: int [n, 2] (sequence_one, sequence_two); rects: optional list (one entry per
-        pair) of lists of (y0, y1, x0, x1) inclusive zero rectangles."""
+        pair) of lists of (y0, y1, x0, x1) inclusive zero rectangles, or an int array [n, k, 4]."""
         self.arena = arena
         self.pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
         self.n = self.pairs.shape[0]
         self.want_paths = bool(want_paths)
         ro = rv = None
-        if rects is not None:
+        if isinstance(rects, np.ndarray):
+            # packed form: int [n, k, 4], the same k rectangles for every pair (k Waterman-Eggert passes)
+            rv = np.ascontiguousarray(rects, dtype=np.int32).reshape(self.n, -1, 4)
+            ro = (np.arange(self.n + 1, dtype=np.int64) * rv.shape[1]).astype(np.int32)
+            rv = rv.reshape(-1, 4)
+            if rv.shape[0] == 0:
+                rv = np.zeros((1, 4), dtype=np.int32)
+        elif rects is not None:
             ro = np.zeros(self.n + 1, dtype=np.int32)
             flat = []
             for p, rl in enumerate(rects):
@@ -289,6 +313,18 @@ class Plan(object):
         ms = ctypes.c_float(0.0)
         _check(lib().praline_plan_last_timing(self._h, ctypes.byref(ms)))
         return float(ms.value)
+
+    def add_counts(self, threshold=None, local=False):
+        """Fold this plan's (master, slave) paths into the arena's preprofile counts on the device
+        (praline_plan_add_counts): compress_path + extend_path_local + merge + get_frequencies."""
+        _check(lib().praline_plan_add_counts(self._h, 0 if threshold is None else 1,
+                                             0.0 if threshold is None else float(threshold), 1 if local else 0))
+
+    def path_bounds(self):
+        """int32 [n, 4]: (y0, y1, x0, x1) of every path - the next Waterman-Eggert mask rectangle."""
+        out = np.zeros((max(self.n, 1), 4), dtype=np.int32)
+        _check(lib().praline_plan_path_bounds(self._h, out.ctypes.data))
+        return out[:self.n]
 
     def paths_packed(self):
         """(buf int32 [capacity, 2], off int64 [n], rows int32 [n]): path p is buf[off[p]:off[p] + rows[p]]."""

@@ -85,6 +85,44 @@ def test_master_slave_aligners_and_profile_builder(env, seqs):
         assert np.array_equal(prof['profile_track'].profile, d[key + "profile_f32"]), key
 
 
+def test_device_preprofile_stage(env, seqs):
+    """build_preprofiles: the counting over the master-slave merge runs on the device paths.  Pinned to the
+    reference's own ProfileBuilder counts (goldens) and, on a synthetic set with short and empty-ish local
+    alignments, to the mirrored component chain."""
+    d = load_golden("preprofile.npz")
+    blosum = env["blosum"]
+    for key, mode, master, kw in (("global_m0_", "global", 0, {}), ("global_m2_", "global", 2, {}),
+                                  ("local_m0_", "local", 0, {}), ("local_m4_", "local", 4, {}),
+                                  ("local_thr_m0_", "local", 0, {"score_threshold": 100.0}),
+                                  ("local_we3_m0_", "local", 0, {"waterman_eggert_iterations": 3})):
+        tracks = comp.build_preprofiles(seqs, ct.TRACK_ID_INPUT, blosum, mode=mode, **kw)
+        assert np.array_equal(tracks[master].counts, d[key + "profile_counts"]), key
+        assert np.array_equal(tracks[master].profile, d[key + "profile_f32"]), key
+    # synthetic: 9 sequences, lengths 3..70, some unrelated (tiny local alignments, starts at slave index 0)
+    rng = np.random.default_rng(23)
+    lens = [3, 7, 20, 33, 40, 41, 64, 65, 70]
+    base = rng.integers(0, 20, 80)
+    vals = []
+    for n, L in enumerate(lens):
+        v = base[:L].copy() if n % 3 else rng.integers(0, 20, L)
+        flip = rng.random(L) < 0.15
+        v[flip] = rng.integers(0, 20, int(flip.sum()))
+        vals.append(v)
+    syn = [ct.Sequence("s%d" % n, [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=v))])
+           for n, v in enumerate(vals)]
+    for mode, component, kw in (("global", comp.GlobalMasterSlaveAligner, {}),
+                                ("local", comp.LocalMasterSlaveAligner, {}),
+                                ("local", comp.LocalMasterSlaveAligner, {"score_threshold": 20.0}),
+                                ("global", comp.GlobalMasterSlaveAligner, {"score_threshold": 0.0})):
+        tracks = comp.build_preprofiles(syn, ct.TRACK_ID_INPUT, blosum, mode=mode, **kw)
+        for master in range(len(syn)):
+            slaves = [s for k, s in enumerate(syn) if k != master]
+            out = run_one(env["serial"], component, kw, master_sequence=syn[master], slave_sequences=slaves,
+                          track_id_sets=T_IN, score_matrices=[blosum])
+            prof = run_one(env["serial"], comp.ProfileBuilder, alignment=out['alignment'], track_id=ct.TRACK_ID_INPUT)
+            assert np.array_equal(tracks[master].counts, prof['profile_track'].counts), (mode, kw, master)
+
+
 def test_guide_tree_on_preprofiles(env, seqs):
     d = load_golden("profile_profile.npz")
     pre = [ct.Sequence(s.name, [(ct.TRACK_ID_INPUT, s.get_track(ct.TRACK_ID_INPUT)),
