@@ -474,8 +474,85 @@ class GuideTreeBuilder(Component):
         yield CompleteMessage({'guide_tree': tree})
 
 
+# ---- callers: progressive alignment along the guide tree -------------------------------------------
+def _count_cluster(index, sequence, track_id_sets):
+    """A cluster starts as its sequence with every aligned track turned into integer counts
+    (praline/component/msa.py:71-98): plain tracks become one-hot counts, profile tracks keep theirs."""
+    cluster = Sequence("Cluster #{0}".format(index), [])
+    seen = set()
+    for ids in track_id_sets:
+        for trid in ids:
+            if trid in seen:
+                continue
+            seen.add(trid)
+            track = sequence.get_track(trid)
+            if track.tid == PlainTrack.tid:
+                counts = np.zeros((len(track), track.alphabet.size), dtype=np.int32)
+                counts[np.arange(len(track)), track.values] = 1
+            elif track.tid == ProfileTrack.tid:
+                counts = np.array(track.counts, dtype=np.int32)
+            else:
+                raise DataError("unknown track type id for this aligner: '{0}'".format(track.tid))
+            cluster.add_track(trid, ProfileTrack(counts, track.alphabet))
+    return cluster
+
+
+class TreeMultipleSequenceAligner(Component):
+    """praline/component/msa.py:18-248: N-1 profile-profile alignments in guide-tree order; after each
+    one the two clusters' count tracks and sub-alignments are merged along the path
+    (container/sequence.py:205-239, container/align.py:30-61).  The steps depend on each other, so every
+    one is its own device submission through the configured aligner component."""
+    tid = "praline.component.TreeMultipleSequenceAligner"
+    inputs = {'sequences': Port([Sequence.tid]),
+              'guide_tree': Port(SequenceTree.tid),
+              'track_id_sets': Port([[str]]),
+              'score_matrices': Port([ScoreMatrix.tid])}
+    outputs = {'alignment': Port(Alignment.tid)}
+    options = {'gap_series': [float], 'aligner': str, 'aligner_env': Environment.tid, 'merge_mode': str,
+               'debug': int, 'log_track_ids': [str]}
+    defaults = {'gap_series': [-11.0, -1.0], 'aligner': PairwiseAligner.tid, 'aligner_env': Environment({}),
+                'merge_mode': 'semiglobal', 'debug': 0, 'log_track_ids': [TRACK_ID_INPUT]}
+
+    def execute(self, sequences, guide_tree, track_id_sets, score_matrices):
+        merge_mode = self.environment['merge_mode']
+        if merge_mode not in ("global", "semiglobal", "semiglobal_auto"):
+            raise ComponentError("unknown merge mode '{0}'".format(merge_mode))
+        aligner = self.manager.index.resolve(self.environment['aligner'])
+        alignments = {i: _identity_alignment(seq) for i, seq in enumerate(sequences)}
+        clusters = {i: _count_cluster(i, seq, track_id_sets) for i, seq in enumerate(sequences)}
+        steps = list(guide_tree.merge_orders)
+        for done, (i, j) in enumerate(steps):
+            one, two = clusters[i], clusters[j]
+            if merge_mode == "global":
+                mode = "global"
+            elif merge_mode == "semiglobal":
+                mode = "semiglobal_both"
+            else:
+                mode = auto_align_mode(one, two)
+            execution = Execution(self.manager, self.tag)
+            task = execution.add_task(aligner)
+            task.environment(self.environment, self.environment['aligner_env'])
+            task.inputs(mode=mode, sequence_one=one, sequence_two=two, track_id_sets_one=track_id_sets,
+                        track_id_sets_two=track_id_sets, score_matrices=score_matrices)
+            for message in execution.run():
+                yield message
+            path = np.array(execution.outputs[0]['alignment'].path)
+            merged = []
+            for ids in track_id_sets:
+                for trid in ids:
+                    merged.append((trid, one.get_track(trid).merge(two.get_track(trid), path)))
+                    one.del_track(trid)
+            for trid, track in merged:
+                one.add_track(trid, track)
+            alignments[i] = alignments[i].merge(alignments[j], path)
+            del clusters[j]
+            del alignments[j]
+            yield ProgressMessage((done + 1) / float(len(steps)))
+        yield CompleteMessage(outputs={'alignment': list(alignments.values())[0]})
+
+
 COMPONENTS = [PairwiseAligner, RawPairwiseAligner, ProfileBuilder, DummyMasterSlaveAligner,
-              GlobalMasterSlaveAligner, LocalMasterSlaveAligner, GuideTreeBuilder]
+              GlobalMasterSlaveAligner, LocalMasterSlaveAligner, GuideTreeBuilder, TreeMultipleSequenceAligner]
 
 
 # ---- the batching seam -----------------------------------------------------------------------------

@@ -19,6 +19,9 @@ Fixtures (all arrays little-endian numpy):
                            master-slave alignment paths, profile counts
   profile_profile.npz      PairwiseAligner on preprofile tracks (float scoring): profiles, m,
                            score, path for all pairs; GuideTreeBuilder distance matrix
+  treemsa.npz              GuideTreeBuilder + TreeMultipleSequenceAligner on preprofile and input tracks,
+                           merge modes semiglobal / global / semiglobal_auto: every merge step's mode,
+                           score and path, the final alignment path
   multitrack.npz           num_sets = 2 and 3 match-score matrices + alignments
   synthetic_c1.npz         BASELINE config 0: seed 1, N=8, mu=100, one-hot, BLOSUM62, global
   synthetic_dna.npz        small DNA (A=15, packaged nucleotide matrix) cases, all modes
@@ -314,6 +317,43 @@ def main():
                score_matrices=[blosum62])
     pp["merge_order"] = np.array(list(tree["guide_tree"].merge_orders), dtype=np.int64)
     save("profile_profile.npz", **pp)
+
+    # ---------------------------------------------------------------- progressive MSA (msa.py:124-237)
+    msa = {}
+    tree_in = run(pc.GuideTreeBuilder, {}, sequences=seqs, track_id_sets=T_IN, score_matrices=[blosum62])
+    msa["merge_order_input"] = np.array(list(tree_in["guide_tree"].merge_orders), dtype=np.int64)
+    for tag, sset, tracks, gtree in (("pre", pre_seqs, T_PRE, tree["guide_tree"]),
+                                     ("in", seqs, T_IN, tree_in["guide_tree"])):
+        for merge_mode in ("semiglobal", "global", "semiglobal_auto"):
+            calls = []
+            orig = pc.PairwiseAligner.execute
+
+            def spy(self, mode, sequence_one, sequence_two, track_id_sets_one, track_id_sets_two,
+                    zero_idxs, score_matrices, _orig=orig, _calls=calls):
+                for msg in _orig(self, mode, sequence_one, sequence_two, track_id_sets_one,
+                                 track_id_sets_two, zero_idxs, score_matrices):
+                    if msg.kind == core.MESSAGE_KIND_COMPLETE and msg.outputs is not None \
+                            and "alignment" in msg.outputs:
+                        _calls.append((mode, float(msg.outputs["score"]),
+                                       np.array(msg.outputs["alignment"].path, dtype=np.int64),
+                                       len(sequence_one), len(sequence_two)))
+                    yield msg
+            pc.PairwiseAligner.execute = spy
+            try:
+                out = run(pc.TreeMultipleSequenceAligner, {"merge_mode": merge_mode}, sequences=sset,
+                          guide_tree=gtree, track_id_sets=tracks, score_matrices=[blosum62])
+            finally:
+                pc.PairwiseAligner.execute = orig
+            key = "%s_%s_" % (tag, merge_mode)
+            msa[key + "path"] = np.array(out["alignment"].path, dtype=np.int64)
+            msa[key + "names"] = np.array([s.name for s in out["alignment"].items])
+            msa[key + "n_steps"] = np.int64(len(calls))
+            for c, (mode, sc, path, l1, l2) in enumerate(calls):
+                msa[key + "step%d_mode" % c] = np.array(mode)
+                msa[key + "step%d_score" % c] = np.float64(sc)
+                msa[key + "step%d_path" % c] = path
+                msa[key + "step%d_lens" % c] = np.array([l1, l2], dtype=np.int64)
+    save("treemsa.npz", **msa)
 
     # ---------------------------------------------------------------- multi-track sets
     mt = {}

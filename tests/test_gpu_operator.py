@@ -213,3 +213,46 @@ def test_error_behaviour(env, seqs):
                                       [one_hot(seqs[1].get_track(ct.TRACK_ID_INPUT).values, 27)], [env["blosum"].matrix],
                                       gap_series=[-4.0])
     assert out['score'] == s_ref and np.array_equal(np.array(out['alignment'].path), p_ref)
+
+
+def test_tree_msa_against_reference(env, seqs):
+    """GuideTreeBuilder + TreeMultipleSequenceAligner (msa.py:124-237) on the BBA0184 set, preprofile
+    tracks (float scoring) and input tracks (integer scoring), three merge modes: every merge step's
+    mode, score and path and the final multiple alignment against the real reference's run."""
+    d = load_golden("treemsa.npz")
+    pp = load_golden("profile_profile.npz")
+    pre = [ct.Sequence(s.name, [(ct.TRACK_ID_INPUT, s.get_track(ct.TRACK_ID_INPUT)),
+                                (ct.TRACK_ID_PREPROFILE, ct.ProfileTrack(pp["counts%d" % i], ct.ALPHABET_AA))])
+           for i, s in enumerate(seqs)]
+    for tag, sset, tracks in (("pre", pre, [[ct.TRACK_ID_PREPROFILE]]), ("in", seqs, T_IN)):
+        tree = run_one(env["serial"], comp.GuideTreeBuilder, sequences=sset, track_id_sets=tracks,
+                       score_matrices=[env["blosum"]])['guide_tree']
+        want_order = pp["merge_order"] if tag == "pre" else d["merge_order_input"]
+        assert [tuple(x) for x in tree.merge_orders] == [tuple(x) for x in want_order]
+        for merge_mode in ("semiglobal", "global", "semiglobal_auto"):
+            key = "%s_%s_" % (tag, merge_mode)
+            steps = []
+            orig = comp.PairwiseAligner.execute
+
+            def spy(self, *a, _orig=orig, _steps=steps, **kw):
+                for msg in _orig(self, *a, **kw):
+                    if msg.kind == core.MESSAGE_KIND_COMPLETE and msg.outputs and 'alignment' in msg.outputs:
+                        _steps.append((kw.get('mode', a[0] if a else None), msg.outputs['score'],
+                                       np.array(msg.outputs['alignment'].path)))
+                    yield msg
+            comp.PairwiseAligner.execute = spy
+            try:
+                out = run_one(env["serial"], comp.TreeMultipleSequenceAligner, {"merge_mode": merge_mode},
+                              sequences=sset, guide_tree=tree, track_id_sets=tracks, score_matrices=[env["blosum"]])
+            finally:
+                comp.PairwiseAligner.execute = orig
+            assert len(steps) == int(d[key + "n_steps"])
+            for c, (mode, score, path) in enumerate(steps):
+                assert mode == str(d[key + "step%d_mode" % c]), (key, c)
+                ref = float(d[key + "step%d_score" % c])
+                # merged clusters are count fractions, so all but single-sequence steps are float scoring
+                assert abs(score - ref) <= 1e-5 * abs(ref), (key, c)
+                assert np.array_equal(path, d[key + "step%d_path" % c]), (key, c)
+            aln = out['alignment']
+            assert [s.name for s in aln.items] == [str(x) for x in d[key + "names"]]
+            assert np.array_equal(np.asarray(aln.path), d[key + "path"]), key

@@ -117,6 +117,10 @@ def test_component_declarations_match_reference():
     assert raw.defaults == {'debug': 0, 'accelerate': True}
     pb = comp.ProfileBuilder
     assert pb.tid == "praline.component.ProfileBuilder" and set(pb.inputs) == {'alignment', 'track_id'}
+    tm = comp.TreeMultipleSequenceAligner    # msa.py:56-69
+    assert tm.tid == "praline.component.TreeMultipleSequenceAligner"
+    assert set(tm.inputs) == {'sequences', 'guide_tree', 'track_id_sets', 'score_matrices'}
+    assert tm.defaults['merge_mode'] == 'semiglobal' and tm.defaults['aligner'] == pa.tid
     idx = core.TypeIndex()
     idx.autoregister()
     for cls in comp.COMPONENTS:
