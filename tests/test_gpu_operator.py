@@ -256,3 +256,38 @@ def test_tree_msa_against_reference(env, seqs):
             aln = out['alignment']
             assert [s.name for s in aln.items] == [str(x) for x in d[key + "names"]]
             assert np.array_equal(np.asarray(aln.path), d[key + "path"]), key
+
+
+def test_end_to_end_msa_reproduces_shipped_alignment(env):
+    """The reference's only shipped known-answer file, extra/data/BBA0184.aln (committed as data under
+    tests/golden/), was produced by: FASTA in -> GlobalMasterSlaveAligner + ProfileBuilder per sequence
+    -> GuideTreeBuilder (average linkage, global) on the preprofiles -> TreeMultipleSequenceAligner
+    (merge global) -> aligned FASTA out.  The same pipeline on the device path must
+    give the same bytes; the preprofile stage is also run in its one-call device form."""
+    import os
+    from conftest import GOLDEN as GOLDEN_DIR
+    from praline_amd import io as pio
+    seqs = pio.load_sequence_fasta(os.path.join(GOLDEN_DIR, "BBA0184.tfa"), ct.ALPHABET_AA)
+    want = open(os.path.join(GOLDEN_DIR, "BBA0184.aln")).read()
+    blosum = env["blosum"]
+    for manager, fused in ((env["serial"], False), (env["batch"], True)):
+        if fused:
+            tracks = comp.build_preprofiles(seqs, ct.TRACK_ID_INPUT, blosum, mode="global")
+        else:
+            tracks = []
+            for m, master in enumerate(seqs):
+                slaves = [s for k, s in enumerate(seqs) if k != m]
+                aln = run_one(manager, comp.GlobalMasterSlaveAligner, master_sequence=master, slave_sequences=slaves,
+                              track_id_sets=T_IN, score_matrices=[blosum])['alignment']
+                tracks.append(run_one(manager, comp.ProfileBuilder, alignment=aln,
+                                      track_id=ct.TRACK_ID_INPUT)['profile_track'])
+        pre = [ct.Sequence(s.name, [(ct.TRACK_ID_INPUT, s.get_track(ct.TRACK_ID_INPUT)), (ct.TRACK_ID_PREPROFILE, t)])
+               for s, t in zip(seqs, tracks)]
+        t_pre = [[ct.TRACK_ID_PREPROFILE]]
+        keys = {"linkage_method": "average", "dist_mode": "global", "merge_mode": "global"}
+        tree = run_one(manager, comp.GuideTreeBuilder, keys, sequences=pre, track_id_sets=t_pre,
+                       score_matrices=[blosum])['guide_tree']
+        msa = run_one(manager, comp.TreeMultipleSequenceAligner, keys, sequences=pre, guide_tree=tree,
+                      track_id_sets=t_pre, score_matrices=[blosum])['alignment']
+        import io
+        assert pio.write_alignment_fasta(io.StringIO(), msa, ct.TRACK_ID_INPUT) == want, "fused" if fused else "components"

@@ -228,3 +228,30 @@ def test_all_pairs_sharding_helpers():
         assert loads.max() <= 1.15 * loads.mean()
     d, dist = allpairs.scores_to_distance(3, [(0, 1), (0, 2), (1, 2)], np.array([5.0, -2.0, 1.0], np.float32))
     assert d[0, 1] == d[1, 0] == 5.0 and d[1, 1] == 0.0 and np.array_equal(dist, (-d) + 5.0)
+
+
+def test_fasta_io_round_trip(tmp_path):
+    """praline_amd.io: reader (names, upper-casing, wrapped lines) and aligned-FASTA writer (72 columns,
+    '-' where a sequence does not advance) on the shipped data file."""
+    import os
+    from conftest import GOLDEN as GOLDEN_DIR
+    from praline_amd import io as pio, container as ct
+    seqs = pio.load_sequence_fasta(os.path.join(GOLDEN_DIR, "BBA0184.tfa"), ct.ALPHABET_AA)
+    assert [s.name for s in seqs] == ["seq%03d" % i for i in range(1, 6)]
+    assert [len(s) for s in seqs] == [326, 335, 304, 305, 118]
+    a, b = seqs[4], seqs[2]
+    path = np.array([(0, 0), (1, 1), (2, 1), (2, 2), (3, 3)])
+    aln = ct.Alignment([a, b], path)
+    rows = pio.alignment_rows(aln)
+    sym = lambda s, k: ct.ALPHABET_AA.index_to_symbol(int(s.get_track(ct.TRACK_ID_INPUT).values[k]))
+    assert rows[0] == sym(a, 0) + sym(a, 1) + "-" + sym(a, 2)
+    assert rows[1] == sym(b, 0) + "-" + sym(b, 1) + sym(b, 2)
+    out = tmp_path / "x.aln"
+    text = pio.write_alignment_fasta(str(out), aln)
+    assert out.read_text() == text == ">seq005\n%s\n>seq003\n%s\n" % (rows[0], rows[1])
+    # the shipped alignment parses back into the shipped sequences once the gaps are removed
+    gapped = ct.Alphabet("gapped", [(sy, ct.ALPHABET_AA.symbol_to_index(sy)) for sy in ct.ALPHABET_AA.symbols] + [("-", 99)])
+    aligned = pio.load_sequence_fasta(os.path.join(GOLDEN_DIR, "BBA0184.aln"), gapped)
+    for s, g in zip(seqs, aligned):
+        v = g.get_track(ct.TRACK_ID_INPUT).values
+        assert np.array_equal(v[v != 99], s.get_track(ct.TRACK_ID_INPUT).values)
