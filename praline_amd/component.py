@@ -497,6 +497,18 @@ def _count_cluster(index, sequence, track_id_sets):
     return cluster
 
 
+def _merge_clusters(one, two, track_id_sets, path):
+    """Replace every aligned track of cluster `one` by its merge with `two`'s along `path`
+    (container/sequence.py:205-239)."""
+    merged = []
+    for ids in track_id_sets:
+        for trid in ids:
+            merged.append((trid, one.get_track(trid).merge(two.get_track(trid), path)))
+            one.del_track(trid)
+    for trid, track in merged:
+        one.add_track(trid, track)
+
+
 class TreeMultipleSequenceAligner(Component):
     """praline/component/msa.py:18-248: N-1 profile-profile alignments in guide-tree order; after each
     one the two clusters' count tracks and sub-alignments are merged along the path
@@ -537,13 +549,7 @@ class TreeMultipleSequenceAligner(Component):
             for message in execution.run():
                 yield message
             path = np.array(execution.outputs[0]['alignment'].path)
-            merged = []
-            for ids in track_id_sets:
-                for trid in ids:
-                    merged.append((trid, one.get_track(trid).merge(two.get_track(trid), path)))
-                    one.del_track(trid)
-            for trid, track in merged:
-                one.add_track(trid, track)
+            _merge_clusters(one, two, track_id_sets, path)
             alignments[i] = alignments[i].merge(alignments[j], path)
             del clusters[j]
             del alignments[j]
@@ -551,8 +557,87 @@ class TreeMultipleSequenceAligner(Component):
         yield CompleteMessage(outputs={'alignment': list(alignments.values())[0]})
 
 
+class AdHocMultipleSequenceAligner(Component):
+    """praline/component/msa.py:250-558: no guide tree - every round scores all pairs of current clusters
+    (dist_mode), joins the best-scoring pair with a merge_mode alignment and repeats.  Scores of pairs that
+    do not involve the cluster changed in the previous round are reused (msa.py:508-519), so a round is one
+    fan-out of at most n-1 alignments: one device submission under BatchManager."""
+    tid = "praline.component.AdHocMultipleSequenceAligner"
+    inputs = {'sequences': Port([Sequence.tid]),
+              'track_id_sets': Port([[str]]),
+              'score_matrices': Port([ScoreMatrix.tid])}
+    outputs = {'alignment': Port(Alignment.tid)}
+    options = {'gap_series': [float], 'aligner': str, 'aligner_env': Environment.tid, 'merge_mode': str,
+               'dist_mode': str, 'debug': int, 'log_track_ids': [str]}
+    defaults = {'gap_series': [-11.0, -1.0], 'aligner': PairwiseAligner.tid, 'aligner_env': Environment({}),
+                'merge_mode': 'semiglobal', 'dist_mode': 'global', 'debug': 0, 'log_track_ids': [TRACK_ID_INPUT]}
+
+    @staticmethod
+    def _align_mode(kind, one, two):
+        if kind == "global":
+            return "global"
+        if kind == "semiglobal":
+            return "semiglobal_both"
+        return auto_align_mode(one, two)
+
+    def _fan_out(self, requests, track_id_sets, score_matrices):
+        """Run (mode, cluster_one, cluster_two) requests as ONE Execution; leaves the outputs in
+        self._last_outputs (a generator cannot return them to a for loop)."""
+        aligner = self.manager.index.resolve(self.environment['aligner'])
+        execution = Execution(self.manager, self.tag)
+        for mode, one, two in requests:
+            task = execution.add_task(aligner)
+            task.environment(self.environment, self.environment['aligner_env'])
+            task.inputs(mode=mode, sequence_one=one, sequence_two=two, track_id_sets_one=track_id_sets,
+                        track_id_sets_two=track_id_sets, score_matrices=score_matrices)
+        for message in execution.run():
+            yield message
+        self._last_outputs = execution.outputs
+
+    def execute(self, sequences, track_id_sets, score_matrices):
+        merge_mode, dist_mode = self.environment['merge_mode'], self.environment['dist_mode']
+        if merge_mode not in ("global", "semiglobal", "semiglobal_auto"):
+            raise ComponentError("unknown merge mode '{0}'".format(merge_mode))
+        if dist_mode not in ("global", "semiglobal", "semiglobal_auto"):
+            raise ComponentError("unknown distance mode '{0}'".format(dist_mode))
+        alignments = {i: _identity_alignment(seq) for i, seq in enumerate(sequences)}
+        clusters = {i: _count_cluster(i, seq, track_id_sets) for i, seq in enumerate(sequences)}
+        known = {}      # (cluster id a, cluster id b), a before b in cluster order -> score (float32)
+        changed = None  # the cluster that grew in the previous round: its scores are stale
+        total = max(len(clusters) - 1, 1)
+        done = 0
+        while len(clusters) > 1:
+            ids = list(clusters.keys())
+            pending = [(a, b) for x, a in enumerate(ids) for b in ids[x + 1:]
+                       if changed is None or changed in (a, b)]
+            for message in self._fan_out([(self._align_mode(dist_mode, clusters[a], clusters[b]), clusters[a], clusters[b])
+                                          for a, b in pending], track_id_sets, score_matrices):
+                yield message
+            for (a, b), out in zip(pending, self._last_outputs):
+                known[(a, b)] = np.float32(out['score'])
+            s = np.full((len(ids), len(ids)), -(2 ** 32), dtype=np.float32)
+            for x, a in enumerate(ids):
+                for y in range(x + 1, len(ids)):
+                    s[x, y] = s[y, x] = known[(a, ids[y])]
+            x, y = np.unravel_index(s.argmax(), s.shape)     # first maximum in row-major order (msa.py:552)
+            i, j = ids[x], ids[y]
+            one, two = clusters[i], clusters[j]
+            for message in self._fan_out([(self._align_mode(merge_mode, one, two), one, two)], track_id_sets, score_matrices):
+                yield message
+            path = np.array(self._last_outputs[0]['alignment'].path)
+            _merge_clusters(one, two, track_id_sets, path)
+            alignments[i] = alignments[i].merge(alignments[j], path)
+            del clusters[j]
+            del alignments[j]
+            changed = i
+            done += 1
+            yield ProgressMessage(done / float(total))
+        yield CompleteMessage(outputs={'alignment': list(alignments.values())[0]})
+
+
 COMPONENTS = [PairwiseAligner, RawPairwiseAligner, ProfileBuilder, DummyMasterSlaveAligner,
-              GlobalMasterSlaveAligner, LocalMasterSlaveAligner, GuideTreeBuilder, TreeMultipleSequenceAligner]
+              GlobalMasterSlaveAligner, LocalMasterSlaveAligner, GuideTreeBuilder, TreeMultipleSequenceAligner,
+              AdHocMultipleSequenceAligner]
 
 
 # ---- the batching seam -----------------------------------------------------------------------------

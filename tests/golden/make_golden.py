@@ -22,6 +22,8 @@ Fixtures (all arrays little-endian numpy):
   treemsa.npz              GuideTreeBuilder + TreeMultipleSequenceAligner on preprofile and input tracks,
                            merge modes semiglobal / global / semiglobal_auto: every merge step's mode,
                            score and path, the final alignment path
+  adhoc.npz                AdHocMultipleSequenceAligner: the sequence of inner PairwiseAligner calls (mode,
+                           cluster names, lengths, score) and the final alignment, 4 mode combinations
   multitrack.npz           num_sets = 2 and 3 match-score matrices + alignments
   synthetic_c1.npz         BASELINE config 0: seed 1, N=8, mu=100, one-hot, BLOSUM62, global
   synthetic_dna.npz        small DNA (A=15, packaged nucleotide matrix) cases, all modes
@@ -354,6 +356,39 @@ def main():
                 msa[key + "step%d_path" % c] = path
                 msa[key + "step%d_lens" % c] = np.array([l1, l2], dtype=np.int64)
     save("treemsa.npz", **msa)
+
+    # ---------------------------------------------------------------- ad hoc MSA (msa.py:250-558)
+    adhoc = {}
+    for tag, sset, tracks in (("pre", pre_seqs, T_PRE), ("in", seqs, T_IN)):
+        for merge_mode, dist_mode in (("semiglobal", "global"), ("global", "global"),
+                                      ("semiglobal_auto", "semiglobal_auto"), ("global", "semiglobal")):
+            calls = []
+            orig = pc.PairwiseAligner.execute
+
+            def spy(self, mode, sequence_one, sequence_two, track_id_sets_one, track_id_sets_two,
+                    zero_idxs, score_matrices, _orig=orig, _calls=calls):
+                for msg in _orig(self, mode, sequence_one, sequence_two, track_id_sets_one,
+                                 track_id_sets_two, zero_idxs, score_matrices):
+                    if msg.kind == core.MESSAGE_KIND_COMPLETE and msg.outputs is not None \
+                            and "alignment" in msg.outputs:
+                        _calls.append((mode, sequence_one.name, sequence_two.name, len(sequence_one),
+                                       len(sequence_two), float(msg.outputs["score"])))
+                    yield msg
+            pc.PairwiseAligner.execute = spy
+            try:
+                out = run(pc.AdHocMultipleSequenceAligner, {"merge_mode": merge_mode, "dist_mode": dist_mode},
+                          sequences=sset, track_id_sets=tracks, score_matrices=[blosum62])
+            finally:
+                pc.PairwiseAligner.execute = orig
+            key = "%s_%s_%s_" % (tag, merge_mode, dist_mode)
+            adhoc[key + "path"] = np.array(out["alignment"].path, dtype=np.int64)
+            adhoc[key + "names"] = np.array([s.name for s in out["alignment"].items])
+            adhoc[key + "call_modes"] = np.array([c[0] for c in calls])
+            adhoc[key + "call_one"] = np.array([c[1] for c in calls])
+            adhoc[key + "call_two"] = np.array([c[2] for c in calls])
+            adhoc[key + "call_lens"] = np.array([[c[3], c[4]] for c in calls], dtype=np.int64)
+            adhoc[key + "call_scores"] = np.array([c[5] for c in calls], dtype=np.float64)
+    save("adhoc.npz", **adhoc)
 
     # ---------------------------------------------------------------- multi-track sets
     mt = {}

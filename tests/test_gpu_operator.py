@@ -291,3 +291,45 @@ def test_end_to_end_msa_reproduces_shipped_alignment(env):
                       track_id_sets=t_pre, score_matrices=[blosum])['alignment']
         import io
         assert pio.write_alignment_fasta(io.StringIO(), msa, ct.TRACK_ID_INPUT) == want, "fused" if fused else "components"
+
+
+def test_adhoc_msa_against_reference(env, seqs):
+    """AdHocMultipleSequenceAligner (msa.py:250-558) with its score cache: the exact sequence of inner
+    alignments (mode, clusters, lengths; scores within 1e-5) under the serial manager, and the final
+    alignment under both managers (BatchManager turns every round into one device submission)."""
+    d = load_golden("adhoc.npz")
+    pp = load_golden("profile_profile.npz")
+    pre = [ct.Sequence(s.name, [(ct.TRACK_ID_INPUT, s.get_track(ct.TRACK_ID_INPUT)),
+                                (ct.TRACK_ID_PREPROFILE, ct.ProfileTrack(pp["counts%d" % i], ct.ALPHABET_AA))])
+           for i, s in enumerate(seqs)]
+    for tag, sset, tracks in (("pre", pre, [[ct.TRACK_ID_PREPROFILE]]), ("in", seqs, T_IN)):
+        for merge_mode, dist_mode in (("semiglobal", "global"), ("global", "global"),
+                                      ("semiglobal_auto", "semiglobal_auto"), ("global", "semiglobal")):
+            key = "%s_%s_%s_" % (tag, merge_mode, dist_mode)
+            keys = {"merge_mode": merge_mode, "dist_mode": dist_mode}
+            calls = []
+            orig = comp.PairwiseAligner.execute
+
+            def spy(self, mode, sequence_one, sequence_two, *a, _orig=orig, _calls=calls, **kw):
+                for msg in _orig(self, mode, sequence_one, sequence_two, *a, **kw):
+                    if msg.kind == core.MESSAGE_KIND_COMPLETE and msg.outputs and 'alignment' in msg.outputs:
+                        _calls.append((mode, sequence_one.name, sequence_two.name, len(sequence_one), len(sequence_two),
+                                       msg.outputs['score']))
+                    yield msg
+            comp.PairwiseAligner.execute = spy
+            try:
+                out = run_one(env["serial"], comp.AdHocMultipleSequenceAligner, keys, sequences=sset,
+                              track_id_sets=tracks, score_matrices=[env["blosum"]])
+            finally:
+                comp.PairwiseAligner.execute = orig
+            assert [c[0] for c in calls] == [str(x) for x in d[key + "call_modes"]], key
+            assert [c[1] for c in calls] == [str(x) for x in d[key + "call_one"]], key
+            assert [c[2] for c in calls] == [str(x) for x in d[key + "call_two"]], key
+            assert np.array_equal(np.array([[c[3], c[4]] for c in calls]), d[key + "call_lens"]), key
+            got = np.array([c[5] for c in calls])
+            assert np.all(np.abs(got - d[key + "call_scores"]) <= 1e-5 * np.abs(d[key + "call_scores"])), key
+            out_b = run_one(env["batch"], comp.AdHocMultipleSequenceAligner, keys, sequences=sset,
+                            track_id_sets=tracks, score_matrices=[env["blosum"]])
+            for o in (out, out_b):
+                assert [s.name for s in o['alignment'].items] == [str(x) for x in d[key + "names"]], key
+                assert np.array_equal(np.asarray(o['alignment'].path), d[key + "path"]), key

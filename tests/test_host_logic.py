@@ -121,6 +121,10 @@ def test_component_declarations_match_reference():
     assert tm.tid == "praline.component.TreeMultipleSequenceAligner"
     assert set(tm.inputs) == {'sequences', 'guide_tree', 'track_id_sets', 'score_matrices'}
     assert tm.defaults['merge_mode'] == 'semiglobal' and tm.defaults['aligner'] == pa.tid
+    ah = comp.AdHocMultipleSequenceAligner   # msa.py:289-301
+    assert ah.tid == "praline.component.AdHocMultipleSequenceAligner"
+    assert set(ah.inputs) == {'sequences', 'track_id_sets', 'score_matrices'}
+    assert ah.defaults['merge_mode'] == 'semiglobal' and ah.defaults['dist_mode'] == 'global'
     idx = core.TypeIndex()
     idx.autoregister()
     for cls in comp.COMPONENTS:
