@@ -270,6 +270,12 @@ def main():
         sample_cells = int(cells[idx].sum())
         gpu_scores = d_slice.cpu().numpy()[idx] if world == 1 else None
         max_rel = float(np.max(np.abs(gpu_scores - cpu_scores) / np.maximum(1.0, np.abs(cpu_scores))))
+        # 1-thread figure on a small sample (SURVEY 8(d) asks for both)
+        n1 = int(max(8, min(len(pairs), n_sample * 2.0 / max(threads * (tc1 - tc0), 1e-3))))
+        idx1 = np.linspace(0, len(pairs) - 1, n1).astype(np.int64)
+        t_a = time.perf_counter()
+        orc.batch_scores(args.mode, arena_cat, row_off, lens.astype(np.int32), S, pairs[idx1], GAP_OPEN, GAP_EXTEND, threads=1)
+        dt1 = time.perf_counter() - t_a
         out["cpu_baseline"] = {
             "value": sample_cells / (tc1 - tc0) / 1e9, "unit": "GCUPS", "cores": threads,
             "kind": "port",
@@ -277,6 +283,7 @@ def main():
                       "(build_nonzero + build_scores + fill + end cell per pair, OpenMP)" % (
                           n_sample, len(pairs), tc1 - tc0),
             "max_rel_diff_vs_gpu": max_rel,
+            "value_1_thread": int(cells[idx1].sum()) / dt1 / 1e9,
         }
     if rank == 0:
         print(json.dumps(out))

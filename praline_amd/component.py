@@ -409,23 +409,34 @@ def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_seri
 # ---- callers: guide tree (all-pairs distance stage) ----------------------------------------------
 def merge_order(distance_matrix, linkage):
     """Agglomerative clustering merge order (praline/util/cluster.py:27-114): repeatedly merge the two
-    clusters with the smallest linkage distance (first minimum in cluster-id order), the merged
-    cluster keeps the id of the first."""
+    clusters with the smallest linkage distance (first minimum in cluster-id order, both (i, j) and (j, i)
+    present), the merged cluster keeps the id of the first.
+
+    Linkage distances are evaluated exactly as the reference does - reduce(d[ix_(ci, cj)]) per ordered
+    pair, so a float32 mean keeps its summation order - but only for the cluster that changed: the other
+    entries of the previous round are reused (they would be recomputed to the same values).  O(N^2) reduce
+    calls in total instead of O(N^3)."""
     d = np.asarray(distance_matrix, dtype=float)
     reduce_fn = {'single': np.min, 'complete': np.max, 'average': np.mean}[linkage]
-    clusters = {i: [i] for i in range(d.shape[0])}
+    n = d.shape[0]
+    members = {i: [i] for i in range(n)}
+    alive = list(range(n))
+    link = np.full((n, n), np.inf)          # link[i, j] for live cluster ids, by id
+    if n > 1:
+        link[:, :] = d
+        np.fill_diagonal(link, np.inf)
     order = []
-    while len(clusters) > 1:
-        ids = list(clusters.keys())
-        a = np.full((len(ids), len(ids)), np.inf)
-        for i, ci in enumerate(ids):
-            for j, cj in enumerate(ids):
-                if ci != cj:
-                    a[i, j] = reduce_fn(d[np.ix_(clusters[ci], clusters[cj])])
-        i, j = np.unravel_index(a.argmin(), a.shape)
-        one, two = ids[i], ids[j]
-        clusters[one] = clusters[one] + clusters[two]
-        del clusters[two]
+    while len(alive) > 1:
+        sub = link[np.ix_(alive, alive)]
+        x, y = np.unravel_index(sub.argmin(), sub.shape)
+        one, two = alive[x], alive[y]
+        members[one] = members[one] + members[two]
+        del members[two]
+        alive.remove(two)
+        for c in alive:
+            if c != one:
+                link[one, c] = reduce_fn(d[np.ix_(members[one], members[c])])
+                link[c, one] = reduce_fn(d[np.ix_(members[c], members[one])])
         order.append((one, two))
     return order
 

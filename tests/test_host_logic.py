@@ -259,3 +259,34 @@ def test_fasta_io_round_trip(tmp_path):
     for s, g in zip(seqs, aligned):
         v = g.get_track(ct.TRACK_ID_INPUT).values
         assert np.array_equal(v[v != 99], s.get_track(ct.TRACK_ID_INPUT).values)
+
+
+def test_merge_order_incremental_equals_full_recomputation():
+    """merge_order caches linkage distances between rounds; the reference recomputes the whole table every
+    round (cluster.py:27-114).  Same reduce calls, so the orders must be identical - also on tie-heavy
+    integer matrices, where the first-minimum rule decides."""
+    def full(distance_matrix, linkage):
+        d = np.asarray(distance_matrix, dtype=float)
+        reduce_fn = {'single': np.min, 'complete': np.max, 'average': np.mean}[linkage]
+        clusters = {i: [i] for i in range(d.shape[0])}
+        order = []
+        while len(clusters) > 1:
+            ids = list(clusters.keys())
+            a = np.full((len(ids), len(ids)), np.inf)
+            for i, ci in enumerate(ids):
+                for j, cj in enumerate(ids):
+                    if ci != cj:
+                        a[i, j] = reduce_fn(d[np.ix_(clusters[ci], clusters[cj])])
+            i, j = np.unravel_index(a.argmin(), a.shape)
+            clusters[ids[i]] = clusters[ids[i]] + clusters[ids[j]]
+            del clusters[ids[j]]
+            order.append((ids[i], ids[j]))
+        return order
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 7, 24):
+        for ties in (True, False):
+            m = rng.integers(0, 6, (n, n)).astype(np.float32) if ties else rng.random((n, n)).astype(np.float32)
+            m = m + m.T
+            np.fill_diagonal(m, 0)
+            for linkage in ('single', 'complete', 'average'):
+                assert comp.merge_order(m, linkage) == full(m, linkage), (n, ties, linkage)
