@@ -385,7 +385,9 @@ def test_batch_c2_slice_properties(nat, bba):
     plan.run("semiglobal_both", *GAPS)
     semi = plan.scores()
     plan.close()
-    assert (loc >= semi).all() and (semi >= sc[::97]).all()
+    # semiglobal frees end gaps of the global alignment; local is NOT an upper bound of semiglobal in the
+    # reference (penalised boundary in local mode, align.py:371-385), only of 0
+    assert (semi >= sc[::97]).all() and (loc >= 0).all()
     for k in range(0, len(pairs), 4001):
         i, j = pairs[k]
         s_or, _ = oracle_dp_on_m("global", arena.match_scores(i, j, 1))
