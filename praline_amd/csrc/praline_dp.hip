@@ -519,7 +519,10 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     // (A first attempt - whole length classes per XCD - was 30-40 % slower: it put all expensive tasks on
     // one XCD.)
     {
-        int G = 16;  // measured (N = 512, staged stream): none 1984, G = 4 2115, G = 16 2393 GCUPS
+        // group size ~ tasks / 128, i.e. ~16 group rounds per XCD (measured, float profiles, GCUPS:
+        // 4 336 tasks: none 1984, G = 4 2115, 16 2393, 32 2384, 64 2314;
+        // 33 049 tasks (one rank of C4): none 1674, 16 1817, 64 2242, 256 2634, 1024 2613, 4096 1677)
+        int G = (int)std::min<size_t>(1024, std::max<size_t>(16, halves.size() / 128));
         if (const char *env = getenv("PRALINE_XCD_GROUP")) G = atoi(env);
         if (G > 1 && halves.size() >= (size_t)(16 * G)) {
             HalfTask empty;
