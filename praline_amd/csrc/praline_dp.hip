@@ -275,7 +275,8 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (n_seqs <= 0 || !lens || !profiles || !S) return fail(PRALINE_ERR_ARG, "NULL or empty arena input");
-    if (A <= 0 || A > 32) return fail(PRALINE_ERR_ARG, "alphabet size %d not in 1..32 (concatenated track sets)", A);
+    // the raw (concatenated) alphabet may be wide; what the kernels bound is the number of ACTIVE symbols (<= 32)
+    if (A <= 0 || A > 254) return fail(PRALINE_ERR_ARG, "alphabet size %d not in 1..254 (concatenated track sets)", A);
     RC(ensure_runtime(-1));
     praline_arena *a = new praline_arena();
     a->n_seqs = n_seqs;
@@ -315,7 +316,12 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     const int need = std::max(1, (a->n_active + 1) / 2);
     a->nstep = 0;
     for (int c : kNstepChoices) if (c >= need) { a->nstep = c; break; }
-    if (!a->nstep) { delete a; return fail(PRALINE_ERR_ARG, "too many active symbols (%d)", a->n_active); }
+    if (!a->nstep) {
+        const int n_act = a->n_active;
+        delete a;
+        return fail(PRALINE_ERR_UNSUPPORTED, "%d active symbols (symbols with mass in some profile and a non-zero score row); "
+                    "the kernels handle up to 32", n_act);
+    }
     a->KS = (a->nstep + 3) / 4 * 4;
     a->KP = 2 * a->KS;
     a->nr16 = a->n_active <= 16 ? 1 : (a->n_active <= 32 ? 2 : 0);
@@ -1056,7 +1062,7 @@ extern "C" int praline_build_scores(int num_sets, const praline_array *i1s, cons
             return fail(PRALINE_ERR_ARG, "set %d: score matrix shape does not match the profiles", n);
         A += std::max(i1s[n].dim[1], i2s[n].dim[1]);
     }
-    if (A > 32) return fail(PRALINE_ERR_UNSUPPORTED, "concatenated alphabet size %lld > 32", (long long)A);
+    if (A > 254) return fail(PRALINE_ERR_UNSUPPORTED, "concatenated alphabet size %lld > 254", (long long)A);
     // concatenate the track sets along the alphabet axis: P = [P_1 | P_2 ...], S = blockdiag(S_n)
     std::vector<float> prof((size_t)((L1 + L2) * A), 0.0f), S((size_t)(A * A), 0.0f), tmp;
     int64_t off = 0;

@@ -354,6 +354,39 @@ def test_shared_wave_boundaries_vs_oracle(nat, bba, kind):
     arena.close()
 
 
+def test_wide_concatenated_alphabet(nat, bba):
+    """Two track sets whose concatenated alphabet (27 + 12 = 39 symbols) exceeds 32 while the ACTIVE symbols
+    (20 residues + 10 states) do not: parity entry point and batched plan against the multi-set oracle
+    (cext.c:389-420 sums the sets)."""
+    rng = np.random.default_rng(31)
+    S1 = bba["S"]
+    S2 = np.zeros((12, 12), dtype=np.float32)
+    S2[:10, :10] = rng.integers(-3, 6, (10, 10)).astype(np.float32)
+    S2 = np.maximum(S2, S2.T)
+    L1, L2 = 57, 70
+    a1, a2 = rng.integers(0, 20, L1), rng.integers(0, 20, L2)
+    b1, b2 = rng.integers(0, 10, L1), rng.integers(0, 10, L2)
+    i1s, i2s = [one_hot(a1, 27), one_hot(b1, 12)], [one_hot(a2, 27), one_hot(b2, 12)]
+    m = np.zeros((L1, L2), dtype=np.float32)
+    nat.cext_build_scores(i1s, i2s, None, None, [S1, S2], m)
+    want = S1[np.ix_(a1, a2)] + S2[np.ix_(b1, b2)]
+    assert np.array_equal(m, want)
+    cat = lambda x, y: np.concatenate([x, y], axis=1)
+    Sbig = np.zeros((39, 39), dtype=np.float32)
+    Sbig[:27, :27] = S1
+    Sbig[27:, 27:] = S2
+    arena = nat.Arena([cat(*i1s), cat(*i2s)], Sbig)
+    assert arena.info()["n_active"] == 30
+    for mode in MODES:
+        plan = nat.Plan(arena, np.array([(0, 1)], dtype=np.int32), want_paths=True)
+        plan.run(mode, *GAPS)
+        s_or, p_or = oracle_dp_on_m(mode, want)
+        assert plan.scores()[0] == np.float32(s_or), mode
+        assert np.array_equal(plan.paths()[0], p_or), mode
+        plan.close()
+    arena.close()
+
+
 def test_batch_c2_slice_properties(nat, bba):
     """BASELINE config 1 shape (256 x ~400 aa profiles, all pairs, global): properties that do not
     need the oracle at full size + oracle spot checks."""
