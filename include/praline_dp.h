@@ -131,7 +131,9 @@ typedef struct praline_plan praline_plan;   /* a scheduled pair list (wave tasks
  * Several track sets are passed concatenated along the alphabet axis (A = sum A_t) with
  * S = blockdiag(S_t) (cext.c:389-420 sums the sets).  S: float32 [A][A], row = symbol of
  * sequence one, column = symbol of sequence two (align.py:205).  Runs the profile x matrix
- * pre-multiply (MFMA) on the device. */
+ * pre-multiply (MFMA) on the device.
+ * Limits: A <= 254; at most 32 ACTIVE symbols - symbols that have mass in some profile and a non-zero
+ * row in S (BLOSUM62 on 20-residue data: 20 of 27) - otherwise PRALINE_ERR_UNSUPPORTED. */
 int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t A, const float *profiles,
                          const float *S, praline_arena **out);
 int praline_arena_destroy(praline_arena *arena);
