@@ -306,6 +306,11 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
 // saturates the CU's texture-address path (measured: scripts/exp_step.py, 0.47 -> 0.32 us per step and
 // SIMD without these loads) - but looked up in a one-hot table in LDS by the row's symbol; the symbols
 // arrive as one dword per lane and four rows.
+#ifdef PRALINE_TRACE
+// experiments only (scripts/exp_trace.py): per wave {block, wave | share << 8, HW_ID, XCC_ID, start, end} (s_memtime)
+__device__ unsigned long long *praline_trace_buf = nullptr;
+#endif
+
 // BSRC = 2: the LDS-staged operand stream described above (one wave per workgroup).
 //
 // WPG = 4 (staged stream only): workgroups of FOUR waves described by wg[blockIdx.x] (WgDesc): `share`
@@ -329,6 +334,9 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
     static_assert(WPG == 1 || (WPG == 4 && BSRC == 2), "four-wave workgroups use the staged stream");
     constexpr bool MW = WPG > 1;
+#ifdef PRALINE_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memtime();
+#endif
     constexpr bool ONEHOT = BSRC == 1;
     constexpr bool STAGED = BSRC == 2;
     static_assert(!ONEHOT || NTERM == 1, "the one-hot table path is an exact-mode path");
@@ -643,6 +651,16 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     }
 
     if constexpr (STAGED) PRALINE_VMCNT(0);  // no DMA may be in flight when the wave ends
+#ifdef PRALINE_TRACE
+    if (praline_trace_buf != nullptr && (threadIdx.x & 63) == 0) {
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        unsigned long long *rec = praline_trace_buf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 6;
+        rec[0] = blockIdx.x; rec[1] = (threadIdx.x >> 6) | ((unsigned)share << 8) | ((unsigned)task << 16);
+        rec[2] = hw_id; rec[3] = xcc_id; rec[4] = trace_t0; rec[5] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 
     float corner_all = __builtin_fmaxf(out_corner, partner_value(out_corner, h));
     float rowmax_all = __builtin_fmaxf(out_rowmax, partner_value(out_rowmax, h));

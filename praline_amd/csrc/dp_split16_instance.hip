@@ -92,3 +92,10 @@ int praline_launch_split16_tb(const LaunchArgs &la, const Arena16Dev &a16, int n
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }
+
+#ifdef PRALINE_TRACE
+extern "C" int praline_trace_set(void *device_buffer)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(praline_trace_buf), &device_buffer, sizeof(void *)) == hipSuccess ? 0 : -2;
+}
+#endif
