@@ -15,6 +15,15 @@
 #pragma once
 #include "dp_split16.hip.h"
 
+// w = (w << 1) | (open < extend): the sign bit of open - extend, shifted in with v_alignbit_b32.  The
+// subtraction is opaque to the optimiser (the kernels are built -fno-honor-nans and -inf - -inf is a NaN).
+__device__ __forceinline__ unsigned shift_in_sign(unsigned w, float open, float extend)
+{
+    float d;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(open), "v"(extend));
+    return __builtin_amdgcn_alignbit(w, __builtin_bit_cast(unsigned, d), 31);
+}
+
 struct TbCarry {
     float xm, xu, xl;     // upper half: states of the cell left of its first column, same row (handed over)
     float pxm, pxu, pxl;  // upper half: the same for the previous row (= its diagonal input)
@@ -53,7 +62,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             zmask |= in ? ((0xffffu >> (15 - hi)) & (0xffffu << lo)) : 0u;
         }
     }
-    unsigned w_code = 0, w_ul = 0;  // 16 x 2-bit match sources; 16 U-extend bits | 16 L-extend bits << 16
+    unsigned w_code = 0, w_u = 0, w_l = 0;  // 16 x 2-bit match sources; U-extend / L-extend bits, column c in bit 15 - c
     __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -64,6 +73,9 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         const int ia = (term == 0) ? NR + r : r;
         const int ib = (term == 1) ? NR + r : r;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+        // pin the MFMA at the START of its chunk: left alone the scheduler sinks it to the end of the step and
+        // then pads ~35 s_nop for the MFMA -> VALU result hazard in front of the next step's select
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = (16 * k) / NM; c < (16 * (k + 1)) / NM; ++c) {
             // exact candidate sums (cext.c:185-201), maxima and first-match flags (cext.c:207-295)
@@ -84,7 +96,11 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
                 if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; code = 0u; }  // cext.c:141-149
             }
             w_code |= code << (2 * c);
-            w_ul |= ((uo >= ue) ? 0u : (1u << c)) | ((lo >= le) ? 0u : (0x10000u << c));
+            // "from extend" bits = sign of (open - extend), shifted in with one v_alignbit each: no compare, so
+            // no VCC write -> v_cndmask wait states (the compare form cost ~35 s_nop per step).  Column c lands
+            // in bit 15 - c; reversed once per row below.  (-inf) - (-inf) only happens in cells no path enters.
+            w_u = shift_in_sign(w_u, uo, ue);
+            w_l = shift_in_sign(w_l, lo, le);
             md = Mp[c]; ud = Up[c]; ld = Lp[c];
             Mp[c] = M; Up[c] = U; Lp[c] = Lc;
             mleft = M; lleft = Lc;
@@ -131,7 +147,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 
     if (h) *reinterpret_cast<float4 *>(bnd_st) = make_float4(Mp[15], Up[15], Lp[15], 0.0f);
     bnd_st += 32 * sizeof(float4);
-    *tb_st = make_uint2(w_code, w_ul);
+    *tb_st = make_uint2(w_code, (__builtin_bitreverse32(w_u) >> 16) | (__builtin_bitreverse32(w_l) & 0xffff0000u));
     tb_st += 64;
 }
 
@@ -274,14 +290,17 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
             }
         }
         const char *b_next = pB + 3 * b_stride;
-        const char *bnd_ld = my_bnd + 2 * BROW;
+        // boundary states two rows ahead, in two alternating registers (one row = 1 us at one wave per SIMD is
+        // not enough for a load that misses L2; measured with the 1-deep version: 27 % of the cycles waiting)
+        const char *bnd_ld = my_bnd + 3 * BROW;
         char *bnd_st = my_bnd;                                               // upper half stores row yy = t - 1 (row 0: dummy)
-        float4 bnd_pref = *reinterpret_cast<const float4 *>(my_bnd + BROW);  // row 1
+        float4 bnd_prefA = *reinterpret_cast<const float4 *>(my_bnd + BROW);      // row 1
+        float4 bnd_prefB = *reinterpret_cast<const float4 *>(my_bnd + 2 * BROW);  // row 2
         uint2 *tb_st = my_tb + (int64_t)s * tb_rows * 64 + (h ? 0 : 64);     // row yy = t - h of step t = 1
 
-#define PRALINE_TB_STEP(T, CUR, PREV, BSET)                                                                          \
+#define PRALINE_TB_STEP(T, CUR, PREV, BSET, PREF)                                                                    \
         split16_tb_step<NR, NTERM, LOCAL, MASK>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld,  \
-                                                bnd_st, bnd_pref, tb_st, Mp, Up, Lp, cxm, cxu, cxl, cpxm, cpxu, cpxl, cdM,  \
+                                                bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl, cpxm, cpxu, cpxl, cdM,      \
                                                 cdU, cdL, best_run, best_y, best_x, best_k, go, ge, xb, rect)
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         {
             const float best_s = best_run;
             const int by = best_y, bx = best_x, bk = best_k;
-            PRALINE_TB_STEP(1, accA, accB, bX);
+            PRALINE_TB_STEP(1, accA, accB, bX, bnd_prefA);
             if (h) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
@@ -316,9 +335,9 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
             PRALINE_TB_TAILS(1)
         }
         for (int t = 2; t <= max_l1 + 1; t += 2) {
-            PRALINE_TB_STEP(t, accB, accA, bY);
+            PRALINE_TB_STEP(t, accB, accA, bY, bnd_prefB);
             PRALINE_TB_TAILS(t)
-            PRALINE_TB_STEP(t + 1, accA, accB, bX);
+            PRALINE_TB_STEP(t + 1, accA, accB, bX, bnd_prefA);
             PRALINE_TB_TAILS(t + 1)
         }
 #undef PRALINE_TB_STEP
