@@ -542,13 +542,67 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
 
 #ifdef PRALINE_AUX_KERNELS
 // --------------------------------------------------------------------------------------------
+struct PairLoc { int32_t task; int32_t lane; };
+
+// Semiglobal end cell (praline/component/align.py:406-424): the maxima of the last row o[L1, x, k] and the last
+// column o[y, L2, k] (boundary cells included) and, for the side that wins, the cell the reference finds scanning
+// from the far end (x from L2 down / y from L1 down) and k = 0, 1, 2: the largest coordinate holding the maximum,
+// smallest k there.  The scratch rows interleave the pairs of a task (one 128-byte row per (coordinate, state)),
+// so the scan runs per TASK - thread = (task, lane), every lane walks its own pair but all lanes of a task read the
+// same row together.  (Scanning per pair touched a whole line per value: k_traceback took 4.7 ms instead of 1.2.)
+__global__ __launch_bounds__(64) void k_semiglobal_end(ArenaDev ar, const WaveTask *__restrict__ tasks,
+                                                        const int32_t *__restrict__ lane_one,
+                                                        const int32_t *__restrict__ lane_pair, const int32_t *__restrict__ pairs,
+                                                        const float *__restrict__ aux, int32_t *__restrict__ end_cells,
+                                                        float *__restrict__ scores, RunParams rp, int32_t task_lo,
+                                                        int32_t task_hi, int layout)
+{
+    const int ls = layout ? 32 : 64;                 // lanes (pairs) per task = lane stride of the scratch
+    const int t = task_lo + (int)((blockIdx.x * 64 + threadIdx.x) / ls);
+    const int lane = (int)(threadIdx.x % ls);
+    if (t >= task_hi) return;
+    const int64_t p = lane_pair[(int64_t)t * ls + lane];
+    if (p < 0) return;
+    const WaveTask tk = tasks[t];
+    const int L1 = ar.len[pairs[2 * p]], L2 = ar.len[pairs[2 * p + 1]];
+    const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
+    const float *lastcol = aux + tk.aux_off + lane;
+    const float *lastrow = aux + tk.aux_off + (int64_t)(tk.max_l1 + 1) * 3 * ls + lane;
+    // scanning upwards with >= keeps the LARGEST coordinate; k upwards with > keeps the smallest k there
+    float rmax = PRALINE_NEG_INF, cmax = PRALINE_NEG_INF;
+    int rx = 0, rk = 0, cy = 0, ck = 0;
+    {
+        const float b1 = boundary_value(L1, rp.go1, rp.ge1, free_one);   // o[L1, 0, :] = (-inf, b1, -inf)
+        rmax = b1; rx = 0; rk = 1;
+        if (!(b1 > PRALINE_NEG_INF)) rk = 0;
+        const float b2 = boundary_value(L2, rp.go2, rp.ge2, free_two);   // o[0, L2, :] = (-inf, -inf, b2)
+        cmax = b2; cy = 0; ck = 2;
+        if (!(b2 > PRALINE_NEG_INF)) ck = 0;
+    }
+    for (int xx = 1; xx <= L2; ++xx) {
+        const float *q = lastrow + (int64_t)(xx - 1) * 3 * ls;
+        const float v0 = q[0], v1 = q[ls], v2 = q[2 * ls];
+        const float m = max3f(v0, v1, v2);
+        if (m >= rmax) { rmax = m; rx = xx; rk = (v0 == m) ? 0 : ((v1 == m) ? 1 : 2); }
+    }
+    for (int yy = 1; yy <= L1; ++yy) {
+        const float *q = lastcol + (int64_t)yy * 3 * ls;
+        const float v0 = q[0], v1 = q[ls], v2 = q[2 * ls];
+        const float m = max3f(v0, v1, v2);
+        if (m >= cmax) { cmax = m; cy = yy; ck = (v0 == m) ? 0 : ((v1 == m) ? 1 : 2); }
+    }
+    const bool from_row = rmax > cmax && free_two;   // align.py:411
+    end_cells[p * 4 + 0] = from_row ? L1 : cy;
+    end_cells[p * 4 + 1] = from_row ? rx : L2;
+    end_cells[p * 4 + 2] = from_row ? rk : ck;
+    scores[p] = from_row ? rmax : cmax;
+}
+
 // Device traceback over the packed planes: one lane per pair.
 // get_paths (praline/util/align.py:144-185) + end-cell rules (praline/component/align.py:401-431)
 // + extend_path_semiglobal (praline/util/align.py:268-297).  Paths are written backwards from the
 // end of the pair's slot, so they come out in start->end order: rows [path_start, slot_end).
 // --------------------------------------------------------------------------------------------
-struct PairLoc { int32_t task; int32_t lane; };
-
 __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
                             const PairLoc *__restrict__ loc, const int32_t *__restrict__ pairs,
                             const uint4 *__restrict__ tb, const float *__restrict__ aux, RectList rl,
@@ -571,37 +625,7 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
     const uint2 *my_tb2 = reinterpret_cast<const uint2 *>(tb) + tk.tb_off + pl.lane;
 
     int y = end_cells[p * 4 + 0], x = end_cells[p * 4 + 1], k = end_cells[p * 4 + 2];
-    if (semiglobal) {
-        const int ls = layout ? 32 : 64;  // lane stride of the end-cell scratch
-        const float *lastcol = aux + tk.aux_off + pl.lane;
-        const float *lastrow = aux + tk.aux_off + (int64_t)(tk.max_l1 + 1) * 3 * ls + pl.lane;
-        // o[L1, x, k] and o[y, L2, k] including the boundary cells (align.py:406-410)
-        auto row_at = [&](int xx, int kk) -> float {
-            if (xx == 0) return kk == 1 ? boundary_value(L1, rp.go1, rp.ge1, free_one) : PRALINE_NEG_INF;
-            return lastrow[((int64_t)(xx - 1) * 3 + kk) * ls];
-        };
-        auto col_at = [&](int yy, int kk) -> float {
-            if (yy == 0) return kk == 2 ? boundary_value(L2, rp.go2, rp.ge2, free_two) : PRALINE_NEG_INF;
-            return lastcol[((int64_t)yy * 3 + kk) * ls];
-        };
-        float rmax = PRALINE_NEG_INF, cmax = PRALINE_NEG_INF;
-        for (int xx = 0; xx <= L2; ++xx)
-            for (int kk = 0; kk < 3; ++kk) rmax = __builtin_fmaxf(rmax, row_at(xx, kk));
-        for (int yy = 0; yy <= L1; ++yy)
-            for (int kk = 0; kk < 3; ++kk) cmax = __builtin_fmaxf(cmax, col_at(yy, kk));
-        bool found = false;
-        if (rmax > cmax && free_two) {  // trace_from_row (align.py:411-417)
-            for (int xx = L2; xx >= 0 && !found; --xx)
-                for (int kk = 0; kk < 3; ++kk)
-                    if (row_at(xx, kk) == rmax) { y = L1; x = xx; k = kk; found = true; break; }
-            scores[p] = rmax;
-        } else {  // align.py:418-422
-            for (int yy = L1; yy >= 0 && !found; --yy)
-                for (int kk = 0; kk < 3; ++kk)
-                    if (col_at(yy, kk) == cmax) { y = yy; x = L2; k = kk; found = true; break; }
-            scores[p] = cmax;
-        }
-    }
+    // (semiglobal: k_semiglobal_end has put the end cell into end_cells and the score into scores)
 
     int n_rects = 0, r0 = 0;
     if (rl.rect_off != nullptr) { r0 = rl.rect_off[p]; n_rects = rl.rect_off[p + 1] - r0; }

@@ -892,6 +892,12 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             // k_traceback runs over all pairs and skips those whose task is outside [t0, t1)
             const int threads = 64;
             const int64_t blocks = (pl.n_pairs + threads - 1) / threads;
+            if (mode >= PRALINE_MODE_SEMIGLOBAL_BOTH) {   // end cells of the semiglobal modes, scanned per task
+                const int64_t lanes = (int64_t)(t1 - t0) * (pl.split ? 32 : 64);
+                hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar,
+                                   pl.d_tasks.p, pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, pl.d_aux.p,
+                                   pl.d_end_cells.p, la.scores, la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
+            }
             hipLaunchKernelGGL(k_traceback, dim3((unsigned)blocks), dim3(threads), 0, st, la.ar, pl.d_tasks.p,
                                pl.d_loc.p, pl.d_pairs.p, (const uint4 *)pl.d_tb.p, pl.d_aux.p, la.rl, pl.d_end_cells.p,
                                la.scores, pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs,
