@@ -415,6 +415,10 @@ struct praline_plan {
     // small batches: four-wave workgroups whose waves share long tasks (k_dp_split16 WPG = 4, WgDesc)
     std::vector<WgDesc> wg;
     DevBuf<WgDesc> d_wg;
+    // large batches in LOCAL mode: the same kernel with four independent tasks per workgroup (its one-wave LOCAL
+    // instances need 256 VGPRs + ~130 AGPRs, the four-wave ones 185-219: two waves per SIMD)
+    std::vector<WgDesc> wg_singles;
+    DevBuf<WgDesc> d_wg_singles;
     DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
@@ -688,6 +692,24 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         }
     }
 
+    if (split && !want_paths && pl->wg.empty()) {
+        // workgroup w runs on XCD w % 8: give it the next four tasks of THAT XCD's queue (placed positions
+        // 8 (4 q + r) + x, r = 0..3), so the XCD grouping of the task list survives
+        const size_t nt = pl->tasks.size();
+        const size_t n_wg = (nt + 31) / 32 * 8;
+        pl->wg_singles.resize(n_wg);
+        for (size_t w = 0; w < n_wg; ++w) {
+            WgDesc d;
+            d.share = 1; d.barriers = 0; d.pad[0] = d.pad[1] = 0;
+            const size_t q = w / 8, x = w % 8;
+            for (int r = 0; r < 4; ++r) {
+                const size_t t = 8 * (4 * q + r) + x;
+                d.task[r] = (t < nt && pl->tasks[t].max_l1 > 0) ? (int32_t)t : -1;
+            }
+            pl->wg_singles[w] = d;
+        }
+    }
+
     pl->slot_off.resize((size_t)n_pairs);
     int64_t cap = 0, cells = 0;
     for (int64_t p = 0; p < n_pairs; ++p) {
@@ -841,6 +863,16 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             if (!pl.d_wg.p) { RC(pl.d_wg.upload(pl.wg, st)); }
             la.wg = pl.d_wg.p;
             la.n_wg = (unsigned)pl.wg.size();
+            a16.sym8 = nullptr;
+        }
+        // large batches: four independent tasks per workgroup for LOCAL mode (see wg_singles) and for arenas
+        // without the one-hot table (measured, float profiles, global: +0..6 %; one-hot arenas are faster on the
+        // table path: 4.38 vs 3.14 TCUPS)
+        else if ((local || a16.sym8 == nullptr) && !pl.wg_singles.empty() && la.a16 != nullptr && a16.stage &&
+                 !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')) {
+            if (!pl.d_wg_singles.p) { RC(pl.d_wg_singles.upload(pl.wg_singles, st)); }
+            la.wg = pl.d_wg_singles.p;
+            la.n_wg = (unsigned)pl.wg_singles.size();
             a16.sym8 = nullptr;
         }
         HIPCHK(hipEventRecord(g_rt.ev0, st));
