@@ -79,6 +79,9 @@ __host__ __device__ constexpr int stage_lds_bytes(int NOPB) { return 1024 + 4 * 
 // swizzle of pair p's row: chunk c is kept at chunk position c ^ stage_swz(p)
 template <int C> __device__ __forceinline__ unsigned stage_swz(unsigned p) { return (p / (16 / C)) & (C - 1); }
 
+// (M0, the DMA's LDS base, is written in the statement that uses it and not restored: nothing else in these
+// kernels reads M0 - LDS instructions do not need it on gfx9 - and the compiler never assumes it survives asm.
+// %0 is an unused scratch SGPR kept so that the operand numbers stay put.)
 // One step's DMA: NOPB pieces of operand rows (wave-uniform row cursor curB, per-lane byte offsets gofs,
 // LDS slot address ldsB) and one boundary row (cursor curN, lane offset gofs_n, LDS address ldsN).
 // The instruction offset moves source AND destination (checked: scripts/micro/glds_test.hip); gofs[i]
@@ -89,33 +92,30 @@ __device__ __forceinline__ void stage_issue(unsigned long long curB, const unsig
 {
     unsigned keep;
     if constexpr (NOPB == 4)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+        asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %5\n\t"
                      "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
                      "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
                      "global_load_lds_dwordx4 %4, %5 offset:3072\n\t"
                      "s_mov_b32 m0, %9\n\ts_nop 0\n\t"
                      "global_load_lds_dword %7, %8\n\t"
-                     "s_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(gofs[0]), "v"(gofs[1]), "v"(gofs[2]), "v"(gofs[3]), "s"(curB), "s"(ldsB), "v"(gofs_n), "s"(curN), "s"(ldsN)
                      : "memory");
     else if constexpr (NOPB == 2)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %3\n\t"
                      "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
                      "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
                      "global_load_lds_dword %5, %6\n\t"
-                     "s_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(gofs[0]), "v"(gofs[1]), "s"(curB), "s"(ldsB), "v"(gofs_n), "s"(curN), "s"(ldsN)
                      : "memory");
     else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %2\n\t"
                      "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
                      "global_load_lds_dword %4, %5\n\t"
-                     "s_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(gofs[0]), "s"(curB), "s"(ldsB), "v"(gofs_n), "s"(curN), "s"(ldsN)
                      : "memory");
@@ -126,27 +126,24 @@ __device__ __forceinline__ void stage_issue_rows(unsigned long long curB, const 
 {
     unsigned keep;
     if constexpr (NOPB == 4)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+        asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %5\n\t"
                      "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
                      "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
                      "global_load_lds_dwordx4 %4, %5 offset:3072\n\t"
-                     "s_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(gofs[0]), "v"(gofs[1]), "v"(gofs[2]), "v"(gofs[3]), "s"(curB), "s"(ldsB)
                      : "memory");
     else if constexpr (NOPB == 2)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %3\n\t"
                      "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
-                     "s_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(gofs[0]), "v"(gofs[1]), "s"(curB), "s"(ldsB)
                      : "memory");
     else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %2\n\t"
-                     "s_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(gofs[0]), "s"(curB), "s"(ldsB)
                      : "memory");
@@ -155,9 +152,8 @@ __device__ __forceinline__ void stage_issue_rows(unsigned long long curB, const 
 __device__ __forceinline__ void stage_issue_bnd(unsigned long long curN, unsigned gofs_n, unsigned ldsN)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                  "global_load_lds_dword %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gofs_n), "s"(curN), "s"(ldsN)
                  : "memory");
@@ -183,7 +179,7 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
                                              float4 *BFILL = nullptr, const char *stage_lds = nullptr,
                                              const unsigned *stage_rd = nullptr, unsigned stage_rd_bnd = 0,
                                              const unsigned (*stage_gofs)[4] = nullptr, unsigned long long *stage_cur = nullptr,
-                                             unsigned stage_lds_addr = 0, unsigned stage_gofs_n = 0)
+                                             unsigned stage_lds_addr = 0, unsigned stage_gofs_n = 0, bool may_snap = true)
 {
     constexpr bool ONEHOT = BSRC == 1;
     // bnd_pref: this step's boundary value on entry; refilled with the value 3 rows ahead.
@@ -288,7 +284,9 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
 #endif
     bnd_st += 32 * sizeof(float2);
     if (semiglobal && last_owner) col_run = __builtin_fmaxf(col_run, select16s(Hs, cidx));
-    if (have_pair && yy == L1) {
+    // may_snap (wave-uniform): this step can be some lane's last row (the task's pairs are sorted by length, so
+    // for most of a strip it cannot, and a scalar branch replaces the per-lane test)
+    if (may_snap && have_pair && yy == L1) {
         if (LOCAL) out_best = best_run;
         if (semiglobal) {
 #pragma unroll
@@ -456,6 +454,12 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         }
     }
 
+    // shortest sequence one of the task (wave-uniform): no snapshot before row min_l1
+    int min_l1 = have_pair ? L1 : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) min_l1 = min(min_l1, __shfl_xor(min_l1, off));
+    min_l1 = __builtin_amdgcn_readfirstlane(min_l1);
+
     const bool semiglobal = rp.mode >= 2;
     int cidx = clast & 15;
     asm volatile("" : "+v"(cidx));  // keep it a per-lane value so select16 stays a register select tree
@@ -567,14 +571,16 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 #define PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, SYMW, SB)                                                          \
         split16_step<NR, NTERM, LOCAL, BSRC, SB>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld, \
                                        bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
-                                       out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYMW)
+                                       out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYMW, \
+                                       nullptr, nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
 #define PRALINE_STEP16(T, CUR, PREV, BSET, PSLOT) PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, d1, 0)
         // staged stream: BUSE holds row T+1, BFILL receives row T+2, PH = T % 4
 #define PRALINE_STEP16S(T, CUR, PREV, BUSE, BFILL, PH)                                                                \
         split16_step<NR, NTERM, LOCAL, 2, PH>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, b_next, b_stride, bnd_ld,  \
                                        bnd_st, p0, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,     \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, 0u, \
-                                       BFILL, stage_lds, stage_rd, stage_rd_bnd, &stage_gofs, stage_cur, stage_lds_addr, stage_gofs_n)
+                                       BFILL, stage_lds, stage_rd, stage_rd_bnd, &stage_gofs, stage_cur, stage_lds_addr, stage_gofs_n, \
+                                       (T) >= min_l1)
         // step 1: only the lower half has a row; the upper half's garbage is undone right after
         {
             float Hsave[17];
