@@ -260,6 +260,7 @@ def test_batch_random_vs_oracle(nat, bba, kind):
         sc, paths = plan.scores(), plan.paths()
         plan.close()
         plan0 = nat.Plan(arena, pairs)
+        mk = plan0.match_kind()      # how the scores-only kernel evaluates m (honours PRALINE_MM / PRALINE_KERNEL)
         plan0.run(mode, *GAPS)
         sc0 = plan0.scores()
         plan0.close()
@@ -267,7 +268,6 @@ def test_batch_random_vs_oracle(nat, bba, kind):
             assert np.array_equal(bits(sc), bits(sc0)), mode  # integer scoring: all kernels agree bitwise
         else:
             assert np.abs(sc - sc0).max() <= 1e-5 * np.abs(sc).max(), mode
-        mk = 1 if arena.info()["f16_ranges"] > 0 else 0
         for k in range(0, len(pairs), 3):
             i, j = pairs[k]
             s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(i, j, pk))
@@ -398,6 +398,7 @@ def test_batch_c2_slice_properties(nat, bba):
     arena = nat.Arena(profs, S)
     pairs = all_pairs(N)
     plan = nat.Plan(arena, pairs)
+    mk = plan.match_kind()
     plan.run("global", *GAPS)
     sc = plan.scores()
     plan.close()
@@ -423,7 +424,7 @@ def test_batch_c2_slice_properties(nat, bba):
     assert (semi >= sc[::97]).all() and (loc >= 0).all()
     for k in range(0, len(pairs), 4001):
         i, j = pairs[k]
-        s_or, _ = oracle_dp_on_m("global", arena.match_scores(i, j, 1))
+        s_or, _ = oracle_dp_on_m("global", arena.match_scores(i, j, mk))
         assert sc[k] == np.float32(s_or)
         s_ref = orc.pairwise_score_fast("global", profs[i], profs[j], S, *GAPS)
         assert abs(sc[k] - s_ref) <= 1e-5 * abs(s_ref)   # vs the reference evaluation order
