@@ -341,11 +341,23 @@ class LocalMasterSlaveAligner(Component):
             _validate_track_sets(master_sequence, s, track_id_sets, track_id_sets, score_matrices)
         rects = [[] for _ in slave_sequences]
         results = [[] for _ in slave_sequences]   # per slave: (score, path) per iteration
-        for _ in range(iterations):
-            batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
-            for j, s in enumerate(slave_sequences):
-                batch.add("local", master_sequence, s, list(rects[j]))
-            scores, paths = batch.run(want_paths=True)
+        for it in range(iterations):
+            if it > native.MAX_RECTS:
+                # more masked rectangles than the batched kernels carry per pair: dense masks through the
+                # raw path, one pair at a time (same results, rarely needed: the default is 2 iterations)
+                scores, paths = [], []
+                aligner = PairwiseAligner(self.manager, self.environment, self.tag)
+                for j, s in enumerate(slave_sequences):
+                    zero = [(y, x) for (y0, y1, x0, x1) in rects[j] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
+                    out = aligner._execute_raw("local", master_sequence, s, track_id_sets, track_id_sets, zero,
+                                               score_matrices, _normalise_gap_series(self.environment['gap_series']))
+                    scores.append(out['score'])
+                    paths.append(np.array(out['alignment'].path, dtype=int))
+            else:
+                batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
+                for j, s in enumerate(slave_sequences):
+                    batch.add("local", master_sequence, s, list(rects[j]))
+                scores, paths = batch.run(want_paths=True)
             for j in range(len(slave_sequences)):
                 p = np.array(paths[j], dtype=int)
                 results[j].append((scores[j], p))
@@ -368,6 +380,9 @@ def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_seri
     Returns one ProfileTrack per sequence (identical to the component chain's)."""
     if mode not in ("global", "local"):
         raise ComponentError("the preprofile stage aligns in 'global' or 'local' mode, not '{0}'".format(mode))
+    if mode == "local" and waterman_eggert_iterations > native.MAX_RECTS + 1:
+        raise ComponentError("build_preprofiles carries at most {0} masked rectangles per pair ({1} Waterman-Eggert "
+                             "iterations); use LocalMasterSlaveAligner for more".format(native.MAX_RECTS, native.MAX_RECTS + 1))
     tracks = [seq.get_track(track_id) for seq in sequences]
     for t in tracks:
         if t.tid != PlainTrack.tid:

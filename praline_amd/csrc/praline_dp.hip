@@ -223,7 +223,8 @@ struct praline_arena {
     DevBuf<char> d_P16, d_Q16;
     DevBuf<int> d_flag16;
     // one-hot arenas (ordinary sequences): active-symbol index per padded row; see k_dp_split16<.., ONEHOT>
-    bool onehot = false;
+    bool onehot = false;       // one-hot operand table in use
+    bool all_onehot = false;   // every profile row is one-hot (plain sequences): required by the preprofile counting
     DevBuf<unsigned char> d_sym8;
     // preprofile stage (k_path_counts): raw symbol of every one-hot row (255: not one-hot), int32 counts [rows_raw][A]
     DevBuf<unsigned char> d_sym_raw;
@@ -346,6 +347,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
                 sym8[a->row_off_pad[s] + y] = slot_of[hot] >= 0 ? (unsigned char)slot_of[hot] : none;
             }
         const bool want_table = a->nr16 > 0 && !(getenv("PRALINE_NO_ONEHOT") && getenv("PRALINE_NO_ONEHOT")[0] == '1');
+        a->all_onehot = all;
         a->onehot = all && want_table;
         if (!a->onehot) sym8.clear();
     }
@@ -991,6 +993,9 @@ extern "C" int praline_plan_add_counts(praline_plan *plan, int use_threshold, fl
     if (plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "praline_plan_run has not been called");
     praline_arena &a = *plan->arena;
     if (!a.d_counts.p) return fail(PRALINE_ERR_ARG, "praline_arena_counts_reset has not been called");
+    if (!a.all_onehot)
+        return fail(PRALINE_ERR_UNSUPPORTED, "preprofile counting needs one-hot profiles (plain sequences), as "
+                    "ProfileBuilder needs plain tracks (praline/util/align.py:187-213)");
     if (plan->n_pairs == 0) return PRALINE_OK;
     const int threads = 64;
     const int64_t blocks = (plan->n_pairs + threads - 1) / threads;

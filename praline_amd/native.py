@@ -19,6 +19,9 @@ MODES = {"global": 0, "local": 1, "semiglobal_both": 2, "semiglobal_one": 3,
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
 
+MAX_RECTS = 4   # zero rectangles per pair the batched kernels carry (PRALINE_MAX_RECTS, dp_kernels.hip.h)
+
+
 class NativeError(RuntimeError):
     def __init__(self, code, message):
         super(NativeError, self).__init__("libpraline_dp error %d: %s" % (code, message))

@@ -1,0 +1,95 @@
+"""Error behaviour of the C ABI and the operator layer on a GPU box: misuse comes back as an error code with a
+message (the reference has undefined behaviour there, praline/component/align.py:196-199), component-level
+mistakes raise the reference's exception types."""
+import numpy as np
+import pytest
+
+from conftest import one_hot
+from praline_amd import component as comp, container as ct, core
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from praline_amd import native
+    native.init(0)
+    return native
+
+
+def test_c_abi_rejects_misuse(nat, bba):
+    S = bba["S"]
+    p = [one_hot([1, 2, 3, 4], 27), one_hot([4, 3, 2], 27)]
+    with pytest.raises(ValueError):
+        nat.Arena(p, np.zeros((5, 5), np.float32))                       # profile width != matrix size
+    with pytest.raises(nat.NativeError) as e:
+        nat.Arena([np.zeros((0, 27), np.float32)], S)                    # empty sequence
+    assert e.value.code == -1 and "length" in str(e.value)
+    wide = np.zeros((3, 60), np.float32)
+    wide[np.arange(3), [0, 40, 59]] = 1
+    with pytest.raises(nat.NativeError) as e:                            # > 32 active symbols
+        nat.Arena([np.eye(60, dtype=np.float32), wide], np.ones((60, 60), np.float32))
+    assert e.value.code == -4 and "active symbols" in str(e.value)
+    arena = nat.Arena(p, S)
+    with pytest.raises(nat.NativeError) as e:
+        nat.Plan(arena, np.array([(0, 2)], np.int32))                    # sequence index out of range
+    assert e.value.code == -1
+    plan = nat.Plan(arena, np.array([(0, 1)], np.int32))
+    with pytest.raises(KeyError):
+        plan.run("diagonal", -11, -1)                                    # unknown mode (binding)
+    plan.run("global", -11, -1)
+    with pytest.raises(nat.NativeError) as e:
+        plan.paths()                                                     # plan was created without paths
+    assert "want_paths" in str(e.value)
+    with pytest.raises(nat.NativeError):
+        plan.add_counts()
+    plan.close()
+    soft = nat.Arena([np.full((4, 27), 1.0 / 27, np.float32), p[1]], S)  # a non-one-hot profile
+    soft.counts_reset()
+    plan = nat.Plan(soft, np.array([(0, 1)], np.int32), want_paths=True)
+    plan.run("global", -11, -1)
+    with pytest.raises(nat.NativeError) as e:
+        plan.add_counts()                                                # counting needs plain sequences
+    assert e.value.code == -4 and "one-hot" in str(e.value)
+    plan.close()
+    soft.close()
+    with pytest.raises(nat.NativeError) as e:                            # more rectangles than the kernels carry
+        nat.Plan(arena, np.array([(0, 1)], np.int32), want_paths=True, rects=[[(1, 1, 1, 1)] * (nat.MAX_RECTS + 1)])
+    assert e.value.code == -4
+    with pytest.raises(nat.NativeError):
+        nat.Plan(arena, np.array([(0, 1)], np.int32), want_paths=False, rects=[[(1, 1, 1, 1)]])   # masks need paths
+    arena.close()
+
+
+def test_component_errors_match_reference_types(nat, bba):
+    idx = core.TypeIndex()
+    idx.autoregister()
+    manager = core.Manager(idx)
+    blosum = ct.blosum62()
+    mk = lambda name, v: ct.Sequence(name, [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=v))])
+    a, b = mk("a", [1, 2, 3, 4, 5]), mk("b", [5, 4, 3])
+
+    def run(component, keys=None, **inputs):
+        ex = core.Execution(manager, "root")
+        ex.add_task(component).environment(core.Environment({}), core.Environment(dict(keys or {}))).inputs(**inputs)
+        return core.run(ex)[0]
+    T = [[ct.TRACK_ID_INPUT]]
+    with pytest.raises(core.ComponentError):                             # align.py:114-117
+        run(comp.PairwiseAligner, mode="sideways", sequence_one=a, sequence_two=b, track_id_sets_one=T,
+            track_id_sets_two=T, score_matrices=[blosum])
+    with pytest.raises(core.ComponentError):                             # align.py:124-127: one track id per set
+        run(comp.PairwiseAligner, mode="global", sequence_one=a, sequence_two=b,
+            track_id_sets_one=[[ct.TRACK_ID_INPUT, ct.TRACK_ID_INPUT]], track_id_sets_two=T, score_matrices=[blosum])
+    with pytest.raises(core.ComponentError):                             # align.py:186-189: gap series of > 2 values
+        run(comp.PairwiseAligner, {"gap_series": [-11.0, -1.0, -0.5]}, mode="global", sequence_one=a, sequence_two=b,
+            track_id_sets_one=T, track_id_sets_two=T, score_matrices=[blosum])
+    with pytest.raises(core.ComponentError):                             # msa.py:109-111
+        run(comp.TreeMultipleSequenceAligner, {"merge_mode": "local"}, sequences=[a, b],
+            guide_tree=ct.SequenceTree([a, b], [(0, 1)]), track_id_sets=T, score_matrices=[blosum])
+    with pytest.raises(core.ComponentError):
+        comp.build_preprofiles([a, b], ct.TRACK_ID_INPUT, blosum, mode="local", waterman_eggert_iterations=9)
+    # many Waterman-Eggert iterations: beyond the batched kernels' rectangle limit the component falls back to
+    # dense masks and still answers
+    out = run(comp.LocalMasterSlaveAligner, {"waterman_eggert_iterations": 7}, master_sequence=a, slave_sequences=[b],
+              track_id_sets=T, score_matrices=[blosum])
+    assert np.asarray(out['alignment'].path).shape == (6, 8)
