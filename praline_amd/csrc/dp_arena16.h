@@ -1,6 +1,7 @@
 // dp_arena16.h -- device view of the f16 hi/lo operand arrays (see dp_split16.hip.h).
 #pragma once
 #include <stdint.h>
+#include "dp_types.h"
 struct Arena16Dev {
     const char *P16;        // [rows_pad][2][slots][16 bytes]
     const char *Q16;
@@ -13,12 +14,3 @@ struct Arena16Dev {
     int half_bytes;         // 2 (pieces) * NR * 16
 };
 
-// Workgroup descriptor of the four-wave launch of k_dp_split16 (small batches): `share` consecutive waves
-// pipeline one task (share = 1, 2 or 4; the task id sits in the slot of the group's first wave, -1 = idle
-// waves); `barriers` = s_barriers every wave of the workgroup executes (0 when share == 1).
-struct WgDesc {
-    int32_t task[4];
-    int32_t share;
-    int32_t barriers;
-    int32_t pad[2];
-};

@@ -22,11 +22,11 @@
 // single wavefront walking anti-diagonals: lane l owns column x0+l, computes row t-l at step t
 // and receives its left/diagonal neighbours from lane l-1 with __shfl_up.
 #pragma once
+#include "dp_types.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define PRALINE_NEG_INF (-__builtin_inff())
-#define PRALINE_MAX_RECTS 4
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -42,15 +42,6 @@ struct ArenaDev {
     int KS;                  // floats per parity half (multiple of 4)
 };
 
-struct WaveTask {
-    int32_t two[2];   // shared sequence (arena index) of lanes 0-31 / 32-63, -1 = half unused
-    int32_t max_l1;   // longest sequence one among the lanes
-    int32_t nstrips;  // max over halves of ceil(len(two)/32)
-    int64_t bnd_off;  // element offset of the strip-boundary scratch [max_l1+1][64]
-    int64_t tb_off;   // uint4 offset of the packed traceback planes [nstrips][max_l1+1][64]
-    int64_t aux_off;  // float offset of the end-cell scratch: lastcol [max_l1+1][3][64] then
-                      // lastrow [nstrips*32][3][64]  (semiglobal paths only)
-};
 
 struct RunParams {
     int mode;
@@ -542,8 +533,6 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
 
 #ifdef PRALINE_AUX_KERNELS
 // --------------------------------------------------------------------------------------------
-struct PairLoc { int32_t task; int32_t lane; };
-
 // Semiglobal end cell (praline/component/align.py:406-424): the maxima of the last row o[L1, x, k] and the last
 // column o[y, L2, k] (boundary cells included) and, for the side that wins, the cell the reference finds scanning
 // from the far end (x from L2 down / y from L1 down) and k = 0, 1, 2: the largest coordinate holding the maximum,

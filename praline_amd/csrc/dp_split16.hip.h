@@ -158,7 +158,6 @@ __device__ __forceinline__ void stage_issue_bnd(unsigned long long curN, unsigne
                  : "v"(gofs_n), "s"(curN), "s"(ldsN)
                  : "memory");
 }
-#define PRALINE_MW_LAG 2   // iterations between consecutive ranks of a shared task (host: praline_dp.hip)
 #define PRALINE_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // NR: 16-wide k ranges (1: <= 16 active symbols, 2: <= 32); NTERM: 1 exact / 3 split.

@@ -1,0 +1,28 @@
+// dp_types.h -- plain (HIP-free) descriptors shared by the host scheduler (sched.cpp) and the kernels.
+#pragma once
+#include <stdint.h>
+
+struct WaveTask {
+    int32_t two[2];   // shared sequence (arena index) of lanes 0-31 / 32-63, -1 = half unused
+    int32_t max_l1;   // longest sequence one among the lanes
+    int32_t nstrips;  // max over halves of ceil(len(two)/32)
+    int64_t bnd_off;  // element offset of the strip-boundary scratch [max_l1+1][64]
+    int64_t tb_off;   // uint4 offset of the packed traceback planes [nstrips][max_l1+1][64]
+    int64_t aux_off;  // float offset of the end-cell scratch: lastcol [max_l1+1][3][64] then
+                      // lastrow [nstrips*32][3][64]  (semiglobal paths only)
+};
+
+struct PairLoc { int32_t task; int32_t lane; };   // where pair p runs
+
+// Workgroup descriptor of the four-wave launch of k_dp_split16: `share` consecutive waves pipeline one task
+// (share = 1, 2 or 4; the task id sits in the slot of the group's first wave, -1 = idle waves); `barriers` =
+// s_barriers every wave of the workgroup executes (0 when share == 1).
+struct WgDesc {
+    int32_t task[4];
+    int32_t share;
+    int32_t barriers;
+    int32_t pad[2];
+};
+
+#define PRALINE_MAX_RECTS 4   // zero rectangles per pair carried by the batched kernels
+#define PRALINE_MW_LAG 2      // 12-row iterations between consecutive ranks of a shared task

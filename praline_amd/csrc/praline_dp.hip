@@ -14,6 +14,7 @@
 #include "dp_kernels.hip.h"
 #include "dp_launch.hip.h"
 #include "dp_arena16.h"
+#include "sched.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -432,34 +433,11 @@ struct praline_plan {
     int last_mode = -1;
 };
 
-struct HalfTask {
-    int32_t two;
-    int32_t max_l1;
-    int32_t chunk;   // ordinal of this 32-pair chunk inside its sequence-two group (length class of its partners)
-    int32_t one[32];
-    int32_t pair[32];
-};
-
 // traceback scratch budget per launch chunk (bytes)
 static size_t tb_budget_bytes()
 {
     if (const char *env = getenv("PRALINE_TB_BUDGET_MB")) return (size_t)atoll(env) << 20;
     return (size_t)24 << 30;
-}
-
-static const int kMwLag = 2;  // = PRALINE_MW_LAG of dp_split16.hip.h
-
-// Launch order for an ordered list of n work items: groups of G consecutive items on one XCD (block b runs
-// on XCD b % 8), groups dealt round-robin over the XCDs.  Returns, per block, the item it runs (-1: padding).
-static std::vector<int64_t> xcd_group_order(int64_t n0, int G)
-{
-    const int64_t n = (n0 + 8 * G - 1) / (8 * G) * (8 * G);
-    std::vector<int64_t> src((size_t)n, -1);
-    for (int64_t i = 0; i < n0; ++i) {
-        const int64_t g = i / G, x = g % 8, q = (g / 8) * G + i % G;
-        src[(size_t)(8 * q + x)] = i;
-    }
-    return src;
 }
 
 extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, int want_paths,
@@ -487,241 +465,34 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     pl->want_paths = want_paths != 0;
     pl->has_rects = rect_off && rect_off[n_pairs] > 0;
 
-    // ---- group by sequence two, sort by len(one) descending, cut into 32-lane half tasks ----
-    std::vector<int64_t> order((size_t)n_pairs);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
-        const int32_t tx = pairs[2 * x + 1], ty = pairs[2 * y + 1];
-        if (tx != ty) return tx < ty;
-        const int lx = a.len[pairs[2 * x]], ly = a.len[pairs[2 * y]];
-        if (lx != ly) return lx > ly;
-        return x < y;
-    });
-    std::vector<HalfTask> halves;
-    for (int64_t i = 0; i < n_pairs;) {
-        const int32_t two = pairs[2 * order[i] + 1];
-        HalfTask h;
-        h.two = two;
-        h.max_l1 = 0;
-        h.chunk = (!halves.empty() && halves.back().two == two) ? halves.back().chunk + 1 : 0;
-        int n = 0;
-        for (int q = 0; q < 32; ++q) { h.one[q] = -1; h.pair[q] = -1; }
-        while (i < n_pairs && n < 32 && pairs[2 * order[i] + 1] == two) {
-            h.one[n] = pairs[2 * order[i]];
-            h.pair[n] = (int32_t)order[i];
-            h.max_l1 = std::max(h.max_l1, a.len[h.one[n]]);
-            ++n; ++i;
-        }
-        halves.push_back(h);
-    }
-    // longest work first; equal-shaped halves end up adjacent (paired into one wave when TP = 2)
-    std::stable_sort(halves.begin(), halves.end(), [&](const HalfTask &x, const HalfTask &y) {
-        const int sx = (a.len[x.two] + 31) / 32, sy = (a.len[y.two] + 31) / 32;
-        if (sx != sy) return sx > sy;
-        return x.max_l1 > y.max_l1;
-    });
-    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with
-    // a private 4 MB L2).  A task streams the profile rows of its 32 sequences one; neighbours in the
-    // longest-first order are mostly the same length class of partners of different sequences two, i.e.
-    // largely the SAME rows.  Groups of G consecutive tasks are therefore placed on one XCD (they run at
-    // the same time and share those rows in its L2), and the groups rotate over the XCDs so that every
-    // XCD still gets the same cost mix.  (Placement only affects speed, never results.)
-    //   order index i -> group g = i / G, XCD x = g % 8, position q = (g / 8) * G + i % G -> block 8 q + x
-    // The list is padded with empty tasks to a multiple of 8 G.
-    // (A first attempt - whole length classes per XCD - was 30-40 % slower: it put all expensive tasks on
-    // one XCD.)
-    {
-        // group size ~ tasks / 128, i.e. ~16 group rounds per XCD (measured, float profiles, GCUPS:
-        // 4 336 tasks: none 1984, G = 4 2115, 16 2393, 32 2384, 64 2314;
-        // 33 049 tasks (one rank of C4): none 1674, 16 1817, 64 2242, 256 2634, 1024 2613, 4096 1677)
-        int G = (int)std::min<size_t>(1024, std::max<size_t>(16, halves.size() / 128));
-        if (const char *env = getenv("PRALINE_XCD_GROUP")) G = atoi(env);
-        if (G > 1 && halves.size() >= (size_t)(16 * G)) {
-            HalfTask empty;
-            empty.two = halves.back().two;
-            empty.max_l1 = 0;
-            empty.chunk = 0;
-            for (int q = 0; q < 32; ++q) { empty.one[q] = -1; empty.pair[q] = -1; }
-            const std::vector<int64_t> src = xcd_group_order((int64_t)halves.size(), G);
-            std::vector<HalfTask> placed(src.size(), empty);
-            for (size_t b = 0; b < src.size(); ++b)
-                if (src[b] >= 0) placed[b] = halves[(size_t)src[b]];
-            halves.swap(placed);
-        }
-    }
-    int tp = halves.size() >= 4096 ? 2 : 1;
-    if (want_paths) tp = 1;  // the traceback variant keeps three states per column in registers
-    if (const char *env = getenv("PRALINE_TP")) { if (env[0] == '1') tp = 1; else if (env[0] == '2' && !want_paths) tp = 2; }
-    // scores-only plans run on k_dp_split (both halves of the wave on the same 32 pairs)
+    // ---- host scheduling (sched.cpp): tasks, launch order, workgroup descriptors ----
+    SchedOptions opt;
+    opt.want_paths = pl->want_paths;
     // every plan runs on the split-strip kernels (32 pairs per wave, both halves on the same pairs);
     // PRALINE_KERNEL=batch selects the older k_dp_batch layout for A/B comparisons
-    bool split = a.nr16 > 0 || !want_paths;
-    if (const char *env = getenv("PRALINE_KERNEL")) { if (!strcmp(env, "batch")) split = false; }
-    if (split) tp = 1;
-    pl->tp = tp;
-    pl->split = split;
-    const int lanes_per_task = split ? 32 : 64;
-
-    const size_t n_tasks = (halves.size() + tp - 1) / tp;
-    pl->tasks.resize(n_tasks);
-    std::vector<int32_t> lane_one(n_tasks * lanes_per_task, -1), lane_pair(n_tasks * lanes_per_task, -1);
-    std::vector<PairLoc> loc((size_t)n_pairs);
-    int64_t bnd = 0;
-    pl->tb_elems.resize(n_tasks);
-    pl->aux_elems.resize(n_tasks);
-    for (size_t t = 0; t < n_tasks; ++t) {
-        WaveTask &wt = pl->tasks[t];
-        wt.two[0] = wt.two[1] = -1;
-        wt.max_l1 = 0;
-        wt.nstrips = 0;
-        for (int hh = 0; hh < tp; ++hh) {
-            const size_t hi = t * tp + hh;
-            if (hi >= halves.size()) break;
-            const HalfTask &h = halves[hi];
-            wt.two[hh] = h.two;
-            wt.max_l1 = std::max(wt.max_l1, h.max_l1);
-            wt.nstrips = std::max(wt.nstrips, (a.len[h.two] + 31) / 32);
-            for (int q = 0; q < 32; ++q) {
-                lane_one[t * lanes_per_task + hh * 32 + q] = h.one[q];
-                lane_pair[t * lanes_per_task + hh * 32 + q] = h.pair[q];
-                if (h.pair[q] >= 0) { loc[h.pair[q]].task = (int32_t)t; loc[h.pair[q]].lane = hh * 32 + q; }
-            }
-        }
-        wt.bnd_off = bnd;
-        bnd += split ? (int64_t)(wt.max_l1 + 24) * 32 : (int64_t)(wt.max_l1 + 1) * 64;  // (the 12x unrolled loops read ahead)
-        wt.tb_off = 0;
-        wt.aux_off = 0;
-        // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]
-        pl->tb_elems[t] = split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
-        pl->aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * (split ? 32 : 64);
-    }
-    pl->bnd_elems = bnd;
-
-    // Small batches (fewer tasks than the chip's 2048 wave slots, 2 per SIMD): the waves of a workgroup
-    // share long tasks (k_dp_split16 WPG = 4).  Every task gets W = 1, 2 or 4 waves - the smallest W that
-    // brings its per-wave cost under c*, c* the smallest value for which all waves fit the slots.
-    if (split && !want_paths && !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')) {
-        int64_t slots = 2048;
-        if (const char *env = getenv("PRALINE_W_SLOTS")) slots = atoll(env);
-        struct Cand { int64_t cost; int task; int iter, nstrips, wmax; };
-        std::vector<Cand> cand;
-        for (size_t t = 0; t < n_tasks; ++t) {
-            const WaveTask &wt = pl->tasks[t];
-            if (wt.max_l1 <= 0) continue;  // placement padding
-            Cand c;
-            c.task = (int)t;
-            c.iter = (wt.max_l1 - 1) / 12 + 1;
-            c.nstrips = wt.nstrips;
-            c.cost = (int64_t)wt.nstrips * (12 * c.iter + 1);
-            // rank r runs kMwLag iterations behind rank r - 1; the wrap-around hand-off (last rank -> rank 0's
-            // next strip) then has iter - (W - 1) kMwLag iterations, which must also be >= kMwLag
-            c.wmax = (c.nstrips >= 4 && c.iter >= 4 * kMwLag) ? 4 : (c.nstrips >= 2 && c.iter >= 2 * kMwLag) ? 2 : 1;
-            cand.push_back(c);
-        }
-        std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.cost != y.cost ? x.cost > y.cost : x.task < y.task; });
-        // per-wave cost of a task run by W waves: rank 0's strips plus the last rank's start delay
-        auto wave_cost = [](const Cand &c, int W) {
-            const int n0 = (c.nstrips + W - 1) / W;
-            return (int64_t)(n0 * c.iter + (W - 1) * kMwLag) * 12;
-        };
-        auto choose = [&](const Cand &c, int64_t cstar) {
-            int W = 1;
-            while (W < c.wmax && wave_cost(c, W) > cstar) W *= 2;
-            return W;
-        };
-        auto slots_for = [&](int64_t cstar) {
-            int64_t n1 = 0, n2 = 0, n4 = 0;
-            for (const Cand &c : cand) { const int W = choose(c, cstar); (W == 1 ? n1 : W == 2 ? n2 : n4)++; }
-            return 4 * (n4 + (n2 + 1) / 2 + (n1 + 3) / 4);
-        };
-        if (!cand.empty() && (int64_t)cand.size() < slots) {
-            int64_t lo = 1, hi = cand[0].cost;  // smallest c* whose workgroups fit
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) / 2;
-                if (slots_for(mid) <= slots) hi = mid; else lo = mid + 1;
-            }
-            std::vector<const Cand *> by_w[5];
-            for (const Cand &c : cand) by_w[choose(c, lo)].push_back(&c);
-            if (!by_w[2].empty() || !by_w[4].empty()) {
-                auto barriers = [](const Cand &c, int W) {
-                    int total = 0;
-                    for (int r = 0; r < W; ++r) {
-                        const int nr = c.nstrips > r ? (c.nstrips - r + W - 1) / W : 0;
-                        total = std::max(total, r * kMwLag + nr * c.iter);
-                    }
-                    return total;
-                };
-                struct Built { int64_t cost; WgDesc d; };
-                std::vector<Built> built;
-                for (const Cand *c : by_w[4]) {
-                    Built b; b.cost = wave_cost(*c, 4);
-                    b.d.task[0] = c->task; b.d.task[1] = b.d.task[2] = b.d.task[3] = -1;
-                    b.d.share = 4; b.d.barriers = barriers(*c, 4); b.d.pad[0] = b.d.pad[1] = 0;
-                    built.push_back(b);
-                }
-                for (size_t i = 0; i < by_w[2].size(); i += 2) {
-                    const Cand *c0 = by_w[2][i], *c1 = i + 1 < by_w[2].size() ? by_w[2][i + 1] : nullptr;
-                    Built b; b.cost = wave_cost(*c0, 2);
-                    b.d.task[0] = c0->task; b.d.task[1] = -1; b.d.task[2] = c1 ? c1->task : -1; b.d.task[3] = -1;
-                    b.d.share = 2; b.d.barriers = std::max(barriers(*c0, 2), c1 ? barriers(*c1, 2) : 0); b.d.pad[0] = b.d.pad[1] = 0;
-                    built.push_back(b);
-                }
-                for (size_t i = 0; i < by_w[1].size(); i += 4) {
-                    Built b; b.cost = by_w[1][i]->cost;
-                    for (int q = 0; q < 4; ++q) b.d.task[q] = i + q < by_w[1].size() ? by_w[1][i + q]->task : -1;
-                    b.d.share = 1; b.d.barriers = 0; b.d.pad[0] = b.d.pad[1] = 0;
-                    built.push_back(b);
-                }
-                std::stable_sort(built.begin(), built.end(), [](const Built &x, const Built &y) { return x.cost > y.cost; });
-                // Launch order.  A CU holds two of these workgroups and the dispatcher deals them round-robin,
-                // so blocks b and b + 256 end up on the same CU (same SIMDs): the 256 longest go first in
-                // descending order, then the SHORTEST 256 in ascending order (the longest shares its SIMDs
-                // with the shortest), then whatever is left in the middle.
-                const size_t nb = built.size();
-                int snake = 1;
-                if (const char *env = getenv("PRALINE_W_SNAKE")) snake = atoi(env);
-                if (snake && nb > 256) {
-                    std::vector<size_t> order;
-                    for (size_t i = 0; i < 256; ++i) order.push_back(i);
-                    const size_t tail = std::min<size_t>(256, nb - 256);
-                    for (size_t i = 0; i < tail; ++i) order.push_back(nb - 1 - i);
-                    for (size_t i = 256; i < nb - tail; ++i) order.push_back(i);
-                    for (size_t i : order) pl->wg.push_back(built[i].d);
-                } else {
-                    for (const Built &b : built) pl->wg.push_back(b.d);
-                }
-            }
-        }
-    }
-
-    if (split && !want_paths && pl->wg.empty()) {
-        // workgroup w runs on XCD w % 8: give it the next four tasks of THAT XCD's queue (placed positions
-        // 8 (4 q + r) + x, r = 0..3), so the XCD grouping of the task list survives
-        const size_t nt = pl->tasks.size();
-        const size_t n_wg = (nt + 31) / 32 * 8;
-        pl->wg_singles.resize(n_wg);
-        for (size_t w = 0; w < n_wg; ++w) {
-            WgDesc d;
-            d.share = 1; d.barriers = 0; d.pad[0] = d.pad[1] = 0;
-            const size_t q = w / 8, x = w % 8;
-            for (int r = 0; r < 4; ++r) {
-                const size_t t = 8 * (4 * q + r) + x;
-                d.task[r] = (t < nt && pl->tasks[t].max_l1 > 0) ? (int32_t)t : -1;
-            }
-            pl->wg_singles[w] = d;
-        }
-    }
-
-    pl->slot_off.resize((size_t)n_pairs);
-    int64_t cap = 0, cells = 0;
-    for (int64_t p = 0; p < n_pairs; ++p) {
-        const int64_t l1 = a.len[pairs[2 * p]], l2 = a.len[pairs[2 * p + 1]];
-        pl->slot_off[p] = cap;
-        cap += l1 + l2 + 2;
-        cells += l1 * l2;
-    }
-    pl->path_cap = cap;
-    pl->cells = cells;
+    opt.split_layout = a.nr16 > 0 || !want_paths;
+    if (const char *env = getenv("PRALINE_KERNEL")) { if (!strcmp(env, "batch")) opt.split_layout = false; }
+    if (const char *env = getenv("PRALINE_TP")) opt.tp = atoi(env);
+    if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
+    if (const char *env = getenv("PRALINE_NO_W2")) opt.shared_waves = env[0] != '1';
+    if (const char *env = getenv("PRALINE_W_SLOTS")) opt.wave_slots = atoll(env);
+    if (const char *env = getenv("PRALINE_W_SNAKE")) opt.snake = atoi(env) != 0;
+    Schedule sch;
+    build_schedule(a.len.data(), n_pairs, pairs, opt, sch);
+    pl->tp = sch.tp;
+    pl->split = sch.split;
+    pl->tasks.swap(sch.tasks);
+    pl->tb_elems.swap(sch.tb_elems);
+    pl->aux_elems.swap(sch.aux_elems);
+    pl->bnd_elems = sch.bnd_elems;
+    pl->wg.swap(sch.wg);
+    pl->wg_singles.swap(sch.wg_singles);
+    pl->slot_off.swap(sch.slot_off);
+    pl->path_cap = sch.path_cap;
+    pl->cells = sch.cells;
+    const std::vector<int32_t> &lane_one = sch.lane_one, &lane_pair = sch.lane_pair;
+    const std::vector<PairLoc> &loc = sch.loc;
+    const int64_t bnd = pl->bnd_elems, cap = pl->path_cap;
 
     hipStream_t st = g_rt.stream;
     int rc = PRALINE_OK;

@@ -1,0 +1,315 @@
+// sched.cpp -- pair list -> wavefront tasks -> launch order and workgroup descriptors.  Pure host logic.
+//
+// 1. Pairs are grouped by their sequence TWO (a task's 32 pairs share it: it is the A operand of the MFMA tile),
+//    sorted by the length of sequence one inside a group and cut into 32-pair half tasks.
+// 2. Tasks are ordered longest first and placed on the XCDs in groups of neighbours (same partners -> same
+//    operand rows in that XCD's L2).
+// 3. Small batches get four-wave workgroups whose waves share long tasks; large batches a list with four
+//    independent tasks per workgroup.
+#include "sched.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace {
+
+struct HalfTask {
+    int32_t two;
+    int32_t max_l1;
+    int32_t one[32];
+    int32_t pair[32];
+};
+
+HalfTask empty_half(int32_t two)
+{
+    HalfTask h;
+    h.two = two;
+    h.max_l1 = 0;
+    for (int q = 0; q < 32; ++q) { h.one[q] = -1; h.pair[q] = -1; }
+    return h;
+}
+
+// step 1: group by sequence two, sort by len(one) descending, cut into 32-lane half tasks
+std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs)
+{
+    std::vector<int64_t> order((size_t)n_pairs);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+        const int32_t tx = pairs[2 * x + 1], ty = pairs[2 * y + 1];
+        if (tx != ty) return tx < ty;
+        const int lx = lens[pairs[2 * x]], ly = lens[pairs[2 * y]];
+        if (lx != ly) return lx > ly;
+        return x < y;
+    });
+    std::vector<HalfTask> halves;
+    for (int64_t i = 0; i < n_pairs;) {
+        const int32_t two = pairs[2 * order[i] + 1];
+        HalfTask h = empty_half(two);
+        int n = 0;
+        while (i < n_pairs && n < 32 && pairs[2 * order[i] + 1] == two) {
+            h.one[n] = pairs[2 * order[i]];
+            h.pair[n] = (int32_t)order[i];
+            h.max_l1 = std::max(h.max_l1, lens[h.one[n]]);
+            ++n; ++i;
+        }
+        halves.push_back(h);
+    }
+    // longest work first; equal-shaped halves end up adjacent (paired into one wave when TP = 2)
+    std::stable_sort(halves.begin(), halves.end(), [&](const HalfTask &x, const HalfTask &y) {
+        const int sx = (lens[x.two] + 31) / 32, sy = (lens[y.two] + 31) / 32;
+        if (sx != sy) return sx > sy;
+        return x.max_l1 > y.max_l1;
+    });
+    return halves;
+}
+
+// step 2: XCD-aware placement.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with a
+// private 4 MB L2).  A task streams the profile rows of its 32 sequences one; neighbours in the longest-first
+// order are mostly the same length class of partners of different sequences two, i.e. largely the SAME rows.
+// Groups of G consecutive tasks are therefore placed on one XCD (they run at the same time and share those rows
+// in its L2), and the groups rotate over the XCDs so that every XCD still gets the same cost mix.  Placement
+// only affects speed, never results.  G ~ tasks / 128, i.e. ~16 group rounds per XCD (measured, float profiles,
+// GCUPS: 4 336 tasks: none 1984, G = 4 2115, 16 2393, 32 2384, 64 2314; 33 049 tasks (one rank of C4): none
+// 1674, 16 1817, 64 2242, 256 2634, 1024 2613, 4096 1677; whole length classes per XCD on C2: 30-40 % slower).
+void place_on_xcds(std::vector<HalfTask> &halves, int group)
+{
+    if (halves.empty()) return;
+    int G = group >= 0 ? group : (int)std::min<size_t>(1024, std::max<size_t>(16, halves.size() / 128));
+    if (G <= 1 || halves.size() < (size_t)(16 * G)) return;
+    const std::vector<int64_t> src = xcd_group_order((int64_t)halves.size(), G);
+    std::vector<HalfTask> placed(src.size(), empty_half(halves.back().two));
+    for (size_t b = 0; b < src.size(); ++b)
+        if (src[b] >= 0) placed[b] = halves[(size_t)src[b]];
+    halves.swap(placed);
+}
+
+// step 3a: shared waves.  Every task gets W = 1, 2 or 4 waves - the smallest W that brings its per-wave cost
+// under c*, c* the smallest value for which all workgroups fit the wave slots.
+struct Cand { int64_t cost; int task; int iter, nstrips, wmax; };
+
+int64_t wave_cost(const Cand &c, int W)   // rank 0's strips plus the last rank's start delay, in steps
+{
+    const int n0 = (c.nstrips + W - 1) / W;
+    return (int64_t)(n0 * c.iter + (W - 1) * PRALINE_MW_LAG) * 12;
+}
+
+int waves_for(const Cand &c, int64_t cstar)
+{
+    int W = 1;
+    while (W < c.wmax && wave_cost(c, W) > cstar) W *= 2;
+    return W;
+}
+
+int barriers_of(const Cand &c, int W)   // barriers every wave of the share group executes (max over ranks)
+{
+    int total = 0;
+    for (int r = 0; r < W; ++r) {
+        const int nr = c.nstrips > r ? (c.nstrips - r + W - 1) / W : 0;
+        total = std::max(total, r * PRALINE_MW_LAG + nr * c.iter);
+    }
+    return total;
+}
+
+std::vector<WgDesc> share_waves(const std::vector<WaveTask> &tasks, const SchedOptions &opt)
+{
+    std::vector<Cand> cand;
+    for (size_t t = 0; t < tasks.size(); ++t) {
+        const WaveTask &wt = tasks[t];
+        if (wt.max_l1 <= 0) continue;  // placement padding
+        Cand c;
+        c.task = (int)t;
+        c.iter = (wt.max_l1 - 1) / 12 + 1;
+        c.nstrips = wt.nstrips;
+        c.cost = (int64_t)wt.nstrips * (12 * c.iter + 1);
+        // rank r runs PRALINE_MW_LAG iterations behind rank r - 1; the wrap-around hand-off (last rank -> rank 0's
+        // next strip) then has iter - (W - 1) LAG iterations, which must also be >= LAG
+        c.wmax = (c.nstrips >= 4 && c.iter >= 4 * PRALINE_MW_LAG) ? 4 : (c.nstrips >= 2 && c.iter >= 2 * PRALINE_MW_LAG) ? 2 : 1;
+        cand.push_back(c);
+    }
+    std::vector<WgDesc> out;
+    if (cand.empty() || (int64_t)cand.size() >= opt.wave_slots) return out;
+    std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.cost != y.cost ? x.cost > y.cost : x.task < y.task; });
+    auto slots_for = [&](int64_t cstar) {
+        int64_t n1 = 0, n2 = 0, n4 = 0;
+        for (const Cand &c : cand) { const int W = waves_for(c, cstar); (W == 1 ? n1 : W == 2 ? n2 : n4)++; }
+        return 4 * (n4 + (n2 + 1) / 2 + (n1 + 3) / 4);
+    };
+    int64_t lo = 1, hi = cand[0].cost;  // smallest c* whose workgroups fit
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (slots_for(mid) <= opt.wave_slots) hi = mid; else lo = mid + 1;
+    }
+    std::vector<const Cand *> by_w[5];
+    for (const Cand &c : cand) by_w[waves_for(c, lo)].push_back(&c);
+    if (by_w[2].empty() && by_w[4].empty()) return out;
+
+    struct Built { int64_t cost; WgDesc d; };
+    std::vector<Built> built;
+    auto blank = [](int share) { WgDesc d; d.task[0] = d.task[1] = d.task[2] = d.task[3] = -1; d.share = share; d.barriers = 0; d.pad[0] = d.pad[1] = 0; return d; };
+    for (const Cand *c : by_w[4]) {
+        Built b; b.cost = wave_cost(*c, 4); b.d = blank(4);
+        b.d.task[0] = c->task; b.d.barriers = barriers_of(*c, 4);
+        built.push_back(b);
+    }
+    for (size_t i = 0; i < by_w[2].size(); i += 2) {
+        const Cand *c0 = by_w[2][i], *c1 = i + 1 < by_w[2].size() ? by_w[2][i + 1] : nullptr;
+        Built b; b.cost = wave_cost(*c0, 2); b.d = blank(2);
+        b.d.task[0] = c0->task; b.d.task[2] = c1 ? c1->task : -1;
+        b.d.barriers = std::max(barriers_of(*c0, 2), c1 ? barriers_of(*c1, 2) : 0);
+        built.push_back(b);
+    }
+    for (size_t i = 0; i < by_w[1].size(); i += 4) {
+        Built b; b.cost = by_w[1][i]->cost; b.d = blank(1);
+        for (int q = 0; q < 4; ++q) b.d.task[q] = i + q < by_w[1].size() ? by_w[1][i + q]->task : -1;
+        built.push_back(b);
+    }
+    std::stable_sort(built.begin(), built.end(), [](const Built &x, const Built &y) { return x.cost > y.cost; });
+    // Launch order.  A CU holds two of these workgroups and the dispatcher deals them round-robin, so blocks b and
+    // b + 256 end up on the same CU (same SIMDs; confirmed with the trace build): the 256 longest go first in
+    // descending order, then the SHORTEST 256 in ascending order (the longest shares its SIMDs with the
+    // shortest), then whatever is left in the middle.
+    const size_t nb = built.size();
+    if (opt.snake && nb > 256) {
+        const size_t tail = std::min<size_t>(256, nb - 256);
+        for (size_t i = 0; i < 256; ++i) out.push_back(built[i].d);
+        for (size_t i = 0; i < tail; ++i) out.push_back(built[nb - 1 - i].d);
+        for (size_t i = 256; i < nb - tail; ++i) out.push_back(built[i].d);
+    } else {
+        for (const Built &b : built) out.push_back(b.d);
+    }
+    return out;
+}
+
+// step 3b: four independent tasks per workgroup.  Workgroup w runs on XCD w % 8: it gets the next four tasks of
+// THAT XCD's queue (placed positions 8 (4 q + r) + x, r = 0..3), so the XCD grouping of the task list survives.
+std::vector<WgDesc> four_singles(const std::vector<WaveTask> &tasks)
+{
+    const size_t nt = tasks.size();
+    std::vector<WgDesc> out((nt + 31) / 32 * 8);
+    for (size_t w = 0; w < out.size(); ++w) {
+        WgDesc d;
+        d.share = 1; d.barriers = 0; d.pad[0] = d.pad[1] = 0;
+        const size_t q = w / 8, x = w % 8;
+        for (int r = 0; r < 4; ++r) {
+            const size_t t = 8 * (4 * q + r) + x;
+            d.task[r] = (t < nt && tasks[t].max_l1 > 0) ? (int32_t)t : -1;
+        }
+        out[w] = d;
+    }
+    return out;
+}
+
+}  // namespace
+
+std::vector<int64_t> xcd_group_order(int64_t n0, int G)
+{
+    const int64_t n = (n0 + 8 * G - 1) / (8 * G) * (8 * G);
+    std::vector<int64_t> src((size_t)n, -1);
+    for (int64_t i = 0; i < n0; ++i) {
+        const int64_t g = i / G, x = g % 8, q = (g / 8) * G + i % G;
+        src[(size_t)(8 * q + x)] = i;
+    }
+    return src;
+}
+
+void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, const SchedOptions &opt, Schedule &out)
+{
+    std::vector<HalfTask> halves = cut_half_tasks(lens, n_pairs, pairs);
+    place_on_xcds(halves, opt.xcd_group);
+
+    out.split = opt.split_layout;
+    int tp = halves.size() >= 4096 ? 2 : 1;
+    if (opt.want_paths) tp = 1;  // the traceback variant keeps three states per column in registers
+    if (opt.tp == 1 || (opt.tp == 2 && !opt.want_paths)) tp = opt.tp;
+    if (out.split) tp = 1;       // split-strip kernels: both halves of the wave work on the same 32 pairs
+    out.tp = tp;
+    out.lanes_per_task = out.split ? 32 : 64;
+    const int lanes = out.lanes_per_task;
+
+    const size_t n_tasks = (halves.size() + tp - 1) / tp;
+    out.tasks.assign(n_tasks, WaveTask());
+    out.lane_one.assign(n_tasks * lanes, -1);
+    out.lane_pair.assign(n_tasks * lanes, -1);
+    out.loc.assign((size_t)n_pairs, PairLoc());
+    out.tb_elems.assign(n_tasks, 0);
+    out.aux_elems.assign(n_tasks, 0);
+    int64_t bnd = 0;
+    for (size_t t = 0; t < n_tasks; ++t) {
+        WaveTask &wt = out.tasks[t];
+        wt.two[0] = wt.two[1] = -1;
+        wt.max_l1 = 0;
+        wt.nstrips = 0;
+        for (int hh = 0; hh < tp; ++hh) {
+            const size_t hi = t * tp + hh;
+            if (hi >= halves.size()) break;
+            const HalfTask &h = halves[hi];
+            wt.two[hh] = h.two;
+            wt.max_l1 = std::max(wt.max_l1, h.max_l1);
+            wt.nstrips = std::max(wt.nstrips, (lens[h.two] + 31) / 32);
+            for (int q = 0; q < 32; ++q) {
+                out.lane_one[t * lanes + hh * 32 + q] = h.one[q];
+                out.lane_pair[t * lanes + hh * 32 + q] = h.pair[q];
+                if (h.pair[q] >= 0) { out.loc[h.pair[q]].task = (int32_t)t; out.loc[h.pair[q]].lane = hh * 32 + q; }
+            }
+        }
+        wt.bnd_off = bnd;
+        // strip-boundary rows: the 12x unrolled loops of the split kernels read ahead
+        bnd += out.split ? (int64_t)(wt.max_l1 + 24) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
+        wt.tb_off = 0;
+        wt.aux_off = 0;
+        // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]
+        out.tb_elems[t] = out.split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
+        out.aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * (out.split ? 32 : 64);
+    }
+    out.bnd_elems = bnd;
+
+    out.wg.clear();
+    out.wg_singles.clear();
+    if (out.split && !opt.want_paths && opt.shared_waves) {
+        out.wg = share_waves(out.tasks, opt);
+        if (out.wg.empty()) out.wg_singles = four_singles(out.tasks);
+    }
+
+    out.slot_off.assign((size_t)n_pairs, 0);
+    int64_t cap = 0, cells = 0;
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int64_t l1 = lens[pairs[2 * p]], l2 = lens[pairs[2 * p + 1]];
+        out.slot_off[p] = cap;
+        cap += l1 + l2 + 2;
+        cells += l1 * l2;
+    }
+    out.path_cap = cap;
+    out.cells = cells;
+}
+
+// ---- C entry point for the CPU unit tests (tests/test_scheduler_cpu.py; not part of libpraline_dp's ABI) ----
+extern "C" int praline_sched_test(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, int want_paths, int xcd_group,
+                                  int64_t wave_slots, int64_t cap_tasks, int64_t cap_wg, int64_t *n_tasks_out,
+                                  int32_t *task_fields /* [cap_tasks][4]: two, max_l1, nstrips, pad */,
+                                  int32_t *lane_pair /* [cap_tasks][32] */, int64_t *n_wg_out,
+                                  int32_t *wg_fields /* [cap_wg][6]: task[4], share, barriers */, int64_t *n_singles_out)
+{
+    SchedOptions opt;
+    opt.want_paths = want_paths != 0;
+    opt.xcd_group = xcd_group;
+    opt.wave_slots = wave_slots;
+    Schedule s;
+    build_schedule(lens, n_pairs, pairs, opt, s);
+    *n_tasks_out = (int64_t)s.tasks.size();
+    *n_wg_out = (int64_t)s.wg.size();
+    *n_singles_out = (int64_t)s.wg_singles.size();
+    if ((int64_t)s.tasks.size() > cap_tasks || (int64_t)s.wg.size() > cap_wg) return -1;
+    for (size_t t = 0; t < s.tasks.size(); ++t) {
+        task_fields[4 * t + 0] = s.tasks[t].two[0];
+        task_fields[4 * t + 1] = s.tasks[t].max_l1;
+        task_fields[4 * t + 2] = s.tasks[t].nstrips;
+        task_fields[4 * t + 3] = 0;
+        for (int q = 0; q < 32; ++q) lane_pair[32 * t + q] = s.lane_pair[32 * t + q];
+    }
+    for (size_t w = 0; w < s.wg.size(); ++w) {
+        for (int q = 0; q < 4; ++q) wg_fields[6 * w + q] = s.wg[w].task[q];
+        wg_fields[6 * w + 4] = s.wg[w].share;
+        wg_fields[6 * w + 5] = s.wg[w].barriers;
+    }
+    return 0;
+}

@@ -1,0 +1,39 @@
+// sched.h -- host-side scheduling of a pair list onto wavefront tasks (no HIP in here: sched.cpp also builds with
+// g++ for the CPU unit tests, tests/test_scheduler_cpu.py).
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "dp_types.h"
+
+struct SchedOptions {
+    bool want_paths = false;
+    bool split_layout = true;     // split-strip kernels (32 pairs per task); false: k_dp_batch (PRALINE_KERNEL=batch)
+    int tp = 0;                   // k_dp_batch only: sequence-two groups per wave (0 = automatic)
+    int xcd_group = -1;           // XCD placement group size (-1 = automatic: tasks / 128 clamped to 16..1024, 0 = none)
+    bool shared_waves = true;     // build the four-wave workgroup lists
+    int64_t wave_slots = 2048;    // resident wave slots assumed by the share search (256 CUs x 4 SIMDs x 2)
+    bool snake = true;            // launch order: longest workgroups share a CU with the shortest
+};
+
+struct Schedule {
+    bool split = true;
+    int tp = 1;
+    int lanes_per_task = 32;
+    std::vector<WaveTask> tasks;          // launch order (XCD placement applied; max_l1 == 0: padding)
+    std::vector<int32_t> lane_one, lane_pair;   // [tasks][lanes_per_task], -1 = empty lane
+    std::vector<PairLoc> loc;             // per pair
+    std::vector<int64_t> tb_elems, aux_elems;   // per task scratch sizes (path plans)
+    int64_t bnd_elems = 0;
+    std::vector<WgDesc> wg;               // small batches: shared waves (empty when not applicable)
+    std::vector<WgDesc> wg_singles;       // large batches: four independent tasks per workgroup
+    std::vector<int64_t> slot_off;        // per pair: row offset of its path slot (capacity l1 + l2 + 2)
+    int64_t path_cap = 0, cells = 0;
+};
+
+// Launch order for an ordered list of n work items: groups of G consecutive items on one XCD (block b runs on
+// XCD b % 8), groups dealt round-robin over the XCDs.  Returns, per block, the item it runs (-1: padding).
+std::vector<int64_t> xcd_group_order(int64_t n, int G);
+
+// lens: length of every arena sequence; pairs: int32 [n_pairs][2] = (sequence one, sequence two), validated by
+// the caller.
+void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, const SchedOptions &opt, Schedule &out);

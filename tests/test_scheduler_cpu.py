@@ -1,0 +1,140 @@
+"""CPU unit tests of the host scheduler (praline_amd/csrc/sched.cpp, built with g++ without HIP): the pair list ->
+wavefront tasks -> launch order -> workgroup descriptors logic that praline_plan_create runs on the GPU box."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, synth_lengths
+
+CSRC = os.path.join(ROOT, "praline_amd", "csrc")
+LIB = os.path.join(ROOT, "praline_amd", "libpraline_sched_test.so")
+LAG = 2   # PRALINE_MW_LAG
+
+
+@pytest.fixture(scope="module")
+def sched():
+    src = os.path.join(CSRC, "sched.cpp")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", LIB], check=True, cwd=CSRC)
+    lib = ctypes.CDLL(LIB)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.praline_sched_test.argtypes = [vp, i64, vp, ctypes.c_int, ctypes.c_int, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    lib.praline_sched_test.restype = ctypes.c_int
+
+    def run(lens, pairs, want_paths=False, xcd_group=-1, wave_slots=2048):
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        cap_t = len(pairs) + 8 * 1024 + 64
+        cap_w = cap_t
+        n_t, n_w, n_s = i64(0), i64(0), i64(0)
+        tf = np.zeros((cap_t, 4), np.int32)
+        lp = np.zeros((cap_t, 32), np.int32)
+        wf = np.zeros((cap_w, 6), np.int32)
+        rc = lib.praline_sched_test(lens.ctypes.data, len(pairs), pairs.ctypes.data, int(want_paths), xcd_group, wave_slots,
+                                    cap_t, cap_w, ctypes.byref(n_t), tf.ctypes.data, lp.ctypes.data, ctypes.byref(n_w),
+                                    wf.ctypes.data, ctypes.byref(n_s))
+        assert rc == 0
+        return tf[:n_t.value], lp[:n_t.value], wf[:n_w.value], n_s.value
+    return run
+
+
+def all_pairs(n):
+    i, j = np.triu_indices(n, k=1)
+    return np.stack([i, j], axis=1).astype(np.int32)
+
+
+def check_tasks(lens, pairs, tf, lp):
+    seen = lp[lp >= 0]
+    assert np.array_equal(np.sort(seen), np.arange(len(pairs)))            # every pair in exactly one lane
+    for t in range(len(tf)):
+        ps = lp[t][lp[t] >= 0]
+        if len(ps) == 0:
+            assert tf[t, 1] == 0                                            # placement padding
+            continue
+        assert np.all(pairs[ps, 1] == tf[t, 0])                             # one shared sequence two per task
+        assert tf[t, 1] == lens[pairs[ps, 0]].max()                         # max_l1
+        assert tf[t, 2] == (lens[tf[t, 0]] + 31) // 32                      # strips of 32 columns
+        assert np.all(np.diff(lens[pairs[ps, 0]]) <= 0)                     # partners sorted by length
+
+
+def test_tasks_cover_the_pair_list(sched):
+    rng = np.random.default_rng(0)
+    for n, mu in ((2, 40), (9, 70), (70, 150), (200, 400)):
+        lens = synth_lengths(rng, n, mu)
+        for pairs in (all_pairs(n), np.array([(i, j) for i in range(n) for j in range(n) if i != j and (3 * i + j) % 4 == 0], np.int32)):
+            if len(pairs) == 0:
+                continue
+            for want_paths in (False, True):
+                tf, lp, wf, ns = sched(lens, pairs, want_paths=want_paths)
+                check_tasks(lens, pairs, tf, lp)
+                if want_paths:
+                    assert len(wf) == 0 and ns == 0                          # workgroup lists are for score plans
+
+
+def test_xcd_placement_keeps_groups_on_one_xcd(sched):
+    rng = np.random.default_rng(1)
+    n = 420
+    lens = synth_lengths(rng, n, 300)
+    pairs = all_pairs(n)
+    tf0, lp0, _, _ = sched(lens, pairs, xcd_group=0)
+    assert np.all(tf0[:, 1] > 0)                                            # no padding without placement
+    cost = tf0[:, 2].astype(np.int64) * 100000 + tf0[:, 1]
+    assert np.all(np.diff(cost) <= 0)                                       # longest first
+    G = 16
+    tf, lp, _, _ = sched(lens, pairs, xcd_group=G)
+    check_tasks(lens, pairs, tf, lp)
+    assert len(tf) % (8 * G) == 0
+    # the i-th task of the unplaced order sits at block 8 q + x with g = i // G, x = g % 8, q = (g // 8) * G + i % G
+    key0 = [tuple(sorted(r[r >= 0])) for r in lp0]
+    key = {tuple(sorted(r[r >= 0])): b for b, r in enumerate(lp) if (r >= 0).any()}
+    for i, k in enumerate(key0):
+        g = i // G
+        assert key[k] == 8 * ((g // 8) * G + i % G) + g % 8
+
+
+def barriers(nstrips, it, W):
+    return max(r * LAG + (((nstrips - r + W - 1) // W) if nstrips > r else 0) * it for r in range(W))
+
+
+def test_shared_wave_descriptors(sched):
+    rng = np.random.default_rng(2)
+    for n, slots in ((40, 2048), (256, 2048), (300, 2048), (128, 512)):
+        lens = synth_lengths(rng, n, 400)
+        pairs = all_pairs(n)
+        tf, lp, wf, ns = sched(lens, pairs, wave_slots=slots)
+        real = np.nonzero(tf[:, 1] > 0)[0]
+        if len(real) >= slots:
+            assert len(wf) == 0 and ns > 0
+            continue
+        assert len(wf) > 0 and ns == 0
+        assert 4 * len(wf) <= slots                                          # every workgroup resident
+        leaders = []
+        for task4, share, nbar in zip(wf[:, :4], wf[:, 4], wf[:, 5]):
+            assert share in (1, 2, 4)
+            if share == 1:
+                assert nbar == 0
+                leaders += [t for t in task4 if t >= 0]
+                continue
+            want = 0
+            for slot in range(0, 4, share):
+                t = task4[slot]
+                assert np.all(task4[slot + 1:slot + share] == -1)           # only the group's first slot names the task
+                if t < 0:
+                    continue
+                leaders.append(t)
+                nstrips, it = tf[t, 2], (tf[t, 1] - 1) // 12 + 1
+                assert nstrips >= share and it >= share * LAG                # hand-off distances stay >= LAG iterations
+                want = max(want, barriers(nstrips, it, share))
+            assert nbar == want                                              # what every wave of the workgroup executes
+        assert sorted(leaders) == sorted(real.tolist())                      # every task exactly once
+
+
+def test_four_singles_keep_the_xcd_queues(sched):
+    rng = np.random.default_rng(3)
+    n = 720
+    lens = synth_lengths(rng, n, 200)
+    tf, lp, wf, ns = sched(lens, all_pairs(n))
+    assert len(wf) == 0 and ns == (len(tf) + 31) // 32 * 8
