@@ -429,3 +429,57 @@ def test_batch_c2_slice_properties(nat, bba):
         s_ref = orc.pairwise_score_fast("global", profs[i], profs[j], S, *GAPS)
         assert abs(sc[k] - s_ref) <= 1e-5 * abs(s_ref)   # vs the reference evaluation order
     arena.close()
+
+
+def test_edge_cases_vs_oracle(nat, bba):
+    """Empty pair list, self and duplicate pairs, length-1 sequences, a hopeless local alignment (nothing
+    scores above 0) and one long pair (3 000 x 9 000, 283 strips, shared by four waves): scores and paths
+    against the oracle in all modes."""
+    S = bba["S"]
+    rng = np.random.default_rng(41)
+    arena = nat.Arena([one_hot([3], 27), one_hot([3, 4], 27)], S)
+    plan = nat.Plan(arena, np.zeros((0, 2), np.int32))
+    plan.run("global", *GAPS)
+    assert plan.scores().shape == (0,)
+    plan.close()
+    arena.close()
+    # W (index of tryptophan) against cysteine-free junk: BLOSUM62 off-diagonals here are all negative
+    vals = [np.array([3]), np.array([7]), rng.integers(0, 20, 40), np.full(25, 17), np.full(31, 4), rng.integers(0, 20, 40)]
+    profs = [one_hot(v, 27) for v in vals]
+    arena = nat.Arena(profs, S)
+    pairs = np.array([(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (2, 2), (2, 5), (2, 5), (3, 4), (4, 3), (0, 3)], dtype=np.int32)
+    for mode in MODES:
+        plan = nat.Plan(arena, pairs, want_paths=True)
+        plan.run(mode, *GAPS)
+        sc, paths = plan.scores(), plan.paths()
+        plan.close()
+        plan = nat.Plan(arena, pairs)
+        plan.run(mode, *GAPS)
+        sc0 = plan.scores()
+        plan.close()
+        assert np.array_equal(bits(sc), bits(sc0)), mode
+        for k, (i, j) in enumerate(pairs):
+            s_or, p_or = orc.pairwise_score_fast(mode, profs[i], profs[j], S, *GAPS, want_path=True)
+            assert sc[k] == np.float32(s_or), (mode, i, j)
+            assert np.array_equal(paths[k], p_or), (mode, i, j)
+    arena.close()
+    # one long pair: 283 strips x 3000 rows; a single task, pipelined by four waves of one workgroup
+    d = load_golden("synthetic_dna.npz")
+    Sd = d["matrix"]
+    a, b = rng.integers(0, 4, 3000), rng.integers(0, 4, 9040)
+    b[100:2900] = a[60:2860]                 # a long common stretch so that local / semiglobal paths are long
+    pa, pb = one_hot(a, 15), one_hot(b, 15)
+    arena = nat.Arena([pa, pb], Sd)
+    for mode in MODES:
+        plan = nat.Plan(arena, np.array([(0, 1)], np.int32))
+        plan.run(mode, *GAPS)
+        s_dev = plan.scores()[0]
+        plan.close()
+        plan = nat.Plan(arena, np.array([(0, 1)], np.int32), want_paths=True)
+        plan.run(mode, *GAPS)
+        s_tb, p_tb = plan.scores()[0], plan.paths()[0]
+        plan.close()
+        s_or, p_or = orc.pairwise_score_fast(mode, pa, pb, Sd, *GAPS, want_path=True)
+        assert s_dev == np.float32(s_or) and s_tb == np.float32(s_or), mode
+        assert np.array_equal(p_tb, p_or), mode
+    arena.close()
