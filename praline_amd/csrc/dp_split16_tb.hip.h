@@ -24,13 +24,58 @@ __device__ __forceinline__ unsigned shift_in_sign(unsigned w, float open, float 
     return __builtin_amdgcn_alignbit(w, __builtin_bit_cast(unsigned, d), 31);
 }
 
+// ---- chain mode: one wave per (task, strip), strips of a task pipelined ACROSS workgroups --------------------
+// A single alignment (every merge step of the progressive MSA) is one task: run strip after strip by one wave
+// it takes nstrips x rows steps with the rest of the chip idle (400 x 400 with paths: 4.1 ms; 3000 x 3000:
+// 215 ms).  In chain mode every strip has its own wave and its own boundary column in HBM; the wave of strip
+// s + 1 follows the wave of strip s a few rows behind.  The hand-off follows the write-through recipe of the CDNA
+// guide: the producer stores the boundary rows with agent-scope relaxed atomics (sc1, write-through, visible to
+// every XCD), drains them (vmcnt(0)) and publishes the number of finished rows in a flag word with the same kind
+// of store; the consumer polls that word (relaxed, agent scope), then ONE agent-scope acquire drops its stale
+// cache lines and plain loads follow.  Blocks are dispatched in index order and the grid is strip-major, so the
+// producer of any resident wave has been dispatched before it: the polling always makes progress.
+typedef __attribute__((address_space(1))) unsigned long long chain_u64;
+typedef __attribute__((address_space(1))) unsigned chain_u32;
+#define PRALINE_CHAIN_DONE 0x3fffffff
+
+__device__ __forceinline__ void chain_store_row(char *dst, float m, float u, float l)
+{
+    const unsigned long long mu = (unsigned long long)__builtin_bit_cast(unsigned, m) |
+                                  ((unsigned long long)__builtin_bit_cast(unsigned, u) << 32);
+    __hip_atomic_store((chain_u64 *)(dst), mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((chain_u32 *)(dst + 8), __builtin_bit_cast(unsigned, l), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void chain_publish(int *flag, int rows, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows are in memory before the flag says so
+    if (lane == 0)
+        __hip_atomic_store((chain_u32 *)(flag), (unsigned)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wait until the producer has published at least `rows` rows; returns what it has published
+__device__ __forceinline__ int chain_wait(const int *flag, int rows, int seen)
+{
+    if (rows <= seen) return seen;
+    int v;
+    for (;;) {
+        v = (int)__hip_atomic_load((const chain_u32 *)(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v >= rows) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return v;
+}
+
 struct TbCarry {
     float xm, xu, xl;     // upper half: states of the cell left of its first column, same row (handed over)
     float pxm, pxu, pxl;  // upper half: the same for the previous row (= its diagonal input)
     float dM, dU, dL;     // lower half: states of the boundary cell (y-1, x0)
 };
 
-template <int NR, int NTERM, bool LOCAL, bool MASK>
+template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false>
 __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                                 float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
                                                 const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR], const char *&b_next,
@@ -39,7 +84,8 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
                                                 float &cxm, float &cxu, float &cxl, float &cpxm, float &cpxu, float &cpxl,
                                                 float &cdM, float &cdU, float &cdL, float &best_run, int &best_y,
                                                 int &best_x, int &best_k, float go, float ge, int xb,
-                                                const int (&rect)[PRALINE_MAX_RECTS][4])
+                                                const int (&rect)[PRALINE_MAX_RECTS][4], const int *chain_in = nullptr,
+                                                int *chain_seen = nullptr, int load_row = 0)
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NM = NTERM * NR;
@@ -48,6 +94,9 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     for (int c = 0; c < 16; ++c) m[c] = h ? PREV[c] : CUR[c];
 
     const float4 bv = bnd_pref;  // states (M, U, L) of the boundary cell (yy, x0)
+    if constexpr (CHAIN) {
+        if (chain_in != nullptr) *chain_seen = chain_wait(chain_in, load_row, *chain_seen);   // row load_row is published
+    }
     bnd_pref = *reinterpret_cast<const float4 *>(bnd_ld);
     bnd_ld += 32 * sizeof(float4);
     float md = h ? cpxm : cdM, ud = h ? cpxu : cdU, ld = h ? cpxl : cdL;  // states of (yy-1, x-1)
@@ -145,7 +194,11 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     cxu = from_lower_half(Up[15]);
     cxl = from_lower_half(Lp[15]);
 
-    if (h) *reinterpret_cast<float4 *>(bnd_st) = make_float4(Mp[15], Up[15], Lp[15], 0.0f);
+    if constexpr (CHAIN) {
+        if (h) chain_store_row(bnd_st, Mp[15], Up[15], Lp[15]);
+    } else {
+        if (h) *reinterpret_cast<float4 *>(bnd_st) = make_float4(Mp[15], Up[15], Lp[15], 0.0f);
+    }
     bnd_st += 32 * sizeof(float4);
     *tb_st = make_uint2(w_code, (__builtin_bitreverse32(w_u) >> 16) | (__builtin_bitreverse32(w_l) & 0xffff0000u));
     tb_st += 64;
@@ -154,17 +207,21 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #ifndef PRALINE_TB_WAVES_PER_SIMD
 #define PRALINE_TB_WAVES_PER_SIMD 1
 #endif
-template <int NR, int NTERM, bool LOCAL, bool MASK>
+template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false>
 __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one,
                                                        const int32_t *__restrict__ lane_pair, float4 *bnd,
                                                        uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,
                                                        float *__restrict__ scores, int32_t *__restrict__ end_cells,
-                                                       RunParams rp, int n_tasks)
+                                                       RunParams rp, int n_tasks, int *chain_flags = nullptr,
+                                                       int chain_stride = 0)
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
-    const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    static_assert(!CHAIN || !LOCAL, "chain mode covers the global and semiglobal modes");
+    // CHAIN: one wave per block; block b = strip-major (strip, task): producers are dispatched before consumers
+    const int task = CHAIN ? (int)(blockIdx.x % n_tasks) : (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int chain_strip = CHAIN ? (int)(blockIdx.x / n_tasks) : 0;
     if (task >= n_tasks) return;
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -194,8 +251,15 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
     const int acol = 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
     const char *qA = ar.Q16 + ((int64_t)ar.row_off[two] + acol) * ar.row_bytes + h * ar.half_bytes;
 
-    char *my_bnd = reinterpret_cast<char *>(bnd + tk.bnd_off + j);  // float4 [y][32]
+    if (CHAIN && chain_strip >= nstrips) return;
+    // boundary columns: float4 [y][32]; chain mode keeps one per strip boundary, [strip][y][32]
+    const int64_t chain_col = CHAIN ? (int64_t)(max_l1 + 24) * 32 : 0;
+    char *my_bnd = reinterpret_cast<char *>(bnd + tk.bnd_off + chain_col * chain_strip + j);          // read by this wave
+    char *my_bnd_out = reinterpret_cast<char *>(bnd + tk.bnd_off + chain_col * (chain_strip + 1) + j);  // written (CHAIN)
     constexpr int BROW = 32 * (int)sizeof(float4);
+    const int *chain_in = (CHAIN && chain_strip > 0) ? chain_flags + (int64_t)task * chain_stride + chain_strip - 1 : nullptr;
+    int *chain_out = CHAIN ? chain_flags + (int64_t)task * chain_stride + chain_strip : nullptr;
+    int chain_seen = 0;
     uint2 *my_tb = tb + tk.tb_off + lane;                            // [strip][y][64]
     float *lastcol = aux + tk.aux_off + j;                                   // [y][3][32]
     float *lastrow = aux + tk.aux_off + (int64_t)(max_l1 + 1) * 3 * 32 + j;  // [x-1][3][32]
@@ -226,7 +290,7 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
     const float o002 = free_two ? 0.0f : (go - ge);
 
     // strip 0 reads its boundary column like every other strip: states of (y, 0) = (-inf, o[y,0,1], -inf)
-    if (h == 0)
+    if (h == 0 && chain_strip == 0)
         for (int y = 1; y <= max_l1 + 4; ++y)
             *reinterpret_cast<float4 *>(my_bnd + (int64_t)y * BROW) =
                 make_float4(PRALINE_NEG_INF, boundary_value(y, go, ge, free_one), PRALINE_NEG_INF, 0.0f);
@@ -242,7 +306,7 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
     }
     float corner_m = PRALINE_NEG_INF, corner_u = PRALINE_NEG_INF, corner_l = PRALINE_NEG_INF;
 
-    for (int s = 0; s < nstrips; ++s) {
+    for (int s = CHAIN ? chain_strip : 0; s < (CHAIN ? chain_strip + 1 : nstrips); ++s) {
         const int x0 = s * 32;
         const int xb = x0 + 16 * h;
         const bool last_owner = (s == nstrips - 1) && own_last;
@@ -293,15 +357,19 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         // boundary states two rows ahead, in two alternating registers (one row = 1 us at one wave per SIMD is
         // not enough for a load that misses L2; measured with the 1-deep version: 27 % of the cycles waiting)
         const char *bnd_ld = my_bnd + 3 * BROW;
-        char *bnd_st = my_bnd;                                               // upper half stores row yy = t - 1 (row 0: dummy)
+        char *bnd_st = CHAIN ? my_bnd_out : my_bnd;                          // upper half stores row yy = t - 1 (row 0: dummy)
+        if constexpr (CHAIN) {
+            if (chain_in != nullptr) chain_seen = chain_wait(chain_in, 2, chain_seen);
+        }
         float4 bnd_prefA = *reinterpret_cast<const float4 *>(my_bnd + BROW);      // row 1
         float4 bnd_prefB = *reinterpret_cast<const float4 *>(my_bnd + 2 * BROW);  // row 2
         uint2 *tb_st = my_tb + (int64_t)s * tb_rows * 64 + (h ? 0 : 64);     // row yy = t - h of step t = 1
 
 #define PRALINE_TB_STEP(T, CUR, PREV, BSET, PREF)                                                                    \
-        split16_tb_step<NR, NTERM, LOCAL, MASK>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld,  \
-                                                bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl, cpxm, cpxu, cpxl, cdM,      \
-                                                cdU, cdL, best_run, best_y, best_x, best_k, go, ge, xb, rect)
+        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride,   \
+                                                bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl, cpxm, cpxu, cpxl,   \
+                                                cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge, xb, rect,          \
+                                                chain_in, &chain_seen, (T) + 2)
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
             const int yy_ = (T) - h;                                                                                 \
@@ -335,6 +403,10 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
             PRALINE_TB_TAILS(1)
         }
         for (int t = 2; t <= max_l1 + 1; t += 2) {
+            if constexpr (CHAIN) {
+                // the steps up to t - 1 have stored the boundary rows up to t - 2
+                if ((t & 6) == 0) chain_publish(chain_out, t - 2, lane);
+            }
             PRALINE_TB_STEP(t, accB, accA, bY, bnd_prefB);
             PRALINE_TB_TAILS(t)
             PRALINE_TB_STEP(t + 1, accA, accB, bX, bnd_prefA);
@@ -342,7 +414,9 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         }
 #undef PRALINE_TB_STEP
 #undef PRALINE_TB_TAILS
+        if constexpr (CHAIN) chain_publish(chain_out, PRALINE_CHAIN_DONE, lane);
     }
+    if (CHAIN && chain_strip != nstrips - 1) return;   // the last strip's wave reports the end cell
 
     // ---- combine the halves: end cell (y, x, k) and score (align.py:401-431) ----
     if (LOCAL) {

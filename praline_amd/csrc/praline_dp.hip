@@ -426,12 +426,25 @@ struct praline_plan {
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
     DevBuf<char> d_bnd;
+    DevBuf<char> d_bnd_chain;   // chain mode: one boundary column per strip boundary
+    DevBuf<int> d_chain_flags;  // chain mode: rows published per (task, strip)
     DevBuf<char> d_tb;
     DevBuf<int64_t> d_slot_off, d_path_start;
     std::vector<int64_t> slot_off;
     float last_kernel_ms = 0.0f;
     int last_mode = -1;
 };
+
+// chain mode (one wave per task and strip) for plans of up to this many tasks.  Measured with paths, float
+// profiles, ms per run task mode -> chain mode: 120 pairs 6.6 -> 0.93, 2 016 pairs 6.6 -> 1.5, 8 128 pairs
+// 7.1 -> 3.0, C2 (32 640 pairs, 1 144 tasks) 9.6 -> 7.5, 2 048 tasks 5.2 -> 5.2, 4 600 tasks 10.6 -> 11.5.
+// Blocks are dispatched in index order and a strip's producer has the smaller index, so a chain never waits for
+// a wave that has not been dispatched, whatever fits on the chip at once.
+static int64_t chain_max_tasks()
+{
+    if (const char *env = getenv("PRALINE_CHAIN_MAX_TASKS")) return atoll(env);
+    return 1536;
+}
 
 // traceback scratch budget per launch chunk (bytes)
 static size_t tb_budget_bytes()
@@ -685,7 +698,30 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         la.tb = (uint4 *)pl.d_tb.p;
         la.aux = pl.d_aux.p;
         la.n_tasks = (unsigned)(t1 - t0);
-        if (pl.split) {
+        // Chain mode for small plans (single alignments, the merge steps of the progressive MSA): one wave per
+        // (task, strip), pipelined across workgroups (dp_split16_tb.hip.h); the plan must be one chunk.
+        int max_strips = 0;
+        for (size_t t = t0; t < t1; ++t) max_strips = std::max(max_strips, (int)pl.tasks[t].nstrips);
+        const bool chain = pl.split && la.a16 != nullptr && !local && !pl.has_rects && t0 == 0 && t1 == nt && max_strips >= 2 &&
+                           (int64_t)nt <= chain_max_tasks() && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
+        if (chain) {
+            std::vector<WaveTask> ct(pl.tasks.begin(), pl.tasks.end());
+            int64_t bnd_e = 0;
+            for (WaveTask &wt : ct) {
+                wt.bnd_off = bnd_e;
+                bnd_e += (int64_t)(wt.nstrips + 1) * (wt.max_l1 + 24) * 32;   // float4 elements, [strip boundary][row][32]
+            }
+            if (pl.d_bnd_chain.n < (size_t)bnd_e * sizeof(float4)) RC(pl.d_bnd_chain.alloc((size_t)bnd_e * sizeof(float4)));
+            const size_t n_flags = nt * (size_t)(max_strips + 1);
+            if (pl.d_chain_flags.n < n_flags) RC(pl.d_chain_flags.alloc(n_flags));
+            HIPCHK(hipMemsetAsync(pl.d_chain_flags.p, 0, n_flags * sizeof(int), st));
+            HIPCHK(hipMemcpyAsync(pl.d_tasks.p, ct.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));   // ct goes out of scope
+            la.bnd = pl.d_bnd_chain.p;
+            int rc = praline_launch_split16_tb_chain(la, a16, a.nr16, a.nterm16, max_strips, pl.d_chain_flags.p);
+            if (rc != PRALINE_OK) return fail(rc, "no chain instance of k_dp_split16_tb for nr=%d nterm=%d", a.nr16, a.nterm16);
+            la.bnd = pl.d_bnd.p;
+        } else if (pl.split) {
             int rc = praline_launch_split16_tb(la, a16, a.nr16, a.nterm16, local, pl.has_rects);
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16_tb instance for nr=%d nterm=%d", a.nr16, a.nterm16);
         } else {
