@@ -533,6 +533,32 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
 
 #ifdef PRALINE_AUX_KERNELS
 // --------------------------------------------------------------------------------------------
+// Chain mode, local alignments: the first flat argmax of o (align.py:402) over the candidates the strips of a
+// task reported - largest value, then smallest y, then smallest x.  Thread = (task, lane).
+__global__ void k_chain_local_end(const WaveTask *__restrict__ tasks, const int32_t *__restrict__ lane_pair,
+                                  const float4 *__restrict__ cand, int n_tasks, int stride, int32_t *__restrict__ end_cells,
+                                  float *__restrict__ scores)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)(gid / 32), lane = (int)(gid % 32);
+    if (t >= n_tasks) return;
+    const int64_t p = lane_pair[(int64_t)t * 32 + lane];
+    if (p < 0) return;
+    const int nstrips = tasks[t].nstrips;
+    float best = PRALINE_NEG_INF;
+    int by = 0, bx = 0, bk = 0;
+    for (int s = 0; s < nstrips; ++s) {
+        const float4 c = cand[((int64_t)t * stride + s) * 32 + lane];
+        const int y = __builtin_bit_cast(int, c.y), x = __builtin_bit_cast(int, c.z), k = __builtin_bit_cast(int, c.w);
+        if (c.x > best || (c.x == best && (y < by || (y == by && x < bx)))) { best = c.x; by = y; bx = x; bk = k; }
+    }
+    end_cells[p * 4 + 0] = by;
+    end_cells[p * 4 + 1] = bx;
+    end_cells[p * 4 + 2] = bk;
+    end_cells[p * 4 + 3] = 0;
+    scores[p] = best;
+}
+
 // Semiglobal end cell (praline/component/align.py:406-424): the maxima of the last row o[L1, x, k] and the last
 // column o[y, L2, k] (boundary cells included) and, for the side that wins, the cell the reference finds scanning
 // from the far end (x from L2 down / y from L1 down) and k = 0, 1, 2: the largest coordinate holding the maximum,

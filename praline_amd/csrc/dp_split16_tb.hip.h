@@ -214,11 +214,10 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
                                                        uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,
                                                        float *__restrict__ scores, int32_t *__restrict__ end_cells,
                                                        RunParams rp, int n_tasks, int *chain_flags = nullptr,
-                                                       int chain_stride = 0)
+                                                       int chain_stride = 0, float4 *chain_cand = nullptr)
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
-    static_assert(!CHAIN || !LOCAL, "chain mode covers the global and semiglobal modes");
     // CHAIN: one wave per block; block b = strip-major (strip, task): producers are dispatched before consumers
     const int task = CHAIN ? (int)(blockIdx.x % n_tasks) : (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chain_strip = CHAIN ? (int)(blockIdx.x / n_tasks) : 0;
@@ -415,6 +414,20 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
 #undef PRALINE_TB_STEP
 #undef PRALINE_TB_TAILS
         if constexpr (CHAIN) chain_publish(chain_out, PRALINE_CHAIN_DONE, lane);
+    }
+    if (CHAIN && LOCAL) {
+        // every strip reports its own first-argmax candidate (value, y, x, k); k_chain_local_end picks per pair
+        const float pv = partner_value(out_best, h);
+        const int py = __builtin_bit_cast(int, partner_value(__builtin_bit_cast(float, out_y), h));
+        const int px = __builtin_bit_cast(int, partner_value(__builtin_bit_cast(float, out_x), h));
+        const int pk = __builtin_bit_cast(int, partner_value(__builtin_bit_cast(float, out_k), h));
+        if (pv > out_best || (pv == out_best && (py < out_y || (py == out_y && px < out_x)))) {
+            out_best = pv; out_y = py; out_x = px; out_k = pk;
+        }
+        if (h == 0)
+            chain_cand[((int64_t)task * chain_stride + chain_strip) * 32 + j] =
+                make_float4(out_best, __builtin_bit_cast(float, out_y), __builtin_bit_cast(float, out_x), __builtin_bit_cast(float, out_k));
+        return;
     }
     if (CHAIN && chain_strip != nstrips - 1) return;   // the last strip's wave reports the end cell
 

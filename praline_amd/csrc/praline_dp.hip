@@ -428,6 +428,7 @@ struct praline_plan {
     DevBuf<char> d_bnd;
     DevBuf<char> d_bnd_chain;   // chain mode: one boundary column per strip boundary
     DevBuf<int> d_chain_flags;  // chain mode: rows published per (task, strip)
+    DevBuf<float4> d_chain_cand;  // chain mode, local: first-argmax candidate per (task, strip, pair)
     DevBuf<char> d_tb;
     DevBuf<int64_t> d_slot_off, d_path_start;
     std::vector<int64_t> slot_off;
@@ -702,7 +703,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         // (task, strip), pipelined across workgroups (dp_split16_tb.hip.h); the plan must be one chunk.
         int max_strips = 0;
         for (size_t t = t0; t < t1; ++t) max_strips = std::max(max_strips, (int)pl.tasks[t].nstrips);
-        const bool chain = pl.split && la.a16 != nullptr && !local && !pl.has_rects && t0 == 0 && t1 == nt && max_strips >= 2 &&
+        const bool chain = pl.split && la.a16 != nullptr && t0 == 0 && t1 == nt && max_strips >= 2 &&
                            (int64_t)nt <= chain_max_tasks() && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
         if (chain) {
             std::vector<WaveTask> ct(pl.tasks.begin(), pl.tasks.end());
@@ -718,8 +719,15 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             HIPCHK(hipMemcpyAsync(pl.d_tasks.p, ct.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st));   // ct goes out of scope
             la.bnd = pl.d_bnd_chain.p;
-            int rc = praline_launch_split16_tb_chain(la, a16, a.nr16, a.nterm16, max_strips, pl.d_chain_flags.p);
+            if (local && pl.d_chain_cand.n < n_flags * 32) RC(pl.d_chain_cand.alloc(n_flags * 32));
+            int rc = praline_launch_split16_tb_chain(la, a16, a.nr16, a.nterm16, local, pl.has_rects, max_strips,
+                                                     pl.d_chain_flags.p, pl.d_chain_cand.p);
             if (rc != PRALINE_OK) return fail(rc, "no chain instance of k_dp_split16_tb for nr=%d nterm=%d", a.nr16, a.nterm16);
+            if (local) {
+                const int64_t lanes = (int64_t)nt * 32;
+                hipLaunchKernelGGL(k_chain_local_end, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, pl.d_tasks.p,
+                                   pl.d_lane_pair.p, pl.d_chain_cand.p, (int)nt, max_strips + 1, pl.d_end_cells.p, la.scores);
+            }
             la.bnd = pl.d_bnd.p;
         } else if (pl.split) {
             int rc = praline_launch_split16_tb(la, a16, a.nr16, a.nterm16, local, pl.has_rects);
