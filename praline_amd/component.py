@@ -477,23 +477,17 @@ class GuideTreeBuilder(Component):
         if dist_mode not in ('semiglobal', 'global', 'semiglobal_auto'):
             raise ComponentError("unknown alignment mode '{0}'".format(dist_mode))
         n = len(sequences)
+        # what the per-pair checks of the aligner test is per sequence (alphabets against the matrices): once each
+        for s in sequences:
+            _validate_track_sets(s, s, track_id_sets, track_id_sets, score_matrices)
         batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
-        idxs = []
-        for i in range(n):
-            for j in range(i + 1, n):  # tree.py:105-129: each unordered pair once, i outer
-                _validate_track_sets(sequences[i], sequences[j], track_id_sets, track_id_sets, score_matrices)
-                if dist_mode == "semiglobal":
-                    mode = "semiglobal_both"
-                elif dist_mode == "global":
-                    mode = "global"
-                else:
-                    mode = auto_align_mode(sequences[i], sequences[j])
-                batch.add(mode, sequences[i], sequences[j])
-                idxs.append((i, j))
+        fixed = {"semiglobal": "semiglobal_both", "global": "global"}.get(dist_mode)
+        ii, jj = np.triu_indices(n, k=1)   # tree.py:105-129: each unordered pair once, i outer, j inner
+        for i, j in zip(ii.tolist(), jj.tolist()):
+            batch.add(fixed or auto_align_mode(sequences[i], sequences[j]), sequences[i], sequences[j])
         scores, _ = batch.run(want_paths=False)
         d = np.zeros((n, n), dtype=np.float32)  # tree.py:99-100,131: diagonal 0
-        for (i, j), sc in zip(idxs, scores):
-            d[i, j] = d[j, i] = sc
+        d[ii, jj] = d[jj, ii] = np.asarray(scores, dtype=np.float32)
         self.score_matrix = d
         dist = (-d) + d.max()  # tree.py:147
         tree = SequenceTree(sequences, merge_order(dist, linkage))
