@@ -1,0 +1,75 @@
+"""Randomised parity stress: random batch shapes through every kernel path (scores-only with shared waves /
+singles / table / staged stream, paths in task and chain mode, masks) against the oracle DP on the device's match
+scores (integer scoring: also against the reference order).  usage: stress.py [seconds] [seed]"""
+import sys, os, time, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from praline_amd import native as nat
+from praline_amd.matrices import blosum62_matrix, nucleotide_matrix
+from oracle import oracle as orc
+from conftest import synth_profile
+nat.init(0)
+MODES = ["global", "local", "semiglobal_both", "semiglobal_one", "semiglobal_two"]
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + budget
+n_cases = n_pairs_checked = 0
+def dp_on_m(mode, m, rects=None):
+    g1, g2 = orc.gap_arrays(m.shape[0], m.shape[1], (-11.0, -1.0))
+    zero = None
+    if rects:
+        zero = [(y, x) for (y0, y1, x0, x1) in rects for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
+    return orc.raw_pairwise_align(mode, np.ascontiguousarray(m), g1, g2, zero)
+while time.time() < t_end:
+    kind = rng.choice(["onehot", "profile", "dna"])
+    N = int(rng.choice([2, 3, 5, 9, 17, 33, 48]))
+    mu = int(rng.choice([3, 20, 40, 70, 130, 260, 520])) if kind != "dna" else int(rng.choice([50, 300, 900]))
+    lens = np.maximum(1, rng.integers(max(1, mu // 2), mu * 3 // 2 + 1, N))
+    if kind == "dna":
+        S, A = nucleotide_matrix(), 15
+        profs = [np.eye(A, dtype=np.float32)[rng.integers(0, 4, int(L))] for L in lens]
+    elif kind == "onehot":
+        S, A = blosum62_matrix(), 27
+        profs = [np.eye(A, dtype=np.float32)[rng.integers(0, 20, int(L))] for L in lens]
+    else:
+        S, A = blosum62_matrix(), 27
+        profs = [synth_profile(rng, int(L))[0] for L in lens]
+    allp = np.array([(i, j) for i in range(N) for j in range(N)], dtype=np.int32)
+    pairs = allp[rng.random(len(allp)) < rng.choice([0.15, 0.5, 1.0])]
+    if len(pairs) == 0:
+        continue
+    mode = MODES[int(rng.integers(0, 5))]
+    want_paths = bool(rng.integers(0, 2))
+    rects = None
+    if want_paths and mode == "local" and rng.random() < 0.5:
+        rects = []
+        for (i, j) in pairs:
+            k = int(rng.integers(0, 3))
+            rr = []
+            for _ in range(k):
+                y0 = int(rng.integers(1, lens[i] + 1)); x0 = int(rng.integers(1, lens[j] + 1))
+                rr.append((y0, min(int(lens[i]), y0 + int(rng.integers(0, 12))), x0, min(int(lens[j]), x0 + int(rng.integers(0, 12)))))
+            rects.append(rr)
+    arena = nat.Arena(profs, S)
+    plan = nat.Plan(arena, pairs, want_paths=want_paths, rects=rects)
+    mk = plan.match_kind()
+    plan.run(mode, -11.0, -1.0)
+    sc = plan.scores()
+    paths = plan.paths() if want_paths else None
+    plan.close()
+    check = rng.permutation(len(pairs))[:24]
+    for k in check:
+        i, j = pairs[k]
+        m = arena.match_scores(int(i), int(j), mk)
+        s_or, p_or = dp_on_m(mode, m, rects[k] if rects else None)
+        if sc[k] != np.float32(s_or) or (want_paths and not np.array_equal(paths[k], p_or)):
+            print("MISMATCH kind=%s N=%d mu=%d mode=%s paths=%s rects=%s pair=(%d,%d) lens=(%d,%d) dev=%r oracle=%r" % (
+                kind, N, mu, mode, want_paths, rects[k] if rects else None, i, j, lens[i], lens[j], sc[k], s_or), flush=True)
+            sys.exit(1)
+        if kind != "profile" and rects is None and k % 3 == 0:
+            ref = orc.pairwise_score_fast(mode, profs[i], profs[j], S, -11.0, -1.0)
+            assert sc[k] == np.float32(ref), ("reference order", kind, mode, i, j)
+        n_pairs_checked += 1
+    arena.close()
+    n_cases += 1
+print("stress ok: %d random batches, %d pairs checked against the oracle" % (n_cases, n_pairs_checked))
