@@ -22,7 +22,7 @@ def dp_on_m(mode, m, rects=None):
     return orc.raw_pairwise_align(mode, np.ascontiguousarray(m), g1, g2, zero)
 while time.time() < t_end:
     kind = rng.choice(["onehot", "profile", "dna"])
-    N = int(rng.choice([2, 3, 5, 9, 17, 33, 48]))
+    N = int(rng.choice([64, 128, 200, 300])) if os.environ.get("STRESS_BIG") == "1" else int(rng.choice([2, 3, 5, 9, 17, 33, 48]))
     mu = int(rng.choice([3, 20, 40, 70, 130, 260, 520])) if kind != "dna" else int(rng.choice([50, 300, 900]))
     lens = np.maximum(1, rng.integers(max(1, mu // 2), mu * 3 // 2 + 1, N))
     if kind == "dna":
