@@ -302,10 +302,28 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
 
     // active symbols: i contributes to m = sum_i P1[y,i] * Q2[x,i] only if some profile has mass on
     // it and row i of S is not all zero; dropping the others is exact (their terms are +-0).
+    // One pass over the raw profiles gathers everything the host needs from them: which symbols carry mass, and per
+    // row whether it is one-hot and on which symbol (counted branch-free so that the loop vectorises).
     std::vector<char> has_mass(A, 0), has_score(A, 0);
-    for (int64_t r = 0; r < rr; ++r)
-        for (int i = 0; i < A; ++i)
-            if (profiles[r * A + i] != 0.0f) has_mass[i] = 1;
+    std::vector<unsigned char> sym_raw((size_t)rr, 255);
+    bool all_onehot_rows = true;
+    {
+        std::vector<int> col_nz(A, 0);
+        for (int64_t r = 0; r < rr; ++r) {
+            const float *row = profiles + r * A;
+            int nz = 0, hot = 0, ones = 0;
+            for (int i = 0; i < A; ++i) {
+                const int is_nz = row[i] != 0.0f;
+                col_nz[i] |= is_nz;
+                nz += is_nz;
+                hot += is_nz * i;
+                ones += row[i] == 1.0f;
+            }
+            if (nz == 1 && ones == 1) sym_raw[(size_t)r] = (unsigned char)hot;
+            else all_onehot_rows = false;
+        }
+        for (int i = 0; i < A; ++i) has_mass[i] = (char)col_nz[i];
+    }
     for (int i = 0; i < A; ++i)
         for (int j = 0; j < A; ++j)
             if (S[i * A + j] != 0.0f) has_score[i] = 1;
@@ -328,29 +346,21 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     a->KP = 2 * a->KS;
     a->nr16 = a->n_active <= 16 ? 1 : (a->n_active <= 32 ? 2 : 0);
 
-    // one-hot profiles (every row: a single 1, zeros elsewhere): raw symbol per row (preprofile counting) and,
-    // when ALL rows are one-hot, active-symbol bytes for the one-hot operand table
-    std::vector<unsigned char> sym8, sym_raw((size_t)rr, 255);
+    // one-hot arenas (every row: a single 1, zeros elsewhere): active-symbol bytes for the one-hot operand table
+    std::vector<unsigned char> sym8;
     {
-        const unsigned char none = (unsigned char)(16 * std::max(a->nr16, 1));
-        std::vector<int> slot_of(A, -1);
-        for (int k = 0; k < a->n_active; ++k) slot_of[a->active[k]] = k;
-        sym8.assign((size_t)a->rows_pad + 64, none);
-        bool all = true;
-        for (int64_t s = 0; s < n_seqs; ++s)
-            for (int y = 0; y < lens[s]; ++y) {
-                const float *row = profiles + (a->row_off_raw[s] + y) * (int64_t)A;
-                int hot = -1, nz = 0;
-                for (int i = 0; i < A; ++i)
-                    if (row[i] != 0.0f) { ++nz; hot = i; }
-                if (nz != 1 || row[hot] != 1.0f) { all = false; continue; }
-                sym_raw[(size_t)(a->row_off_raw[s] + y)] = (unsigned char)hot;
-                sym8[a->row_off_pad[s] + y] = slot_of[hot] >= 0 ? (unsigned char)slot_of[hot] : none;
-            }
         const bool want_table = a->nr16 > 0 && !(getenv("PRALINE_NO_ONEHOT") && getenv("PRALINE_NO_ONEHOT")[0] == '1');
-        a->all_onehot = all;
-        a->onehot = all && want_table;
-        if (!a->onehot) sym8.clear();
+        a->all_onehot = all_onehot_rows;
+        a->onehot = all_onehot_rows && want_table;
+        if (a->onehot) {
+            const unsigned char none = (unsigned char)(16 * a->nr16);
+            std::vector<unsigned char> slot_of(256, none);
+            for (int k = 0; k < a->n_active; ++k) slot_of[a->active[k]] = (unsigned char)k;
+            sym8.assign((size_t)a->rows_pad + 64, none);
+            for (int64_t s = 0; s < n_seqs; ++s)
+                for (int y = 0; y < lens[s]; ++y)
+                    sym8[a->row_off_pad[s] + y] = slot_of[sym_raw[(size_t)(a->row_off_raw[s] + y)]];
+        }
     }
 
     std::vector<int32_t> seq_of_rowp((size_t)a->rows_pad, -1);
