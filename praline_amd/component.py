@@ -600,10 +600,23 @@ class AdHocMultipleSequenceAligner(Component):
             return "semiglobal_both"
         return auto_align_mode(one, two)
 
-    def _fan_out(self, requests, track_id_sets, score_matrices):
+    def _fan_out(self, requests, track_id_sets, score_matrices, scores_only=False):
         """Run (mode, cluster_one, cluster_two) requests as ONE Execution; leaves the outputs in
-        self._last_outputs (a generator cannot return them to a for loop)."""
+        self._last_outputs (a generator cannot return them to a for loop).  scores_only: the caller reads
+        nothing but 'score' - under the batching manager and the default aligner that is one scores-only
+        device submission (k_dp_split16) instead of alignments with paths."""
         aligner = self.manager.index.resolve(self.environment['aligner'])
+        if scores_only and aligner is PairwiseAligner and isinstance(self.manager, BatchManager) and len(requests) > 1:
+            for _, one, two in requests:
+                _validate_track_sets(one, two, track_id_sets, track_id_sets, score_matrices)
+            # the aligner's effective environment: ours, overridden by aligner_env (Execution.add_task / collapse)
+            gap_series = self.environment['aligner_env'].get('gap_series', self.environment['gap_series'])
+            batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, gap_series)
+            for mode, one, two in requests:
+                batch.add(mode, one, two)
+            scores, _ = batch.run(want_paths=False)
+            self._last_outputs = [{'score': sc} for sc in scores]
+            return
         execution = Execution(self.manager, self.tag)
         for mode, one, two in requests:
             task = execution.add_task(aligner)
@@ -631,7 +644,7 @@ class AdHocMultipleSequenceAligner(Component):
             pending = [(a, b) for x, a in enumerate(ids) for b in ids[x + 1:]
                        if changed is None or changed in (a, b)]
             for message in self._fan_out([(self._align_mode(dist_mode, clusters[a], clusters[b]), clusters[a], clusters[b])
-                                          for a, b in pending], track_id_sets, score_matrices):
+                                          for a, b in pending], track_id_sets, score_matrices, scores_only=True):
                 yield message
             for (a, b), out in zip(pending, self._last_outputs):
                 known[(a, b)] = np.float32(out['score'])
