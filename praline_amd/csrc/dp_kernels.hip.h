@@ -69,20 +69,39 @@ __device__ __forceinline__ float max3f(float a, float b, float c)
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);  // folds to v_max3_f32
 }
 
+// One entry of the f16 hi/lo operand layout (dp_split16.hip.h): src is P or Q in the fp32 parity layout
+// [rowp][hh][KS] (k = 2 s + hh); dst: [rowp][hh][piece][r][8 halves], slot (piece, r) element jj holds
+// k = 16 r + 8 hh + jj.  Returns whether the value needs a non-zero lo piece (exact single-term mode not applicable).
+__device__ __forceinline__ bool split_f16_entry(const float *__restrict__ src, int KP, int KS, int n_active, int NR,
+                                                int64_t idx, _Float16 *__restrict__ dst)
+{
+    const int per_row = 2 * NR * 8;  // (hh, r, jj) triples per row
+    const int64_t rowp = idx / per_row;
+    const int rem = (int)(idx % per_row);
+    const int hh = rem / (NR * 8), r = (rem / 8) % NR, jj = rem % 8;
+    const int k = 16 * r + 8 * hh + jj;
+    float v = 0.0f;
+    if (k < n_active) v = src[rowp * KP + (k & 1) * KS + (k >> 1)];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const int64_t half_elems = 2 * NR * 8;  // halves per (rowp, hh)
+    _Float16 *o = dst + (rowp * 2 + hh) * half_elems;
+    o[(0 * NR + r) * 8 + jj] = hi;
+    o[(1 * NR + r) * 8 + jj] = lo;
+    return (float)lo != 0.0f || (float)hi + (float)lo != v;
+}
+
 #ifdef PRALINE_AUX_KERNELS  // non-template kernels: defined in praline_dp.hip's translation unit only
 // --------------------------------------------------------------------------------------------
 // Arena packing + the profile x matrix pre-multiply
 // --------------------------------------------------------------------------------------------
 // raw: [rows][A] fp32 (host layout, sequences concatenated); P: parity-split, compacted to the
 // active symbols: P[rowp][h][s] = raw[row][active[2s+h]], zero in padding rows / columns.
-__global__ void k_pack_profiles(const float *__restrict__ raw, const int32_t *__restrict__ seq_of_rowp,
-                                const int32_t *__restrict__ row_off_pad,
-                                const int32_t *__restrict__ row_off_raw,
-                                const int32_t *__restrict__ len, const int32_t *__restrict__ active,
-                                int n_active, int A, int KP, int KS, int64_t rows_pad, float *__restrict__ P)
+__device__ __forceinline__ void pack_entry(int64_t idx, const float *__restrict__ raw, const int32_t *__restrict__ seq_of_rowp,
+                                           const int32_t *__restrict__ row_off_pad, const int32_t *__restrict__ row_off_raw,
+                                           const int32_t *__restrict__ len, const int32_t *__restrict__ active, int n_active,
+                                           int A, int KP, int KS, float *__restrict__ P)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows_pad * KP) return;
     const int64_t rowp = idx / KP;
     const int c = (int)(idx % KP);
     const int h = c / KS, s = c % KS;
@@ -96,12 +115,23 @@ __global__ void k_pack_profiles(const float *__restrict__ raw, const int32_t *__
     P[idx] = v;
 }
 
+__global__ void k_pack_profiles(const float *__restrict__ raw, const int32_t *__restrict__ seq_of_rowp,
+                                const int32_t *__restrict__ row_off_pad,
+                                const int32_t *__restrict__ row_off_raw,
+                                const int32_t *__restrict__ len, const int32_t *__restrict__ active,
+                                int n_active, int A, int KP, int KS, int64_t rows_pad, float *__restrict__ P)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows_pad * KP) return;
+    pack_entry(idx, raw, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, P);
+}
+
 // Q2[x][i] = sum_j S[i][j] * P2[x][j], an fp32 fmaf chain over j ascending, evaluated with
 // v_mfma_f32_32x32x2_f32: one wave computes 32 rows x 32 (compacted) symbols.
 //   A operand (lane l: row l&31, k = l>>5)  = raw[row0 + (l&31)][2s + (l>>5)]
 //   B operand (lane l: k = l>>5, col l&31)  = S[active[c0 + (l&31)]][2s + (l>>5)]
 // D[i][j]: lane holds column j = l&31 (symbol), rows i = (r&3) + 8(r>>2) + 4(l>>5).
-__global__ __launch_bounds__(64) void k_premultiply(const float *__restrict__ raw,
+__device__ __forceinline__ void premultiply_block(int64_t rowp0, int c0, const float *__restrict__ raw,
                                                      const float *__restrict__ S,
                                                      const int32_t *__restrict__ seq_of_rowp,
                                                      const int32_t *__restrict__ row_off_pad,
@@ -113,8 +143,6 @@ __global__ __launch_bounds__(64) void k_premultiply(const float *__restrict__ ra
 {
     const int lane = threadIdx.x;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t rowp0 = (int64_t)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
     const int64_t rowp = rowp0 + j;
     const float *src = nullptr;
     if (rowp < rows_pad) {
@@ -140,6 +168,44 @@ __global__ __launch_bounds__(64) void k_premultiply(const float *__restrict__ ra
             const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int64_t rp = rowp0 + i;
             if (rp < rows_pad) Q[rp * KP + hh * KS + ss] = (c < n_active) ? acc[r] : 0.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_premultiply(const float *__restrict__ raw, const float *__restrict__ S,
+                                                     const int32_t *__restrict__ seq_of_rowp,
+                                                     const int32_t *__restrict__ row_off_pad,
+                                                     const int32_t *__restrict__ row_off_raw,
+                                                     const int32_t *__restrict__ len,
+                                                     const int32_t *__restrict__ active, int n_active, int A, int KP, int KS,
+                                                     int64_t rows_pad, float *__restrict__ Q)
+{
+    premultiply_block((int64_t)blockIdx.x * 32, blockIdx.y * 32, raw, S, seq_of_rowp, row_off_pad, row_off_raw, len, active,
+                      n_active, A, KP, KS, rows_pad, Q);
+}
+
+// Everything praline_arena_premultiply does, for 32 rows per wave in ONE launch: pack P, Q = P . S^T (MFMA), and the
+// f16 hi/lo pieces of both (the four separate launches cost ~0.1 ms of a 2.3 ms bench step in launch gaps).
+__global__ __launch_bounds__(64) void k_prepare_rows(const float *__restrict__ raw, const float *__restrict__ S,
+                                                      const int32_t *__restrict__ seq_of_rowp,
+                                                      const int32_t *__restrict__ row_off_pad,
+                                                      const int32_t *__restrict__ row_off_raw,
+                                                      const int32_t *__restrict__ len,
+                                                      const int32_t *__restrict__ active, int n_active, int A, int KP, int KS,
+                                                      int64_t rows_pad, float *__restrict__ P, float *__restrict__ Q, int NR,
+                                                      _Float16 *__restrict__ P16, _Float16 *__restrict__ Q16)
+{
+    const int64_t rowp0 = (int64_t)blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 32 * KP; i += 64)
+        pack_entry(rowp0 * KP + i, raw, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, P);
+    for (int c0 = 0; c0 < KP; c0 += 32)
+        premultiply_block(rowp0, c0, raw, S, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, rows_pad, Q);
+    if (NR > 0) {
+        __syncthreads();   // this wave's P and Q rows are visible to all its lanes
+        const int per_row = 2 * NR * 8;
+        for (int i = threadIdx.x; i < 32 * per_row; i += 64) {
+            split_f16_entry(P, KP, KS, n_active, NR, rowp0 * per_row + i, P16);
+            split_f16_entry(Q, KP, KS, n_active, NR, rowp0 * per_row + i, Q16);
         }
     }
 }

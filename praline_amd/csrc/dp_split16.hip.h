@@ -709,21 +709,9 @@ __global__ void k_split_f16(const float *__restrict__ src, int KP, int KS, int n
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int per_row = 2 * NR * 8;  // (hh, r, jj) triples per row
     if (idx >= rows_pad * per_row) return;  // (total is a multiple of 64: whole waves leave together)
-    const int64_t rowp = idx / per_row;
-    const int rem = (int)(idx % per_row);
-    const int hh = rem / (NR * 8), r = (rem / 8) % NR, jj = rem % 8;
-    const int k = 16 * r + 8 * hh + jj;
-    float v = 0.0f;
-    if (k < n_active) v = src[rowp * KP + (k & 1) * KS + (k >> 1)];
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
-    const int64_t half_elems = 2 * NR * 8;  // halves per (rowp, hh)
-    _Float16 *o = dst + (rowp * 2 + hh) * half_elems;
-    o[(0 * NR + r) * 8 + jj] = hi;
-    o[(1 * NR + r) * 8 + jj] = lo;
+    const bool inexact = split_f16_entry(src, KP, KS, n_active, NR, idx, dst);
     // flag == nullptr: the representability check was already done when the arena was created
     if (flag != nullptr) {
-        const bool inexact = (float)lo != 0.0f || (float)hi + (float)lo != v;
         if (__ballot(inexact) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
     }
 }

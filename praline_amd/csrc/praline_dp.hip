@@ -251,6 +251,14 @@ struct praline_arena {
 
 static int arena_launch_premultiply(praline_arena *a, bool check_f16 = false)
 {
+    if (!check_f16) {   // the recurring call: everything in one launch
+        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)(a->rows_pad / 32)), dim3(64), 0, g_rt.stream, a->d_raw.p, a->d_S.p,
+                           a->d_seq_of_rowp.p, a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, a->d_active.p, a->n_active,
+                           a->A, a->KP, a->KS, a->rows_pad, a->d_P.p, a->d_Q.p, a->nr16, (_Float16 *)a->d_P16.p,
+                           (_Float16 *)a->d_Q16.p);
+        HIPCHK(hipGetLastError());
+        return PRALINE_OK;
+    }
     const int64_t total = a->rows_pad * a->KP;
     const int threads = 256;
     const int64_t blocks = (total + threads - 1) / threads;

@@ -483,3 +483,26 @@ def test_edge_cases_vs_oracle(nat, bba):
         assert s_dev == np.float32(s_or) and s_tb == np.float32(s_or), mode
         assert np.array_equal(p_tb, p_or), mode
     arena.close()
+
+
+@pytest.mark.parametrize("kind", ["onehot", "profile"])
+def test_premultiply_relaunch_is_idempotent(nat, bba, kind):
+    """praline_arena_premultiply (pack + P.S^T + f16 split in one launch) must reproduce exactly what arena
+    creation computed with the separate kernels: same scores, same match-score matrices."""
+    rng = np.random.default_rng(53)
+    lens = [1, 31, 32, 33, 64, 97, 130]
+    profs = [one_hot(rng.integers(0, 20, L), 27) if kind == "onehot" else synth_profile(rng, L)[0] for L in lens]
+    arena = nat.Arena(profs, bba["S"])
+    pairs = all_pairs(len(lens))
+    plan = nat.Plan(arena, pairs)
+    plan.run("global", *GAPS)
+    before = plan.scores().copy()
+    m_before = [arena.match_scores(2, 6, k).copy() for k in (0, 1)]
+    for _ in range(2):
+        arena.premultiply()
+    plan.run("global", *GAPS)
+    assert np.array_equal(bits(plan.scores()), bits(before))
+    for k in (0, 1):
+        assert np.array_equal(bits(arena.match_scores(2, 6, k)), bits(m_before[k]))
+    plan.close()
+    arena.close()
