@@ -169,20 +169,39 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         // state are located only inside the update block, which a wave-level vote skips almost always.
         // Inside one strip rows ascend, so a tie only wins with a smaller row (a later strip); ties between
         // the two halves of a pair are resolved when their results are combined.
-        float rowH = max3f(Mp[0], Up[0], Lp[0]);
+        // With strictly negative gap scores U and L are always smaller than some earlier M (U = M' + go + k ge), so the
+        // maximum of o is attained by M cells only (never tied by a U or L cell): 8 ops per row instead of 31.
+        if (go < 0.0f && ge < 0.0f) {
+            const float r0 = max3f(Mp[0], Mp[1], Mp[2]), r1 = max3f(Mp[3], Mp[4], Mp[5]), r2 = max3f(Mp[6], Mp[7], Mp[8]);
+            const float r3 = max3f(Mp[9], Mp[10], Mp[11]), r4 = max3f(Mp[12], Mp[13], Mp[14]);
+            const float rowH = max3f(max3f(r0, r1, r2), max3f(r3, r4, Mp[15]), PRALINE_NEG_INF);
+            const bool better = rowH > best_run || (rowH == best_run && yy < best_y);
+            if (__ballot(better) != 0ull) {
+                if (better) {
+                    best_run = rowH;
+                    best_y = yy;
+                    best_k = 0;
 #pragma unroll
-        for (int c = 1; c < 16; ++c) rowH = __builtin_fmaxf(rowH, max3f(Mp[c], Up[c], Lp[c]));
-        const bool better = rowH > best_run || (rowH == best_run && yy < best_y);
-        if (__ballot(better) != 0ull) {
-            if (better) {
-                best_run = rowH;
-                best_y = yy;
+                    for (int c = 15; c >= 0; --c)   // descending: the smallest column with the maximum wins
+                        if (Mp[c] == rowH) best_x = xb + c + 1;
+                }
+            }
+        } else {
+            float rowH = max3f(Mp[0], Up[0], Lp[0]);
 #pragma unroll
-                for (int c = 15; c >= 0; --c)   // descending: the smallest column with the maximum wins
-                    if (max3f(Mp[c], Up[c], Lp[c]) == rowH) {
-                        best_x = xb + c + 1;
-                        best_k = (Mp[c] == rowH) ? 0 : ((Up[c] == rowH) ? 1 : 2);
-                    }
+            for (int c = 1; c < 16; ++c) rowH = __builtin_fmaxf(rowH, max3f(Mp[c], Up[c], Lp[c]));
+            const bool better = rowH > best_run || (rowH == best_run && yy < best_y);
+            if (__ballot(better) != 0ull) {
+                if (better) {
+                    best_run = rowH;
+                    best_y = yy;
+#pragma unroll
+                    for (int c = 15; c >= 0; --c)   // descending: the smallest column with the maximum wins
+                        if (max3f(Mp[c], Up[c], Lp[c]) == rowH) {
+                            best_x = xb + c + 1;
+                            best_k = (Mp[c] == rowH) ? 0 : ((Up[c] == rowH) ? 1 : 2);
+                        }
+                }
             }
         }
     }

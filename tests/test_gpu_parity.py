@@ -278,6 +278,35 @@ def test_batch_random_vs_oracle(nat, bba, kind):
     arena.close()
 
 
+@pytest.mark.parametrize("gaps", [(0.0, 0.0), (-3.0, 0.0), (0.0, -2.0), (-1.0, -1.0), (-4.5, -0.25)])
+def test_unusual_gap_scores_vs_oracle(nat, bba, gaps):
+    """Zero gap scores make U and L tie with M everywhere (end-cell and traceback tie-breaks; the local
+    kernel's M-only maximum is valid for strictly negative gap scores only and must not be used here)."""
+    rng = np.random.default_rng(int(-gaps[0] * 8 - gaps[1] * 64) + 5)
+    N = 14
+    lens = synth_lengths(rng, N, 60)
+    lens[0], lens[1] = 1, 33
+    profs = [one_hot(rng.integers(0, 20, L), 27) for L in lens]
+    arena = nat.Arena(profs, bba["S"])
+    pairs = np.array([(i, j) for i in range(N) for j in range(N) if (i + 2 * j) % 3 == 0], dtype=np.int32)
+    for mode in MODES:
+        plan = nat.Plan(arena, pairs, want_paths=True)
+        pk = plan.match_kind()
+        plan.run(mode, *gaps)
+        sc, paths = plan.scores(), plan.paths()
+        plan.close()
+        plan0 = nat.Plan(arena, pairs)
+        plan0.run(mode, *gaps)
+        assert np.array_equal(bits(sc), bits(plan0.scores())), (mode, gaps)
+        plan0.close()
+        for k in range(len(pairs)):
+            i, j = pairs[k]
+            s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(i, j, pk), gaps)
+            assert sc[k] == np.float32(s_or), (mode, gaps, i, j)
+            assert np.array_equal(paths[k], p_or), (mode, gaps, i, j)
+    arena.close()
+
+
 @pytest.mark.parametrize("kind", ["onehot", "profile", "dna"])
 def test_operand_stream_variants_agree_bitwise(nat, bba, kind, monkeypatch):
     """k_dp_split16 has three sources for the sequence-one operands (LDS one-hot table, LDS-staged
