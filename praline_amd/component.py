@@ -427,32 +427,66 @@ def merge_order(distance_matrix, linkage):
     clusters with the smallest linkage distance (first minimum in cluster-id order, both (i, j) and (j, i)
     present), the merged cluster keeps the id of the first.
 
-    Linkage distances are evaluated exactly as the reference does - reduce(d[ix_(ci, cj)]) per ordered
-    pair, so a float32 mean keeps its summation order - but only for the cluster that changed: the other
-    entries of the previous round are reused (they would be recomputed to the same values).  O(N^2) reduce
-    calls in total instead of O(N^3)."""
-    d = np.asarray(distance_matrix, dtype=float)
-    reduce_fn = {'single': np.min, 'complete': np.max, 'average': np.mean}[linkage]
+    The reference rebuilds the whole cluster-by-cluster table from the N x N distances every round
+    (O(N^4) element reads over a run; minutes at N = 400, days at N = 4096).  Here the table lives across
+    rounds and a merge touches one row and one column: min / max of the two old rows for single / complete
+    linkage (order-free, exact), and for average linkage the float64 SUMS of the member distances are kept
+    and divided by the member count, which is what `a.mean()` evaluates (cluster.py:99-114).  Sums of
+    integer-valued distances - integer scoring - are exact in any order, so the table is bit-identical to the
+    reference's; for float scoring the sums may differ in the last bit of a float64 (from the reference's
+    pairwise summation order), which matters only between candidates closer than 1e-16 relative.
+    The first minimum is found from per-row (value, column) minima that are only recomputed for the rows
+    whose minimum pointed at one of the two merged clusters: O(N^2) work in total for typical inputs."""
+    d = np.array(distance_matrix, dtype=float)
     n = d.shape[0]
-    members = {i: [i] for i in range(n)}
-    alive = list(range(n))
-    link = np.full((n, n), np.inf)          # link[i, j] for live cluster ids, by id
-    if n > 1:
-        link[:, :] = d
-        np.fill_diagonal(link, np.inf)
+    if linkage not in ('single', 'complete', 'average'):
+        raise KeyError(linkage)
+    if n < 2:
+        return []
+    link = d.copy()
+    np.fill_diagonal(link, np.inf)
+    sums, size = (d, np.ones(n)) if linkage == 'average' else (None, None)
+    alive = np.ones(n, dtype=bool)
+    row_val = link.min(axis=1)
+    row_col = link.argmin(axis=1)              # first minimum of the row = lowest cluster id
     order = []
-    while len(alive) > 1:
-        sub = link[np.ix_(alive, alive)]
-        x, y = np.unravel_index(sub.argmin(), sub.shape)
-        one, two = alive[x], alive[y]
-        members[one] = members[one] + members[two]
-        del members[two]
-        alive.remove(two)
-        for c in alive:
-            if c != one:
-                link[one, c] = reduce_fn(d[np.ix_(members[one], members[c])])
-                link[c, one] = reduce_fn(d[np.ix_(members[c], members[one])])
+    for _ in range(n - 1):
+        one = int(row_val.argmin())            # first row holding the smallest value
+        two = int(row_col[one])
         order.append((one, two))
+        if linkage == 'average':
+            sums[one, :] += sums[two, :]
+            sums[:, one] += sums[:, two]
+            size[one] += size[two]
+            with np.errstate(invalid='ignore'):
+                new_row = sums[one, :] / (size[one] * size)
+                new_col = sums[:, one] / (size * size[one])
+        elif linkage == 'single':
+            new_row, new_col = np.minimum(link[one, :], link[two, :]), np.minimum(link[:, one], link[:, two])
+        else:
+            new_row, new_col = np.maximum(link[one, :], link[two, :]), np.maximum(link[:, one], link[:, two])
+        alive[two] = False
+        dead = ~alive
+        new_row[dead] = np.inf
+        new_col[dead] = np.inf
+        new_row[one] = new_col[one] = np.inf
+        link[one, :] = new_row
+        link[:, one] = new_col
+        link[two, :] = np.inf
+        link[:, two] = np.inf
+        row_val[two] = np.inf
+        # rows whose minimum sat in a column that changed or died: rescan; any other row can only have gained
+        # a new minimum in column `one`
+        rescan = alive & ((row_col == one) | (row_col == two))
+        rescan[one] = True
+        rows = np.flatnonzero(rescan)
+        sub = link[rows]
+        row_val[rows] = sub.min(axis=1)
+        row_col[rows] = sub.argmin(axis=1)
+        v = link[:, one]
+        better = alive & ~rescan & ((v < row_val) | ((v == row_val) & (one < row_col)))
+        row_val[better] = v[better]
+        row_col[better] = one
     return order
 
 

@@ -262,9 +262,9 @@ def test_fasta_io_round_trip(tmp_path):
 
 
 def test_merge_order_incremental_equals_full_recomputation():
-    """merge_order caches linkage distances between rounds; the reference recomputes the whole table every
-    round (cluster.py:27-114).  Same reduce calls, so the orders must be identical - also on tie-heavy
-    integer matrices, where the first-minimum rule decides."""
+    """merge_order keeps the linkage table (and per-row minima) across rounds; the reference recomputes the
+    whole table every round (cluster.py:27-114).  The orders must be identical - also on tie-heavy integer
+    matrices, where the first-minimum rule decides, and on asymmetric ones."""
     def full(distance_matrix, linkage):
         d = np.asarray(distance_matrix, dtype=float)
         reduce_fn = {'single': np.min, 'complete': np.max, 'average': np.mean}[linkage]
@@ -283,10 +283,12 @@ def test_merge_order_incremental_equals_full_recomputation():
             order.append((ids[i], ids[j]))
         return order
     rng = np.random.default_rng(0)
-    for n in (1, 2, 3, 7, 24):
+    for n in (1, 2, 3, 7, 24, 48):
         for ties in (True, False):
-            m = rng.integers(0, 6, (n, n)).astype(np.float32) if ties else rng.random((n, n)).astype(np.float32)
-            m = m + m.T
-            np.fill_diagonal(m, 0)
-            for linkage in ('single', 'complete', 'average'):
-                assert comp.merge_order(m, linkage) == full(m, linkage), (n, ties, linkage)
+            for symmetric in (True, False):   # the reference evaluates (i, j) and (j, i) separately
+                m = rng.integers(0, 6, (n, n)).astype(np.float32) if ties else rng.random((n, n)).astype(np.float32)
+                if symmetric:
+                    m = m + m.T
+                np.fill_diagonal(m, 0)
+                for linkage in ('single', 'complete', 'average'):
+                    assert comp.merge_order(m, linkage) == full(m, linkage), (n, ties, symmetric, linkage)
