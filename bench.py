@@ -55,6 +55,79 @@ def synth_profile(rng, L):
     return np.array(counts / totals[:, np.newaxis], dtype=np.float32)
 
 
+def cpu_threads():
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # the GPU box gives one GPU a share of 16 host cores; do not oversubscribe it
+    return int(os.environ.get("BENCH_CPU_THREADS", min(threads, 16)))
+
+
+class ReferenceCpuBaseline:
+    """cpu_baseline kind "reference": oracle/ref_baseline.py children run the reference's own compiled cext
+    (oracle/_ref) over evenly spaced pairs, one process per core as the reference itself scales.  The
+    children are started BEFORE this process initialises the GPU (no fork/exec afterwards), idle on stdin
+    during the timed region and are released by `run`; they use neither the GPU nor /root/reference."""
+
+    def __init__(self, workers, seconds, mode):
+        import glob
+        import subprocess
+        self.workers, self.seconds, self.mode, self.procs = workers, seconds, mode, []
+        if mode not in ("global", "local") or not glob.glob(os.path.join(ROOT, "oracle", "_ref", "cext*.so")):
+            return
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        self.procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "ref_baseline.py"), "-",
+                                        str(w), str(workers), str(seconds), mode],
+                                       stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+                      for w in range(workers)]
+
+    def close(self):
+        for p in self.procs:
+            if p.poll() is None:
+                p.stdin.close()
+        for p in self.procs:
+            p.wait()
+        self.procs = []
+
+    def run(self, arena_cat, row_off, lens, S, pairs, gpu_scores):
+        if not self.procs:
+            return None
+        import tempfile
+        n = int(min(len(pairs), self.workers * 4096))
+        idx = np.linspace(0, len(pairs) - 1, n).astype(np.int64)
+        outs = []
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "batch.npz")
+            np.savez(path, arena=arena_cat, row_off=row_off, lens=lens, S=S, pairs=pairs[idx],
+                     gaps=np.array([GAP_OPEN, GAP_EXTEND], dtype=np.float32))
+            for p in self.procs:
+                p.stdin.write((path + "\n").encode())
+                p.stdin.flush()
+            for p in self.procs:
+                so, _ = p.communicate()
+                if p.returncode == 0 and so.strip():
+                    outs.append(json.loads(so.decode().strip().splitlines()[-1]))
+        ok = len(outs) == len(self.procs)
+        self.procs = []
+        if not ok:
+            return None
+        done = np.concatenate([np.asarray(o["pairs"], dtype=np.int64) for o in outs])
+        ref_scores = np.concatenate([np.asarray(o["scores"], dtype=np.float64) for o in outs])
+        max_rel = float(np.max(np.abs(gpu_scores[idx[done]] - ref_scores) / np.maximum(1.0, np.abs(ref_scores))))
+        return {
+            "value": sum(o["cells"] / o["seconds"] for o in outs) / 1e9, "unit": "GCUPS", "cores": self.workers,
+            "kind": "reference",
+            "sample": "%d of %d pairs (evenly spaced), %d processes x %.1f s, oracle/_ref = the reference's own "
+                      "praline/util/cext.c (cext_build_scores + cext_align_%s + numpy boundary init / end cell "
+                      "per pair; nonzero index matrices prebuilt per sequence)" % (
+                          len(done), len(pairs), self.workers, max(o["seconds"] for o in outs), self.mode),
+            "max_rel_diff_vs_gpu": max_rel,
+            "value_1_process": float(np.mean([o["cells"] / o["seconds"] for o in outs])) / 1e9,
+        }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +147,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+
+    ref_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ref_baseline = ReferenceCpuBaseline(cpu_threads(), args.cpu_seconds, args.mode)
 
     import torch
     from praline_amd import native
@@ -243,13 +320,7 @@ def main():
     # ---- CPU baseline: the oracle (C restatement of the reference path) on the host cores ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
-        threads = os.cpu_count() or 1
-        try:
-            threads = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
-        # the GPU box gives one GPU a share of 16 host cores; do not oversubscribe it
-        threads = int(os.environ.get("BENCH_CPU_THREADS", min(threads, 16)))
+        threads = cpu_threads()
         arena_cat = np.concatenate(profs, axis=0)
         row_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
 
@@ -276,7 +347,7 @@ def main():
         t_a = time.perf_counter()
         orc.batch_scores(args.mode, arena_cat, row_off, lens.astype(np.int32), S, pairs[idx1], GAP_OPEN, GAP_EXTEND, threads=1)
         dt1 = time.perf_counter() - t_a
-        out["cpu_baseline"] = {
+        port = {
             "value": sample_cells / (tc1 - tc0) / 1e9, "unit": "GCUPS", "cores": threads,
             "kind": "port",
             "sample": "%d of %d pairs (evenly spaced), %.1f s, oracle/praline_oracle.c "
@@ -285,6 +356,16 @@ def main():
             "max_rel_diff_vs_gpu": max_rel,
             "value_1_thread": int(cells[idx1].sum()) / dt1 / 1e9,
         }
+        # the REAL reference C extension (oracle/_ref, built from the reference's own cext.c), one child
+        # process per core as the reference itself scales; falls back to the port when _ref is absent
+        ref = ref_baseline.run(arena_cat, row_off, lens, S, pairs, d_slice.cpu().numpy())
+        if ref is not None:
+            ref["port"] = port
+            out["cpu_baseline"] = ref
+        else:
+            out["cpu_baseline"] = port
+    if ref_baseline is not None:
+        ref_baseline.close()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
