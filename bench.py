@@ -186,7 +186,10 @@ def main():
 
     arena = native.Arena(profs, S)
     plan = native.Plan(arena, my_pairs)
-    d_slice = torch.zeros(slice_len, dtype=torch.float32, device="cuda")
+    # two score buffers: step k + 1 computes into the other one while step k's slice is still being gathered
+    d_slices = [torch.zeros(slice_len, dtype=torch.float32, device="cuda") for _ in range(2)]
+    gathered = [None, None]
+    d_slice = d_slices[0]
     d_all = torch.zeros(slice_len * world, dtype=torch.float32, device="cuda") if dist is not None else None
     # gathered shard slot -> position in the reference's row-major pair order
     if dist is not None:
@@ -197,14 +200,20 @@ def main():
         d_ordered = torch.zeros(len(pairs), dtype=torch.float32, device="cuda")
     lib_stream = torch.cuda.ExternalStream(native.stream_handle())
 
-    def step():
+    def step(k):
+        buf = d_slices[k & 1]
+        if gathered[k & 1] is not None:
+            lib_stream.wait_event(gathered[k & 1])   # the gather that last read this buffer has finished
         arena.premultiply()
-        plan.run(args.mode, GAP_OPEN, GAP_EXTEND, d_scores=d_slice.data_ptr())
+        plan.run(args.mode, GAP_OPEN, GAP_EXTEND, d_scores=buf.data_ptr())
         if dist is not None:
             # the exchange step: all ranks obtain every score slice (RCCL all-gather over xGMI)
-            torch.cuda.current_stream().wait_stream(lib_stream)
-            dist.all_gather_into_tensor(d_all, d_slice)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(lib_stream)
+            dist.all_gather_into_tensor(d_all, buf)
             d_ordered[d_dst] = d_all[d_src]   # back into the reference's pair order (tree.py:142-145)
+            gathered[k & 1] = torch.cuda.Event()
+            gathered[k & 1].record(cur)
 
     def fence():
         if dist is not None:
@@ -212,15 +221,13 @@ def main():
         native.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if rank == 0 and len(kernel_ms) < 1:
-            pass
+    for k in range(args.steps):
+        step(args.warmup + k)
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
