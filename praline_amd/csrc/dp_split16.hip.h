@@ -166,20 +166,35 @@ __device__ __forceinline__ void stage_issue_bnd(unsigned long long curN, unsigne
 //   1  one-hot arenas: looked up in the one-hot operand table in LDS by the row's symbol (byte SB of symw)
 //   2  LDS-staged stream (see above): SB = t % 4 selects the ring slots; BOPS holds row t+1, BFILL
 //      receives row t+2 from LDS; the boundary value of the next step is read from LDS into bnd_pref
-template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int SB = 0>
+//
+// DM ("double MFMA", staged stream only): the two halves of the wave need the tiles of DIFFERENT rows (lower
+// half row t, upper half row t-1).  Without DM both tiles are kept and every lane selects its 16 values
+// (16 v_cndmask per step, 11 % of the VALU work).  With DM the tile is built for both at once: the A operand
+// is split by output row into aop (rows delivered to the lower half, zero elsewhere) and aopH (the complement),
+// and the accumulator receives mfma(aop, row t+1) + mfma(aopH, row t): each lane's 16 values are its own row's,
+// the extra products are exact zeros (x + 0 = x), the order of the real terms is unchanged -> same bits.
+// Used in exact mode only (NTERM = 1: two MFMAs per step instead of one, +4 % on C2 one-hot); with the three-term
+// split the six dependent MFMAs per step outweigh the selects (measured: 2224 -> 2050 GCUPS on C2 float profiles).
+template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int SB = 0, bool DM = false>
 __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                              float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
-                                             const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR], const char *&b_next,
+                                             const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR],
+                                             const float4 (&aopH)[(NTERM == 1 ? 1 : 2) * NR],    // DM only
+                                             const float4 (&BPREV)[(NTERM == 1 ? 1 : 2) * NR],   // DM only: row t
+                                             float4 (&BFILL)[(NTERM == 1 ? 1 : 2) * NR],         // staged stream: receives row t+2;
+                                                                                                 // one-hot table with DM: row t+4
+                                             const char *&b_next,
                                              int b_stride, const char *&bnd_ld, char *&bnd_st, float2 &bnd_pref,
                                              float (&Hs)[17], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
                                              float &best_run, float &col_run, float &out_best, float &out_rowmax, float &out_colmax,
                                              float &out_corner, float go, float ge, bool semiglobal, bool last_owner, int cidx,
                                              int xb, int L2, const char *onehot_lane = nullptr, unsigned symw = 0,
-                                             float4 *BFILL = nullptr, const char *stage_lds = nullptr,
+                                             const char *stage_lds = nullptr,
                                              const unsigned *stage_rd = nullptr, unsigned stage_rd_bnd = 0,
                                              const unsigned (*stage_gofs)[4] = nullptr, unsigned long long *stage_cur = nullptr,
                                              unsigned stage_lds_addr = 0, unsigned stage_gofs_n = 0, bool may_snap = true)
 {
+    static_assert(!DM || BSRC == 2 || BSRC == 1, "the double-MFMA tile is wired for the staged stream and the one-hot table");
     constexpr bool ONEHOT = BSRC == 1;
     // bnd_pref: this step's boundary value on entry; refilled with the value 3 rows ahead.
     // BOPS: B operands of row t+1 on entry; refilled with row t+4 (3-deep rings, the caller rotates
@@ -189,7 +204,10 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     // ---- match scores of this lane's row: lower half row t (CUR), upper half row t-1 (PREV) ----
     f2 m2[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { m2[c].x = h ? PREV[2 * c] : CUR[2 * c]; m2[c].y = h ? PREV[2 * c + 1] : CUR[2 * c + 1]; }
+    for (int c = 0; c < 8; ++c) {
+        if constexpr (DM) { m2[c].x = CUR[2 * c]; m2[c].y = CUR[2 * c + 1]; }
+        else { m2[c].x = h ? PREV[2 * c] : CUR[2 * c]; m2[c].y = h ? PREV[2 * c + 1] : CUR[2 * c + 1]; }
+    }
 
     const float2 bv = bnd_pref;
     if constexpr (BSRC == 2) {
@@ -227,6 +245,7 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         const int ib = (term == 1) ? NR + r : r;          // B piece: lo for term 1, hi otherwise
 #if !(PRALINE_S16_ABLATE & 4)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+        if constexpr (DM) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aopH[ia]), as_half8(BPREV[ib]), acc, 0, 0, 0);
 #else
         acc[k] += BOPS[ib].x * aop[ia].x;
 #endif
@@ -265,7 +284,10 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         const unsigned sym = (symw >> (8 * SB)) & 0xffu;
         const float4 *bsrc = reinterpret_cast<const float4 *>(onehot_lane + sym * onehot_stride(NR));
 #pragma unroll
-        for (int q = 0; q < NR; ++q) BOPS[q] = bsrc[q];
+        for (int q = 0; q < NR; ++q) {
+            if constexpr (DM) BFILL[q] = bsrc[q];   // into the registers of row t (consumed by this step's MFMAs)
+            else BOPS[q] = bsrc[q];
+        }
     } else {
 #if !(PRALINE_S16_ABLATE & 1)
         const float4 *bsrc = reinterpret_cast<const float4 *>(b_next);
@@ -303,6 +325,9 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
 // saturates the CU's texture-address path (measured: scripts/exp_step.py, 0.47 -> 0.32 us per step and
 // SIMD without these loads) - but looked up in a one-hot table in LDS by the row's symbol; the symbols
 // arrive as one dword per lane and four rows.
+#ifndef PRALINE_S16_DM
+#define PRALINE_S16_DM 1
+#endif
 #ifdef PRALINE_TRACE
 // experiments only (scripts/exp_trace.py): per wave {block, wave | share << 8, HW_ID, XCC_ID, start, end} (s_memtime)
 __device__ unsigned long long *praline_trace_buf = nullptr;
@@ -336,6 +361,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 #endif
     constexpr bool ONEHOT = BSRC == 1;
     constexpr bool STAGED = BSRC == 2;
+    constexpr bool DM = (STAGED || ONEHOT) && NTERM == 1 && (PRALINE_S16_DM != 0);   // one tile for both halves (see split16_step)
     static_assert(!ONEHOT || NTERM == 1, "the one-hot table path is an exact-mode path");
     __shared__ __attribute__((aligned(16))) char onehot_tab[ONEHOT ? onehot_bytes(NR) : 16];
     __shared__ __attribute__((aligned(16))) char stage_lds_all[STAGED ? WPG * stage_lds_bytes(NP * NR) : 16];
@@ -480,6 +506,21 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 #pragma unroll
             for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
         }
+        float4 aopH[NOP];
+        if constexpr (DM) {
+            // A row j feeds output row j; rows with (j >> 2) & 1 are the ones the upper half receives
+            // (bit masks, not vector selects: the compiler turns a select between float4 values into an indexed
+            // stack array)
+            const unsigned mh = 0u - (((unsigned)j >> 2) & 1u), ml = ~mh;
+#pragma unroll
+            for (int q = 0; q < NOP; ++q) {
+                const float4 a = aop[q];
+                aopH[q] = make_float4(__uint_as_float(__float_as_uint(a.x) & mh), __uint_as_float(__float_as_uint(a.y) & mh),
+                                      __uint_as_float(__float_as_uint(a.z) & mh), __uint_as_float(__float_as_uint(a.w) & mh));
+                aop[q] = make_float4(__uint_as_float(__float_as_uint(a.x) & ml), __uint_as_float(__float_as_uint(a.y) & ml),
+                                     __uint_as_float(__float_as_uint(a.z) & ml), __uint_as_float(__float_as_uint(a.w) & ml));
+            }
+        }
         float Hs[17], Uc[16];  // Hs[c + 1] = H[y-1] of this lane's column c; Hs[0] is handed in per row
         Hs[0] = PRALINE_NEG_INF;
 #pragma unroll
@@ -493,7 +534,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         float col_run = out_colmax;
 
         // pipeline prologue: B operands of rows 1..4, MFMAs of row 1, boundary column of rows 1..3
-        float4 b0[NOP], b1[NOP], b2[NOP];
+        float4 b0[NOP], b1[NOP], b2[NOP], b3[NOP];   // b3: one-hot table with DM (four sets: rows t .. t+3)
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
         unsigned d1 = 0, d2 = 0, d3 = 0, d4 = 0;  // ONEHOT: symbols of the rows the next 12 steps refill
@@ -531,6 +572,10 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(br1[ib]), accA, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DM) {
+#pragma unroll
+                for (int q = 0; q < NOP; ++q) b2[q] = br1[q];   // row 1 again: the upper half's share of the next tile
+            }
             // row 5 takes row 1's slot (its operands are in the accumulator now)
             stage_issue_rows<NOP>(cb, stage_gofs, stage_lds_addr + 1024 + 1 * SLOT);
             cb += 64 * NR;
@@ -553,7 +598,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                 s4 = reinterpret_cast<const float4 *>(pB + 3 * b_stride);
             }
 #pragma unroll
-            for (int q = 0; q < NOP; ++q) { br1[q] = s1[q]; b0[q] = s2[q]; b1[q] = s3[q]; b2[q] = s4[q]; }
+            for (int q = 0; q < NOP; ++q) { br1[q] = s1[q]; b0[q] = s2[q]; b1[q] = s3[q]; b2[q] = s4[q]; b3[q] = s1[q]; }
 #pragma unroll
             for (int k = 0; k < NTERM * NR; ++k) {
                 const int term = (NTERM == 1) ? 2 : k / NR;
@@ -568,25 +613,35 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         }
 
 #define PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, SYMW, SB)                                                          \
-        split16_step<NR, NTERM, LOCAL, BSRC, SB>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride, bnd_ld, \
+        split16_step<NR, NTERM, LOCAL, BSRC, SB>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, aop, BSET, BSET, b_next, b_stride, bnd_ld, \
                                        bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYMW, \
-                                       nullptr, nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
+                                       nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
 #define PRALINE_STEP16(T, CUR, PREV, BSET, PSLOT) PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, d1, 0)
+        // one-hot table with DM: BUSE holds row T+1, BOLD row T (refilled with row T+4 once its MFMAs are issued)
+#define PRALINE_STEP16XD(T, CUR, PREV, BUSE, BOLD, PSLOT, SYMW, SB)                                                   \
+        split16_step<NR, NTERM, LOCAL, BSRC, SB, true>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BOLD, BOLD, b_next, b_stride, bnd_ld, \
+                                       bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
+                                       out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYMW, \
+                                       nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
         // staged stream: BUSE holds row T+1, BFILL receives row T+2, PH = T % 4
-#define PRALINE_STEP16S(T, CUR, PREV, BUSE, BFILL, PH)                                                                \
-        split16_step<NR, NTERM, LOCAL, 2, PH>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, b_next, b_stride, bnd_ld,  \
+#define PRALINE_STEP16D(T, CUR, PREV, BUSE, BFILL, PH, BOLD) PRALINE_STEP16Y(T, CUR, PREV, BUSE, BFILL, PH, BOLD, DM)
+#define PRALINE_STEP16Y(T, CUR, PREV, BUSE, BFILL, PH, BOLD, DMF)                                                     \
+        split16_step<NR, NTERM, LOCAL, 2, PH, DMF>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BOLD, BFILL, b_next, b_stride, bnd_ld,  \
                                        bnd_st, p0, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,     \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, 0u, \
-                                       BFILL, stage_lds, stage_rd, stage_rd_bnd, &stage_gofs, stage_cur, stage_lds_addr, stage_gofs_n, \
+                                       stage_lds, stage_rd, stage_rd_bnd, &stage_gofs, stage_cur, stage_lds_addr, stage_gofs_n, \
                                        (T) >= min_l1)
+#define PRALINE_STEP16S(T, CUR, PREV, BUSE, BFILL, PH) PRALINE_STEP16Y(T, CUR, PREV, BUSE, BFILL, PH, BUSE, false)
         // step 1: only the lower half has a row; the upper half's garbage is undone right after
         {
             float Hsave[17];
 #pragma unroll
             for (int c = 0; c < 17; ++c) Hsave[c] = Hs[c];
             const float best_s = best_run, col_s = col_run;
-            if constexpr (STAGED) PRALINE_STEP16S(1, accA, accB, b0, b1, 1);
+            if constexpr (DM && ONEHOT) PRALINE_STEP16XD(1, accA, accB, b0, b3, p0, d1, 0);
+            else if constexpr (DM) PRALINE_STEP16D(1, accA, accB, b0, b1, 1, b2);
+            else if constexpr (STAGED) PRALINE_STEP16S(1, accA, accB, b0, b1, 1);
             else PRALINE_STEP16(1, accA, accB, b0, p0);
             if (h) {
 #pragma unroll
@@ -605,6 +660,21 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                 if constexpr (MW) {
                     if (share > 1) { __builtin_amdgcn_s_barrier(); --mw_left; }
                 }
+                if constexpr (DM) {
+                    // operand sets: (row t, row t+1, row t+2 arriving) rotate with period 3
+                    PRALINE_STEP16D(t, accB, accA, b1, b2, 2, b0);
+                    PRALINE_STEP16D(t + 1, accA, accB, b2, b0, 3, b1);
+                    PRALINE_STEP16D(t + 2, accB, accA, b0, b1, 0, b2);
+                    PRALINE_STEP16D(t + 3, accA, accB, b1, b2, 1, b0);
+                    PRALINE_STEP16D(t + 4, accB, accA, b2, b0, 2, b1);
+                    PRALINE_STEP16D(t + 5, accA, accB, b0, b1, 3, b2);
+                    PRALINE_STEP16D(t + 6, accB, accA, b1, b2, 0, b0);
+                    PRALINE_STEP16D(t + 7, accA, accB, b2, b0, 1, b1);
+                    PRALINE_STEP16D(t + 8, accB, accA, b0, b1, 2, b2);
+                    PRALINE_STEP16D(t + 9, accA, accB, b1, b2, 3, b0);
+                    PRALINE_STEP16D(t + 10, accB, accA, b2, b0, 0, b1);
+                    PRALINE_STEP16D(t + 11, accA, accB, b0, b1, 1, b2);
+                } else {
                 PRALINE_STEP16S(t, accB, accA, b1, b0, 2);
                 PRALINE_STEP16S(t + 1, accA, accB, b0, b1, 3);
                 PRALINE_STEP16S(t + 2, accB, accA, b1, b0, 0);
@@ -617,6 +687,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                 PRALINE_STEP16S(t + 9, accA, accB, b0, b1, 3);
                 PRALINE_STEP16S(t + 10, accB, accA, b1, b0, 0);
                 PRALINE_STEP16S(t + 11, accA, accB, b0, b1, 1);
+                }
             }
         } else if constexpr (ONEHOT) {
             // twelve per iteration: the step at t refills the operands of row t + 4, i.e. symbol t + 3 of
@@ -626,6 +697,20 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
             for (int t = 2; t <= max_l1 + 1; t += 12) {
                 const unsigned n2 = pn[0], n3 = pn[1], n4 = pn[2];
                 pn += 3;
+                if constexpr (DM) {
+                    PRALINE_STEP16XD(t, accB, accA, b1, b0, p1, d1, 1);
+                    PRALINE_STEP16XD(t + 1, accA, accB, b2, b1, p2, d1, 2);
+                    PRALINE_STEP16XD(t + 2, accB, accA, b3, b2, p0, d1, 3);
+                    PRALINE_STEP16XD(t + 3, accA, accB, b0, b3, p1, d2, 0);
+                    PRALINE_STEP16XD(t + 4, accB, accA, b1, b0, p2, d2, 1);
+                    PRALINE_STEP16XD(t + 5, accA, accB, b2, b1, p0, d2, 2);
+                    PRALINE_STEP16XD(t + 6, accB, accA, b3, b2, p1, d2, 3);
+                    PRALINE_STEP16XD(t + 7, accA, accB, b0, b3, p2, d3, 0);
+                    PRALINE_STEP16XD(t + 8, accB, accA, b1, b0, p0, d3, 1);
+                    PRALINE_STEP16XD(t + 9, accA, accB, b2, b1, p1, d3, 2);
+                    PRALINE_STEP16XD(t + 10, accB, accA, b3, b2, p2, d3, 3);
+                    PRALINE_STEP16XD(t + 11, accA, accB, b0, b3, p0, d4, 0);
+                } else {
                 PRALINE_STEP16X(t, accB, accA, b1, p1, d1, 1);
                 PRALINE_STEP16X(t + 1, accA, accB, b2, p2, d1, 2);
                 PRALINE_STEP16X(t + 2, accB, accA, b0, p0, d1, 3);
@@ -638,6 +723,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                 PRALINE_STEP16X(t + 9, accA, accB, b1, p1, d3, 2);
                 PRALINE_STEP16X(t + 10, accB, accA, b2, p2, d3, 3);
                 PRALINE_STEP16X(t + 11, accA, accB, b0, p0, d4, 0);
+                }
                 d1 = d4; d2 = n2; d3 = n3; d4 = n4;
             }
         } else {
@@ -652,7 +738,10 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         }
 #undef PRALINE_STEP16
 #undef PRALINE_STEP16S
+#undef PRALINE_STEP16D
+#undef PRALINE_STEP16Y
 #undef PRALINE_STEP16X
+#undef PRALINE_STEP16XD
     }
 
     if constexpr (STAGED) PRALINE_VMCNT(0);  // no DMA may be in flight when the wave ends
