@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
-    static_assert(WPG == 1 || (WPG == 4 && BSRC == 2), "four-wave workgroups use the staged stream");
+    static_assert(WPG == 1 || (WPG == 4 && BSRC != 0), "four-wave workgroups use the staged stream or the one-hot table");
     constexpr bool MW = WPG > 1;
 #ifdef PRALINE_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memtime();

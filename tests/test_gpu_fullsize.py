@@ -130,6 +130,16 @@ def test_c4_rank_share_full_size(nat, bba):
     for k in rng.integers(0, len(mine), 5):
         i, j = mine[k]
         assert sc[k] == np.float32(orc.pairwise_score_fast("global", one_hot(vals[i], 27), one_hot(vals[j], 27), S, GO, GE))
+    # the other modes on the full shard (local runs the one-hot table kernel in four-wave workgroups)
+    for mode in ("local", "semiglobal_both"):
+        plan = nat.Plan(arena, mine)
+        plan.run(mode, GO, GE)
+        scm = plan.scores()
+        plan.close()
+        assert np.isfinite(scm).all() and (scm >= sc).all()      # both only free something the global path pays for
+        for k in rng.integers(0, len(mine), 5):
+            i, j = mine[k]
+            assert scm[k] == np.float32(orc.pairwise_score_fast(mode, one_hot(vals[i], 27), one_hot(vals[j], 27), S, GO, GE)), mode
     arena.close()
     # float profiles on a 150 k-pair part of the same shard
     profs = [synth_profile(rng, int(L))[0] for L in lens]
