@@ -175,7 +175,7 @@ __device__ __forceinline__ void stage_issue_bnd(unsigned long long curN, unsigne
 // the extra products are exact zeros (x + 0 = x), the order of the real terms is unchanged -> same bits.
 // Used in exact mode only (NTERM = 1: two MFMAs per step instead of one, +4 % on C2 one-hot); with the three-term
 // split the six dependent MFMAs per step outweigh the selects (measured: 2224 -> 2050 GCUPS on C2 float profiles).
-template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int SB = 0, bool DM = false>
+template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int SB = 0, bool DM = false, bool SNAPBR = false>
 __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                              float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
                                              const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR],
@@ -308,6 +308,10 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     // may_snap (wave-uniform): this step can be some lane's last row (the task's pairs are sorted by length, so
     // for most of a strip it cannot, and a scalar branch replaces the per-lane test)
     if (may_snap && have_pair && yy == L1) {
+        // SNAPBR: keep this a real branch.  In the one-wave LOCAL kernels only out_best is live here; the compiler
+        // turns the block into a select, the twelve unrolled steps fuse into one basic block and the scheduler
+        // takes 256 VGPRs + ~110 AGPRs for it (one wave per SIMD); with the branch kept: ~190 VGPRs, two waves.
+        if constexpr (SNAPBR) asm volatile("");
         if (LOCAL) out_best = best_run;
         if (semiglobal) {
 #pragma unroll
@@ -354,8 +358,9 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
-    static_assert(WPG == 1 || (WPG == 4 && BSRC != 0), "four-wave workgroups use the staged stream or the one-hot table");
+    static_assert(WPG == 1 || (WPG == 4 && BSRC == 2), "four-wave workgroups use the staged stream");
     constexpr bool MW = WPG > 1;
+    constexpr bool SNAPBR = LOCAL && !MW;   // see split16_step
 #ifdef PRALINE_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -613,21 +618,21 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         }
 
 #define PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, SYMW, SB)                                                          \
-        split16_step<NR, NTERM, LOCAL, BSRC, SB>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, aop, BSET, BSET, b_next, b_stride, bnd_ld, \
+        split16_step<NR, NTERM, LOCAL, BSRC, SB, false, SNAPBR>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, aop, BSET, BSET, b_next, b_stride, bnd_ld, \
                                        bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYMW, \
                                        nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
 #define PRALINE_STEP16(T, CUR, PREV, BSET, PSLOT) PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, d1, 0)
         // one-hot table with DM: BUSE holds row T+1, BOLD row T (refilled with row T+4 once its MFMAs are issued)
 #define PRALINE_STEP16XD(T, CUR, PREV, BUSE, BOLD, PSLOT, SYMW, SB)                                                   \
-        split16_step<NR, NTERM, LOCAL, BSRC, SB, true>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BOLD, BOLD, b_next, b_stride, bnd_ld, \
+        split16_step<NR, NTERM, LOCAL, BSRC, SB, true, SNAPBR>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BOLD, BOLD, b_next, b_stride, bnd_ld, \
                                        bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYMW, \
                                        nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
         // staged stream: BUSE holds row T+1, BFILL receives row T+2, PH = T % 4
 #define PRALINE_STEP16D(T, CUR, PREV, BUSE, BFILL, PH, BOLD) PRALINE_STEP16Y(T, CUR, PREV, BUSE, BFILL, PH, BOLD, DM)
 #define PRALINE_STEP16Y(T, CUR, PREV, BUSE, BFILL, PH, BOLD, DMF)                                                     \
-        split16_step<NR, NTERM, LOCAL, 2, PH, DMF>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BOLD, BFILL, b_next, b_stride, bnd_ld,  \
+        split16_step<NR, NTERM, LOCAL, 2, PH, DMF, SNAPBR>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BOLD, BFILL, b_next, b_stride, bnd_ld,  \
                                        bnd_st, p0, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,     \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, 0u, \
                                        stage_lds, stage_rd, stage_rd_bnd, &stage_gofs, stage_cur, stage_lds_addr, stage_gofs_n, \

@@ -14,18 +14,6 @@ template <int NR, int NTERM> static void launch16(const LaunchArgs &la, const Ar
                        la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks)
     if constexpr (NTERM == 1) {
         if (a16.sym8 != nullptr) {  // one-hot arena: operand table in LDS
-            if (la.wg != nullptr) {
-                // four independent tasks per workgroup (wg_singles): the same code, but the compiler keeps this
-                // form at two waves per SIMD where the one-wave LOCAL kernel ends up with 256 + 101 registers
-                const dim3 g4(la.n_wg), b4(256);
-                if (local)
-                    hipLaunchKernelGGL((k_dp_split16<NR, NTERM, true, 1, 4>), g4, b4, 0, la.stream, a16, la.tasks, la.lane_one,
-                                       la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
-                else
-                    hipLaunchKernelGGL((k_dp_split16<NR, NTERM, false, 1, 4>), g4, b4, 0, la.stream, a16, la.tasks, la.lane_one,
-                                       la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
-                return;
-            }
             if (local) PRALINE_LAUNCH16(true, 1, grid, block); else PRALINE_LAUNCH16(false, 1, grid, block);
             return;
         }

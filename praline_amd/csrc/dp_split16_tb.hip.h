@@ -153,6 +153,9 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             md = Mp[c]; ud = Up[c]; ld = Lp[c];
             Mp[c] = M; Up[c] = U; Lp[c] = Lc;
             mleft = M; lleft = Lc;
+#ifdef PRALINE_TB_SB_COLS
+            if ((c + 1) % PRALINE_TB_SB_COLS == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -670,18 +670,14 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             la.n_wg = (unsigned)pl.wg.size();
             a16.sym8 = nullptr;
         }
-        // large batches: four independent tasks per workgroup for LOCAL mode (see wg_singles) and for arenas
-        // without the one-hot table (measured, float profiles, global: +0..6 %; one-hot arenas are faster on the
-        // table path: 4.38 vs 3.14 TCUPS, and in LOCAL mode the table kernel itself runs in this four-wave form:
-        // 3.07 -> 3.90 TCUPS on a C4 rank share; global / semiglobal: no difference, they keep one wave per group)
-        else if ((local || a16.sym8 == nullptr) && !pl.wg_singles.empty() && la.a16 != nullptr && a16.stage &&
+        // large batches: four independent tasks per workgroup (wg_singles) for arenas without the one-hot table
+        // (measured, float profiles: +0..6 %); one-hot arenas are faster on the table path in every mode (C4 rank
+        // share: 4.4 TCUPS global, 4.0 local against 3.1 on this list)
+        else if (a16.sym8 == nullptr && !pl.wg_singles.empty() && la.a16 != nullptr && a16.stage &&
                  !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')) {
             if (!pl.d_wg_singles.p) { RC(pl.d_wg_singles.upload(pl.wg_singles, st)); }
             la.wg = pl.d_wg_singles.p;
             la.n_wg = (unsigned)pl.wg_singles.size();
-            // one-hot arenas keep the table path (sym8) inside the four-wave workgroups; every descriptor of
-            // this list has share = 1, which is all the table path supports
-            if (getenv("PRALINE_SINGLES_STAGED") && getenv("PRALINE_SINGLES_STAGED")[0] == '1') a16.sym8 = nullptr;
         }
         HIPCHK(hipEventRecord(g_rt.ev0, st));
         RC(launch_dp(a.nstep, la, pl.tp, local, 0, false));
