@@ -4,9 +4,11 @@
 // The three states are carried separately so ties resolve exactly as get_paths does
 // (praline/util/align.py:161-174: first set flag in the order MM, MU, ML / UO, UE / LO, LE): the
 // candidate sums are formed individually and compared with == as in praline/util/cext.c:224-295.
-// Per lane and DP row two words are stored (16 x 2-bit match source 1 MM / 2 MU / 3 ML / 0 stop; 16 bits
-// "U from extend" | 16 bits "L from extend" << 16) = 8 bytes per 16 cells:
-//     tb2[(strip * tb_rows + y) * 64 + lane] = { code_c << 2c,  ubit_c << c | lbit_c << (16 + c) }
+// Per lane and DP row two words are stored (match source; 16 bits "U from extend" | 16 bits "L from extend"
+// << 16) = 8 bytes per 16 cells:
+//     tb2[(strip * tb_rows + y) * 64 + lane] = { source word,  ubit_c << c | lbit_c << (16 + c) }
+// source word, local mode:  code_c << 2c with code 1 MM / 2 MU / 3 ML / 0 stop (the clamp won);
+//              other modes: notMM_c << c | notMU_c << (16 + c)  (first match MM, then MU, else ML; never a stop)
 // lane j holds strip columns 1..16, lane j + 32 columns 17..32 of pair j.
 // Zero rectangles (Waterman-Eggert, praline/component/preprofile.py:247-255) force M = U = L = 0 and
 // stop codes (cext.c:141-149).  End cells: the global corner triple, the local first argmax and the
@@ -111,7 +113,9 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             zmask |= in ? ((0xffffu >> (15 - hi)) & (0xffffu << lo)) : 0u;
         }
     }
-    unsigned w_code = 0, w_u = 0, w_l = 0;  // 16 x 2-bit match sources; U-extend / L-extend bits, column c in bit 15 - c
+    // LOCAL: w_code = 16 x 2-bit match sources; otherwise w_code / w_nu = "not MM" / "not MU" bits.  U-extend /
+    // L-extend bits in w_u / w_l.  The shifted-in words hold column c in bit 15 - c (reversed once per row below).
+    unsigned w_code = 0, w_nu = 0, w_u = 0, w_l = 0;
     __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -138,13 +142,25 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             // 2-bit match source, first match in the order MM, MU, ML (1 / 2 / 3; 0 = stop), by nested selects:
             // no scalar mask logic.  Without the local clamp one of the three sums IS the maximum, so ML needs
             // no compare of its own.
-            unsigned code = LOCAL ? ((sML == M) ? 3u : 0u) : 3u;
-            code = (sMU == M) ? 2u : code;
-            code = (sMM == M) ? 1u : code;
-            if constexpr (MASK) {
-                if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; code = 0u; }  // cext.c:141-149
+            if constexpr (LOCAL) {
+                unsigned code = (sML == M) ? 3u : 0u;
+                code = (sMU == M) ? 2u : code;
+                code = (sMM == M) ? 1u : code;
+                if constexpr (MASK) {
+                    if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; code = 0u; }  // cext.c:141-149
+                }
+                w_code |= code << (2 * c);
+            } else {
+                // without the clamp one of the three sums IS the maximum: "MM is not it" and "MU is not it" (the
+                // signs of sMM - M and sMU - M, both <= 0) say which, first match in the order MM, MU, ML; shifted
+                // in like the extend bits: no compare, no VCC, one op less per cell.  M is finite in every interior
+                // cell (one state of each boundary cell is), so no NaN here.
+                w_code = shift_in_sign(w_code, sMM, M);
+                w_nu = shift_in_sign(w_nu, sMU, M);
+                if constexpr (MASK) {
+                    if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; }  // the traceback stops at masked cells itself
+                }
             }
-            w_code |= code << (2 * c);
             // "from extend" bits = sign of (open - extend), shifted in with one v_alignbit each: no compare, so
             // no VCC write -> v_cndmask wait states (the compare form cost ~35 s_nop per step).  Column c lands
             // in bit 15 - c; reversed once per row below.  (-inf) - (-inf) only happens in cells no path enters.
@@ -222,7 +238,8 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         if (h) *reinterpret_cast<float4 *>(bnd_st) = make_float4(Mp[15], Up[15], Lp[15], 0.0f);
     }
     bnd_st += 32 * sizeof(float4);
-    *tb_st = make_uint2(w_code, (__builtin_bitreverse32(w_u) >> 16) | (__builtin_bitreverse32(w_l) & 0xffff0000u));
+    const unsigned w_src = LOCAL ? w_code : ((__builtin_bitreverse32(w_code) >> 16) | (__builtin_bitreverse32(w_nu) & 0xffff0000u));
+    *tb_st = make_uint2(w_src, (__builtin_bitreverse32(w_u) >> 16) | (__builtin_bitreverse32(w_l) & 0xffff0000u));
     tb_st += 64;
 }
 
