@@ -91,6 +91,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NM = NTERM * NR;
+    constexpr bool INTS = NTERM == 1;
     float m[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) m[c] = h ? PREV[c] : CUR[c];
@@ -132,9 +133,22 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #pragma unroll
         for (int c = (16 * k) / NM; c < (16 * (k + 1)) / NM; ++c) {
             // exact candidate sums (cext.c:185-201), maxima and first-match flags (cext.c:207-295)
-            const float sMM = md + m[c], sMU = ud + m[c], sML = ld + m[c];
-            float M = max3f(sMM, sMU, sML);
+            // INTS (the single-term instances; the host selects them for integer scoring only, praline_plan_run):
+            // every value is exact in float32, so max3(md, ud, ld) + m IS the maximum of the three sums and a state
+            // ties exactly when its sum does - the three candidate adds are not needed.
+            float sMM, sMU, sML, M, Mref;
+            if constexpr (INTS) {
+                sMM = md; sMU = ud; sML = ld;
+                Mref = max3f(md, ud, ld);
+                M = Mref + m[c];
+            } else {
+                sMM = md + m[c]; sMU = ud + m[c]; sML = ld + m[c];
+                M = max3f(sMM, sMU, sML);
+                Mref = M;
+            }
+            const bool clamp_won = LOCAL && INTS && M < 0.0f;   // local, INTS: no candidate reaches the clamp -> stop
             if (LOCAL) M = __builtin_fmaxf(M, 0.0f);
+            if constexpr (LOCAL && !INTS) Mref = M;
             const float uo = Mp[c] + go, ue = Up[c] + ge;
             float U = __builtin_fmaxf(uo, ue);
             const float lo = mleft + go, le = lleft + ge;
@@ -143,9 +157,16 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             // no scalar mask logic.  Without the local clamp one of the three sums IS the maximum, so ML needs
             // no compare of its own.
             if constexpr (LOCAL) {
-                unsigned code = (sML == M) ? 3u : 0u;
-                code = (sMU == M) ? 2u : code;
-                code = (sMM == M) ? 1u : code;
+                unsigned code;
+                if constexpr (INTS) {
+                    code = (sMU == Mref) ? 2u : 3u;
+                    code = (sMM == Mref) ? 1u : code;
+                    code = clamp_won ? 0u : code;
+                } else {
+                    code = (sML == Mref) ? 3u : 0u;
+                    code = (sMU == Mref) ? 2u : code;
+                    code = (sMM == Mref) ? 1u : code;
+                }
                 if constexpr (MASK) {
                     if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; code = 0u; }  // cext.c:141-149
                 }
@@ -155,8 +176,8 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
                 // signs of sMM - M and sMU - M, both <= 0) say which, first match in the order MM, MU, ML; shifted
                 // in like the extend bits: no compare, no VCC, one op less per cell.  M is finite in every interior
                 // cell (one state of each boundary cell is), so no NaN here.
-                w_code = shift_in_sign(w_code, sMM, M);
-                w_nu = shift_in_sign(w_nu, sMU, M);
+                w_code = shift_in_sign(w_code, sMM, Mref);
+                w_nu = shift_in_sign(w_nu, sMU, Mref);
                 if constexpr (MASK) {
                     if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; }  // the traceback stops at masked cells itself
                 }

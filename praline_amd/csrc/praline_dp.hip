@@ -17,6 +17,7 @@
 #include "sched.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -226,6 +227,8 @@ struct praline_arena {
     // one-hot arenas (ordinary sequences): active-symbol index per padded row; see k_dp_split16<.., ONEHOT>
     bool onehot = false;       // one-hot operand table in use
     bool all_onehot = false;   // every profile row is one-hot (plain sequences): required by the preprofile counting
+    int s_scale_bits = -1;     // smallest k <= 8 with S * 2^k integral in every entry (-1: none); s_absmax = max |S|
+    float s_absmax = 0.0f;
     DevBuf<unsigned char> d_sym8;
     // preprofile stage (k_path_counts): raw symbol of every one-hot row (255: not one-hot), int32 counts [rows_raw][A]
     DevBuf<unsigned char> d_sym_raw;
@@ -335,6 +338,15 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     for (int i = 0; i < A; ++i)
         for (int j = 0; j < A; ++j)
             if (S[i * A + j] != 0.0f) has_score[i] = 1;
+    for (int k = 0; k <= 8 && a->s_scale_bits < 0; ++k) {
+        bool ok = true;
+        for (int i = 0; i < A * A && ok; ++i) {
+            const float v = S[i] * (float)(1 << k);
+            ok = std::isfinite(v) && v == std::nearbyint(v);
+        }
+        if (ok) a->s_scale_bits = k;
+    }
+    for (int i = 0; i < A * A; ++i) a->s_absmax = std::max(a->s_absmax, std::fabs(S[i]));
     for (int i = 0; i < A; ++i)
         if (has_mass[i] && has_score[i]) a->active.push_back(i);
     a->n_active = (int)a->active.size();
@@ -687,6 +699,24 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     }
 
     // ---- with paths: chunk the tasks so the packed traceback fits the scratch budget ----
+    // k_dp_split16_tb's single-term instances take the tie flags from the predecessor states instead of the candidate
+    // sums (dp_split16_tb.hip.h, INTS): valid when every DP value is a multiple of 2^-k that float32 holds exactly -
+    // one-hot profiles, S and gap scores integral after scaling by 2^k, (L1 + L2) * max |score| * 2^k < 2^24.
+    // Other exact-mode arenas run the three-term instances (their lo pieces are zero: same match scores).
+    int tb_nterm = a.nterm16;
+    if (a.nterm16 == 1) {
+        bool ints = a.all_onehot && a.s_scale_bits >= 0 && !(getenv("PRALINE_NO_INTS") && getenv("PRALINE_NO_INTS")[0] == '1');
+        if (ints) {
+            int k = a.s_scale_bits;
+            for (; k <= 8; ++k) {
+                const float sc = (float)(1 << k), g1 = gap_open * sc, g2 = gap_extend * sc;
+                if (std::isfinite(g1) && std::isfinite(g2) && g1 == std::nearbyint(g1) && g2 == std::nearbyint(g2)) break;
+            }
+            const double big = std::max((double)a.s_absmax, std::max(std::fabs((double)gap_open), std::fabs((double)gap_extend)));
+            ints = k <= 8 && (2.0 * a.max_len + 4.0) * big * (double)(1 << std::min(k, 8)) < 16777216.0;
+        }
+        tb_nterm = ints ? 1 : 3;
+    }
     const size_t budget = tb_budget_bytes();
     const bool semiglobal = mode >= 2;
     const size_t tb_elem_bytes = pl.split ? sizeof(uint2) : sizeof(uint4);
@@ -737,9 +767,9 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             HIPCHK(hipStreamSynchronize(st));   // ct goes out of scope
             la.bnd = pl.d_bnd_chain.p;
             if (local && pl.d_chain_cand.n < n_flags * 32) RC(pl.d_chain_cand.alloc(n_flags * 32));
-            int rc = praline_launch_split16_tb_chain(la, a16, a.nr16, a.nterm16, local, pl.has_rects, max_strips,
+            int rc = praline_launch_split16_tb_chain(la, a16, a.nr16, tb_nterm, local, pl.has_rects, max_strips,
                                                      pl.d_chain_flags.p, pl.d_chain_cand.p);
-            if (rc != PRALINE_OK) return fail(rc, "no chain instance of k_dp_split16_tb for nr=%d nterm=%d", a.nr16, a.nterm16);
+            if (rc != PRALINE_OK) return fail(rc, "no chain instance of k_dp_split16_tb for nr=%d nterm=%d", a.nr16, tb_nterm);
             if (local) {
                 const int64_t lanes = (int64_t)nt * 32;
                 hipLaunchKernelGGL(k_chain_local_end, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, pl.d_tasks.p,
@@ -747,8 +777,8 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             }
             la.bnd = pl.d_bnd.p;
         } else if (pl.split) {
-            int rc = praline_launch_split16_tb(la, a16, a.nr16, a.nterm16, local, pl.has_rects);
-            if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16_tb instance for nr=%d nterm=%d", a.nr16, a.nterm16);
+            int rc = praline_launch_split16_tb(la, a16, a.nr16, tb_nterm, local, pl.has_rects);
+            if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16_tb instance for nr=%d nterm=%d", a.nr16, tb_nterm);
         } else {
             la.split = 0;
             RC(launch_dp(a.nstep, la, 1, local, 1, pl.has_rects));

@@ -215,6 +215,66 @@ def test_exact_mode_for_integer_scoring(nat, bba):
     arena.close()
 
 
+@pytest.mark.parametrize("case", ["integer", "half_integer_scores", "half_integer_gaps", "odd_gaps", "dyadic_profiles"])
+def test_traceback_tie_flags_exact_arithmetic(nat, bba, case, monkeypatch):
+    """The single-term traceback instances take the tie flags from the predecessor states (valid when every DP
+    value is exact in float32: one-hot rows, scores and gap scores on a common dyadic grid); anything else runs
+    the instances that compare the candidate sums.  Scores and paths against the oracle in every mode (with
+    Waterman-Eggert rectangles in local mode), and bitwise the same with the shortcut switched off."""
+    rng = np.random.default_rng(17)
+    N = 12
+    lens = synth_lengths(rng, N, 70)
+    lens[0], lens[1] = 1, 34
+    S = np.array(bba["S"], dtype=np.float32)
+    gaps = GAPS
+    if case == "half_integer_scores":
+        S = S * np.float32(0.5)
+    elif case == "half_integer_gaps":
+        gaps = (-10.5, -0.5)
+    elif case == "odd_gaps":
+        gaps = (-10.3, -0.7)          # not on a dyadic grid: the sums are rounded, the shortcut must not be taken
+    if case == "dyadic_profiles":     # exact in f16 but not one-hot
+        profs = []
+        for L in lens:
+            p = np.zeros((int(L), 27), dtype=np.float32)
+            a, b = rng.integers(0, 20, int(L)), rng.integers(0, 20, int(L))
+            p[np.arange(int(L)), a] += 0.5
+            p[np.arange(int(L)), b] += 0.5
+            profs.append(p)
+    else:
+        profs = [one_hot(rng.integers(0, 20, int(L)), 27) for L in lens]
+    arena = nat.Arena(profs, S)
+    assert arena.info()["f16_terms"] == 1
+    pairs = np.array([(i, j) for i in range(N) for j in range(N) if (i + j) % 2 == 1], dtype=np.int32)
+    rects = [[(3, 9, 2, 8)] if k % 3 == 0 else [] for k in range(len(pairs))]
+    results = {}
+    for shortcut in ("1", "0"):
+        monkeypatch.setenv("PRALINE_NO_INTS", "0" if shortcut == "1" else "1")
+        for mode in MODES:
+            plan = nat.Plan(arena, pairs, want_paths=True, rects=rects if mode == "local" else None)
+            pk = plan.match_kind()
+            plan.run(mode, *gaps)
+            results[(shortcut, mode)] = (plan.scores().copy(), [p.copy() for p in plan.paths()])
+            plan.close()
+            if shortcut == "0":
+                continue
+            sc, paths = results[(shortcut, mode)]
+            for k in range(len(pairs)):
+                i, j = pairs[k]
+                zero = None
+                if mode == "local" and rects[k]:
+                    zero = [(y, x) for (y0, y1, x0, x1) in rects[k] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)
+                            if y <= lens[i] and x <= lens[j]]
+                s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(i, j, pk), gaps, zero)
+                assert sc[k] == np.float32(s_or), (case, mode, i, j)
+                assert np.array_equal(paths[k], p_or), (case, mode, i, j)
+    for mode in MODES:
+        a, b = results[("1", mode)], results[("0", mode)]
+        assert np.array_equal(bits(a[0]), bits(b[0])), (case, mode)
+        assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1])), (case, mode)
+    arena.close()
+
+
 def test_batch_waterman_eggert_masks(nat, bba):
     """LocalMasterSlaveAligner's inner calls (praline/component/preprofile.py:227-267)."""
     d = load_golden("preprofile.npz")
