@@ -260,7 +260,16 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     }
     bnd_st += 32 * sizeof(float4);
     const unsigned w_src = LOCAL ? w_code : ((__builtin_bitreverse32(w_code) >> 16) | (__builtin_bitreverse32(w_nu) & 0xffff0000u));
-    *tb_st = make_uint2(w_src, (__builtin_bitreverse32(w_u) >> 16) | (__builtin_bitreverse32(w_l) & 0xffff0000u));
+    // Task mode: streaming store.  The planes (0.5 B per cell, GBs per launch) are read once, by k_traceback, much
+    // later - they must not push the strip-boundary columns and the operand rows out of L2 (global / semiglobal
+    // with paths +11 %).  Not in chain mode: there the producer drains its stores before every publish and a
+    // streaming store takes longer to retire.
+    {
+        const unsigned w_ext = (__builtin_bitreverse32(w_u) >> 16) | (__builtin_bitreverse32(w_l) & 0xffff0000u);
+        const unsigned long long w64 = (unsigned long long)w_src | ((unsigned long long)w_ext << 32);
+        if constexpr (CHAIN) *reinterpret_cast<unsigned long long *>(tb_st) = w64;
+        else __builtin_nontemporal_store(w64, reinterpret_cast<unsigned long long *>(tb_st));
+    }
     tb_st += 64;
 }
 

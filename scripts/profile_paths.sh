@@ -1,0 +1,31 @@
+#!/bin/bash
+# usage: scripts/profile_paths.sh <tag>   (run on the GPU box via gpurun)
+# PMC counters of the with-paths pipeline (scripts/exp_paths_prof.py, N=256): per-launch averages per kernel.
+set -e
+TAG=${1:-paths}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp N=256
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE"; do
+  name=$(echo $set | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$name -- python3 scripts/exp_paths_prof.py > $OUT/pmc_$name.log 2>&1 || { echo "pmc $set failed"; tail -3 $OUT/pmc_$name.log; continue; }
+done
+python3 - "$OUT" <<'PY'
+import csv, sys, glob, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in sorted(glob.glob(out + '/pmc_*/**/*counter_collection.csv', recursive=True)):
+    for row in csv.DictReader(open(f)):
+        k = row['Kernel_Name'].split('(')[0][:48]
+        a = agg[k][row['Counter_Name']]; a[0] += float(row['Counter_Value']); a[1] += 1
+with open(out + '/summary.txt', 'w') as fo:
+    for k, cs in agg.items():
+        if 'k_dp' not in k and 'k_trace' not in k and 'k_semi' not in k: continue
+        fo.write("== %s\n" % k)
+        for c, (v, n) in cs.items(): fo.write("  %-28s %.6g\n" % (c, v / n))
+        if 'SQ_WAVE_CYCLES' in cs:
+            wc = cs['SQ_WAVE_CYCLES'][0] / cs['SQ_WAVE_CYCLES'][1]
+            g = lambda c: cs[c][0] / cs[c][1] / wc if c in cs else float('nan')
+            fo.write("  # share of wave cycles: wait_any %.2f wait_inst %.2f active_any %.2f active_valu %.2f\n" % (g('SQ_WAIT_ANY'), g('SQ_WAIT_INST_ANY'), g('SQ_ACTIVE_INST_ANY'), g('SQ_ACTIVE_INST_VALU')))
+print(open(out + '/summary.txt').read())
+PY
