@@ -744,12 +744,10 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
                 p_mlo = word.x; p_mhi = word.y; p_u = word.z; p_l = word.w;
             } else {
                 const uint2 word = my_tb2[((int64_t)s * (tk.max_l1 + 8) + y) * 64 + 32 * (c >> 4)];
-                // word.x: match sources (local: 16 two-bit codes; otherwise "not MM" bits | "not MU" bits << 16);
-                // word.y: U-extend bits | L-extend bits << 16
+                // word.x: match source as two bit planes (low bits | high bits << 16); word.y: U-extend bits |
+                // L-extend bits << 16
                 bit = c & 15;
-                const unsigned not_mm = (word.x >> bit) & 1u, not_mu = (word.x >> (16 + bit)) & 1u;
-                const unsigned code2 = (rp.mode == PRALINE_MODE_LOCAL) ? ((word.x >> (2 * bit)) & 3u)
-                                                                       : (not_mm ? (not_mu ? 3u : 2u) : 1u);
+                const unsigned code2 = ((word.x >> bit) & 1u) | (((word.x >> (16 + bit)) & 1u) << 1);
                 p_mlo = (code2 & 1u) << bit; p_mhi = (code2 >> 1) << bit; p_u = word.y & 0xffffu; p_l = word.y >> 16;
             }
             if (k == 0) {

@@ -7,8 +7,7 @@
 // Per lane and DP row two words are stored (match source; 16 bits "U from extend" | 16 bits "L from extend"
 // << 16) = 8 bytes per 16 cells:
 //     tb2[(strip * tb_rows + y) * 64 + lane] = { source word,  ubit_c << c | lbit_c << (16 + c) }
-// source word, local mode:  code_c << 2c with code 1 MM / 2 MU / 3 ML / 0 stop (the clamp won);
-//              other modes: notMM_c << c | notMU_c << (16 + c)  (first match MM, then MU, else ML; never a stop)
+// source word: lo_c << c | hi_c << (16 + c), code = lo | hi << 1: 1 MM / 2 MU / 3 ML / 0 stop (local: the clamp won)
 // lane j holds strip columns 1..16, lane j + 32 columns 17..32 of pair j.
 // Zero rectangles (Waterman-Eggert, praline/component/preprofile.py:247-255) force M = U = L = 0 and
 // stop codes (cext.c:141-149).  End cells: the global corner triple, the local first argmax and the
@@ -114,9 +113,9 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             zmask |= in ? ((0xffffu >> (15 - hi)) & (0xffffu << lo)) : 0u;
         }
     }
-    // LOCAL: w_code = 16 x 2-bit match sources; otherwise w_code / w_nu = "not MM" / "not MU" bits.  U-extend /
-    // L-extend bits in w_u / w_l.  The shifted-in words hold column c in bit 15 - c (reversed once per row below).
-    unsigned w_code = 0, w_nu = 0, w_u = 0, w_l = 0;
+    // "not MM" / "not MU" / (local) "clamp won" bits and the U-extend / L-extend bits of this lane's 16 cells; the
+    // shifted-in words hold column c in bit 15 - c (reversed once per row below).
+    unsigned w_nm = 0, w_nu = 0, w_stop = 0, w_u = 0, w_l = 0;
     __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -136,51 +135,34 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             // INTS (the single-term instances; the host selects them for integer scoring only, praline_plan_run):
             // every value is exact in float32, so max3(md, ud, ld) + m IS the maximum of the three sums and a state
             // ties exactly when its sum does - the three candidate adds are not needed.
-            float sMM, sMU, sML, M, Mref;
+            float sMM, sMU, M, Mref;
             if constexpr (INTS) {
-                sMM = md; sMU = ud; sML = ld;
+                sMM = md; sMU = ud;
                 Mref = max3f(md, ud, ld);
                 M = Mref + m[c];
             } else {
-                sMM = md + m[c]; sMU = ud + m[c]; sML = ld + m[c];
-                M = max3f(sMM, sMU, sML);
+                sMM = md + m[c]; sMU = ud + m[c];
+                M = max3f(sMM, sMU, ld + m[c]);
                 Mref = M;
             }
-            const bool clamp_won = LOCAL && INTS && M < 0.0f;   // local, INTS: no candidate reaches the clamp -> stop
-            if (LOCAL) M = __builtin_fmaxf(M, 0.0f);
-            if constexpr (LOCAL && !INTS) Mref = M;
             const float uo = Mp[c] + go, ue = Up[c] + ge;
             float U = __builtin_fmaxf(uo, ue);
             const float lo = mleft + go, le = lleft + ge;
             float Lc = __builtin_fmaxf(lo, le);
-            // 2-bit match source, first match in the order MM, MU, ML (1 / 2 / 3; 0 = stop), by nested selects:
-            // no scalar mask logic.  Without the local clamp one of the three sums IS the maximum, so ML needs
-            // no compare of its own.
+            // Match source, first match in the order MM, MU, ML: without the clamp one of the three sums IS the
+            // maximum, so "MM is not it" and "MU is not it" (the signs of sMM - max and sMU - max, both <= 0) say
+            // which; in local mode the clamp wins - stop - exactly when that maximum is negative (its own sign).
+            // All three are shifted in like the extend bits below: no compare, no VCC write -> v_cndmask wait
+            // states, no scalar mask logic.  The maximum is finite in every interior cell (one state of each
+            // boundary cell is), so no NaN here.
+            w_nm = shift_in_sign(w_nm, sMM, Mref);
+            w_nu = shift_in_sign(w_nu, sMU, Mref);
             if constexpr (LOCAL) {
-                unsigned code;
-                if constexpr (INTS) {
-                    code = (sMU == Mref) ? 2u : 3u;
-                    code = (sMM == Mref) ? 1u : code;
-                    code = clamp_won ? 0u : code;
-                } else {
-                    code = (sML == Mref) ? 3u : 0u;
-                    code = (sMU == Mref) ? 2u : code;
-                    code = (sMM == Mref) ? 1u : code;
-                }
-                if constexpr (MASK) {
-                    if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; code = 0u; }  // cext.c:141-149
-                }
-                w_code |= code << (2 * c);
-            } else {
-                // without the clamp one of the three sums IS the maximum: "MM is not it" and "MU is not it" (the
-                // signs of sMM - M and sMU - M, both <= 0) say which, first match in the order MM, MU, ML; shifted
-                // in like the extend bits: no compare, no VCC, one op less per cell.  M is finite in every interior
-                // cell (one state of each boundary cell is), so no NaN here.
-                w_code = shift_in_sign(w_code, sMM, Mref);
-                w_nu = shift_in_sign(w_nu, sMU, Mref);
-                if constexpr (MASK) {
-                    if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; }  // the traceback stops at masked cells itself
-                }
+                w_stop = __builtin_amdgcn_alignbit(w_stop, __builtin_bit_cast(unsigned, M), 31);
+                M = __builtin_fmaxf(M, 0.0f);                                    // cext.c:208-209
+            }
+            if constexpr (MASK) {
+                if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; }          // cext.c:141-149 (stop code: row end)
             }
             // "from extend" bits = sign of (open - extend), shifted in with one v_alignbit each: no compare, so
             // no VCC write -> v_cndmask wait states (the compare form cost ~35 s_nop per step).  Column c lands
@@ -259,14 +241,20 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         if (h) *reinterpret_cast<float4 *>(bnd_st) = make_float4(Mp[15], Up[15], Lp[15], 0.0f);
     }
     bnd_st += 32 * sizeof(float4);
-    const unsigned w_src = LOCAL ? w_code : ((__builtin_bitreverse32(w_code) >> 16) | (__builtin_bitreverse32(w_nu) & 0xffff0000u));
-    // Task mode: streaming store.  The planes (0.5 B per cell, GBs per launch) are read once, by k_traceback, much
-    // later - they must not push the strip-boundary columns and the operand rows out of L2 (global / semiglobal
-    // with paths +11 %).  Not in chain mode: there the producer drains its stores before every publish and a
-    // streaming store takes longer to retire.
+    // match source as two bit planes, code = lo | hi << 1: 1 MM / 2 MU / 3 ML / 0 stop (masked cell, or the clamp won)
     {
+        const unsigned r_nm = __builtin_bitreverse32(w_nm) >> 16, r_nu = __builtin_bitreverse32(w_nu) >> 16;
+        unsigned go_on = 0xffffu;
+        if constexpr (LOCAL) go_on &= ~(__builtin_bitreverse32(w_stop) >> 16);
+        if constexpr (MASK) go_on &= ~zmask;
+        const unsigned hi = r_nm & go_on, lo_bits = (~r_nm | r_nu) & go_on;
+        const unsigned w_src = lo_bits | (hi << 16);
         const unsigned w_ext = (__builtin_bitreverse32(w_u) >> 16) | (__builtin_bitreverse32(w_l) & 0xffff0000u);
         const unsigned long long w64 = (unsigned long long)w_src | ((unsigned long long)w_ext << 32);
+        // Task mode: streaming store.  The planes (0.5 B per cell, GBs per launch) are read once, by k_traceback,
+        // much later - they must not push the strip-boundary columns and the operand rows out of L2 (global /
+        // semiglobal with paths +11 %).  Not in chain mode: there the producer drains its stores before every
+        // publish and a streaming store takes longer to retire.
         if constexpr (CHAIN) *reinterpret_cast<unsigned long long *>(tb_st) = w64;
         else __builtin_nontemporal_store(w64, reinterpret_cast<unsigned long long *>(tb_st));
     }
