@@ -40,7 +40,7 @@ def synth_lengths(rng, n, mu):
     return np.clip(np.rint(rng.normal(mu, 0.1 * mu, n)), 0.5 * mu, 1.5 * mu).astype(int)
 
 
-VALU_PER_STEP = 143.0                      # k_dp_split16, 3-term, global: profiles/r01_i_final_pmc_summary.txt
+VALU_PER_STEP = 143.0                      # k_dp_split16, 3-term, global: profiles/r01_j_final_pmc_summary.txt
 PEAK_VALU_GINSTR = 256 * 4 * 2.4 / 4.0     # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
 
 
@@ -273,7 +273,7 @@ def main():
                  "frac_of_fp32_mfma_peak": alg_flops / ksec / 1e12 / PEAK_F32_MFMA_TFLOPS,
                  "f16_terms": info["f16_terms"], "f16_ranges": info["f16_ranges"]},
         # what actually bounds the recurrence: VALU issue.  VALU_PER_STEP is the PMC-measured dynamic count
-        # (profiles/r01_i_*: SQ_INSTS_VALU / steps); peak = 1024 SIMDs x one wave64 instruction per 4 cycles.
+        # (profiles/r01_j_*: SQ_INSTS_VALU / steps); peak = 1024 SIMDs x one wave64 instruction per 4 cycles.
         "valu": {"achieved": plan.steps * VALU_PER_STEP / ksec / 1e9, "peak": PEAK_VALU_GINSTR,
                  "unit": "G wave-instr/s", "frac": plan.steps * VALU_PER_STEP / ksec / 1e9 / PEAK_VALU_GINSTR,
                  "valu_per_step": VALU_PER_STEP, "steps": plan.steps, "tasks": plan.tasks},
