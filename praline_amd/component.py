@@ -394,7 +394,9 @@ def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_seri
     profiles = [_track_profile(t) for t in tracks]
     lens = np.array([len(t.values) for t in tracks], dtype=np.int64)
     row_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
-    pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32).reshape(-1, 2)
+    ii, jj = np.divmod(np.arange(n * n, dtype=np.int64), n)      # every ordered pair (master i, slave j != i), i outer
+    keep = ii != jj
+    pairs = np.stack([ii[keep], jj[keep]], axis=1).astype(np.int32)
     arena = native.Arena(profiles, S)
     try:
         arena.counts_reset()

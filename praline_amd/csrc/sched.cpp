@@ -32,15 +32,22 @@ HalfTask empty_half(int32_t two)
 // step 1: group by sequence two, sort by len(one) descending, cut into 32-lane half tasks
 std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs)
 {
+    // order = pair indices by (sequence two ascending, length of sequence one descending, index ascending): a counting
+    // sort into the groups of equal sequence two (ascending index inside a group), then a stable sort by length per
+    // group - one comparison sort over the whole list cost 15 of the 19 ms of a 261 632-pair plan
     std::vector<int64_t> order((size_t)n_pairs);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
-        const int32_t tx = pairs[2 * x + 1], ty = pairs[2 * y + 1];
-        if (tx != ty) return tx < ty;
-        const int lx = lens[pairs[2 * x]], ly = lens[pairs[2 * y]];
-        if (lx != ly) return lx > ly;
-        return x < y;
-    });
+    {
+        int32_t max_two = -1;
+        for (int64_t i = 0; i < n_pairs; ++i) max_two = std::max(max_two, pairs[2 * i + 1]);
+        std::vector<int64_t> start((size_t)max_two + 2, 0);
+        for (int64_t i = 0; i < n_pairs; ++i) ++start[(size_t)pairs[2 * i + 1] + 1];
+        for (size_t t = 1; t < start.size(); ++t) start[t] += start[t - 1];
+        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        for (int64_t i = 0; i < n_pairs; ++i) order[(size_t)fill[(size_t)pairs[2 * i + 1]]++] = i;
+        for (size_t t = 0; t + 1 < start.size(); ++t)
+            std::stable_sort(order.begin() + start[t], order.begin() + start[t + 1],
+                             [&](int64_t x, int64_t y) { return lens[pairs[2 * x]] > lens[pairs[2 * y]]; });
+    }
     std::vector<HalfTask> halves;
     for (int64_t i = 0; i < n_pairs;) {
         const int32_t two = pairs[2 * order[i] + 1];
