@@ -76,10 +76,16 @@ struct TbCarry {
     float dM, dU, dL;     // lower half: states of the boundary cell (y-1, x0)
 };
 
-template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false>
+// DM (single-term instances): one score tile serves both halves of the wave - the A operand is split by output row
+// (aop: rows the lower half receives, aopH: the upper half's) and the accumulator takes mfma(aop, row t+1) +
+// mfma(aopH, row t); see split16_step in dp_split16.hip.h.  BOLD holds row t and is refilled with row t+3 once its
+// MFMAs are issued (three operand sets rotate); without DM, BOLD is BOPS itself.
+template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool DM = false>
 __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                                 float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
-                                                const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR], const char *&b_next,
+                                                float4 (&BOLD)[(NTERM == 1 ? 1 : 2) * NR],
+                                                const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR],
+                                                const float4 (&aopH)[(NTERM == 1 ? 1 : 2) * NR], const char *&b_next,
                                                 int b_stride, const char *&bnd_ld, char *&bnd_st, float4 &bnd_pref,
                                                 uint2 *&tb_st, float (&Mp)[16], float (&Up)[16], float (&Lp)[16],
                                                 float &cxm, float &cxu, float &cxl, float &cpxm, float &cpxu, float &cpxl,
@@ -93,7 +99,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     constexpr bool INTS = NTERM == 1;
     float m[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) m[c] = h ? PREV[c] : CUR[c];
+    for (int c = 0; c < 16; ++c) m[c] = DM ? CUR[c] : (h ? PREV[c] : CUR[c]);
 
     const float4 bv = bnd_pref;  // states (M, U, L) of the boundary cell (yy, x0)
     if constexpr (CHAIN) {
@@ -126,6 +132,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         const int ia = (term == 0) ? NR + r : r;
         const int ib = (term == 1) ? NR + r : r;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+        if constexpr (DM) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aopH[ia]), as_half8(BOLD[ib]), acc, 0, 0, 0);
         // pin the MFMA at the START of its chunk: left alone the scheduler sinks it to the end of the step and
         // then pads ~35 s_nop for the MFMA -> VALU result hazard in front of the next step's select
         __builtin_amdgcn_sched_barrier(0);
@@ -182,7 +189,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     {
         const float4 *bsrc = reinterpret_cast<const float4 *>(b_next);
 #pragma unroll
-        for (int q = 0; q < NP * NR; ++q) BOPS[q] = bsrc[q];
+        for (int q = 0; q < NP * NR; ++q) BOLD[q] = bsrc[q];   // (BOLD is BOPS without DM)
     }
     b_next += b_stride;
     if (LOCAL) {
@@ -264,6 +271,9 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #ifndef PRALINE_TB_WAVES_PER_SIMD
 #define PRALINE_TB_WAVES_PER_SIMD 1
 #endif
+#ifndef PRALINE_TB_DM
+#define PRALINE_TB_DM 1
+#endif
 template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false>
 __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one,
@@ -275,6 +285,7 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
+    constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0);   // see split16_tb_step
     // CHAIN: one wave per block; block b = strip-major (strip, task): producers are dispatched before consumers
     const int task = CHAIN ? (int)(blockIdx.x % n_tasks) : (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chain_strip = CHAIN ? (int)(blockIdx.x / n_tasks) : 0;
@@ -373,6 +384,20 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
 #pragma unroll
             for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
         }
+        float4 aopH[NOP];
+        if constexpr (DM) {
+            // A row j feeds output row j; rows with (j >> 2) & 1 are the ones the upper half receives (bit masks:
+            // a select between float4 values becomes an indexed stack array)
+            const unsigned mh = 0u - (((unsigned)j >> 2) & 1u), ml = ~mh;
+#pragma unroll
+            for (int q = 0; q < NOP; ++q) {
+                const float4 a = aop[q];
+                aopH[q] = make_float4(__uint_as_float(__float_as_uint(a.x) & mh), __uint_as_float(__float_as_uint(a.y) & mh),
+                                      __uint_as_float(__float_as_uint(a.z) & mh), __uint_as_float(__float_as_uint(a.w) & mh));
+                aop[q] = make_float4(__uint_as_float(__float_as_uint(a.x) & ml), __uint_as_float(__float_as_uint(a.y) & ml),
+                                     __uint_as_float(__float_as_uint(a.z) & ml), __uint_as_float(__float_as_uint(a.w) & ml));
+            }
+        }
         float Mp[16], Up[16], Lp[16];  // states of the previous row, per column (o[0,x,:] to start with)
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -390,7 +415,7 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         float best_run = out_best;
         int best_y = out_y, best_x = out_x, best_k = out_k;
 
-        float4 bX[NOP], bY[NOP];
+        float4 bX[NOP], bY[NOP], bZ[NOP];   // bZ: DM only (rows t, t+1, t+2 rotate through three sets)
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
         {
@@ -399,7 +424,7 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
             const float4 *s2 = reinterpret_cast<const float4 *>(pB + b_stride);
             const float4 *s3 = reinterpret_cast<const float4 *>(pB + 2 * b_stride);
 #pragma unroll
-            for (int q = 0; q < NOP; ++q) { b1[q] = s1[q]; bX[q] = s2[q]; bY[q] = s3[q]; }
+            for (int q = 0; q < NOP; ++q) { b1[q] = s1[q]; bX[q] = s2[q]; bY[q] = s3[q]; bZ[q] = s1[q]; }
 #pragma unroll
             for (int k = 0; k < NTERM * NR; ++k) {
                 const int term = (NTERM == 1) ? 2 : k / NR;
@@ -410,22 +435,25 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
             }
         }
         const char *b_next = pB + 3 * b_stride;
-        // boundary states two rows ahead, in two alternating registers (one row = 1 us at one wave per SIMD is
+        // boundary states three rows ahead, in three rotating registers (one row = 0.7 us at one wave per SIMD is
         // not enough for a load that misses L2; measured with the 1-deep version: 27 % of the cycles waiting)
-        const char *bnd_ld = my_bnd + 3 * BROW;
+        const char *bnd_ld = my_bnd + 4 * BROW;
         char *bnd_st = CHAIN ? my_bnd_out : my_bnd;                          // upper half stores row yy = t - 1 (row 0: dummy)
         if constexpr (CHAIN) {
-            if (chain_in != nullptr) chain_seen = chain_wait(chain_in, 2, chain_seen);
+            if (chain_in != nullptr) chain_seen = chain_wait(chain_in, 3, chain_seen);
         }
         float4 bnd_prefA = *reinterpret_cast<const float4 *>(my_bnd + BROW);      // row 1
         float4 bnd_prefB = *reinterpret_cast<const float4 *>(my_bnd + 2 * BROW);  // row 2
+        float4 bnd_prefC = *reinterpret_cast<const float4 *>(my_bnd + 3 * BROW);  // row 3
         uint2 *tb_st = my_tb + (int64_t)s * tb_rows * 64 + (h ? 0 : 64);     // row yy = t - h of step t = 1
 
-#define PRALINE_TB_STEP(T, CUR, PREV, BSET, PREF)                                                                    \
-        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN>((T) - h, L1, have_pair, h, CUR, PREV, BSET, aop, b_next, b_stride,   \
+        // BUSE holds operand row T + 1; BOLD row T (DM; otherwise BUSE again); PREF the boundary states of row T
+#define PRALINE_TB_STEP(T, CUR, PREV, BUSE, BOLD, PREF)                                                              \
+        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, DM>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, BOLD, aop, aopH,     \
+                                                b_next, b_stride,                                                           \
                                                 bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl, cpxm, cpxu, cpxl,   \
                                                 cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge, xb, rect,          \
-                                                chain_in, &chain_seen, (T) + 2)
+                                                chain_in, &chain_seen, (T) + 3)
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
             const int yy_ = (T) - h;                                                                                 \
@@ -448,7 +476,8 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         {
             const float best_s = best_run;
             const int by = best_y, bx = best_x, bk = best_k;
-            PRALINE_TB_STEP(1, accA, accB, bX, bnd_prefA);
+            if constexpr (DM) PRALINE_TB_STEP(1, accA, accB, bX, bZ, bnd_prefA);
+            else PRALINE_TB_STEP(1, accA, accB, bX, bX, bnd_prefA);
             if (h) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
@@ -458,15 +487,41 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
             }
             PRALINE_TB_TAILS(1)
         }
-        for (int t = 2; t <= max_l1 + 1; t += 2) {
+        // six steps per iteration: the accumulators ping-pong (period 2), the boundary prefetch registers and - with
+        // DM - the operand sets rotate with period 3 (without DM two operand sets alternate); the steps past
+        // max_l1 + 1 compute rows that nobody reports
+        for (int t = 2; t <= max_l1 + 1; t += 6) {
             if constexpr (CHAIN) {
                 // the steps up to t - 1 have stored the boundary rows up to t - 2
-                if ((t & 6) == 0) chain_publish(chain_out, t - 2, lane);
+                if (t > 2) chain_publish(chain_out, t - 2, lane);
             }
-            PRALINE_TB_STEP(t, accB, accA, bY, bnd_prefB);
-            PRALINE_TB_TAILS(t)
-            PRALINE_TB_STEP(t + 1, accA, accB, bX, bnd_prefA);
-            PRALINE_TB_TAILS(t + 1)
+            if constexpr (DM) {
+                PRALINE_TB_STEP(t, accB, accA, bY, bX, bnd_prefB);
+                PRALINE_TB_TAILS(t)
+                PRALINE_TB_STEP(t + 1, accA, accB, bZ, bY, bnd_prefC);
+                PRALINE_TB_TAILS(t + 1)
+                PRALINE_TB_STEP(t + 2, accB, accA, bX, bZ, bnd_prefA);
+                PRALINE_TB_TAILS(t + 2)
+                PRALINE_TB_STEP(t + 3, accA, accB, bY, bX, bnd_prefB);
+                PRALINE_TB_TAILS(t + 3)
+                PRALINE_TB_STEP(t + 4, accB, accA, bZ, bY, bnd_prefC);
+                PRALINE_TB_TAILS(t + 4)
+                PRALINE_TB_STEP(t + 5, accA, accB, bX, bZ, bnd_prefA);
+                PRALINE_TB_TAILS(t + 5)
+            } else {
+                PRALINE_TB_STEP(t, accB, accA, bY, bY, bnd_prefB);
+                PRALINE_TB_TAILS(t)
+                PRALINE_TB_STEP(t + 1, accA, accB, bX, bX, bnd_prefC);
+                PRALINE_TB_TAILS(t + 1)
+                PRALINE_TB_STEP(t + 2, accB, accA, bY, bY, bnd_prefA);
+                PRALINE_TB_TAILS(t + 2)
+                PRALINE_TB_STEP(t + 3, accA, accB, bX, bX, bnd_prefB);
+                PRALINE_TB_TAILS(t + 3)
+                PRALINE_TB_STEP(t + 4, accB, accA, bY, bY, bnd_prefC);
+                PRALINE_TB_TAILS(t + 4)
+                PRALINE_TB_STEP(t + 5, accA, accB, bX, bX, bnd_prefA);
+                PRALINE_TB_TAILS(t + 5)
+            }
         }
 #undef PRALINE_TB_STEP
 #undef PRALINE_TB_TAILS
