@@ -275,6 +275,51 @@ def test_traceback_tie_flags_exact_arithmetic(nat, bba, case, monkeypatch):
     arena.close()
 
 
+@pytest.mark.parametrize("kind", ["onehot", "profile"])
+def test_path_plan_execution_forms_agree(nat, bba, kind, monkeypatch):
+    """A path plan runs in chain mode (one wave per task and strip; small plans), in task mode, or in task mode cut
+    into chunks that fit a traceback-plane budget.  Same scores, end cells and paths in all three, every mode,
+    with rectangles in local mode; spot-checked against the oracle."""
+    rng = np.random.default_rng(23)
+    N = 26
+    lens = synth_lengths(rng, N, 110)
+    lens[0], lens[1], lens[2] = 1, 32, 65
+    profs = [one_hot(rng.integers(0, 20, int(L)), 27) if kind == "onehot" else synth_profile(rng, int(L))[0] for L in lens]
+    arena = nat.Arena(profs, bba["S"])
+    pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j], dtype=np.int32)
+    rects = [[(2, 20, 3, 30)] if k % 4 == 0 else ([(5, 9, 1, 4), (30, 60, 40, 64)] if k % 4 == 1 else [])
+             for k in range(len(pairs))]
+    forms = {"chain": {}, "tasks": {"PRALINE_NO_CHAIN": "1"}, "chunks": {"PRALINE_NO_CHAIN": "1", "PRALINE_TB_BUDGET_MB": "1"}}
+    out = {}
+    for form, env in forms.items():
+        for key in ("PRALINE_NO_CHAIN", "PRALINE_TB_BUDGET_MB"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        for mode in MODES:
+            plan = nat.Plan(arena, pairs, want_paths=True, rects=rects if mode == "local" else None)
+            pk = plan.match_kind()
+            plan.run(mode, *GAPS)
+            out[(form, mode)] = (plan.scores().copy(), [p.copy() for p in plan.paths()])
+            plan.close()
+    for mode in MODES:
+        ref_sc, ref_paths = out[("chain", mode)]
+        for form in ("tasks", "chunks"):
+            sc, paths = out[(form, mode)]
+            assert np.array_equal(bits(sc), bits(ref_sc)), (form, mode)
+            assert all(np.array_equal(a, b) for a, b in zip(paths, ref_paths)), (form, mode)
+        for k in range(0, len(pairs), 37):
+            i, j = pairs[k]
+            zero = None
+            if mode == "local" and rects[k]:
+                zero = [(y, x) for (y0, y1, x0, x1) in rects[k] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)
+                        if y <= lens[i] and x <= lens[j]]
+            s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(i, j, pk), GAPS, zero)
+            assert ref_sc[k] == np.float32(s_or), (mode, i, j)
+            assert np.array_equal(ref_paths[k], p_or), (mode, i, j)
+    arena.close()
+
+
 def test_batch_waterman_eggert_masks(nat, bba):
     """LocalMasterSlaveAligner's inner calls (praline/component/preprofile.py:227-267)."""
     d = load_golden("preprofile.npz")
