@@ -660,17 +660,35 @@ __global__ __launch_bounds__(64) void k_semiglobal_end(ArenaDev ar, const WaveTa
         cmax = b2; cy = 0; ck = 2;
         if (!(b2 > PRALINE_NEG_INF)) ck = 0;
     }
-    for (int xx = 1; xx <= L2; ++xx) {
-        const float *q = lastrow + (int64_t)(xx - 1) * 3 * ls;
-        const float v0 = q[0], v1 = q[ls], v2 = q[2 * ls];
-        const float m = max3f(v0, v1, v2);
-        if (m >= rmax) { rmax = m; rx = xx; rk = (v0 == m) ? 0 : ((v1 == m) ? 1 : 2); }
+    // eight coordinates per round, all their loads issued before the first compare: one memory latency per round
+    // instead of per coordinate (a single alignment spent 0.36 ms here, as long as a 147 072-pair batch).  The tail
+    // repeats the last coordinate, which the >= rule absorbs.
+    constexpr int SCAN = 8;
+    for (int x0 = 1; x0 <= L2; x0 += SCAN) {
+        float v[SCAN][3];
+#pragma unroll
+        for (int i = 0; i < SCAN; ++i) {
+            const float *q = lastrow + (int64_t)(min(x0 + i, L2) - 1) * 3 * ls;
+            v[i][0] = q[0]; v[i][1] = q[ls]; v[i][2] = q[2 * ls];
+        }
+#pragma unroll
+        for (int i = 0; i < SCAN; ++i) {
+            const float m = max3f(v[i][0], v[i][1], v[i][2]);
+            if (m >= rmax) { rmax = m; rx = min(x0 + i, L2); rk = (v[i][0] == m) ? 0 : ((v[i][1] == m) ? 1 : 2); }
+        }
     }
-    for (int yy = 1; yy <= L1; ++yy) {
-        const float *q = lastcol + (int64_t)yy * 3 * ls;
-        const float v0 = q[0], v1 = q[ls], v2 = q[2 * ls];
-        const float m = max3f(v0, v1, v2);
-        if (m >= cmax) { cmax = m; cy = yy; ck = (v0 == m) ? 0 : ((v1 == m) ? 1 : 2); }
+    for (int y0 = 1; y0 <= L1; y0 += SCAN) {
+        float v[SCAN][3];
+#pragma unroll
+        for (int i = 0; i < SCAN; ++i) {
+            const float *q = lastcol + (int64_t)min(y0 + i, L1) * 3 * ls;
+            v[i][0] = q[0]; v[i][1] = q[ls]; v[i][2] = q[2 * ls];
+        }
+#pragma unroll
+        for (int i = 0; i < SCAN; ++i) {
+            const float m = max3f(v[i][0], v[i][1], v[i][2]);
+            if (m >= cmax) { cmax = m; cy = min(y0 + i, L1); ck = (v[i][0] == m) ? 0 : ((v[i][1] == m) ? 1 : 2); }
+        }
     }
     const bool from_row = rmax > cmax && free_two;   // align.py:411
     end_cells[p * 4 + 0] = from_row ? L1 : cy;
