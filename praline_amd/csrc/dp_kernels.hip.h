@@ -906,8 +906,27 @@ __global__ __launch_bounds__(64) void k_raw_align(int local_mode, const float *_
             go2 = g2[(x - 1) * 2]; ge2 = g2[(x - 1) * 2 + 1];
         }
         float curM = 0.0f, curU = 0.0f, curL = 0.0f;
+        // inputs of the NEXT step's cell are fetched one step ahead (the step is a chain of dependent loads otherwise)
+        float n_ms = 0.0f, n_go1 = 0.0f, n_ge1 = 0.0f;
+        uint8_t n_z = 0;
+        {
+            const int y1 = 1 - lane;
+            if (y1 >= 1 && y1 <= L1 && col_ok) {
+                n_ms = m[(int64_t)(y1 - 1) * L2 + (x - 1)]; n_z = z[(int64_t)y1 * C + x];
+                n_go1 = g1[(y1 - 1) * 2]; n_ge1 = g1[(y1 - 1) * 2 + 1];
+            }
+        }
         for (int step = 1; step <= L1 + 63; ++step) {
             const int y = step - lane;
+            const float ms = n_ms, go1 = n_go1, ge1 = n_ge1;
+            const uint8_t zc = n_z;
+            {
+                const int yn = y + 1;
+                if (yn >= 1 && yn <= L1 && col_ok) {
+                    n_ms = m[(int64_t)(yn - 1) * L2 + (x - 1)]; n_z = z[(int64_t)yn * C + x];
+                    n_go1 = g1[(yn - 1) * 2]; n_ge1 = g1[(yn - 1) * 2 + 1];
+                }
+            }
             // left neighbour (y, x-1): what lane-1 produced in the previous step
             float lfM = __shfl_up(curM, 1), lfU = __shfl_up(curU, 1), lfL = __shfl_up(curL, 1);
             const bool row_ok = y >= 1 && y <= L1;
@@ -917,12 +936,10 @@ __global__ __launch_bounds__(64) void k_raw_align(int local_mode, const float *_
             }
             if (row_ok && col_ok) {
                 const int64_t cell = (int64_t)y * C + x;
-                if (z[cell]) {
+                if (zc) {
                     // masked: the cell keeps whatever the caller pre-initialised (cext.c:147-149)
                     curM = o[cell * 3]; curU = o[cell * 3 + 1]; curL = o[cell * 3 + 2];
                 } else {
-                    const float go1 = g1[(y - 1) * 2], ge1 = g1[(y - 1) * 2 + 1];
-                    const float ms = m[(int64_t)(y - 1) * L2 + (x - 1)];
                     const float up_open = upM + go1, up_ext = upU + ge1;
                     const float lf_open = lfM + go2, lf_ext = lfL + ge2;
                     const float mm = dgM + ms, mu = dgU + ms, ml = dgL + ms;
