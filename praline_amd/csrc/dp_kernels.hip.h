@@ -879,22 +879,29 @@ __global__ void k_raw_init(int mode, const float *__restrict__ g1, const float *
     }
 }
 
-// cext_align (praline/util/cext.c:99-306) on the reference's own buffers.  One wavefront; lane l
-// owns column x0 + l + 1 of a 64-column strip and computes row (step - l): the cells of one step
-// form an anti-diagonal.  Left / diagonal neighbours come from lane l-1 via __shfl_up; the up
-// neighbour is the lane's own previous step.  All seven tie flags are reproduced.
-__global__ __launch_bounds__(64) void k_raw_align(int local_mode, const float *__restrict__ m,
-                                                   const float *__restrict__ g1,
-                                                   const float *__restrict__ g2, float *o,
-                                                   uint8_t *t, const uint8_t *__restrict__ z, int L1,
-                                                   int L2)
+// cext_align (praline/util/cext.c:99-306) on the reference's own buffers.  Lane l of a wavefront owns column
+// x0 + l + 1 of a 64-column strip and computes row (step - l): the cells of one step form an anti-diagonal.  Left /
+// diagonal neighbours come from lane l-1 via __shfl_up; the up neighbour is the lane's own previous step.  All
+// seven tie flags are reproduced.  One workgroup of up to 16 wavefronts: wave w takes strip g0 + w and runs 64
+// steps behind wave w - 1, whose last column it receives through LDS (written in one step, read in the next, one
+// barrier per step); groups of 16 strips follow each other and read the previous group's last column back from o.
+#define PRALINE_RAW_WAVES 16
+__global__ __launch_bounds__(64 * PRALINE_RAW_WAVES) void k_raw_align(int local_mode, const float *__restrict__ m,
+                                                                       const float *__restrict__ g1,
+                                                                       const float *__restrict__ g2, float *o,
+                                                                       uint8_t *t, const uint8_t *__restrict__ z, int L1,
+                                                                       int L2)
 {
-    const int lane = threadIdx.x;
+    __shared__ float hand[2][PRALINE_RAW_WAVES][3];   // (M, U, L) of a wave's last column, by step parity
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     const int64_t C = L2 + 1;
     const float base = local_mode ? 0.0f : PRALINE_NEG_INF;
-    for (int x0 = 0; x0 < L2; x0 += 64) {
+    const int nstrips = (L2 + 63) / 64;
+    for (int g0 = 0; g0 < nstrips; g0 += W) {
+        const int wg = min(W, nstrips - g0);              // strips (= busy waves) of this group
+        const int x0 = (g0 + wave) * 64;
         const int x = x0 + lane + 1;
-        const bool col_ok = x <= L2;
+        const bool col_ok = wave < wg && x <= L2;
         // up neighbour (y-1, x): starts at the boundary row
         float upM = PRALINE_NEG_INF, upU = PRALINE_NEG_INF, upL = PRALINE_NEG_INF;
         // diagonal neighbour (y-1, x-1)
@@ -910,14 +917,15 @@ __global__ __launch_bounds__(64) void k_raw_align(int local_mode, const float *_
         float n_ms = 0.0f, n_go1 = 0.0f, n_ge1 = 0.0f;
         uint8_t n_z = 0;
         {
-            const int y1 = 1 - lane;
+            const int y1 = 1 - 64 * wave - lane;
             if (y1 >= 1 && y1 <= L1 && col_ok) {
                 n_ms = m[(int64_t)(y1 - 1) * L2 + (x - 1)]; n_z = z[(int64_t)y1 * C + x];
                 n_go1 = g1[(y1 - 1) * 2]; n_ge1 = g1[(y1 - 1) * 2 + 1];
             }
         }
-        for (int step = 1; step <= L1 + 63; ++step) {
-            const int y = step - lane;
+        const int total = L1 + 63 + 64 * (wg - 1);
+        for (int gs = 1; gs <= total; ++gs) {
+            const int y = gs - 64 * wave - lane;          // this wave runs 64 steps behind the previous one
             const float ms = n_ms, go1 = n_go1, ge1 = n_ge1;
             const uint8_t zc = n_z;
             {
@@ -931,8 +939,12 @@ __global__ __launch_bounds__(64) void k_raw_align(int local_mode, const float *_
             float lfM = __shfl_up(curM, 1), lfU = __shfl_up(curU, 1), lfL = __shfl_up(curL, 1);
             const bool row_ok = y >= 1 && y <= L1;
             if (lane == 0 && row_ok) {
-                const int64_t i = ((int64_t)y * C + x0) * 3;
-                lfM = o[i]; lfU = o[i + 1]; lfL = o[i + 2];
+                if (wave == 0) {                          // boundary column / the previous group's last column
+                    const int64_t i = ((int64_t)y * C + x0) * 3;
+                    lfM = o[i]; lfU = o[i + 1]; lfL = o[i + 2];
+                } else {                                  // the previous wave's lane 63, one step ago
+                    lfM = hand[(gs - 1) & 1][wave - 1][0]; lfU = hand[(gs - 1) & 1][wave - 1][1]; lfL = hand[(gs - 1) & 1][wave - 1][2];
+                }
             }
             if (row_ok && col_ok) {
                 const int64_t cell = (int64_t)y * C + x;
@@ -970,9 +982,12 @@ __global__ __launch_bounds__(64) void k_raw_align(int local_mode, const float *_
                 upM = curM; upU = curU; upL = curL;
             }
             if (y >= 1) { dgM = lfM; dgU = lfU; dgL = lfL; }  // (y, x-1) is the diagonal of (y+1, x)
+            if (lane == 63) { hand[gs & 1][wave][0] = curM; hand[gs & 1][wave][1] = curU; hand[gs & 1][wave][2] = curL; }
+            __syncthreads();
         }
-        // the next strip's lane 0 reads this strip's last column back from o
+        // the next group's wave 0 reads this group's last column back from o
         __threadfence();
+        __syncthreads();
     }
 }
 

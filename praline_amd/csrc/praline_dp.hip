@@ -1039,7 +1039,7 @@ extern "C" int praline_align(int mode, const praline_array *m, const praline_arr
     if (!arr_ok(o) || !arr_ok(t) || !arr_ok(z)) return fail(PRALINE_ERR_ARG, "NULL o / t / z");
     RawDev d;
     RC(raw_upload(m, g1, g2, o, t, z, d));
-    hipLaunchKernelGGL(k_raw_align, dim3(1), dim3(64), 0, g_rt.stream, mode == PRALINE_MODE_LOCAL ? 1 : 0, d.m.p, d.g1.p,
+    hipLaunchKernelGGL(k_raw_align, dim3(1), dim3(64 * (unsigned)std::min<int64_t>(PRALINE_RAW_WAVES, std::max<int64_t>(1, (d.L2 + 63) / 64))), 0, g_rt.stream, mode == PRALINE_MODE_LOCAL ? 1 : 0, d.m.p, d.g1.p,
                        d.g2.p, d.o.p, d.t.p, d.z.p, (int)d.L1, (int)d.L2);
     HIPCHK(hipGetLastError());
     const size_t cells = (size_t)((d.L1 + 1) * (d.L2 + 1));
@@ -1079,7 +1079,7 @@ extern "C" int praline_raw_align(int mode, const praline_array *m, const praline
     hipStream_t st = g_rt.stream;
     const int L1 = (int)d.L1, L2 = (int)d.L2;
     hipLaunchKernelGGL(k_raw_init, dim3(256), dim3(256), 0, st, mode, d.g1.p, d.g2.p, d.o.p, d.t.p, L1, L2);
-    hipLaunchKernelGGL(k_raw_align, dim3(1), dim3(64), 0, st, mode == PRALINE_MODE_LOCAL ? 1 : 0, d.m.p, d.g1.p, d.g2.p,
+    hipLaunchKernelGGL(k_raw_align, dim3(1), dim3(64 * (unsigned)std::min<int64_t>(PRALINE_RAW_WAVES, std::max<int64_t>(1, ((int64_t)L2 + 63) / 64))), 0, st, mode == PRALINE_MODE_LOCAL ? 1 : 0, d.m.p, d.g1.p, d.g2.p,
                        d.o.p, d.t.p, d.z.p, L1, L2);
     DevBuf<float> d_score;
     DevBuf<int32_t> d_path;
