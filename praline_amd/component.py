@@ -153,7 +153,7 @@ def _path_for_output(mode, path):
     for semiglobal ones (praline/component/align.py:401-433)."""
     if mode.startswith("semiglobal"):
         return np.asarray(path, dtype=int)
-    return [(int(y), int(x)) for y, x in path]
+    return list(map(tuple, np.asarray(path).tolist()))
 
 
 class PairwiseAligner(Component):
