@@ -6,7 +6,7 @@ from praline_amd.matrices import blosum62_matrix
 from bench import synth_lengths, synth_profile
 nat.init(0)
 S = blosum62_matrix()
-for N, mu, ordered in ((16, 400, False), (64, 400, False), (128, 400, False), (256, 400, False), (256, 250, True), (384, 250, True)):
+for N, mu, ordered in ((64, 400, False), (256, 400, False), (300, 400, False), (360, 400, False), (200, 250, True), (256, 250, True), (384, 250, True)):
     rng = np.random.default_rng(3)
     lens = synth_lengths(rng, N, mu)
     profs = [synth_profile(rng, int(L)) for L in lens]
@@ -14,8 +14,8 @@ for N, mu, ordered in ((16, 400, False), (64, 400, False), (128, 400, False), (2
     cells = int((lens[pairs[:, 0]].astype(np.int64) * lens[pairs[:, 1]]).sum())
     ar = nat.Arena(profs, S)
     out = []
-    for cm in ("0", "960", "100000000"):
-        os.environ["PRALINE_CHAIN_MAX"] = cm
+    for cm in ("0", "100000000"):
+        os.environ["PRALINE_CHAIN_MAX_TASKS"] = cm
         pl = nat.Plan(ar, pairs, want_paths=True)
         pl.run("global", -11, -1); nat.synchronize()
         t0 = time.perf_counter()
