@@ -37,7 +37,7 @@ int praline_launch_split_16(const LaunchArgs &la, bool local);
 int praline_launch_split16(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local);
 int praline_launch_split16_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, bool mask);
 int praline_launch_split16_tb_chain(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, bool mask,
-                                    int max_strips, int *flags, void *cand);
+                                    int max_strips, int *flags, void *cand, int every);
 void praline_launch_split_f16(const float *src, int KP, int KS, int n_active, int NR, int64_t rows_pad, void *dst, int *flag,
                               hipStream_t stream);
 int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int one, int two, int L1, int L2, float *m,

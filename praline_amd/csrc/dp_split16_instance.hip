@@ -83,25 +83,25 @@ template <int NR, int NTERM> static void launch16_tb(const LaunchArgs &la, const
 
 // chain mode (dp_split16_tb.hip.h): one wave per (task, strip), grid strip-major
 template <int NR, int NTERM> static void launch16_tb_chain(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask,
-                                                            int max_strips, int *flags, void *cand)
+                                                            int max_strips, int *flags, void *cand, int every)
 {
     const dim3 grid(la.n_tasks * (unsigned)max_strips), block(64);
 #define PRALINE_CHAIN_LAUNCH(LOC, MSK)                                                                                  \
     hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, LOC, MSK, true>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one, \
                        la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells, la.rp,       \
-                       (int)la.n_tasks, flags, max_strips + 1, (float4 *)cand)
+                       (int)la.n_tasks, flags, max_strips + 1, (float4 *)cand, every)
     if (local) { if (mask) PRALINE_CHAIN_LAUNCH(true, true); else PRALINE_CHAIN_LAUNCH(true, false); }
     else { if (mask) PRALINE_CHAIN_LAUNCH(false, true); else PRALINE_CHAIN_LAUNCH(false, false); }
 #undef PRALINE_CHAIN_LAUNCH
 }
 
 int praline_launch_split16_tb_chain(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, bool mask,
-                                    int max_strips, int *flags, void *cand)
+                                    int max_strips, int *flags, void *cand, int every)
 {
-    if (nr == 1 && nterm == 1) launch16_tb_chain<1, 1>(la, a16, local, mask, max_strips, flags, cand);
-    else if (nr == 1 && nterm == 3) launch16_tb_chain<1, 3>(la, a16, local, mask, max_strips, flags, cand);
-    else if (nr == 2 && nterm == 1) launch16_tb_chain<2, 1>(la, a16, local, mask, max_strips, flags, cand);
-    else if (nr == 2 && nterm == 3) launch16_tb_chain<2, 3>(la, a16, local, mask, max_strips, flags, cand);
+    if (nr == 1 && nterm == 1) launch16_tb_chain<1, 1>(la, a16, local, mask, max_strips, flags, cand, every);
+    else if (nr == 1 && nterm == 3) launch16_tb_chain<1, 3>(la, a16, local, mask, max_strips, flags, cand, every);
+    else if (nr == 2 && nterm == 1) launch16_tb_chain<2, 1>(la, a16, local, mask, max_strips, flags, cand, every);
+    else if (nr == 2 && nterm == 3) launch16_tb_chain<2, 3>(la, a16, local, mask, max_strips, flags, cand, every);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }

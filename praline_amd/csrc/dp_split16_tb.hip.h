@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
                                                        uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,
                                                        float *__restrict__ scores, int32_t *__restrict__ end_cells,
                                                        RunParams rp, int n_tasks, int *chain_flags = nullptr,
-                                                       int chain_stride = 0, float4 *chain_cand = nullptr)
+                                                       int chain_stride = 0, float4 *chain_cand = nullptr,
+                                                       int chain_every = 6)
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
@@ -490,10 +491,13 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         // six steps per iteration: the accumulators ping-pong (period 2), the boundary prefetch registers and - with
         // DM - the operand sets rotate with period 3 (without DM two operand sets alternate); the steps past
         // max_l1 + 1 compute rows that nobody reports
+        int chain_next = chain_every;
         for (int t = 2; t <= max_l1 + 1; t += 6) {
             if constexpr (CHAIN) {
-                // the steps up to t - 1 have stored the boundary rows up to t - 2
-                if (t > 2) chain_publish(chain_out, t - 2, lane);
+                // the steps up to t - 1 have stored the boundary rows up to t - 2.  Every publish drains the wave's
+                // stores (~1 us): plans with more waves per strip level than the chip has slots publish rarely -
+                // their consumers are dispatched a round later anyway (chain_every, set by the host)
+                if (t - 2 >= chain_next) { chain_publish(chain_out, t - 2, lane); chain_next = t - 2 + chain_every; }
             }
             if constexpr (DM) {
                 PRALINE_TB_STEP(t, accB, accA, bY, bX, bnd_prefB);

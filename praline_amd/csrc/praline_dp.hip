@@ -767,8 +767,13 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             HIPCHK(hipStreamSynchronize(st));   // ct goes out of scope
             la.bnd = pl.d_bnd_chain.p;
             if (local && pl.d_chain_cand.n < n_flags * 32) RC(pl.d_chain_cand.alloc(n_flags * 32));
+            // rows between two publishes of a strip's progress: few for plans whose strip waves all run at once
+            // (a single alignment: the next strip follows a few rows behind), many once a strip level alone
+            // fills the chip (the consumers are dispatched a round later; every publish drains the stores)
+            int every = nt >= 512 ? 96 : (nt >= 64 ? 24 : 6);
+            if (const char *env = getenv("PRALINE_CHAIN_EVERY")) every = std::max(6, atoi(env));
             int rc = praline_launch_split16_tb_chain(la, a16, a.nr16, tb_nterm, local, pl.has_rects, max_strips,
-                                                     pl.d_chain_flags.p, pl.d_chain_cand.p);
+                                                     pl.d_chain_flags.p, pl.d_chain_cand.p, every);
             if (rc != PRALINE_OK) return fail(rc, "no chain instance of k_dp_split16_tb for nr=%d nterm=%d", a.nr16, tb_nterm);
             if (local) {
                 const int64_t lanes = (int64_t)nt * 32;
