@@ -474,7 +474,7 @@ struct praline_plan {
 static int64_t chain_max_tasks()
 {
     if (const char *env = getenv("PRALINE_CHAIN_MAX_TASKS")) return atoll(env);
-    return 1536;
+    return 2304;   // measured crossover with task mode (scripts/exp_chain.py); within +-5 % of it up to ~4000 tasks
 }
 
 // traceback scratch budget per launch chunk (bytes)

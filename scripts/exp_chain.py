@@ -6,7 +6,7 @@ from praline_amd.matrices import blosum62_matrix
 from bench import synth_lengths, synth_profile
 nat.init(0)
 S = blosum62_matrix()
-for N, mu, ordered in ((64, 400, False), (256, 400, False), (300, 400, False), (360, 400, False), (200, 250, True), (256, 250, True), (384, 250, True)):
+for N, mu, ordered in ((420, 400, False), (480, 400, False), (560, 400, False), (300, 250, True), (384, 250, True)):
     rng = np.random.default_rng(3)
     lens = synth_lengths(rng, N, mu)
     profs = [synth_profile(rng, int(L)) for L in lens]
