@@ -301,7 +301,16 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     l_x = from_lower_half(lrun);
 
 #if !(PRALINE_S16_ABLATE & 2)
+#if PRALINE_S16_NT_BND
+    // streaming store: the column is read once, by the next strip, long after it has left this XCD's L2 anyway -
+    // it should not push operand rows out on its way (+1 %)
+    if (h) {   // H[yy][x0+32], L[yy][x0+33]
+        const unsigned long long v = (unsigned long long)__float_as_uint(Hs[16]) | ((unsigned long long)__float_as_uint(lrun) << 32);
+        __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long *>(bnd_st));
+    }
+#else
     if (h) *reinterpret_cast<float2 *>(bnd_st) = make_float2(Hs[16], lrun);  // H[yy][x0+32], L[yy][x0+33]
+#endif
 #endif
     bnd_st += 32 * sizeof(float2);
     if (semiglobal && last_owner) col_run = __builtin_fmaxf(col_run, select16s(Hs, cidx));
@@ -331,6 +340,9 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
 // arrive as one dword per lane and four rows.
 #ifndef PRALINE_S16_DM
 #define PRALINE_S16_DM 1
+#endif
+#ifndef PRALINE_S16_NT_BND
+#define PRALINE_S16_NT_BND 1
 #endif
 #ifdef PRALINE_TRACE
 // experiments only (scripts/exp_trace.py): per wave {block, wave | share << 8, HW_ID, XCC_ID, start, end} (s_memtime)
