@@ -15,6 +15,7 @@
 // end_cells / aux in the layout k_traceback reads.
 #pragma once
 #include "dp_split16.hip.h"
+#include <type_traits>
 
 // w = (w << 1) | (open < extend): the sign bit of open - extend, shifted in with v_alignbit_b32.  The
 // subtraction is opaque to the optimiser (the kernels are built -fno-honor-nans and -inf - -inf is a NaN).
@@ -114,9 +115,8 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     if constexpr (MASK) {
 #pragma unroll
         for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
-            const int lo = max(rect[r][2] - (xb + 1), 0), hi = min(rect[r][3] - (xb + 1), 15);
-            const bool in = yy >= rect[r][0] && yy <= rect[r][1] && lo <= hi;
-            zmask |= in ? ((0xffffu >> (15 - hi)) & (0xffffu << lo)) : 0u;
+            // rect[r][2] holds this strip's 16-bit column mask of rectangle r (set by the kernel per strip)
+            zmask |= (yy >= rect[r][0] && yy <= rect[r][1]) ? (unsigned)rect[r][2] : 0u;
         }
     }
     // "not MM" / "not MU" / (local) "clamp won" bits and the U-extend / L-extend bits of this lane's 16 cells; the
@@ -125,6 +125,10 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the row's cells, with or without the zero-rectangle handling (MK): rows in which no lane of the wave has a
+    // masked cell - most rows - take the plain version (wave-level vote below)
+    auto row_cells = [&](auto mk_tag) __attribute__((always_inline)) {
+    constexpr bool MK = decltype(mk_tag)::value;
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
         const int term = (NTERM == 1) ? 2 : k / NR;
@@ -168,7 +172,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
                 w_stop = __builtin_amdgcn_alignbit(w_stop, __builtin_bit_cast(unsigned, M), 31);
                 M = __builtin_fmaxf(M, 0.0f);                                    // cext.c:208-209
             }
-            if constexpr (MASK) {
+            if constexpr (MK) {
                 if (zmask & (1u << c)) { M = 0.0f; U = 0.0f; Lc = 0.0f; }          // cext.c:141-149 (stop code: row end)
             }
             // "from extend" bits = sign of (open - extend), shifted in with one v_alignbit each: no compare, so
@@ -179,11 +183,15 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             md = Mp[c]; ud = Up[c]; ld = Lp[c];
             Mp[c] = M; Up[c] = U; Lp[c] = Lc;
             mleft = M; lleft = Lc;
-#ifdef PRALINE_TB_SB_COLS
-            if ((c + 1) % PRALINE_TB_SB_COLS == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    };
+    if constexpr (MASK) {
+        if (__ballot(zmask != 0u) != 0ull) row_cells(std::true_type{});
+        else row_cells(std::false_type{});
+    } else {
+        row_cells(std::false_type{});
     }
     PREV = acc;
     {
@@ -379,6 +387,15 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         const int xb = x0 + 16 * h;
         const bool last_owner = (s == nstrips - 1) && own_last;
 
+        int srect[PRALINE_MAX_RECTS][4];   // rows of the rectangles + their column mask inside this lane's 16 columns
+#pragma unroll
+        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
+            const int lo = max(rect[r][2] - (xb + 1), 0), hi = min(rect[r][3] - (xb + 1), 15);
+            srect[r][0] = rect[r][0];
+            srect[r][1] = rect[r][1];
+            srect[r][2] = (MASK && lo <= hi) ? (int)((0xffffu >> (15 - hi)) & (0xffffu << lo)) : 0;
+            srect[r][3] = 0;
+        }
         float4 aop[NOP];
         {
             const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.row_bytes);
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, DM>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, BOLD, aop, aopH,     \
                                                 b_next, b_stride,                                                           \
                                                 bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl, cpxm, cpxu, cpxl,   \
-                                                cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge, xb, rect,          \
+                                                cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge, xb, srect,         \
                                                 chain_in, &chain_seen, (T) + 3)
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
