@@ -115,6 +115,34 @@ class PairwiseBatch(object):
         self.requests.append((mode, self._arena_index(sequence_one, 0), self._arena_index(sequence_two, 1), rects))
         return len(self.requests) - 1
 
+    def scores_for_pairs(self, sequences, ii, jj, modes):
+        """Scores only, for the pairs (sequences[ii[k]], sequences[jj[k]]) in mode modes[k] (array of mode names):
+        the whole list as one device submission per mode, without a Python-level request per pair (an all-pairs
+        stage of 400 sequences is 79 800 requests).  Both roles must use the same track sets."""
+        if self.ids_one != self.ids_two:
+            raise ComponentError("scores_for_pairs needs identical track id sets for both sequences")
+        ii, jj, modes = np.asarray(ii), np.asarray(jj), np.asarray(modes)
+        out = np.zeros(len(ii), dtype=np.float32)
+        if len(ii) == 0:
+            return out
+        idx = np.array([self._arena_index(seq, 0) for seq in sequences], dtype=np.int32)
+        arena = native.Arena(self._profiles, self.S)
+        try:
+            for mode in MODES:
+                sel = np.flatnonzero(modes == mode)
+                if len(sel) == 0:
+                    continue
+                pairs = np.stack([idx[ii[sel]], idx[jj[sel]]], axis=1).astype(np.int32)
+                plan = native.Plan(arena, pairs, want_paths=False)
+                try:
+                    plan.run(mode, self.gap_open, self.gap_extend)
+                    out[sel] = plan.scores()
+                finally:
+                    plan.close()
+        finally:
+            arena.close()
+        return out
+
     def run(self, want_paths=True):
         """Returns (scores float list, paths list or None) in request order."""
         n = len(self.requests)
@@ -519,11 +547,14 @@ class GuideTreeBuilder(Component):
         batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
         fixed = {"semiglobal": "semiglobal_both", "global": "global"}.get(dist_mode)
         ii, jj = np.triu_indices(n, k=1)   # tree.py:105-129: each unordered pair once, i outer, j inner
-        for i, j in zip(ii.tolist(), jj.tolist()):
-            batch.add(fixed or auto_align_mode(sequences[i], sequences[j]), sequences[i], sequences[j])
-        scores, _ = batch.run(want_paths=False)
+        if fixed:
+            modes = np.full(len(ii), fixed)
+        else:                              # auto_align_mode (util/align.py:299-305), for all pairs at once
+            lens = np.array([len(s) for s in sequences])
+            modes = np.where(lens[ii] > lens[jj], "semiglobal_one", "semiglobal_two")
+        scores = batch.scores_for_pairs(sequences, ii, jj, modes)
         d = np.zeros((n, n), dtype=np.float32)  # tree.py:99-100,131: diagonal 0
-        d[ii, jj] = d[jj, ii] = np.asarray(scores, dtype=np.float32)
+        d[ii, jj] = d[jj, ii] = scores
         self.score_matrix = d
         dist = (-d) + d.max()  # tree.py:147
         tree = SequenceTree(sequences, merge_order(dist, linkage))
