@@ -31,4 +31,4 @@ for stage in ("tree", "msa"):
         msa = run(comp.TreeMultipleSequenceAligner, keys, sequences=pre, guide_tree=tree, track_id_sets=T, score_matrices=[blosum])['alignment']
     pr.disable()
     print("=====", stage)
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(24)
