@@ -771,6 +771,11 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             // (a single alignment: the next strip follows a few rows behind), many once a strip level alone
             // fills the chip (the consumers are dispatched a round later; every publish drains the stores)
             int every = nt >= 512 ? 96 : (nt >= 64 ? 24 : 6);
+            {   // short sequences: at least four publishes per strip (co-resident consumers would wait for the end)
+                int rows = 0;
+                for (const WaveTask &wt : pl.tasks) rows = std::max(rows, (int)wt.max_l1);
+                every = std::min(every, std::max(6, rows / 4));
+            }
             if (const char *env = getenv("PRALINE_CHAIN_EVERY")) every = std::max(6, atoi(env));
             int rc = praline_launch_split16_tb_chain(la, a16, a.nr16, tb_nterm, local, pl.has_rects, max_strips,
                                                      pl.d_chain_flags.p, pl.d_chain_cand.p, every);
