@@ -740,6 +740,40 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
     }
     // traceback (praline/util/align.py:155-180)
     emit(y, x);
+    if (layout == 1) {
+        // k_dp_split16_tb planes: the interior walk as a short loop without a branch per state - the lanes of a wave
+        // are at different cells and states, every divergent branch is paid by all of them (and a single alignment
+        // pays the instruction count of one lane: ~120 instructions per step before)
+        const int64_t rows = tk.max_l1 + 8;
+        int guard = L1 + L2 + 2;
+        bool stopped = false;
+        while (y > 0 && x > 0 && guard-- > 0) {
+            bool masked = false;
+            for (int r = 0; r < n_rects; ++r) {
+                const int32_t *q = rl.rects + (int64_t)(r0 + r) * 4;
+                masked = masked || (y >= q[0] && y <= q[1] && x >= q[2] && x <= q[3]);
+            }
+            const int c = (x - 1) & 31, bit = c & 15;
+            const uint2 word = my_tb2[((int64_t)((x - 1) >> 5) * rows + y) * 64 + 32 * (c >> 4)];
+            // word.x: match source as two bit planes (low bits | high bits << 16); word.y: U-extend | L-extend << 16
+            const int code = (int)(((word.x >> bit) & 1u) | (((word.x >> (16 + bit)) & 1u) << 1));
+            const int ub = (int)((word.y >> bit) & 1u), lb = (int)((word.y >> (16 + bit)) & 1u);
+            if (masked || (k == 0 && code == 0)) { stopped = true; break; }   // t is 0 there (cext.c:141-149 / clamp)
+            // M: diagonal, state code - 1 (1 MM, 2 MU, 3 ML); U: up, 0 UO -> M / 1 UE -> U; L: left, 0 LO -> M / 1 LE -> L
+            const int nk = k == 0 ? code - 1 : (k == 1 ? ub : 2 * lb);
+            y -= (k != 2);
+            x -= (k != 1);
+            k = nk;
+            emit(y, x);
+        }
+        // on a boundary cell: the pre-initialised flags (align.py:377,385): t[y>=1,0,1] = UE, t[0,x>=1,2] = LE
+        while (!stopped && guard-- > 0) {
+            if (x == 0 && y >= 1 && k == 1 && !free_one) --y;
+            else if (y == 0 && x >= 1 && k == 2 && !free_two) --x;
+            else break;
+            emit(y, x);
+        }
+    } else
     for (int guard = 0; guard < L1 + L2 + 2; ++guard) {
         int ny, nx, nk;
         if (y == 0 || x == 0) {
