@@ -144,6 +144,31 @@ def test_guide_tree_on_preprofiles(env, seqs):
             assert np.array_equal(np.array(out['alignment'].path), d["path_%d_%d_%s" % (i, j, mode)])
 
 
+def test_guide_tree_distance_modes(env, seqs):
+    """GuideTreeBuilder's all-pairs stage (one device submission per alignment mode, no request per pair) against
+    one PairwiseAligner execution per pair with the mode the reference picks (tree.py:105-129,
+    util/align.py:299-305), for every dist_mode; the merge order follows from the same distances."""
+    T = [[ct.TRACK_ID_INPUT]]
+    n = len(seqs)
+    for dist_mode in ("global", "semiglobal", "semiglobal_auto"):
+        ex = core.Execution(env["serial"], "root")
+        task = ex.add_task(comp.GuideTreeBuilder)
+        task.environment(core.Environment({}), core.Environment({"dist_mode": dist_mode})).inputs(
+            sequences=seqs, track_id_sets=T, score_matrices=[env["blosum"]])
+        tree = core.run(ex)[0]['guide_tree']
+        d = np.zeros((n, n), dtype=np.float32)
+        for i in range(n):
+            for j in range(i + 1, n):
+                if dist_mode == "semiglobal_auto":
+                    mode = "semiglobal_one" if len(seqs[i]) > len(seqs[j]) else "semiglobal_two"
+                else:
+                    mode = {"global": "global", "semiglobal": "semiglobal_both"}[dist_mode]
+                out = run_one(env["serial"], comp.PairwiseAligner, mode=mode, sequence_one=seqs[i], sequence_two=seqs[j],
+                              track_id_sets_one=T, track_id_sets_two=T, score_matrices=[env["blosum"]])
+                d[i, j] = d[j, i] = out['score']
+        assert [tuple(x) for x in tree.merge_orders] == comp.merge_order((-d) + d.max(), "average"), dist_mode
+
+
 def test_multitrack_sets(env, seqs, bba):
     d = load_golden("multitrack.npz")
     motif_alpha = ct.Alphabet("golden.motif", [("*", 0), ("M", 1)])
