@@ -178,11 +178,11 @@ def main():
     total_cells = int(cells.sum())
 
     # this rank's shard of the pair list: whole columns (pairs sharing sequence two), balanced by cells
-    from praline_amd.allpairs import shard_columns
+    from praline_amd.allpairs import shard_columns, gather_maps
     shards = shard_columns(lens, pairs, world)
     my_idx = shards[rank]
     my_pairs = pairs[my_idx]
-    slice_len = int(max(len(ix) for ix in shards))
+    src, dst, slice_len = gather_maps(shards)
 
     arena = native.Arena(profs, S)
     plan = native.Plan(arena, my_pairs)
@@ -193,8 +193,6 @@ def main():
     d_all = torch.zeros(slice_len * world, dtype=torch.float32, device="cuda") if dist is not None else None
     # gathered shard slot -> position in the reference's row-major pair order
     if dist is not None:
-        src = np.concatenate([r * slice_len + np.arange(len(shards[r])) for r in range(world)])
-        dst = np.concatenate(shards)
         d_src = torch.as_tensor(src, device="cuda")
         d_dst = torch.as_tensor(dst, device="cuda")
         d_ordered = torch.zeros(len(pairs), dtype=torch.float32, device="cuda")
@@ -236,6 +234,13 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    if dist is not None:
+        # untimed sanity check of the exchange: this rank's slice sits at its pairs' positions of the gathered list
+        last = d_slices[(args.warmup + args.steps - 1) & 1]
+        if not (torch.equal(d_ordered[torch.as_tensor(my_idx, device="cuda")], last[:len(my_idx)])
+                and bool(torch.isfinite(d_ordered).all())):
+            raise SystemExit("bench.py: the gathered score list does not hold this rank's slice at its pairs' positions")
 
     # separate untimed pass: average DP-kernel duration over a few launches via HIP events
     kms = []

@@ -57,6 +57,16 @@ def shard_columns(lens, pairs, world):
     return [np.nonzero(pair_owner == r)[0].astype(np.int64) for r in range(world)]
 
 
+def gather_maps(shards):
+    """Index maps of the exchange step: every rank contributes a slice padded to the longest shard, the
+    all-gather lines the slices up rank by rank, and `out[dst] = gathered[src]` puts the scores back into the
+    row-major pair order.  Returns (src, dst, shard_len)."""
+    shard_len = int(max(len(ix) for ix in shards))
+    src = np.concatenate([r * shard_len + np.arange(len(ix), dtype=np.int64) for r, ix in enumerate(shards)])
+    dst = np.concatenate([np.asarray(ix, dtype=np.int64) for ix in shards])
+    return src, dst, shard_len
+
+
 def scores_to_distance(n, pairs, scores):
     """tree.py:99-100,131,142-147: d filled symmetrically, diagonal 0, dist = (-d) + d.max()."""
     d = np.zeros((n, n), dtype=np.float32)
@@ -103,15 +113,14 @@ def all_pairs_scores(lens, scorer, rank=0, world=1, group=None, device=None):
     import torch.distributed as dist
     shards = shard_columns(lens, pairs, world)
     mine = scorer(pairs[shards[rank]])
-    shard_len = max(len(ix) for ix in shards)
+    src, dst, shard_len = gather_maps(shards)
     dev = mine.device if device is None else device
     padded = torch.zeros(shard_len, dtype=torch.float32, device=dev)
     padded[:len(shards[rank])] = mine
     gathered = torch.zeros(shard_len * world, dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(gathered, padded, group=group)   # the one exchange step of the path
     out = torch.zeros(len(pairs), dtype=torch.float32, device=dev)  # back into the reference's pair order
-    for r in range(world):
-        out[torch.as_tensor(shards[r], device=dev)] = gathered[r * shard_len:r * shard_len + len(shards[r])]
+    out[torch.as_tensor(dst, device=dev)] = gathered[torch.as_tensor(src, device=dev)]
     return pairs, out
 
 

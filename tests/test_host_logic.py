@@ -213,6 +213,19 @@ def test_all_pairs_sharding_helpers():
     for world in (1, 2, 3, 8, 16):
         b = allpairs.shard_bounds(cells, world)
         assert b[0] == 0 and b[-1] == len(cells) and all(b[i] <= b[i + 1] for i in range(world))
+    # exchange maps: padded slices concatenated rank by rank -> row-major pair order
+    lens9 = np.array([30, 80, 45, 61, 12, 99, 7, 50, 33])
+    pairs9 = allpairs.enumerate_pairs(9)
+    truth = np.arange(len(pairs9), dtype=np.float32) * 1.5
+    for world in (1, 2, 3, 8):
+        shards9 = allpairs.shard_columns(lens9, pairs9, world)
+        src, dst, shard_len = allpairs.gather_maps(shards9)
+        gathered = np.full(shard_len * world, np.nan, dtype=np.float32)
+        for r, ix in enumerate(shards9):
+            gathered[r * shard_len:r * shard_len + len(ix)] = truth[ix]
+        out = np.zeros(len(pairs9), dtype=np.float32)
+        out[dst] = gathered[src]
+        assert np.array_equal(out, truth), world
     # column shards: a partition of the pair list, whole columns per rank, balanced by cells
     rng = np.random.default_rng(4)
     lens = rng.integers(50, 500, 40)
