@@ -19,7 +19,7 @@ from . import native
 from .container import (Alignment, GapScoreModel, MatchScoreModel, PlainTrack, ProfileTrack,
                         ScoreMatrix, Sequence, SequenceTree, TRACK_ID_INPUT)
 from .core import (BeginMessage, CompleteMessage, Component, ComponentError, DataError, Environment,
-                   Execution, Manager, MESSAGE_KIND_COMPLETE, Port, ProgressMessage, T)
+                   Execution, Manager, Port, ProgressMessage, T)
 from .util import (auto_align_mode, compress_path, extend_path_local, get_frequencies,
                    zero_idxs_to_rectangles)
 
