@@ -59,6 +59,11 @@ int praline_init(int device);                 /* bind this process to `device` (
 int praline_shutdown(void);                   /* release streams and cached device buffers */
 int praline_synchronize(void);                /* wait for all work submitted by this library */
 const char *praline_last_error(void);         /* message of the last failure on this thread */
+/* Scratch buffers (strip boundaries, traceback planes, paths) are recycled through a pool of released device
+ * blocks (cap: PRALINE_POOL_KEEP_MB, default 16384).  praline_pool_trim waits for the library's work and returns
+ * every cached block to the driver - call it before handing the GPU's memory to another allocator. */
+int praline_pool_trim(void);
+int64_t praline_pool_cached_bytes(void);
 void *praline_stream(void);                   /* the hipStream_t all kernels are launched on */
 
 /* ============================================================================================
@@ -163,7 +168,8 @@ int64_t praline_plan_path_capacity(const praline_plan *plan); /* rows: sum (L1+L
  * order, or NULL to use the plan's own buffer. */
 int praline_plan_run(praline_plan *plan, int mode, float gap_open, float gap_extend,
                      void *d_scores);
-/* Copies the plan's score buffer (pair order) to the host; synchronises. */
+/* Copies the scores of the last praline_plan_run (pair order) to the host - from the plan's own buffer or from
+ * the d_scores that run was given; synchronises. */
 int praline_plan_scores(praline_plan *plan, float *scores);
 /* Device pointer of the plan's own score buffer. */
 void *praline_plan_device_scores(praline_plan *plan);
@@ -201,8 +207,8 @@ int praline_arena_info(const praline_arena *arena, int32_t *n_active, int32_t *m
                        int32_t *f16_ranges, int32_t *f16_terms);
 int praline_plan_match_kind(const praline_plan *plan);
 
-/* Timing of the last praline_plan_run on this plan, measured with HIP events on the launch
- * stream: kernel_ms = the DP kernel alone. */
+/* Timing of the last praline_plan_run on THIS plan, measured with the plan's own HIP events on the launch
+ * stream: kernel_ms = the DP kernel alone (scores-only plans) / fill + end cells + traceback (path plans). */
 int praline_plan_last_timing(praline_plan *plan, float *kernel_ms);
 
 #ifdef __cplusplus

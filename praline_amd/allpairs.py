@@ -85,10 +85,14 @@ def device_scorer(profiles, score_matrix, mode, gap_open, gap_extend):
     arena = native.Arena(profiles, score_matrix)
 
     def score(pairs):
-        out = torch.zeros(len(pairs), dtype=torch.float32, device="cuda")
+        # every entry is written by the DP kernel: no fill.  The kernel runs on the LIBRARY's stream, which knows
+        # nothing of torch's: order it behind whatever torch has queued on its current stream (a recycled
+        # caching-allocator block may still be in use there), and finish it before torch sees `out`.
+        out = torch.empty(len(pairs), dtype=torch.float32, device="cuda")
         if len(pairs):
             plan = native.Plan(arena, pairs)
             try:
+                torch.cuda.ExternalStream(native.stream_handle()).wait_stream(torch.cuda.current_stream())
                 plan.run(mode, gap_open, gap_extend, d_scores=out.data_ptr())
                 native.synchronize()
             finally:

@@ -54,7 +54,6 @@ struct Runtime {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 static Runtime g_rt;
 
@@ -74,8 +73,6 @@ static int ensure_runtime(int device)
     if (device >= n) return fail(PRALINE_ERR_ARG, "device %d out of range (%d visible)", device, n);
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&g_rt.stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreate(&g_rt.ev0));
-    HIPCHK(hipEventCreate(&g_rt.ev1));
     g_rt.device = device;
     g_rt.ready = true;
     return PRALINE_OK;
@@ -102,8 +99,6 @@ extern "C" int praline_shutdown(void)
     if (!g_rt.ready) return PRALINE_OK;
     (void)hipStreamSynchronize(g_rt.stream);
     pool_clear();
-    (void)hipEventDestroy(g_rt.ev0);
-    (void)hipEventDestroy(g_rt.ev1);
     (void)hipStreamDestroy(g_rt.stream);
     g_rt = Runtime();
     return PRALINE_OK;
@@ -116,6 +111,14 @@ extern "C" int praline_synchronize(void)
     return PRALINE_OK;
 }
 
+extern "C" int praline_pool_trim(void)
+{
+    if (!g_rt.ready) return PRALINE_OK;
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
+    pool_clear();
+    return PRALINE_OK;
+}
+
 extern "C" const char *praline_last_error(void) { return g_err.c_str(); }
 extern "C" void *praline_stream(void) { return g_rt.ready ? (void *)g_rt.stream : nullptr; }
 
@@ -125,7 +128,18 @@ extern "C" void *praline_stream(void) { return g_rt.ready ? (void *)g_rt.stream 
 struct PoolBlock { void *p; size_t bytes; };
 static std::vector<PoolBlock> g_pool;
 static size_t g_pool_bytes = 0;
-static const size_t kPoolKeepBytes = (size_t)96 << 30;
+// Cap of the cached (released, not yet freed) bytes: PRALINE_POOL_KEEP_MB, default 16 GiB - enough for the scratch
+// of a C3-size path plan, small next to what torch / RCCL may want on the same GPU.  praline_pool_trim() returns
+// every cached block to the driver.  The pool, like the rest of the library, is for one host thread per device.
+static size_t pool_keep_bytes()
+{
+    static size_t keep = (size_t)-1;
+    if (keep == (size_t)-1) {
+        keep = (size_t)16 << 30;
+        if (const char *env = getenv("PRALINE_POOL_KEEP_MB")) keep = (size_t)atoll(env) << 20;
+    }
+    return keep;
+}
 
 static void *pool_alloc(size_t bytes, size_t *got)
 {
@@ -157,7 +171,7 @@ static void *pool_alloc(size_t bytes, size_t *got)
 static void pool_release(void *p, size_t bytes)
 {
     if (!p) return;
-    if (bytes < ((size_t)1 << 20) || g_pool_bytes + bytes > kPoolKeepBytes) { (void)hipFree(p); return; }
+    if (bytes < ((size_t)1 << 20) || g_pool_bytes + bytes > pool_keep_bytes()) { (void)hipFree(p); return; }
     g_pool.push_back({p, bytes});
     g_pool_bytes += bytes;
 }
@@ -168,6 +182,8 @@ static void pool_clear()
     g_pool.clear();
     g_pool_bytes = 0;
 }
+
+extern "C" int64_t praline_pool_cached_bytes(void) { return (int64_t)g_pool_bytes; }
 
 // small RAII device buffer
 template <typename T> struct DevBuf {
@@ -464,6 +480,13 @@ struct praline_plan {
     std::vector<int64_t> slot_off;
     float last_kernel_ms = 0.0f;
     int last_mode = -1;
+    float *last_scores = nullptr;   // where the last praline_plan_run wrote the scores (own buffer or the caller's)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last run's launches, on the launch stream
+    ~praline_plan()
+    {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
 };
 
 // chain mode (one wave per task and strip) for plans of up to this many tasks.  Measured with paths, float
@@ -561,6 +584,8 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         }
     }
     hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
     if (e != hipSuccess) { delete pl; return fail(PRALINE_ERR_DEVICE, "plan upload: %s", hipGetErrorString(e)); }
     *out = pl;
     return PRALINE_OK;
@@ -666,6 +691,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     }
     const bool local = mode == PRALINE_MODE_LOCAL;
     pl.last_mode = mode;
+    pl.last_scores = la.scores;
     hipStream_t st = g_rt.stream;
 
     if (!pl.want_paths) {
@@ -691,9 +717,9 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             la.wg = pl.d_wg_singles.p;
             la.n_wg = (unsigned)pl.wg_singles.size();
         }
-        HIPCHK(hipEventRecord(g_rt.ev0, st));
+        HIPCHK(hipEventRecord(pl.ev0, st));
         RC(launch_dp(a.nstep, la, pl.tp, local, 0, false));
-        HIPCHK(hipEventRecord(g_rt.ev1, st));
+        HIPCHK(hipEventRecord(pl.ev1, st));
         HIPCHK(hipGetLastError());
         return PRALINE_OK;
     }
@@ -723,7 +749,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     const int lanes_per_task = pl.split ? 32 : 64;
     size_t t0 = 0;
     const size_t nt = pl.tasks.size();
-    HIPCHK(hipEventRecord(g_rt.ev0, st));
+    HIPCHK(hipEventRecord(pl.ev0, st));
     while (t0 < nt) {
         size_t t1 = t0;
         int64_t tb_e = 0, aux_e = 0;
@@ -812,16 +838,18 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         }
         t0 = t1;
     }
-    HIPCHK(hipEventRecord(g_rt.ev1, st));
+    HIPCHK(hipEventRecord(pl.ev1, st));
     return PRALINE_OK;
 }
 
 extern "C" int praline_plan_last_timing(praline_plan *plan, float *kernel_ms)
 {
     if (!plan || !kernel_ms) return fail(PRALINE_ERR_ARG, "NULL argument");
-    HIPCHK(hipEventSynchronize(g_rt.ev1));
+    if (plan->n_pairs == 0) { *kernel_ms = 0.0f; return PRALINE_OK; }
+    if (plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "praline_plan_run has not been called");
+    HIPCHK(hipEventSynchronize(plan->ev1));
     float ms = 0.0f;
-    HIPCHK(hipEventElapsedTime(&ms, g_rt.ev0, g_rt.ev1));
+    HIPCHK(hipEventElapsedTime(&ms, plan->ev0, plan->ev1));
     plan->last_kernel_ms = ms;
     *kernel_ms = ms;
     return PRALINE_OK;
@@ -831,7 +859,9 @@ extern "C" int praline_plan_scores(praline_plan *plan, float *scores)
 {
     if (!plan || (!scores && plan->n_pairs)) return fail(PRALINE_ERR_ARG, "NULL argument");
     if (plan->n_pairs == 0) return PRALINE_OK;
-    HIPCHK(hipMemcpyAsync(scores, plan->d_scores.p, (size_t)plan->n_pairs * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
+    if (!plan->last_scores) return fail(PRALINE_ERR_ARG, "praline_plan_run has not been called");
+    // the buffer the last run wrote: the plan's own or the caller's d_scores
+    HIPCHK(hipMemcpyAsync(scores, plan->last_scores, (size_t)plan->n_pairs * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
     HIPCHK(hipStreamSynchronize(g_rt.stream));
     return PRALINE_OK;
 }
@@ -872,7 +902,7 @@ extern "C" int praline_plan_add_counts(praline_plan *plan, int use_threshold, fl
     const int threads = 64;
     const int64_t blocks = (plan->n_pairs + threads - 1) / threads;
     hipLaunchKernelGGL(k_path_counts, dim3((unsigned)blocks), dim3(threads), 0, g_rt.stream, plan->d_pairs.p,
-                       plan->d_scores.p, plan->d_paths.p, plan->d_path_start.p, plan->d_path_rows.p, plan->n_pairs,
+                       plan->last_scores, plan->d_paths.p, plan->d_path_start.p, plan->d_path_rows.p, plan->n_pairs,
                        use_threshold, threshold, local, a.d_row_off_raw.p, a.d_len.p, a.d_sym_raw.p, a.A, a.d_counts.p);
     HIPCHK(hipGetLastError());
     return PRALINE_OK;

@@ -53,6 +53,7 @@ def lib():
     L.praline_init.argtypes = [i32]
     L.praline_last_error.restype = ctypes.c_char_p
     L.praline_stream.restype = vp
+    L.praline_pool_cached_bytes.restype = i64
     L.praline_build_scores.argtypes = [i32, pa, pa, pa, pa, pa, pa]
     for name in ("global", "local", "semiglobal_both", "semiglobal_one", "semiglobal_two"):
         getattr(L, "praline_align_" + name).argtypes = [pa, pa, pa, pa, pa, pa]
@@ -116,6 +117,20 @@ def synchronize():
 
 def stream_handle():
     return lib().praline_stream()
+
+
+def pool_trim():
+    """Return the library's cached device blocks to the driver (praline_pool_trim)."""
+    _check(lib().praline_pool_trim())
+
+
+def pool_cached_bytes():
+    return int(lib().praline_pool_cached_bytes())
+
+
+def shutdown():
+    """Release the library's stream and every cached device buffer (praline_shutdown)."""
+    _check(lib().praline_shutdown())
 
 
 def _arr(a):
