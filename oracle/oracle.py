@@ -65,6 +65,8 @@ def lib():
         L.oracle_pairwise.restype = i64
         L.oracle_batch_scores.argtypes = [i32, vp, vp, vp, vp, i64, vp, i64, f32, f32, i32, vp]
         L.oracle_batch_scores.restype = i32
+        L.oracle_batch_align.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, i64, f32, f32, vp, vp, i32, vp, vp, vp, vp]
+        L.oracle_batch_align.restype = i32
         _lib = L
     return _lib
 
@@ -273,3 +275,38 @@ def batch_scores(mode, arena, row_off, lens, s, pairs, gap_open, gap_extend, thr
     if err:
         raise RuntimeError("oracle_batch_scores failed")
     return scores
+
+
+def batch_align(modes, arena, row_off, lens, s, pairs, gap_open, gap_extend, rects=None, threads=1):
+    """Alignments with paths for a pair list in several modes, the match scores of each pair built ONCE in
+    the reference's order (parity tests at BASELINE sizes).  arena: concatenated float32 profiles [sum L][A];
+    rects: optional list (one entry per pair) of (y0, y1, x0, x1) zero rectangles.
+    Returns (scores float32 [n_pairs][n_modes], paths): paths[p][k] is an int32 [rows, 2] array."""
+    arena = _c(arena, np.float32)
+    row_off = _c(row_off, np.int64)
+    lens = _c(lens, np.int32)
+    s = _c(s, np.float32)
+    pairs = _c(pairs, np.int32).reshape(-1, 2)
+    mode_ids = _c([MODES[m] for m in modes], np.int32)
+    n, nm = pairs.shape[0], len(mode_ids)
+    cap = (lens[pairs[:, 0]].astype(np.int64) + lens[pairs[:, 1]] + 2)
+    slot = np.concatenate([[0], np.cumsum(np.repeat(cap, nm))]).astype(np.int64)
+    buf = np.zeros((max(int(slot[-1]), 1), 2), dtype=np.int32)
+    rows = np.zeros(n * nm, dtype=np.int32)
+    scores = np.zeros((n, nm), dtype=np.float32)
+    ro = rv = None
+    if rects is not None:
+        ro = np.zeros(n + 1, dtype=np.int64)
+        flat = []
+        for p_, rl in enumerate(rects):
+            flat.extend(rl)
+            ro[p_ + 1] = ro[p_] + len(rl)
+        rv = _c(np.array(flat, dtype=np.int64).reshape(-1, 4) if flat else np.zeros((1, 4)), np.int64)
+    err = lib().oracle_batch_align(nm, _p(mode_ids), _p(arena), _p(row_off), _p(lens), _p(s), arena.shape[1],
+                                   _p(pairs), n, gap_open, gap_extend, _p(ro) if ro is not None else None,
+                                   _p(rv) if rv is not None else None, int(threads), _p(scores), _p(buf),
+                                   _p(slot), _p(rows))
+    if err:
+        raise RuntimeError("oracle_batch_align failed")
+    paths = [[buf[slot[p_ * nm + k]:slot[p_ * nm + k] + rows[p_ * nm + k]] for k in range(nm)] for p_ in range(n)]
+    return scores, paths
