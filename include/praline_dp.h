@@ -52,6 +52,20 @@ extern "C" {
 #define PRALINE_TB_INSERT_LEFT_OPEN (1 << 6)
 #define PRALINE_TB_INSERT_LEFT_EXTEND (1 << 7)
 
+/* How the batched plans (section B) evaluate the match scores m = sum_sets P1 . S . P2^T (cext.c:33-97,308-455):
+ *   FAST       matrix pipe: exact f16 hi/lo split of the fp32 operands, fp32 accumulation.  Bit-identical to the
+ *              reference for integer scoring (one-hot profiles x integral matrix); within ~1e-6 relative otherwise.
+ *   F32        fp32 MFMA chain (k-ordered fmaf chain); same exactness statement, fp32 operands throughout.
+ *   REFERENCE  the reference's own summation order on the vector ALU: per track set one float32 running sum over the
+ *              nonzeros of both profile rows, every product and sum rounded separately as the reference binary does.
+ *              Bit-identical match scores - hence scores AND alignments identical to the reference's - for ANY
+ *              profiles; ~10-20x slower (an audit / strict-parity mode).
+ * The mode is read when a plan is created.  Default: FAST, or what the environment variable PRALINE_MM
+ * ("f32" / "ref") names; praline_set_match_mode(-1) returns to that default. */
+#define PRALINE_MATCH_FAST 0
+#define PRALINE_MATCH_F32 1
+#define PRALINE_MATCH_REFERENCE 2
+
 /* ---- runtime ------------------------------------------------------------------------------- */
 int praline_abi_version(void);
 int praline_device_count(int *count);         /* number of visible HIP devices */
@@ -65,6 +79,8 @@ const char *praline_last_error(void);         /* message of the last failure on 
 int praline_pool_trim(void);
 int64_t praline_pool_cached_bytes(void);
 void *praline_stream(void);                   /* the hipStream_t all kernels are launched on */
+int praline_set_match_mode(int kind);         /* PRALINE_MATCH_*; -1 = back to the PRALINE_MM default */
+int praline_get_match_mode(void);
 
 /* ============================================================================================
  * A. Parity-layout entry points: the reference's native functions on raw host buffers.
@@ -142,6 +158,10 @@ typedef struct praline_plan praline_plan;   /* a scheduled pair list (wave tasks
 int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t A, const float *profiles,
                          const float *S, praline_arena **out);
 int praline_arena_destroy(praline_arena *arena);
+/* Tells the arena how its alphabet axis is partitioned into track sets (sizes[0] + ... + sizes[n_sets-1] = A).
+ * Only PRALINE_MATCH_REFERENCE needs it: the reference keeps one running sum per set and adds the sets in list
+ * order (cext.c:389-420).  Default: one set of size A. */
+int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets, const int32_t *sizes);
 /* Re-runs the device-side packing + pre-multiply from the resident raw profiles (the part of
  * cext_build_scores that is per sequence, not per pair); asynchronous on praline_stream(). */
 int praline_arena_premultiply(praline_arena *arena);
@@ -196,7 +216,8 @@ int praline_plan_path_bounds(praline_plan *plan, int32_t *bounds);
 int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float gap_extend,
                          int64_t n_pairs, const int32_t *pairs, float *scores);
 
-/* Diagnostics / audits.  praline_arena_match_scores writes the dense match-score matrix
+/* Diagnostics / audits.  praline_plan_match_kind: 0 fp32 MFMA chain, 1 f16 split, 2 reference order.
+ * praline_arena_match_scores writes the dense match-score matrix
  * m (float32 [L1][L2], host) of the arena pair (one, two) exactly as the kernels evaluate it:
  * kind 0 = fp32 MFMA chain (k-ordered fmaf chain, used by the traceback plans and
  * praline_build_scores), kind 1 = f16 hi/lo split on the matrix pipe (used by scores-only plans;

@@ -126,7 +126,7 @@ class PairwiseBatch(object):
         if len(ii) == 0:
             return out
         idx = np.array([self._arena_index(seq, 0) for seq in sequences], dtype=np.int32)
-        arena = native.Arena(self._profiles, self.S)
+        arena = native.Arena(self._profiles, self.S, set_sizes=self.sizes)
         try:
             for mode in MODES:
                 sel = np.flatnonzero(modes == mode)
@@ -150,7 +150,7 @@ class PairwiseBatch(object):
         paths = [None] * n if want_paths else None
         if n == 0:
             return scores, paths
-        arena = native.Arena(self._profiles, self.S)
+        arena = native.Arena(self._profiles, self.S, set_sizes=self.sizes)
         try:
             for mode in MODES:
                 sel = [k for k, r in enumerate(self.requests) if r[0] == mode]

@@ -273,15 +273,21 @@ __device__ __forceinline__ float select32(const float (&v)[32], int idx)
     return b4 ? t2[1] : t2[0];
 }
 
-template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK>
+// MSRC = 1 (reference-order audit mode, PRALINE_MATCH_REFERENCE): the match scores are not formed by MFMAs but read
+// from dense per-pair matrices mref + m_off[pair] ([L1][L2] float32) that k_match_ref wrote in the reference's own
+// summation order; TP must be 1.  Everything after the match scores is the same code.
+template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK, int MSRC = 0>
 __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__restrict__ tasks,
                                                  const int32_t *__restrict__ lane_one,
                                                  const int32_t *__restrict__ lane_pair,
                                                  void *__restrict__ bnd_raw, uint4 *__restrict__ tb,
                                                  float *__restrict__ aux, RectList rl,
                                                  float *__restrict__ scores,
-                                                 int32_t *__restrict__ end_cells, RunParams rp)
+                                                 int32_t *__restrict__ end_cells, RunParams rp,
+                                                 const float *__restrict__ mref = nullptr,
+                                                 const int64_t *__restrict__ m_off = nullptr)
 {
+    static_assert(MSRC == 0 || TP == 1, "the dense match-score source is wired for TP = 1");
     constexpr int NQ = (NSTEP + 3) / 4;  // float4 loads per operand
     const int lane = threadIdx.x;
     const int half = lane >> 5;
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
     const int my_strips = (L2 + 31) >> 5;
     const int clast = (L2 - 1) & 31;
     const int my_pair = have_pair ? lane_pair[base + lane] : -1;
+    const float *my_m = (MSRC == 1 && my_pair >= 0) ? mref + m_off[my_pair] : nullptr;
 
     // ---- MFMA operand sources ----
     // B operand: lane (j, half) feeds k = 2s + half of the profile row of the pair owned by DP
@@ -411,6 +418,14 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
         }
 
         for (int y = 1; y <= tk.max_l1; ++y) {
+            float m[32];
+            if constexpr (MSRC == 1) {
+                // dense reference-order match scores of this lane's own pair
+                const bool row_ok = my_m != nullptr && y <= L1;
+#pragma unroll
+                for (int c = 0; c < 32; ++c)
+                    m[c] = (row_ok && x0 + c < L2) ? my_m[(int64_t)(y - 1) * L2 + x0 + c] : 0.0f;
+            } else {
             // ---- match scores of row y for all lanes: NSTEP MFMAs per tile ----
             float bA[NSTEP], bB[NSTEP];
 #pragma unroll
@@ -439,7 +454,6 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
             }
             // D[i][lane]: register r of half h holds i = (r&3) + 8(r>>2) + 4h.  Exchange halves so
             // every DP lane holds all 32 columns of ITS pair: m[8q+r] = a[4q+r], m[8q+4+r] = b[4q+r].
-            float m[32];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float a = accA[r];
@@ -447,6 +461,7 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
                 swap_halves(a, b);
                 m[8 * (r >> 2) + (r & 3)] = a;
                 m[8 * (r >> 2) + 4 + (r & 3)] = b;
+            }
             }
 
             if (strip_act && y <= L1) {
@@ -881,6 +896,77 @@ __global__ void k_path_bounds(const int32_t *__restrict__ paths, const int64_t *
     bounds[4 * p + 3] = rows > 0 ? path[2 * (rows - 1) + 1] : -1;
 }
 
+
+// --------------------------------------------------------------------------------------------
+// Reference-order match scores (audit mode PRALINE_MATCH_REFERENCE).
+// cext_build_scores / score_match_prof_prof (praline/util/cext.c:33-97,389-420): per track set, one float32 running sum
+// over the nonzeros of row y of profile one (ascending, outer) and of row x of profile two (ascending, inner); the
+// reference binary (built -ffast-math, setup.py:28) evaluates each term as (p2 * score) * p1 - see
+// oracle/praline_oracle.c - and the per-set sums are added in list order to a float32 that starts at 0.
+// Separately rounded multiplies and adds (__fmul_rn / __fadd_rn: no contraction), so the result is bit-identical
+// to the reference's m for ANY profiles; the price is ~nnz1 * nnz2 dependent VALU operations per cell.
+// --------------------------------------------------------------------------------------------
+// per raw profile row: ascending indices of its nonzeros (build_nonzero_matrix, praline/component/align.py:449-458)
+__global__ void k_build_nz(const float *__restrict__ raw, int64_t rows, int A, unsigned char *__restrict__ nzidx,
+                           unsigned char *__restrict__ nzcnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *row = raw + r * A;
+    unsigned char *out = nzidx + r * A;
+    int k = 0;
+    for (int a = 0; a < A; ++a)
+        if (row[a] != 0.0f) out[k++] = (unsigned char)a;
+    nzcnt[r] = (unsigned char)k;
+}
+
+// grid (pairs of the chunk, row groups); a block walks the cells of its rows with x fastest.
+#define PRALINE_REF_ROWS 16
+__global__ __launch_bounds__(256) void k_match_ref(const float *__restrict__ raw, const float *__restrict__ S, int A,
+                                                   const int32_t *__restrict__ row_off_raw, const int32_t *__restrict__ len,
+                                                   const unsigned char *__restrict__ nzidx,
+                                                   const unsigned char *__restrict__ nzcnt,
+                                                   const int32_t *__restrict__ set_lo, int n_sets,
+                                                   const int32_t *__restrict__ pairs, const int32_t *__restrict__ chunk_pairs,
+                                                   const int64_t *__restrict__ m_off, float *__restrict__ mref)
+{
+    const int p = chunk_pairs[blockIdx.x];
+    const int one = pairs[2 * p], two = pairs[2 * p + 1];
+    const int L1 = len[one], L2 = len[two];
+    const int y0 = blockIdx.y * PRALINE_REF_ROWS;
+    if (y0 >= L1) return;
+    const int ny = min(PRALINE_REF_ROWS, L1 - y0);
+    const int64_t r1 = row_off_raw[one], r2 = row_off_raw[two];
+    float *out = mref + m_off[p];
+    for (int c = threadIdx.x; c < ny * L2; c += blockDim.x) {
+        const int y = y0 + c / L2, x = c % L2;
+        const float *p1 = raw + (r1 + y) * A, *p2 = raw + (r2 + x) * A;
+        const unsigned char *i1 = nzidx + (r1 + y) * A, *i2 = nzidx + (r2 + x) * A;
+        const int n1 = nzcnt[r1 + y], n2 = nzcnt[r2 + x];
+        float score = 0.0f;
+        int a = 0;
+        for (int s = 0; s < n_sets; ++s) {
+            const int hi = set_lo[s + 1], lo = set_lo[s];
+            // the nonzeros of row x that fall into this set: [b0, b1)
+            int b0 = 0;
+            while (b0 < n2 && i2[b0] < lo) ++b0;
+            int b1 = b0;
+            while (b1 < n2 && i2[b1] < hi) ++b1;
+            float acc = 0.0f;
+            for (; a < n1 && i1[a] < hi; ++a) {
+                const int i = i1[a];
+                const float v1 = p1[i];
+                const float *srow = S + (int64_t)i * A;
+                for (int b = b0; b < b1; ++b) {
+                    const int j = i2[b];
+                    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(p2[j], srow[j]), v1));
+                }
+            }
+            score = __fadd_rn(score, acc);
+        }
+        out[(int64_t)y * L2 + x] = score;
+    }
+}
 
 // --------------------------------------------------------------------------------------------
 // Raw parity kernels: the reference's buffers (contiguous copies on the device).

@@ -24,6 +24,8 @@ struct LaunchArgs {
     const struct WgDesc *wg;  // non-null: four-wave workgroups (k_dp_split16 WPG = 4), n_wg of them
     unsigned n_wg;
     int split;  // 1: k_dp_split task layout (32 lane entries per task, float2 [max_l1+2][32] boundary)
+    const float *mref = nullptr;     // reference-order audit mode: dense match scores, pair p at mref + m_off[p]
+    const int64_t *m_off = nullptr;
 };
 
 // k_dp_split instances (dp_split_instance.hip, built with -mllvm -amdgpu-mfma-vgpr-form)
@@ -42,6 +44,8 @@ void praline_launch_split_f16(const float *src, int KP, int KS, int n_active, in
                               hipStream_t stream);
 int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int one, int two, int L1, int L2, float *m,
                                  hipStream_t stream);
+// k_dp_batch on dense reference-order match scores (dp_ref_instance.hip)
+int praline_launch_dp_ref(const LaunchArgs &la, bool local, int out, bool mask);
 // k_dp_batch instances (dp_instance.hip)
 int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, bool mask);
 int praline_launch_dp_8(const LaunchArgs &la, int tp, bool local, int out, bool mask);

@@ -111,6 +111,27 @@ extern "C" int praline_synchronize(void)
     return PRALINE_OK;
 }
 
+// Which arithmetic evaluates the match scores m = sum_sets P1 . S . P2^T of the batched plans (include/praline_dp.h).
+static int g_match_mode = -1;   // -1: not set through the API, follow PRALINE_MM
+static int match_mode()
+{
+    if (g_match_mode >= 0) return g_match_mode;
+    if (const char *mm = getenv("PRALINE_MM")) {
+        if (!strcmp(mm, "f32")) return PRALINE_MATCH_F32;
+        if (!strcmp(mm, "ref")) return PRALINE_MATCH_REFERENCE;
+    }
+    return PRALINE_MATCH_FAST;
+}
+
+extern "C" int praline_set_match_mode(int kind)
+{
+    if (kind < -1 || kind > PRALINE_MATCH_REFERENCE) return fail(PRALINE_ERR_ARG, "unknown match-score mode %d", kind);
+    g_match_mode = kind;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_get_match_mode(void) { return match_mode(); }
+
 extern "C" int praline_pool_trim(void)
 {
     if (!g_rt.ready) return PRALINE_OK;
@@ -249,6 +270,11 @@ struct praline_arena {
     // preprofile stage (k_path_counts): raw symbol of every one-hot row (255: not one-hot), int32 counts [rows_raw][A]
     DevBuf<unsigned char> d_sym_raw;
     DevBuf<int32_t> d_counts;
+    // reference-order audit mode (k_match_ref): track-set partition of the alphabet axis and per-row nonzero lists
+    std::vector<int32_t> set_lo;     // n_sets + 1 boundaries, default {0, A}
+    DevBuf<int32_t> d_set_lo;
+    DevBuf<unsigned char> d_nzidx, d_nzcnt;
+    bool ref_ready = false;
     Arena16Dev view16() const
     {
         Arena16Dev v;
@@ -310,6 +336,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     praline_arena *a = new praline_arena();
     a->n_seqs = n_seqs;
     a->A = A;
+    a->set_lo = {0, A};
     a->len.assign(lens, lens + n_seqs);
     a->row_off_pad.resize(n_seqs);
     a->row_off_raw.resize(n_seqs);
@@ -438,6 +465,36 @@ extern "C" int praline_arena_destroy(praline_arena *arena)
     return PRALINE_OK;
 }
 
+extern "C" int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets, const int32_t *sizes)
+{
+    if (!arena || n_sets <= 0 || !sizes) return fail(PRALINE_ERR_ARG, "bad track-set arguments");
+    std::vector<int32_t> lo(1, 0);
+    for (int n = 0; n < n_sets; ++n) {
+        if (sizes[n] <= 0) return fail(PRALINE_ERR_ARG, "track set %d has size %d", n, sizes[n]);
+        lo.push_back(lo.back() + sizes[n]);
+    }
+    if (lo.back() != arena->A) return fail(PRALINE_ERR_ARG, "track-set sizes sum to %d, the arena alphabet is %d", lo.back(), arena->A);
+    arena->set_lo.swap(lo);
+    arena->ref_ready = false;
+    return PRALINE_OK;
+}
+
+// nonzero lists + set boundaries for k_match_ref, built on first use
+static int arena_ensure_ref(praline_arena *a)
+{
+    if (a->ref_ready) return PRALINE_OK;
+    hipStream_t st = g_rt.stream;
+    RC(a->d_set_lo.upload(a->set_lo, st));
+    RC(a->d_nzidx.alloc((size_t)a->rows_raw * a->A));
+    RC(a->d_nzcnt.alloc((size_t)a->rows_raw));
+    hipLaunchKernelGGL(k_build_nz, dim3((unsigned)((a->rows_raw + 255) / 256)), dim3(256), 0, st, a->d_raw.p, a->rows_raw, a->A,
+                       a->d_nzidx.p, a->d_nzcnt.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    a->ref_ready = true;
+    return PRALINE_OK;
+}
+
 extern "C" int praline_arena_premultiply(praline_arena *arena)
 {
     if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
@@ -480,6 +537,13 @@ struct praline_plan {
     std::vector<int64_t> slot_off;
     float last_kernel_ms = 0.0f;
     int last_mode = -1;
+    // reference-order audit mode (PRALINE_MATCH_REFERENCE at plan creation): k_dp_batch layout, dense match scores
+    bool ref = false;
+    std::vector<int32_t> h_lane_pair, h_pairs;
+    std::vector<int64_t> h_m_off;
+    DevBuf<int64_t> d_m_off;
+    DevBuf<int32_t> d_chunk_pairs;
+    DevBuf<float> d_mref;
     float *last_scores = nullptr;   // where the last praline_plan_run wrote the scores (own buffer or the caller's)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last run's launches, on the launch stream
     ~praline_plan()
@@ -540,6 +604,8 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     opt.split_layout = a.nr16 > 0 || !want_paths;
     if (const char *env = getenv("PRALINE_KERNEL")) { if (!strcmp(env, "batch")) opt.split_layout = false; }
     if (const char *env = getenv("PRALINE_TP")) opt.tp = atoi(env);
+    pl->ref = match_mode() == PRALINE_MATCH_REFERENCE;
+    if (pl->ref) { opt.split_layout = false; opt.tp = 1; }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
     if (const char *env = getenv("PRALINE_NO_W2")) opt.shared_waves = env[0] != '1';
     if (const char *env = getenv("PRALINE_W_SLOTS")) opt.wave_slots = atoll(env);
@@ -559,6 +625,10 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     pl->cells = sch.cells;
     const std::vector<int32_t> &lane_one = sch.lane_one, &lane_pair = sch.lane_pair;
     const std::vector<PairLoc> &loc = sch.loc;
+    if (pl->ref) {
+        pl->h_lane_pair = sch.lane_pair;
+        pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);
+    }
     const int64_t bnd = pl->bnd_elems, cap = pl->path_cap;
 
     hipStream_t st = g_rt.stream;
@@ -568,6 +638,9 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         (rc = pl->d_bnd.alloc((size_t)bnd * (want_paths ? sizeof(float4) : sizeof(float2))))) {
         delete pl;
         return rc;
+    }
+    if (pl->ref && !want_paths) {
+        if ((rc = pl->d_pairs.upload(pl->h_pairs, st))) { delete pl; return rc; }
     }
     if (want_paths) {
         std::vector<int32_t> pv(pairs, pairs + 2 * n_pairs);
@@ -654,6 +727,110 @@ static int launch_dp(int nstep, const LaunchArgs &la, int tp, bool local, int ou
     return PRALINE_OK;
 }
 
+// end cells of the semiglobal modes + device traceback for the tasks [t0, t1) of a path plan (after their fill)
+static int launch_traceback(praline_plan &pl, const LaunchArgs &la, size_t t0, size_t t1, int mode)
+{
+    hipStream_t st = g_rt.stream;
+    // k_traceback runs over all pairs and skips those whose task is outside [t0, t1)
+    const int threads = 64;
+    const int64_t blocks = (pl.n_pairs + threads - 1) / threads;
+    if (mode >= PRALINE_MODE_SEMIGLOBAL_BOTH) {   // end cells of the semiglobal modes, scanned per task
+        const int64_t lanes = (int64_t)(t1 - t0) * (pl.split ? 32 : 64);
+        hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar,
+                           pl.d_tasks.p, pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, pl.d_aux.p,
+                           pl.d_end_cells.p, la.scores, la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned)blocks), dim3(threads), 0, st, la.ar, pl.d_tasks.p,
+                       pl.d_loc.p, pl.d_pairs.p, (const uint4 *)pl.d_tb.p, pl.d_aux.p, la.rl, pl.d_end_cells.p,
+                       la.scores, pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs,
+                       la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return PRALINE_OK;
+}
+
+// dense reference-order match scores per launch chunk (bytes)
+static size_t ref_budget_bytes()
+{
+    if (const char *env = getenv("PRALINE_REF_BUDGET_MB")) return (size_t)atoll(env) << 20;
+    return (size_t)8 << 30;
+}
+
+// PRALINE_MATCH_REFERENCE: per chunk of tasks, k_match_ref writes the match scores of the chunk's pairs in the
+// reference's summation order, k_dp_batch<MSRC = 1> runs the fill on them (scores-only or with packed traceback).
+static int plan_run_ref(praline_plan &pl, LaunchArgs la, int mode, bool local)
+{
+    praline_arena &a = *pl.arena;
+    RC(arena_ensure_ref(&a));
+    hipStream_t st = g_rt.stream;
+    const size_t nt = pl.tasks.size();
+    const size_t m_budget = ref_budget_bytes(), tb_budget = tb_budget_bytes();
+    const bool semiglobal = mode >= 2;
+    if (pl.h_m_off.size() != (size_t)pl.n_pairs) pl.h_m_off.assign((size_t)pl.n_pairs, 0);
+    if (!pl.d_m_off.p) RC(pl.d_m_off.alloc((size_t)pl.n_pairs));
+    if (!pl.d_chunk_pairs.p) RC(pl.d_chunk_pairs.alloc((size_t)pl.n_pairs));
+    if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
+    la.split = 0;
+    size_t t0 = 0;
+    std::vector<int32_t> chunk;
+    while (t0 < nt) {
+        size_t t1 = t0;
+        int64_t tb_e = 0, aux_e = 0, m_e = 0;
+        int max_l1 = 0;
+        chunk.clear();
+        while (t1 < nt) {
+            int64_t m_add = 0;
+            for (int l = 0; l < 64; ++l) {
+                const int32_t p = pl.h_lane_pair[t1 * 64 + l];
+                if (p >= 0) m_add += (int64_t)a.len[pl.h_pairs[2 * p]] * a.len[pl.h_pairs[2 * p + 1]];
+            }
+            const int64_t tb_add = pl.want_paths ? pl.tb_elems[t1] : 0;
+            if (t1 > t0 && ((size_t)(m_e + m_add) * sizeof(float) > m_budget || (size_t)(tb_e + tb_add) * sizeof(uint4) > tb_budget)) break;
+            for (int l = 0; l < 64; ++l) {
+                const int32_t p = pl.h_lane_pair[t1 * 64 + l];
+                if (p < 0) continue;
+                pl.h_m_off[p] = m_e;
+                m_e += (int64_t)a.len[pl.h_pairs[2 * p]] * a.len[pl.h_pairs[2 * p + 1]];
+                max_l1 = std::max(max_l1, (int)a.len[pl.h_pairs[2 * p]]);
+                chunk.push_back(p);
+            }
+            pl.tasks[t1].tb_off = tb_e;
+            pl.tasks[t1].aux_off = aux_e;
+            tb_e += tb_add;
+            aux_e += (pl.want_paths && semiglobal) ? pl.aux_elems[t1] : 0;
+            ++t1;
+        }
+        if (pl.d_mref.n < (size_t)std::max<int64_t>(m_e, 1)) RC(pl.d_mref.alloc((size_t)std::max<int64_t>(m_e, 1)));
+        if (pl.want_paths) {
+            if (pl.d_tb.n < (size_t)tb_e * sizeof(uint4)) RC(pl.d_tb.alloc((size_t)tb_e * sizeof(uint4)));
+            if (pl.d_aux.n < (size_t)std::max<int64_t>(aux_e, 1)) RC(pl.d_aux.alloc((size_t)std::max<int64_t>(aux_e, 1)));
+        }
+        HIPCHK(hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(pl.d_m_off.p, pl.h_m_off.data(), (size_t)pl.n_pairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (!chunk.empty()) {
+            HIPCHK(hipMemcpyAsync(pl.d_chunk_pairs.p, chunk.data(), chunk.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_match_ref, dim3((unsigned)chunk.size(), (unsigned)((max_l1 + PRALINE_REF_ROWS - 1) / PRALINE_REF_ROWS)),
+                               dim3(256), 0, st, a.d_raw.p, a.d_S.p, a.A, a.d_row_off_raw.p, a.d_len.p, a.d_nzidx.p, a.d_nzcnt.p,
+                               a.d_set_lo.p, (int)a.set_lo.size() - 1, pl.d_pairs.p, pl.d_chunk_pairs.p, pl.d_m_off.p, pl.d_mref.p);
+            HIPCHK(hipGetLastError());
+        }
+        la.tasks = pl.d_tasks.p + t0;
+        la.lane_one = pl.d_lane_one.p + t0 * 64;
+        la.lane_pair = pl.d_lane_pair.p + t0 * 64;
+        la.tb = (uint4 *)pl.d_tb.p;
+        la.aux = pl.d_aux.p;
+        la.n_tasks = (unsigned)(t1 - t0);
+        la.mref = pl.d_mref.p;
+        la.m_off = pl.d_m_off.p;
+        int rc = praline_launch_dp_ref(la, local, pl.want_paths ? 1 : 0, pl.has_rects);
+        if (rc != PRALINE_OK) return fail(rc, "no reference-order kernel instance (paths=%d mask=%d)", (int)pl.want_paths, (int)pl.has_rects);
+        HIPCHK(hipGetLastError());
+        if (pl.want_paths) RC(launch_traceback(pl, la, t0, t1, mode));
+        HIPCHK(hipStreamSynchronize(st));   // the host lists above are rewritten for the next chunk
+        t0 = t1;
+    }
+    return PRALINE_OK;
+}
+
 extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, float gap_extend, void *d_scores)
 {
     if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
@@ -685,15 +862,18 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     la.a16 = nullptr;
     la.nr16 = a.nr16;
     la.nterm16 = a.nterm16;
-    if (pl.split && a.nr16 > 0) {
-        const char *mm = getenv("PRALINE_MM");
-        if (!(mm && !strcmp(mm, "f32"))) la.a16 = &a16;
-    }
+    if (pl.split && a.nr16 > 0 && match_mode() != PRALINE_MATCH_F32) la.a16 = &a16;
     const bool local = mode == PRALINE_MODE_LOCAL;
     pl.last_mode = mode;
     pl.last_scores = la.scores;
     hipStream_t st = g_rt.stream;
 
+    if (pl.ref) {
+        HIPCHK(hipEventRecord(pl.ev0, st));
+        RC(plan_run_ref(pl, la, mode, local));
+        HIPCHK(hipEventRecord(pl.ev1, st));
+        return PRALINE_OK;
+    }
     if (!pl.want_paths) {
         if (!pl.d_tasks.p) { RC(pl.d_tasks.upload(pl.tasks, st)); }
         la.tasks = pl.d_tasks.p;
@@ -820,22 +1000,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             RC(launch_dp(a.nstep, la, 1, local, 1, pl.has_rects));
         }
         HIPCHK(hipGetLastError());
-        {
-            // k_traceback runs over all pairs and skips those whose task is outside [t0, t1)
-            const int threads = 64;
-            const int64_t blocks = (pl.n_pairs + threads - 1) / threads;
-            if (mode >= PRALINE_MODE_SEMIGLOBAL_BOTH) {   // end cells of the semiglobal modes, scanned per task
-                const int64_t lanes = (int64_t)(t1 - t0) * (pl.split ? 32 : 64);
-                hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar,
-                                   pl.d_tasks.p, pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, pl.d_aux.p,
-                                   pl.d_end_cells.p, la.scores, la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
-            }
-            hipLaunchKernelGGL(k_traceback, dim3((unsigned)blocks), dim3(threads), 0, st, la.ar, pl.d_tasks.p,
-                               pl.d_loc.p, pl.d_pairs.p, (const uint4 *)pl.d_tb.p, pl.d_aux.p, la.rl, pl.d_end_cells.p,
-                               la.scores, pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs,
-                               la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
-            HIPCHK(hipGetLastError());
-        }
+        RC(launch_traceback(pl, la, t0, t1, mode));
         t0 = t1;
     }
     HIPCHK(hipEventRecord(pl.ev1, st));
@@ -1223,10 +1388,10 @@ extern "C" int praline_arena_info(const praline_arena *arena, int32_t *n_active,
 extern "C" int praline_plan_match_kind(const praline_plan *plan)
 {
     if (!plan) return -1;
+    if (plan->ref) return 2;
     if (plan->split && plan->arena->nr16 > 0) {
         if (plan->want_paths) return 1;  // k_dp_split16_tb
-        const char *mm = getenv("PRALINE_MM");
-        if (!(mm && !strcmp(mm, "f32"))) return 1;
+        if (match_mode() != PRALINE_MATCH_F32) return 1;
     }
     return 0;
 }

@@ -62,6 +62,8 @@ def lib():
                                     ctypes.POINTER(i64)]
     L.praline_arena_create.argtypes = [i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
     L.praline_arena_destroy.argtypes = [vp]
+    L.praline_arena_set_track_sets.argtypes = [vp, i32, vp]
+    L.praline_set_match_mode.argtypes = [i32]
     L.praline_arena_premultiply.argtypes = [vp]
     L.praline_plan_create.argtypes = [vp, i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
     L.praline_plan_destroy.argtypes = [vp]
@@ -117,6 +119,20 @@ def synchronize():
 
 def stream_handle():
     return lib().praline_stream()
+
+
+MATCH_MODES = {"fast": 0, "f32": 1, "ref": 2, None: -1}
+
+
+def set_match_mode(kind):
+    """How plans created from now on evaluate the match scores (praline_set_match_mode): "fast" (matrix pipe, f16
+    hi/lo split), "f32" (fp32 MFMA chain), "ref" (the reference's own summation order on the VALU: scores and
+    alignments bit-identical to the reference for any profiles, ~10-20x slower); None = the PRALINE_MM default."""
+    _check(lib().praline_set_match_mode(MATCH_MODES[kind]))
+
+
+def get_match_mode():
+    return {v: k for k, v in MATCH_MODES.items()}[int(lib().praline_get_match_mode())]
 
 
 def pool_trim():
@@ -220,8 +236,9 @@ def raw_align(mode, m, g1, g2, z=None):
 class Arena(object):
     """Profiles of N sequences resident in HBM (praline_arena_create)."""
 
-    def __init__(self, profiles, score_matrix):
-        """profiles: list of float32 [L_s, A] arrays; score_matrix: float32 [A, A]."""
+    def __init__(self, profiles, score_matrix, set_sizes=None):
+        """profiles: list of float32 [L_s, A] arrays; score_matrix: float32 [A, A]; set_sizes: widths of the track
+        sets concatenated along the alphabet axis (only the "ref" match mode needs them)."""
         A = int(score_matrix.shape[0])
         self.lens = np.array([p.shape[0] for p in profiles], dtype=np.int32)
         cat = np.ascontiguousarray(np.concatenate(profiles, axis=0), dtype=np.float32)
@@ -234,6 +251,9 @@ class Arena(object):
         _check(lib().praline_arena_create(self.n_seqs, self.lens.ctypes.data, A, cat.ctypes.data,
                                           S.ctypes.data, ctypes.byref(h)))
         self._h = h
+        if set_sizes is not None and len(set_sizes) > 1:
+            sz = np.ascontiguousarray(set_sizes, dtype=np.int32)
+            _check(lib().praline_arena_set_track_sets(h, len(sz), sz.ctypes.data))
 
     def premultiply(self):
         _check(lib().praline_arena_premultiply(self._h))
@@ -321,7 +341,7 @@ class Plan(object):
         return out
 
     def match_kind(self):
-        """0: this plan's run() evaluates match scores with the fp32 MFMA chain, 1: f16 split."""
+        """0: this plan's run() evaluates match scores with the fp32 MFMA chain, 1: f16 split, 2: reference order."""
         return int(lib().praline_plan_match_kind(self._h))
 
     def device_scores_ptr(self):

@@ -1,0 +1,214 @@
+"""GPU tests of the reference-order match-score mode (PRALINE_MATCH_REFERENCE) and of float-profile ALIGNMENT parity
+at BASELINE C2 scale: the checker is the CPU oracle fed with the REFERENCE-order match scores (never the device's)."""
+import fractions
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODES, ROOT, load_golden, one_hot, synth_lengths, synth_profile
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+GO, GE = -11.0, -1.0
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from praline_amd import native
+    native.init(0)
+    yield native
+    native.set_match_mode(None)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def host_threads():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except Exception:
+        return 8
+
+
+def run_device(nat, arena, pairs, modes, rects=None, want_paths=True):
+    out = {}
+    for mode in modes:
+        plan = nat.Plan(arena, pairs, want_paths=want_paths, rects=rects)
+        kind = plan.match_kind()
+        plan.run(mode, GO, GE)
+        sc = plan.scores()
+        paths = [p.copy() for p in plan.paths()] if want_paths else None
+        plan.close()
+        out[mode] = (sc, paths, kind)
+    return out
+
+
+def test_reference_order_bitexact_small(nat, bba):
+    """ref mode on the reference's own float-profile goldens (profile_profile.npz, produced by the real reference):
+    scores bit-identical, paths identical, all modes; scores-only plans give the same bits."""
+    d = load_golden("profile_profile.npz")
+    profs = [d["profile%d" % i] for i in range(5)]
+    pairs = np.array([(i, j) for i in range(5) for j in range(i + 1, 5)], dtype=np.int32)
+    nat.set_match_mode("ref")
+    try:
+        arena = nat.Arena(profs, bba["S"])
+        res = run_device(nat, arena, pairs, MODES)
+        res0 = run_device(nat, arena, pairs, MODES, want_paths=False)
+        arena.close()
+    finally:
+        nat.set_match_mode(None)
+    for mode in MODES:
+        sc, paths, kind = res[mode]
+        assert kind == 2
+        for k, (i, j) in enumerate(pairs):
+            assert sc[k] == np.float32(d["score_%d_%d_%s" % (i, j, mode)]), (mode, i, j)
+            assert np.array_equal(paths[k], d["path_%d_%d_%s" % (i, j, mode)]), (mode, i, j)
+        assert np.array_equal(bits(res0[mode][0]), bits(sc)), mode
+
+
+def test_reference_order_multiset_and_masks(nat, bba):
+    """Several float track sets (one running sum per set, added in list order, cext.c:389-420) and Waterman-Eggert
+    rectangles in ref mode: bit-identical to the oracle's reference-order evaluation."""
+    rng = np.random.default_rng(23)
+    lens = [41, 70, 33, 64, 9]
+    p27 = [synth_profile(rng, L)[0] for L in lens]
+    p3 = []
+    for L in lens:
+        c = rng.integers(0, 4, (L, 3)).astype(np.float32) + np.float32(0.25)
+        p3.append((c / c.sum(axis=1, keepdims=True)).astype(np.float32))
+    S3 = rng.normal(0, 2, (3, 3)).astype(np.float32)
+    S = np.zeros((30, 30), dtype=np.float32)
+    S[:27, :27] = bba["S"]
+    S[27:, 27:] = S3
+    cat = [np.concatenate([a, b], axis=1) for a, b in zip(p27, p3)]
+    pairs = np.array([(i, j) for i in range(5) for j in range(5) if i != j], dtype=np.int32)
+    rects = [[(3, 8, 2, 9)] if k % 2 else [] for k in range(len(pairs))]
+    nat.set_match_mode("ref")
+    try:
+        arena = nat.Arena(cat, S, set_sizes=[27, 3])
+        res = run_device(nat, arena, pairs, MODES)
+        res_l = run_device(nat, arena, pairs, ["local"], rects=rects)
+        arena.close()
+    finally:
+        nat.set_match_mode(None)
+    for k, (i, j) in enumerate(pairs):
+        for mode in MODES:
+            s_or, p_or = orc.pairwise_align(mode, [p27[i], p3[i]], [p27[j], p3[j]], [bba["S"], S3], (GO, GE))
+            assert res[mode][0][k] == np.float32(s_or), (mode, i, j)
+            assert np.array_equal(res[mode][1][k], p_or), (mode, i, j)
+        zero = [(y, x) for (y0, y1, x0, x1) in rects[k] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)
+                if y <= lens[i] and x <= lens[j]]
+        s_or, p_or = orc.pairwise_align("local", [p27[i], p3[i]], [p27[j], p3[j]], [bba["S"], S3], (GO, GE),
+                                        zero_idxs=zero or None)
+        assert res_l["local"][0][k] == np.float32(s_or), (i, j)
+        assert np.array_equal(res_l["local"][1][k], p_or), (i, j)
+
+
+def exact_path_score(path, p1, p2, S, mode, L1, L2):
+    """Score of an alignment path in EXACT rational arithmetic on the float32 inputs: diagonal steps add
+    sum_ij p1[y,i] S[i,j] p2[x,j]; a run of k gap steps costs GO + (k - 1) GE unless it runs along a free edge
+    (semiglobal, praline/component/align.py:371-385,411-424)."""
+    F = fractions.Fraction
+    path = np.asarray(path)
+    dy, dx = np.diff(path[:, 0]), np.diff(path[:, 1])
+    kinds = np.where((dy == 1) & (dx == 1), 0, np.where(dy == 1, 1, 2))
+    total = F(0)
+    r, n = 0, len(kinds)
+    while r < n:
+        k = kinds[r]
+        if k == 0:
+            y, x = path[r + 1]
+            a, b = p1[y - 1], p2[x - 1]
+            for i in np.flatnonzero(a):
+                for j in np.flatnonzero(b):
+                    total += F(float(a[i])) * F(float(S[i, j])) * F(float(b[j]))
+            r += 1
+            continue
+        e = r
+        while e < n and kinds[e] == k:
+            e += 1
+        free = False
+        if mode.startswith("semiglobal"):
+            y0, x0 = path[r]
+            if k == 1 and ((x0 == 0 and mode in ("semiglobal_both", "semiglobal_one")) or x0 == L2):
+                free = True
+            if k == 2 and (y0 == 0 or y0 == L1) and mode in ("semiglobal_both", "semiglobal_two"):
+                free = True
+        if not free:
+            total += F(GO) + (e - r - 1) * F(GE)
+        r = e
+    return total
+
+
+def test_c2_float_profile_alignments_vs_reference_order(nat, bba):
+    """BASELINE C2's own float profiles (256 seqs ~400 aa, seed 2), 2 048 sampled pairs x 5 modes with paths, checked
+    against the oracle on the REFERENCE-order match scores:
+      * ref mode: every score bit-identical and every path identical to the reference's;
+      * default (matrix-pipe) mode: every score within 1e-5 relative; a path may differ only where the choice is a tie
+        up to float32 rounding - each differing path's score in EXACT rational arithmetic is within 1e-5 relative of
+        the reference path's exact score.  The mismatch statistics are written to gpurun_out/ for profiles/."""
+    rng = np.random.default_rng(2)
+    N = 256
+    lens = synth_lengths(rng, N, 400).astype(np.int32)
+    profs = [synth_profile(rng, int(L))[0] for L in lens]
+    S = bba["S"]
+    allp = np.array([(i, j) for i in range(N) for j in range(i + 1, N)], dtype=np.int32)
+    sel = np.sort(np.random.default_rng(7).choice(len(allp), 2048, replace=False))
+    pairs = allp[sel]
+    cat = np.concatenate(profs, axis=0)
+    row_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    sc_ref, paths_ref = orc.batch_align(MODES, cat, row_off, lens, S, pairs, GO, GE, threads=host_threads())
+
+    nat.set_match_mode("ref")
+    try:
+        arena = nat.Arena(profs, S)
+        strict = run_device(nat, arena, pairs, MODES)
+        arena.close()
+    finally:
+        nat.set_match_mode(None)
+    for q, mode in enumerate(MODES):
+        sc, paths, kind = strict[mode]
+        assert kind == 2
+        assert np.array_equal(bits(sc), bits(sc_ref[:, q])), mode
+        bad = [k for k in range(len(pairs)) if not np.array_equal(paths[k], paths_ref[k][q])]
+        assert not bad, (mode, len(bad), pairs[bad[:3]].tolist())
+
+    arena = nat.Arena(profs, S)
+    fast = run_device(nat, arena, pairs, MODES)
+    arena.close()
+    stats = {"workload": "C2 float profiles (seed 2), %d sampled pairs x %d modes" % (len(pairs), len(MODES)),
+             "alignments": int(len(pairs) * len(MODES)), "modes": {}}
+    worst_rel = 0.0
+    for q, mode in enumerate(MODES):
+        sc, paths, kind = fast[mode]
+        assert kind == 1
+        rel = np.abs(sc - sc_ref[:, q]) / np.maximum(1.0, np.abs(sc_ref[:, q]))
+        assert rel.max() <= 1e-5, (mode, rel.max())
+        worst_rel = max(worst_rel, float(rel.max()))
+        diff = [k for k in range(len(pairs)) if not np.array_equal(paths[k], paths_ref[k][q])]
+        exact_ties = 0
+        for k in diff:
+            i, j = pairs[k]
+            e_dev = exact_path_score(paths[k], profs[i], profs[j], S, mode, lens[i], lens[j])
+            e_ref = exact_path_score(paths_ref[k][q], profs[i], profs[j], S, mode, lens[i], lens[j])
+            # both paths are optimal up to float32 rounding: neither beats the other by more than the tolerance
+            assert abs(e_dev - e_ref) <= fractions.Fraction(1, 100000) * max(1, abs(e_ref)), (mode, i, j, float(e_dev), float(e_ref))
+            exact_ties += e_dev == e_ref
+        stats["modes"][mode] = {"paths_differing": len(diff), "of": int(len(pairs)), "exact_arithmetic_ties": int(exact_ties),
+                                "max_rel_score_diff": float(rel.max())}
+    stats["paths_differing_total"] = int(sum(v["paths_differing"] for v in stats["modes"].values()))
+    stats["max_rel_score_diff"] = worst_rel
+    stats["ref_mode"] = "all %d scores bit-identical, all paths identical" % (len(pairs) * len(MODES))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_c2_float_paths.json"), "w") as f:
+            json.dump(stats, f, indent=1)
+    except OSError:
+        pass
+    print("C2 float-profile path parity:", json.dumps(stats))
+    # the fast mode is allowed to differ only on rounding-level ties, and rarely
+    assert stats["paths_differing_total"] <= 0.02 * stats["alignments"], stats
