@@ -1,5 +1,5 @@
-"""GPU tests at BASELINE.json's full configuration sizes (C3, one rank's share of C4, C5): properties that
-do not need the oracle at full size - the score recomputed from the returned path, mode ordering, symmetry
+"""GPU tests at BASELINE.json's full configuration sizes (all of C3 incl. the second Waterman-Eggert pass, one rank's
+share of C4, all of C5): properties that do not need the oracle at full size - the score recomputed from the returned path, mode ordering, symmetry
 and self-alignment under integer scoring - plus oracle spot checks on sampled pairs."""
 import numpy as np
 import pytest
@@ -57,36 +57,76 @@ def path_score(path, v1, v2, S, mode):
     return total
 
 
+def host_threads():
+    import os
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except Exception:
+        return 8
+
+
 def test_c3_preprofile_modes_full_size(nat, bba):
-    """BASELINE config 2: 1024 seqs ~250 aa, ordered pairs, local and semiglobal with paths (one pass over
-    a 200k-pair slice per mode keeps the test short; the full list runs in scripts/exp_c3.py)."""
+    """BASELINE config 2 at its stated size: 1024 seqs ~250 aa, ALL 1 047 552 ordered (master, slave) pairs with paths.
+    Local mode runs both Waterman-Eggert passes (the second one masking the bounding box of each first-pass path,
+    praline/component/preprofile.py:227-267); global and the three semiglobal modes run one pass.  Checks: the paths'
+    recomputed scores, the mode ordering, oracle scores + paths (with rectangles) on sampled pairs."""
     rng = np.random.default_rng(3)
     N = 1024
-    lens = synth_lengths(rng, N, 250)
+    lens = synth_lengths(rng, N, 250).astype(np.int32)
     vals = [rng.integers(0, 20, int(L)) for L in lens]
     S = bba["S"]
-    arena = nat.Arena([one_hot(v, 27) for v in vals], S)
-    allp = np.array([(i, j) for i in range(0, N, 5) for j in range(N) if i != j], dtype=np.int32)   # 209 k ordered pairs
+    profs = [one_hot(v, 27) for v in vals]
+    arena = nat.Arena(profs, S)
+    ii, jj = np.divmod(np.arange(N * N, dtype=np.int64), N)
+    allp = np.stack([ii[ii != jj], jj[ii != jj]], axis=1).astype(np.int32)
+    assert len(allp) == 1047552
+    cat = np.concatenate(profs, axis=0)
+    row_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    spot = np.sort(rng.choice(len(allp), 48, replace=False))
     results = {}
     for mode in ("global", "local", "semiglobal_both", "semiglobal_one", "semiglobal_two"):
         plan = nat.Plan(arena, allp, want_paths=True)
         plan.run(mode, GO, GE)
         sc = plan.scores()
         buf, off, rows = plan.paths_packed()
+        bounds = plan.path_bounds() if mode == "local" else None
         plan.close()
         results[mode] = sc
         assert np.isfinite(sc).all()
-        for k in rng.integers(0, len(allp), 60):
+        for k in rng.integers(0, len(allp), 200):
             i, j = allp[k]
             path = buf[off[k]:off[k] + rows[k]]
-            if mode == "global" or mode.startswith("semiglobal"):
+            if mode != "local":
                 assert tuple(path[0]) == (0, 0) and tuple(path[-1]) == (lens[i], lens[j]), (mode, i, j)
             assert path_score(path, vals[i], vals[j], S, mode) == sc[k], (mode, i, j)
-        for k in rng.integers(0, len(allp), 6):
-            i, j = allp[k]
-            s_or, p_or = orc.pairwise_score_fast(mode, one_hot(vals[i], 27), one_hot(vals[j], 27), S, GO, GE, want_path=True)
-            assert sc[k] == np.float32(s_or), (mode, i, j)
-            assert np.array_equal(buf[off[k]:off[k] + rows[k]], p_or), (mode, i, j)
+        sc_or, p_or = orc.batch_align([mode], cat, row_off, lens, S, allp[spot], GO, GE, threads=host_threads())
+        for q, k in enumerate(spot):
+            assert sc[k] == sc_or[q, 0], (mode, allp[k])
+            assert np.array_equal(buf[off[k]:off[k] + rows[k]], p_or[q][0]), (mode, allp[k])
+        if mode == "local":
+            # second Waterman-Eggert pass over the full list: every pair masks its own first-pass bounding box
+            for k in spot:
+                pth = buf[off[k]:off[k] + rows[k]]
+                assert tuple(bounds[k]) == (pth[:, 0].min(), pth[:, 0].max(), pth[:, 1].min(), pth[:, 1].max())
+            del buf
+            plan = nat.Plan(arena, allp, want_paths=True, rects=bounds.reshape(-1, 1, 4))
+            plan.run("local", GO, GE)
+            sc2 = plan.scores()
+            buf2, off2, rows2 = plan.paths_packed()
+            plan.close()
+            assert np.isfinite(sc2).all() and (sc2 <= sc).all()      # masking cells can only lower the best local score
+            rect_list = [[tuple(int(v) for v in bounds[k])] for k in spot]
+            sc_or2, p_or2 = orc.batch_align(["local"], cat, row_off, lens, S, allp[spot], GO, GE, rects=rect_list,
+                                            threads=host_threads())
+            for q, k in enumerate(spot):
+                assert sc2[k] == sc_or2[q, 0], allp[k]
+                assert np.array_equal(buf2[off2[k]:off2[k] + rows2[k]], p_or2[q][0]), allp[k]
+                b = bounds[k]
+                pth = buf2[off2[k]:off2[k] + rows2[k]]
+                # no aligned cell of the second path lies inside the masked rectangle
+                inside = (pth[1:, 0] >= b[0]) & (pth[1:, 0] <= b[1]) & (pth[1:, 1] >= b[2]) & (pth[1:, 1] <= b[3])
+                assert not inside.any(), allp[k]
+            del buf2
     # (local >= semiglobal_both does NOT hold in the reference: local mode keeps the penalised global boundary,
     # align.py:371-385, so an alignment that starts in the first row or column scores less than with free ends)
     for hi, lo in (("semiglobal_both", "semiglobal_one"), ("semiglobal_both", "semiglobal_two"),
@@ -94,6 +134,40 @@ def test_c3_preprofile_modes_full_size(nat, bba):
         bad = np.nonzero(~(results[hi] >= results[lo]))[0]
         assert len(bad) == 0, (hi, lo, len(bad), allp[bad[:3]].tolist(), results[hi][bad[:3]], results[lo][bad[:3]])
     arena.close()
+
+
+def test_c3_build_preprofiles_full_size_two_pass_local(nat, bba):
+    """The product call on all of C3: build_preprofiles(mode="local", waterman_eggert_iterations=2) - 2 x 1 047 552
+    alignments with paths, counted on the device - against the operator chain the reference runs per master
+    (LocalMasterSlaveAligner + ProfileBuilder, preprofile.py:213-269, profile.py:41-74) for sampled masters."""
+    from praline_amd import component as comp
+    from praline_amd import container as ct
+    from praline_amd import core
+    rng = np.random.default_rng(3)
+    N = 1024
+    lens = synth_lengths(rng, N, 250).astype(np.int32)
+    vals = [rng.integers(0, 20, int(L)) for L in lens]
+    seqs = [ct.Sequence("s%04d" % i, [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=v))])
+            for i, v in enumerate(vals)]
+    blosum = ct.blosum62()
+    tracks = comp.build_preprofiles(seqs, ct.TRACK_ID_INPUT, blosum, mode="local", waterman_eggert_iterations=2)
+    assert len(tracks) == N
+    total = sum(int(np.asarray(t.counts).sum()) for t in tracks)
+    assert total > int(lens.sum())      # the slaves contributed
+    idx = core.TypeIndex()
+    idx.autoregister()
+    manager = core.Manager(idx)
+    for i in (0, 517, 1023):
+        ex = core.Execution(manager, "root")
+        ex.add_task(comp.LocalMasterSlaveAligner).environment(core.Environment({}), core.Environment({})).inputs(
+            master_sequence=seqs[i], slave_sequences=[s for k, s in enumerate(seqs) if k != i],
+            track_id_sets=[[ct.TRACK_ID_INPUT]], score_matrices=[blosum])
+        aln = core.run(ex)[0]['alignment']
+        ex = core.Execution(manager, "root")
+        ex.add_task(comp.ProfileBuilder).environment(core.Environment({}), core.Environment({})).inputs(
+            alignment=aln, track_id=ct.TRACK_ID_INPUT)
+        want = core.run(ex)[0]['profile_track']
+        assert np.array_equal(np.asarray(tracks[i].counts), np.asarray(want.counts)), i
 
 
 def test_c4_rank_share_full_size(nat, bba):
@@ -158,29 +232,38 @@ def test_c4_rank_share_full_size(nat, bba):
 
 
 def test_c5_long_dna_full_size(nat):
-    """BASELINE config 4: 512 nucleotide seqs ~5 kb (3.3e12 cells for all pairs): a 9 k-pair column shard
-    (1/14 of the list, 2.3e11 cells) in global mode, exact against the oracle on sampled pairs; symmetry."""
+    """BASELINE config 4 at its stated size: 512 nucleotide seqs ~5 kb, ALL 130 816 pairs (3.3e12 cells) in global,
+    local and semiglobal_both mode; exact against the oracle on 24 sampled pairs per mode; symmetry of the scores under
+    integer scoring; mode ordering."""
     from praline_amd import allpairs
     d = load_golden("synthetic_dna.npz")
     S = d["matrix"]
     rng = np.random.default_rng(5)
     N = 512
-    lens = synth_lengths(rng, N, 5000)
+    lens = synth_lengths(rng, N, 5000).astype(np.int32)
     vals = [rng.integers(0, 4, int(L)) for L in lens]
-    arena = nat.Arena([one_hot(v, 15) for v in vals], S)
+    profs = [one_hot(v, 15) for v in vals]
+    arena = nat.Arena(profs, S)
     pairs = allpairs.enumerate_pairs(N)
-    mine = pairs[allpairs.shard_columns(lens, pairs, 14)[5]]
-    plan = nat.Plan(arena, mine)
+    assert len(pairs) == 130816
+    modes = ("global", "local", "semiglobal_both")
+    res = {}
+    for mode in modes:
+        plan = nat.Plan(arena, pairs)
+        plan.run(mode, GO, GE)
+        res[mode] = plan.scores()
+        plan.close()
+        assert np.isfinite(res[mode]).all()
+    assert (res["semiglobal_both"] >= res["global"]).all()
+    spot = np.sort(rng.choice(len(pairs), 24, replace=False))
+    cat = np.concatenate(profs, axis=0)
+    row_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    sc_or, _ = orc.batch_align(modes, cat, row_off, lens, S, pairs[spot], GO, GE, threads=min(8, host_threads()))
+    for q, mode in enumerate(modes):
+        assert np.array_equal(res[mode][spot], sc_or[:, q]), mode
+    sub = rng.integers(0, len(pairs), 600)
+    plan = nat.Plan(arena, pairs[sub][:, ::-1].copy())
     plan.run("global", GO, GE)
-    sc = plan.scores()
-    plan.close()
-    assert np.isfinite(sc).all()
-    for k in rng.integers(0, len(mine), 3):
-        i, j = mine[k]
-        assert sc[k] == np.float32(orc.pairwise_score_fast("global", one_hot(vals[i], 15), one_hot(vals[j], 15), S, GO, GE))
-    sub = rng.integers(0, len(mine), 300)
-    plan = nat.Plan(arena, mine[sub][:, ::-1].copy())
-    plan.run("global", GO, GE)
-    assert np.array_equal(plan.scores(), sc[sub])
+    assert np.array_equal(plan.scores(), res["global"][sub])
     plan.close()
     arena.close()
