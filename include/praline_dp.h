@@ -208,6 +208,10 @@ int praline_plan_paths(praline_plan *plan, int32_t *paths, int64_t *path_off, in
  * symbols are not added.  praline_plan_path_bounds returns (y0, y1, x0, x1) per pair: the bounding box the next
  * Waterman-Eggert iteration masks (preprofile.py:247-255). */
 int praline_arena_counts_reset(praline_arena *arena);
+/* Accumulate the counts in a caller-owned DEVICE buffer int32 [sum of lengths][A] instead of the arena's own (so that a
+ * multi-GPU caller can all-reduce them in place); NULL returns to the arena's buffer.  praline_arena_counts_reset
+ * zeroes whichever buffer is bound, on praline_stream(). */
+int praline_arena_counts_bind(praline_arena *arena, void *d_counts);
 int praline_plan_add_counts(praline_plan *plan, int use_threshold, float threshold, int local);
 int praline_arena_counts_read(praline_arena *arena, int32_t *counts);
 int praline_plan_path_bounds(praline_plan *plan, int32_t *bounds);

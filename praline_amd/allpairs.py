@@ -67,6 +67,60 @@ def gather_maps(shards):
     return src, dst, shard_len
 
 
+def shard_masters(lens, world):
+    """Preprofile stage ("shard by master index"): every master i is aligned against all other
+    sequences, DP cells = L_i * (sum L - L_i).  Masters are dealt longest-first to the least loaded rank, so all
+    N - 1 alignments of a master - and with them its whole count block - live on ONE rank.  Returns per rank
+    the ascending master indices.  Deterministic and identical on every rank."""
+    lens = np.asarray(lens, dtype=np.int64)
+    cells = lens * (lens.sum() - lens)
+    owner = np.zeros(len(lens), dtype=np.int64)
+    load = np.zeros(world, dtype=np.int64)
+    for i in np.argsort(-cells, kind="stable"):
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += cells[i]
+    return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world)]
+
+
+def _group_device(group):
+    """Tensors of a collective live where the group's backend wants them: cuda for nccl (= RCCL), cpu for gloo."""
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def all_gather_scores(local, shards, rank, world, group=None):
+    """The exchange step of the all-pairs stage for host-side callers (GuideTreeBuilder): `local` = this rank's
+    scores in the order of shards[rank]; returns the complete float32 list in pair order, identical on every rank.
+    One all_gather_into_tensor (RCCL over xGMI under the nccl backend)."""
+    import torch
+    import torch.distributed as dist
+    src, dst, shard_len = gather_maps(shards)
+    dev = _group_device(group)
+    padded = torch.zeros(shard_len, dtype=torch.float32, device=dev)
+    padded[:len(shards[rank])] = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float32), device=dev)
+    gathered = torch.zeros(shard_len * world, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    out = np.zeros(sum(len(ix) for ix in shards), dtype=np.float32)
+    out[dst] = gathered.cpu().numpy()[src]
+    return out
+
+
+def all_reduce_counts(counts, group=None):
+    """The exchange step of the preprofile stage: every rank holds the count blocks of ITS masters (zeros elsewhere);
+    one all-reduce (sum) of the int32 count arena [sum L][A] gives every rank all of them.  counts: a torch tensor
+    (on the group's device; reduced in place) or a numpy array (returned reduced)."""
+    import torch
+    import torch.distributed as dist
+    if isinstance(counts, np.ndarray):
+        t = torch.as_tensor(np.ascontiguousarray(counts, dtype=np.int32), device=_group_device(group))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts
+
+
 def scores_to_distance(n, pairs, scores):
     """tree.py:99-100,131,142-147: d filled symmetrically, diagonal 0, dist = (-d) + d.max()."""
     d = np.zeros((n, n), dtype=np.float32)
@@ -121,7 +175,7 @@ def all_pairs_scores(lens, scorer, rank=0, world=1, group=None, device=None):
     dev = mine.device if device is None else device
     padded = torch.zeros(shard_len, dtype=torch.float32, device=dev)
     padded[:len(shards[rank])] = mine
-    gathered = torch.zeros(shard_len * world, dtype=torch.float32, device=dev)
+    gathered = torch.empty(shard_len * world, dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(gathered, padded, group=group)   # the one exchange step of the path
     out = torch.zeros(len(pairs), dtype=torch.float32, device=dev)  # back into the reference's pair order
     out[torch.as_tensor(dst, device=dev)] = gathered[torch.as_tensor(src, device=dev)]

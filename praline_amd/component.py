@@ -18,8 +18,8 @@ import numpy as np
 from . import native
 from .container import (Alignment, GapScoreModel, MatchScoreModel, PlainTrack, ProfileTrack,
                         ScoreMatrix, Sequence, SequenceTree, TRACK_ID_INPUT)
-from .core import (BeginMessage, CompleteMessage, Component, ComponentError, DataError, Environment,
-                   Execution, Manager, Port, ProgressMessage, T)
+from .core import (MESSAGE_KIND_COMPLETE, BeginMessage, CompleteMessage, Component, ComponentError, DataError,
+                   Environment, Execution, Manager, Port, ProgressMessage, T)
 from .util import (auto_align_mode, compress_path, extend_path_local, get_frequencies,
                    zero_idxs_to_rectangles)
 
@@ -286,6 +286,35 @@ class ProfileBuilder(Component):
         yield CompleteMessage(outputs={'profile_track': ProfileTrack(freqs, track.alphabet)})
 
 
+# ---- the `aligner` seam of the callers ------------------------------------------------------------
+def _resolve_aligner(component):
+    """What `index.resolve(env['aligner'])` + `task.environment(root_env, sub_env)` give the reference's callers
+    (praline/component/tree.py:115-127, preprofile.py:127-139,229-241): the aligner class named by the `aligner`
+    option and its EFFECTIVE environment - the aligner's defaults, overridden by the caller's environment,
+    overridden by `aligner_env` (Environment.collapse, praline/core/component.py:150-201)."""
+    cls = component.manager.index.resolve(component.environment['aligner'])
+    return cls, component.environment.collapse(cls, component.environment['aligner_env'])
+
+
+def _is_device_aligner(cls):
+    """The batched device path stands in for an aligner only if that aligner IS this package's PairwiseAligner;
+    any other registered component (a user's own aligner under another or even the same type id) gets the
+    reference's Execution fan-out, one task per alignment."""
+    return cls is PairwiseAligner
+
+
+def _run_single(component, aligner, **inputs):
+    """One alignment through the configured aligner component, as the reference's callers run it; the outputs
+    are left in component._last_outputs (a generator cannot return them to a for loop)."""
+    execution = Execution(component.manager, component.tag)
+    task = execution.add_task(aligner)
+    task.environment(component.environment, component.environment['aligner_env'])
+    task.inputs(**inputs)
+    for message in execution.run():
+        yield message
+    component._last_outputs = execution.outputs[0]
+
+
 # ---- callers: master-slave (preprofile) stage ----------------------------------------------------
 def _identity_alignment(sequence):
     return Alignment([sequence], np.arange(len(sequence) + 1).reshape(len(sequence) + 1, 1))
@@ -337,9 +366,24 @@ class GlobalMasterSlaveAligner(Component):
 
     def execute(self, master_sequence, slave_sequences, track_id_sets, score_matrices):
         threshold = self.environment['score_threshold']
+        aligner, aligner_env = _resolve_aligner(self)
+        if not _is_device_aligner(aligner):
+            # another aligner component: the reference's loop, one Execution per slave (preprofile.py:126-154)
+            results = []
+            for j, s in enumerate(slave_sequences):
+                for message in _run_single(self, aligner, mode="global", sequence_one=master_sequence, sequence_two=s,
+                                           track_id_sets_one=track_id_sets, track_id_sets_two=track_id_sets,
+                                           score_matrices=score_matrices):
+                    yield message
+                out = self._last_outputs
+                results.append([(out['score'], np.array(out['alignment'].path, dtype=int))])
+                yield ProgressMessage((j + 1) / float(len(slave_sequences)))
+            yield CompleteMessage({'alignment': merge_master_slave(master_sequence, slave_sequences, results, threshold,
+                                                                    local=False)})
+            return
         for s in slave_sequences:
             _validate_track_sets(master_sequence, s, track_id_sets, track_id_sets, score_matrices)
-        batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
+        batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, aligner_env['gap_series'])
         for s in slave_sequences:
             batch.add("global", master_sequence, s)
         scores, paths = batch.run(want_paths=True)
@@ -365,6 +409,29 @@ class LocalMasterSlaveAligner(Component):
     def execute(self, master_sequence, slave_sequences, track_id_sets, score_matrices):
         threshold = self.environment['score_threshold']
         iterations = self.environment['waterman_eggert_iterations']
+        aligner, aligner_env = _resolve_aligner(self)
+        if not _is_device_aligner(aligner):
+            # another aligner component: the reference's loops, one Execution per slave and iteration with the
+            # growing zero_idxs list (preprofile.py:226-265)
+            results = []
+            for j, s in enumerate(slave_sequences):
+                zero_idxs = []
+                results.append([])
+                for _ in range(iterations):
+                    for message in _run_single(self, aligner, mode="local", sequence_one=master_sequence, sequence_two=s,
+                                               track_id_sets_one=track_id_sets, track_id_sets_two=track_id_sets,
+                                               score_matrices=score_matrices, zero_idxs=zero_idxs):
+                        yield message
+                    out = self._last_outputs
+                    p = np.array(out['alignment'].path, dtype=int)
+                    zero_idxs = zero_idxs + [(y, x) for y in range(int(p[:, 0].min()), int(p[:, 0].max()) + 1)
+                                             for x in range(int(p[:, 1].min()), int(p[:, 1].max()) + 1)]
+                    results[j].append((out['score'], p))
+                yield ProgressMessage((j + 1) / float(len(slave_sequences)))
+            yield CompleteMessage({'alignment': merge_master_slave(master_sequence, slave_sequences, results, threshold,
+                                                                    local=True)})
+            return
+        gap_series = aligner_env['gap_series']
         for s in slave_sequences:
             _validate_track_sets(master_sequence, s, track_id_sets, track_id_sets, score_matrices)
         rects = [[] for _ in slave_sequences]
@@ -374,15 +441,15 @@ class LocalMasterSlaveAligner(Component):
                 # more masked rectangles than the batched kernels carry per pair: dense masks through the
                 # raw path, one pair at a time (same results, rarely needed: the default is 2 iterations)
                 scores, paths = [], []
-                aligner = PairwiseAligner(self.manager, self.environment, self.tag)
+                raw = PairwiseAligner(self.manager, aligner_env, self.tag)
                 for j, s in enumerate(slave_sequences):
                     zero = [(y, x) for (y0, y1, x0, x1) in rects[j] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
-                    out = aligner._execute_raw("local", master_sequence, s, track_id_sets, track_id_sets, zero,
-                                               score_matrices, _normalise_gap_series(self.environment['gap_series']))
+                    out = raw._execute_raw("local", master_sequence, s, track_id_sets, track_id_sets, zero,
+                                           score_matrices, _normalise_gap_series(gap_series))
                     scores.append(out['score'])
                     paths.append(np.array(out['alignment'].path, dtype=int))
             else:
-                batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
+                batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, gap_series)
                 for j, s in enumerate(slave_sequences):
                     batch.add("local", master_sequence, s, list(rects[j]))
                 scores, paths = batch.run(want_paths=True)
@@ -395,8 +462,37 @@ class LocalMasterSlaveAligner(Component):
         yield CompleteMessage({'alignment': alignment})
 
 
+def _preprofile_slave_counts(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations, counts_out=None):
+    """Device side of build_preprofiles for ONE rank's (master, slave) pair list: `iterations` passes of alignments
+    with paths, the counting on the device paths, Waterman-Eggert bounds rank-local.  Returns the int32 count arena
+    [sum L][A] (the slaves' share; rows of masters that are not in `pairs` stay zero).  counts_out: optional torch
+    int32 CUDA tensor the counts are accumulated in directly (the multi-GPU path all-reduces it in place)."""
+    arena = native.Arena(profiles, S)
+    try:
+        if counts_out is not None:
+            arena.counts_bind(counts_out.data_ptr())
+        arena.counts_reset()
+        rects = None
+        for it in range(iterations if len(pairs) else 0):
+            plan = native.Plan(arena, pairs, want_paths=True, rects=rects)
+            try:
+                plan.run(mode, gap_open, gap_extend)
+                plan.add_counts(score_threshold, local=(mode == "local"))
+                if it + 1 < iterations:
+                    b = plan.path_bounds().reshape(-1, 1, 4)
+                    rects = b if rects is None else np.concatenate([rects, b], axis=1)
+            finally:
+                plan.close()
+        if counts_out is not None:
+            native.synchronize()
+            return counts_out
+        return arena.counts()
+    finally:
+        arena.close()
+
+
 def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_series=(-11.0, -1.0),
-                      score_threshold=None, waterman_eggert_iterations=2):
+                      score_threshold=None, waterman_eggert_iterations=2, rank=0, world=1, group=None):
     """The whole preprofile stage in a few device submissions: for EVERY sequence as master,
     what the reference computes with one Global/LocalMasterSlaveAligner execution (preprofile.py:114-156,
     213-269) followed by ProfileBuilder (profile.py:41-74) - N(N-1) alignments with paths, the master-slave
@@ -405,7 +501,13 @@ def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_seri
     (preprofile.py:247-255) and the count matrix come back.
 
     sequences: Sequences with a PlainTrack under track_id; mode "global" or "local".
-    Returns one ProfileTrack per sequence (identical to the component chain's)."""
+    Returns one ProfileTrack per sequence (identical to the component chain's).
+
+    world > 1 (one process per GPU, torch.distributed group `group`): the masters are dealt to the ranks
+    (allpairs.shard_masters, balanced by DP cells), every rank runs all passes for ITS masters - the Waterman-Eggert
+    bounds never leave the rank - and ONE all-reduce of the int32 count arena [sum L][A] (RCCL over xGMI; C3: 27 MB)
+    gives every rank every master's counts: the workflow's per-master fan-out (praline/component/workflow.py:139-161)
+    with one exchange step.  Every rank returns all N tracks."""
     if mode not in ("global", "local"):
         raise ComponentError("the preprofile stage aligns in 'global' or 'local' mode, not '{0}'".format(mode))
     if mode == "local" and waterman_eggert_iterations > native.MAX_RECTS + 1:
@@ -424,31 +526,40 @@ def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_seri
     row_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
     ii, jj = np.divmod(np.arange(n * n, dtype=np.int64), n)      # every ordered pair (master i, slave j != i), i outer
     keep = ii != jj
+    iterations = waterman_eggert_iterations if mode == "local" else 1
+    if world > 1:
+        from . import allpairs
+        mine = np.zeros(n, dtype=bool)
+        mine[allpairs.shard_masters(lens, world)[rank]] = True
+        keep &= mine[ii]
     pairs = np.stack([ii[keep], jj[keep]], axis=1).astype(np.int32)
-    arena = native.Arena(profiles, S)
-    try:
-        arena.counts_reset()
-        iterations = waterman_eggert_iterations if mode == "local" else 1
-        rects = None
-        for it in range(iterations if len(pairs) else 0):
-            plan = native.Plan(arena, pairs, want_paths=True, rects=rects)
-            try:
-                plan.run(mode, gap_open, gap_extend)
-                plan.add_counts(score_threshold, local=(mode == "local"))
-                if it + 1 < iterations:
-                    b = plan.path_bounds().reshape(-1, 1, 4)
-                    rects = b if rects is None else np.concatenate([rects, b], axis=1)
-            finally:
-                plan.close()
-        counts = arena.counts().astype(int)
-    finally:
-        arena.close()
+    counts = _preprofile_counts_exchange(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations,
+                                         world, group).astype(int)
     out = []
     for i, t in enumerate(tracks):
         c = counts[row_off[i]:row_off[i] + lens[i]].copy()
         c[np.arange(lens[i]), np.asarray(t.values)] += 1      # the master advances in every column
         out.append(ProfileTrack(c, alphabet))
     return out
+
+
+def _preprofile_counts_exchange(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations, world, group):
+    """This rank's counts and, for world > 1, the exchange step: one all-reduce of the count arena."""
+    if world <= 1:
+        return _preprofile_slave_counts(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations)
+    import torch
+    import torch.distributed as dist
+    from . import allpairs
+    if dist.get_backend(group) == "nccl":
+        # accumulate straight into a torch tensor and reduce it in place: the counts never visit the host before the sum
+        rows = int(sum(p.shape[0] for p in profiles))
+        t = torch.zeros(rows * S.shape[0], dtype=torch.int32, device="cuda")
+        torch.cuda.current_stream().synchronize()      # the library's stream must see the zero fill
+        _preprofile_slave_counts(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations, counts_out=t)
+        allpairs.all_reduce_counts(t, group)
+        return t.cpu().numpy().reshape(rows, S.shape[0])
+    local = _preprofile_slave_counts(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations)
+    return allpairs.all_reduce_counts(local, group)
 
 
 # ---- callers: guide tree (all-pairs distance stage) ----------------------------------------------
@@ -541,10 +652,6 @@ class GuideTreeBuilder(Component):
         if dist_mode not in ('semiglobal', 'global', 'semiglobal_auto'):
             raise ComponentError("unknown alignment mode '{0}'".format(dist_mode))
         n = len(sequences)
-        # what the per-pair checks of the aligner test is per sequence (alphabets against the matrices): once each
-        for s in sequences:
-            _validate_track_sets(s, s, track_id_sets, track_id_sets, score_matrices)
-        batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, self.environment['gap_series'])
         fixed = {"semiglobal": "semiglobal_both", "global": "global"}.get(dist_mode)
         ii, jj = np.triu_indices(n, k=1)   # tree.py:105-129: each unordered pair once, i outer, j inner
         if fixed:
@@ -552,13 +659,55 @@ class GuideTreeBuilder(Component):
         else:                              # auto_align_mode (util/align.py:299-305), for all pairs at once
             lens = np.array([len(s) for s in sequences])
             modes = np.where(lens[ii] > lens[jj], "semiglobal_one", "semiglobal_two")
-        scores = batch.scores_for_pairs(sequences, ii, jj, modes)
+        aligner, aligner_env = _resolve_aligner(self)
+        if not _is_device_aligner(aligner):
+            # another aligner component: the reference's fan-out, ONE Execution holding a task per pair
+            # (tree.py:104-140); under a batching / parallel manager that is still one execute_many call
+            sub_env = self.environment['aligner_env']
+            if self.environment['squash_profiles']:
+                sub_env.keys['squash_profiles'] = True        # tree.py:118-119
+            execution = Execution(self.manager, self.tag)
+            for i, j, mode in zip(ii.tolist(), jj.tolist(), modes.tolist()):
+                task = execution.add_task(aligner)
+                task.environment(self.environment, sub_env)
+                task.inputs(mode=mode, sequence_one=sequences[i], sequence_two=sequences[j],
+                            track_id_sets_one=track_id_sets, track_id_sets_two=track_id_sets,
+                            score_matrices=score_matrices)
+            step = 0
+            for message in execution.run():
+                yield message
+                if message.kind == MESSAGE_KIND_COMPLETE and execution.started_task(message.tag):
+                    step += 1
+                    yield ProgressMessage(step / float(len(ii)))
+            scores = np.array([out['score'] for out in execution.outputs], dtype=np.float32)
+        else:
+            # what the per-pair checks of the aligner test is per sequence (alphabets against the matrices): once each
+            for s in sequences:
+                _validate_track_sets(s, s, track_id_sets, track_id_sets, score_matrices)
+            batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, aligner_env['gap_series'])
+            scores = self._all_pairs_scores(batch, sequences, ii, jj, modes)
         d = np.zeros((n, n), dtype=np.float32)  # tree.py:99-100,131: diagonal 0
         d[ii, jj] = d[jj, ii] = scores
         self.score_matrix = d
         dist = (-d) + d.max()  # tree.py:147
         tree = SequenceTree(sequences, merge_order(dist, linkage))
         yield CompleteMessage({'guide_tree': tree})
+
+    def _all_pairs_scores(self, batch, sequences, ii, jj, modes):
+        """Scores of the pairs (ii[k], jj[k]) in row-major order.  Under a manager that belongs to a process group
+        (BatchManager(rank=, world=, group=): one process per GPU) the pair list is sharded by columns, every rank
+        aligns its shard on its own device and the score shards are exchanged with ONE all-gather (allpairs.py);
+        every rank returns the complete list."""
+        world = getattr(self.manager, 'world', 1)
+        if world <= 1 or len(ii) == 0:
+            return batch.scores_for_pairs(sequences, ii, jj, modes)
+        from . import allpairs
+        lens = np.array([len(s) for s in sequences], dtype=np.int64)
+        pairs = np.stack([ii, jj], axis=1)
+        shards = allpairs.shard_columns(lens, pairs, world)
+        mine = shards[self.manager.rank]
+        local = batch.scores_for_pairs(sequences, ii[mine], jj[mine], np.asarray(modes)[mine])
+        return allpairs.all_gather_scores(local, shards, self.manager.rank, world, self.manager.group)
 
 
 # ---- callers: progressive alignment along the guide tree -------------------------------------------
@@ -744,7 +893,18 @@ COMPONENTS = [PairwiseAligner, RawPairwiseAligner, ProfileBuilder, DummyMasterSl
 class BatchManager(Manager):
     """Manager whose execute_many recognises a homogeneous list of PairwiseAligner requests (what
     Execution.run hands over for the reference's all-pairs fan-outs, praline/core/execution.py:158-188)
-    and runs it as one device submission per mode; anything else falls back to the serial loop."""
+    and runs it as one device submission per mode; anything else falls back to the serial loop.
+
+    rank / world / group: this process's place in a torch.distributed process group, one process per GPU - the
+    counterpart of the reference's ParallelExecutionManager worker pool (praline/core/manager.py:401-463).  The
+    all-pairs stages that run under this manager (GuideTreeBuilder) shard their pair list over the ranks and
+    exchange the scores with one all-gather; every rank ends up with the same outputs."""
+
+    def __init__(self, index, rank=0, world=1, group=None):
+        Manager.__init__(self, index)
+        if not (0 <= rank < world):
+            raise ValueError("rank {0} outside a world of {1}".format(rank, world))
+        self.rank, self.world, self.group = rank, world, group
 
     def execute_many(self, requests, parent_tag):
         self._require_open()

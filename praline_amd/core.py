@@ -19,6 +19,8 @@ MESSAGE_KIND_COMPLETE = "complete"
 MESSAGE_KIND_ERROR = "error"
 MESSAGE_KIND_LOG = "log"
 
+ENTRY_POINT_GROUP = "praline.type"   # praline/core/component.py: the setuptools group TypeIndex.autoregister reads
+
 ROOT_TAG = "__ROOT_TAG__"
 
 _PRIMITIVES = (int, float, str, bool)
@@ -244,9 +246,23 @@ class TypeIndex(object):
         del self._types[component_class.tid]
 
     def autoregister(self):
-        from . import component
-        for cls in component.COMPONENTS:
-            self.register(cls)
+        """Register every component published under the `praline.type` entry-point group - what the reference does
+        (manager.py:72-85): this package's own components (setup.py) and any third-party aligner installed beside it.
+        Without packaging metadata (a bare source tree) the in-package list is registered."""
+        found = False
+        try:
+            from importlib import metadata
+            eps = metadata.entry_points()
+            group = eps.select(group=ENTRY_POINT_GROUP) if hasattr(eps, "select") else eps.get(ENTRY_POINT_GROUP, [])
+            for entry_point in group:
+                self.register(entry_point.load())
+                found = True
+        except ImportError:
+            pass
+        if not found:
+            from . import component
+            for cls in component.COMPONENTS:
+                self.register(cls)
 
     def resolve(self, tid):
         try:

@@ -270,6 +270,8 @@ struct praline_arena {
     // preprofile stage (k_path_counts): raw symbol of every one-hot row (255: not one-hot), int32 counts [rows_raw][A]
     DevBuf<unsigned char> d_sym_raw;
     DevBuf<int32_t> d_counts;
+    int32_t *counts_ext = nullptr;   // caller-owned count buffer (praline_arena_counts_bind)
+    int32_t *counts_ptr() const { return counts_ext ? counts_ext : d_counts.p; }
     // reference-order audit mode (k_match_ref): track-set partition of the alphabet axis and per-row nonzero lists
     std::vector<int32_t> set_lo;     // n_sets + 1 boundaries, default {0, A}
     DevBuf<int32_t> d_set_lo;
@@ -1048,8 +1050,15 @@ extern "C" int praline_plan_paths(praline_plan *plan, int32_t *paths, int64_t *p
 extern "C" int praline_arena_counts_reset(praline_arena *arena)
 {
     if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
-    if (!arena->d_counts.p) RC(arena->d_counts.alloc((size_t)arena->rows_raw * arena->A));
-    HIPCHK(hipMemsetAsync(arena->d_counts.p, 0, (size_t)arena->rows_raw * arena->A * sizeof(int32_t), g_rt.stream));
+    if (!arena->counts_ext && !arena->d_counts.p) RC(arena->d_counts.alloc((size_t)arena->rows_raw * arena->A));
+    HIPCHK(hipMemsetAsync(arena->counts_ptr(), 0, (size_t)arena->rows_raw * arena->A * sizeof(int32_t), g_rt.stream));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_counts_bind(praline_arena *arena, void *d_counts)
+{
+    if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    arena->counts_ext = (int32_t *)d_counts;
     return PRALINE_OK;
 }
 
@@ -1059,7 +1068,7 @@ extern "C" int praline_plan_add_counts(praline_plan *plan, int use_threshold, fl
     if (!plan->want_paths) return fail(PRALINE_ERR_ARG, "plan was created without want_paths");
     if (plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "praline_plan_run has not been called");
     praline_arena &a = *plan->arena;
-    if (!a.d_counts.p) return fail(PRALINE_ERR_ARG, "praline_arena_counts_reset has not been called");
+    if (!a.counts_ptr()) return fail(PRALINE_ERR_ARG, "praline_arena_counts_reset has not been called");
     if (!a.all_onehot)
         return fail(PRALINE_ERR_UNSUPPORTED, "preprofile counting needs one-hot profiles (plain sequences), as "
                     "ProfileBuilder needs plain tracks (praline/util/align.py:187-213)");
@@ -1068,7 +1077,7 @@ extern "C" int praline_plan_add_counts(praline_plan *plan, int use_threshold, fl
     const int64_t blocks = (plan->n_pairs + threads - 1) / threads;
     hipLaunchKernelGGL(k_path_counts, dim3((unsigned)blocks), dim3(threads), 0, g_rt.stream, plan->d_pairs.p,
                        plan->last_scores, plan->d_paths.p, plan->d_path_start.p, plan->d_path_rows.p, plan->n_pairs,
-                       use_threshold, threshold, local, a.d_row_off_raw.p, a.d_len.p, a.d_sym_raw.p, a.A, a.d_counts.p);
+                       use_threshold, threshold, local, a.d_row_off_raw.p, a.d_len.p, a.d_sym_raw.p, a.A, a.counts_ptr());
     HIPCHK(hipGetLastError());
     return PRALINE_OK;
 }
@@ -1076,8 +1085,8 @@ extern "C" int praline_plan_add_counts(praline_plan *plan, int use_threshold, fl
 extern "C" int praline_arena_counts_read(praline_arena *arena, int32_t *counts)
 {
     if (!arena || !counts) return fail(PRALINE_ERR_ARG, "NULL argument");
-    if (!arena->d_counts.p) return fail(PRALINE_ERR_ARG, "praline_arena_counts_reset has not been called");
-    HIPCHK(hipMemcpyAsync(counts, arena->d_counts.p, (size_t)arena->rows_raw * arena->A * sizeof(int32_t),
+    if (!arena->counts_ptr()) return fail(PRALINE_ERR_ARG, "praline_arena_counts_reset has not been called");
+    HIPCHK(hipMemcpyAsync(counts, arena->counts_ptr(), (size_t)arena->rows_raw * arena->A * sizeof(int32_t),
                           hipMemcpyDeviceToHost, g_rt.stream));
     HIPCHK(hipStreamSynchronize(g_rt.stream));
     return PRALINE_OK;

@@ -70,6 +70,7 @@ def lib():
     L.praline_plan_cells.argtypes = [vp]
     L.praline_plan_cells.restype = i64
     L.praline_arena_counts_reset.argtypes = [vp]
+    L.praline_arena_counts_bind.argtypes = [vp, vp]
     L.praline_plan_add_counts.argtypes = [vp, ctypes.c_int, f32, ctypes.c_int]
     L.praline_arena_counts_read.argtypes = [vp, vp]
     L.praline_plan_path_bounds.argtypes = [vp, vp]
@@ -264,6 +265,11 @@ class Arena(object):
         m = np.zeros((int(self.lens[one]), int(self.lens[two])), dtype=np.float32)
         _check(lib().praline_arena_match_scores(self._h, int(one), int(two), int(kind), m.ctypes.data))
         return m
+
+    def counts_bind(self, device_ptr):
+        """Accumulate the preprofile counts in a caller-owned DEVICE buffer int32 [sum L][A] (praline_arena_counts_bind);
+        0 / None goes back to the arena's own buffer."""
+        _check(lib().praline_arena_counts_bind(self._h, ctypes.c_void_p(device_ptr or 0)))
 
     def counts_reset(self):
         """Zero the preprofile count buffer int32 [sum L, A] (praline_arena_counts_reset)."""

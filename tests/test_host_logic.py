@@ -1,6 +1,8 @@
 """CPU tests of the host-side mirror of the reference interface (no GPU, no native compute):
 core runtime semantics, containers, path utilities and the master-slave merge logic, checked against
 the golden vectors generated from the real reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -305,3 +307,96 @@ def test_merge_order_incremental_equals_full_recomputation():
                 np.fill_diagonal(m, 0)
                 for linkage in ('single', 'complete', 'average'):
                     assert comp.merge_order(m, linkage) == full(m, linkage), (n, ties, symmetric, linkage)
+
+
+def _spy_aligner_class(calls, bba_S):
+    """A user-registered aligner component (its own type id): records every request and aligns with the CPU oracle."""
+    from oracle import oracle as orc
+
+    class SpyAligner(core.Component):
+        tid = "tests.SpyAligner"
+        inputs = comp.PairwiseAligner.inputs
+        outputs = comp.PairwiseAligner.outputs
+        options = {'gap_series': [float], 'debug': int}
+        defaults = {'gap_series': [-11.0, -1.0], 'debug': 0}
+
+        def execute(self, mode, sequence_one, sequence_two, track_id_sets_one, track_id_sets_two, zero_idxs, score_matrices):
+            gs = list(self.environment['gap_series'])
+            calls.append((mode, sequence_one.name, sequence_two.name, tuple(gs), len(zero_idxs or [])))
+            p1 = comp._track_profile(sequence_one.get_track(track_id_sets_one[0][0]))
+            p2 = comp._track_profile(sequence_two.get_track(track_id_sets_two[0][0]))
+            score, path = orc.pairwise_align(mode, [p1], [p2], [score_matrices[0].matrix], gs, zero_idxs=zero_idxs or None)
+            yield core.CompleteMessage(outputs={'alignment': ct.Alignment([sequence_one, sequence_two],
+                                                                         comp._path_for_output(mode, path)),
+                                                'score': float(score)})
+    return SpyAligner
+
+
+def test_callers_honour_the_aligner_seam(bba):
+    """GuideTreeBuilder and both master-slave aligners resolve the `aligner` option and collapse `aligner_env` like the
+    reference (tree.py:115-127, preprofile.py:127-139,229-241): a user-registered aligner sees EVERY alignment, in the
+    reference's order, with the overridden gap_series - and since the spy aligns with the oracle, the outputs must equal
+    the goldens produced by the real reference pipeline.  No GPU involved: the device path is bypassed entirely."""
+    calls = []
+    spy = _spy_aligner_class(calls, bba["S"])
+    idx = core.TypeIndex()
+    idx.autoregister()
+    idx.register(spy)
+    manager = core.Manager(idx)
+    seqs = [ct.Sequence("seq%03d" % (i + 1), [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=v))])
+            for i, v in enumerate(bba["seqs"])]
+    blosum = ct.blosum62()
+    T_IN = [[ct.TRACK_ID_INPUT]]
+
+    def run_one(component, keys, **inputs):
+        ex = core.Execution(manager, "root")
+        ex.add_task(component).environment(core.Environment({}), core.Environment(keys)).inputs(**inputs)
+        return core.run(ex)[0]
+
+    d = load_golden("preprofile.npz")
+    for key, component, master, keys, per_slave in (("global_m0_", comp.GlobalMasterSlaveAligner, 0, {}, 1),
+                                                    ("local_m4_", comp.LocalMasterSlaveAligner, 4, {}, 2),
+                                                    ("local_we3_m0_", comp.LocalMasterSlaveAligner, 0,
+                                                     {"waterman_eggert_iterations": 3}, 3)):
+        del calls[:]
+        slaves = [s for k, s in enumerate(seqs) if k != master]
+        out = run_one(component, dict(keys, aligner=spy.tid), master_sequence=seqs[master], slave_sequences=slaves,
+                      track_id_sets=T_IN, score_matrices=[blosum])
+        assert np.array_equal(np.asarray(out['alignment'].path), d[key + "msa_path"]), key
+        assert [c[2] for c in calls] == [s.name for s in slaves for _ in range(per_slave)], key
+        assert all(c[1] == seqs[master].name and c[3] == (-11.0, -1.0) for c in calls)
+        if per_slave > 1:   # the zero_idxs list grows from iteration to iteration (preprofile.py:247-255)
+            assert calls[0][4] == 0 and 0 < calls[1][4] and (per_slave < 3 or calls[1][4] < calls[2][4])
+
+    # the guide tree: one task per pair i < j in row-major order, aligner_env overrides the gap series
+    del calls[:]
+    out = run_one(comp.GuideTreeBuilder, {"aligner": spy.tid, "aligner_env": core.Environment({"gap_series": [-5.0, -2.0]})},
+                  sequences=seqs, track_id_sets=T_IN, score_matrices=[blosum])
+    assert [(c[1], c[2]) for c in calls] == [(seqs[i].name, seqs[j].name) for i in range(5) for j in range(i + 1, 5)]
+    assert all(c[0] == "global" and c[3] == (-5.0, -2.0) for c in calls)
+    # ... and an unregistered aligner is an error, not a silent default
+    with pytest.raises(core.ComponentError):
+        run_one(comp.GuideTreeBuilder, {"aligner": "no.such.Aligner"}, sequences=seqs, track_id_sets=T_IN,
+                score_matrices=[blosum])
+
+
+def test_entry_point_metadata_registers_the_components(tmp_path):
+    """setup.py publishes the components under the reference's `praline.type` entry-point group (setup.py:8-20 there);
+    TypeIndex.autoregister reads that group like manager.py:72-85."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, "setup.py", "-q", "egg_info", "--egg-base", str(tmp_path)], cwd=root)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from importlib import metadata\n"
+            "eps = metadata.entry_points().select(group='praline.type')\n"
+            "names = sorted(e.name for e in eps)\n"
+            "from praline_amd import core, component\n"
+            "assert names == sorted(c.__name__ for c in component.COMPONENTS), names\n"
+            "assert all(e.load() is getattr(component, e.name) for e in eps)\n"
+            "idx = core.TypeIndex(); idx._types = {}\n"
+            "component.COMPONENTS = []          # the fallback list is not what registers them\n"
+            "idx.autoregister()\n"
+            "assert idx.resolve('praline.component.PairwiseAligner') is component.PairwiseAligner\n"
+            "assert len(idx._types) == 9\n" % (str(tmp_path), root))
+    subprocess.check_call([sys.executable, "-c", code])
