@@ -235,6 +235,9 @@ int praline_plan_match_kind(const praline_plan *plan);
 /* Timing of the last praline_plan_run on THIS plan, measured with the plan's own HIP events on the launch
  * stream: kernel_ms = the DP kernel alone (scores-only plans) / fill + end cells + traceback (path plans). */
 int praline_plan_last_timing(praline_plan *plan, float *kernel_ms);
+/* The DP kernel instance the last praline_plan_run launched, spelled as rocprofv3 prints it without the leading
+ * "void " (e.g. "k_dp_split16<2, 3, false, 2, 4>"); bench.py matches profile files against it. */
+int praline_plan_kernel_name(const praline_plan *plan, char *buf, int64_t size);
 
 #ifdef __cplusplus
 }

@@ -546,6 +546,7 @@ struct praline_plan {
     DevBuf<int64_t> d_m_off;
     DevBuf<int32_t> d_chunk_pairs;
     DevBuf<float> d_mref;
+    std::string last_kernel;        // the DP kernel instance the last run launched (as rocprofv3 names it)
     float *last_scores = nullptr;   // where the last praline_plan_run wrote the scores (own buffer or the caller's)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last run's launches, on the launch stream
     ~praline_plan()
@@ -870,6 +871,21 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     pl.last_scores = la.scores;
     hipStream_t st = g_rt.stream;
 
+    {
+        char kn[160];
+        const char *lb = local ? "true" : "false", *mb = pl.has_rects ? "true" : "false";
+        if (pl.ref) snprintf(kn, sizeof(kn), "k_dp_batch<2, 1, %s, %d, %s, 1>", lb, pl.want_paths ? 1 : 0, mb);
+        else if (!pl.split) snprintf(kn, sizeof(kn), "k_dp_batch<%d, %d, %s, %d, %s, 0>", a.nstep, pl.want_paths ? 1 : pl.tp, lb, pl.want_paths ? 1 : 0, mb);
+        else if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // refined below (nterm, chain)
+        else if (la.a16 == nullptr) snprintf(kn, sizeof(kn), "k_dp_split<%d, %s>", a.nstep, lb);
+        else {
+            const bool table = a.nterm16 == 1 && a16.sym8 != nullptr && !(!pl.wg.empty() && a16.stage);
+            const bool four = a16.stage && !table && (!pl.wg.empty() || (!pl.wg_singles.empty() &&
+                              !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')));
+            snprintf(kn, sizeof(kn), "k_dp_split16<%d, %d, %s, %d, %d>", a.nr16, a.nterm16, lb, table ? 1 : (a16.stage ? 2 : 0), four ? 4 : 1);
+        }
+        pl.last_kernel = kn;
+    }
     if (pl.ref) {
         HIPCHK(hipEventRecord(pl.ev0, st));
         RC(plan_run_ref(pl, la, mode, local));
@@ -1006,6 +1022,13 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         t0 = t1;
     }
     HIPCHK(hipEventRecord(pl.ev1, st));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_kernel_name(const praline_plan *plan, char *buf, int64_t size)
+{
+    if (!plan || !buf || size <= 0) return fail(PRALINE_ERR_ARG, "NULL argument");
+    snprintf(buf, (size_t)size, "%s", plan->last_kernel.c_str());
     return PRALINE_OK;
 }
 

@@ -93,6 +93,7 @@ def lib():
     L.praline_arena_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                      ctypes.POINTER(i32)]
     L.praline_plan_match_kind.argtypes = [vp]
+    L.praline_plan_kernel_name.argtypes = [vp, ctypes.c_char_p, i64]
     if L.praline_abi_version() != 1:
         raise NativeError(ERR_ARG, "ABI version mismatch")
     _lib = L
@@ -352,6 +353,12 @@ class Plan(object):
 
     def device_scores_ptr(self):
         return lib().praline_plan_device_scores(self._h)
+
+    def kernel_name(self):
+        """The DP kernel instance the last run() launched, as rocprofv3 names it (praline_plan_kernel_name)."""
+        buf = ctypes.create_string_buffer(200)
+        _check(lib().praline_plan_kernel_name(self._h, buf, 200))
+        return buf.value.decode()
 
     def kernel_ms(self):
         ms = ctypes.c_float(0.0)
