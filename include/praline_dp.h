@@ -153,8 +153,10 @@ typedef struct praline_plan praline_plan;   /* a scheduled pair list (wave tasks
  * S = blockdiag(S_t) (cext.c:389-420 sums the sets).  S: float32 [A][A], row = symbol of
  * sequence one, column = symbol of sequence two (align.py:205).  Runs the profile x matrix
  * pre-multiply (MFMA) on the device.
- * Limits: A <= 254; at most 32 ACTIVE symbols - symbols that have mass in some profile and a non-zero
- * row in S (BLOSUM62 on 20-residue data: 20 of 27) - otherwise PRALINE_ERR_UNSUPPORTED. */
+ * Limits: A <= 254.  The MFMA operand layouts hold up to 32 ACTIVE symbols - symbols that have mass in some
+ * profile and a non-zero row in S (BLOSUM62 on 20-residue data: 20 of 27); an arena with more keeps the raw
+ * profiles only and its plans take the PRALINE_MATCH_REFERENCE path whatever the match mode (correct for any
+ * alphabet, bit-identical to the reference, an order of magnitude slower). */
 int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t A, const float *profiles,
                          const float *S, praline_arena **out);
 int praline_arena_destroy(praline_arena *arena);
@@ -170,7 +172,10 @@ int praline_arena_premultiply(praline_arena *arena);
  * indices, any order, duplicates allowed).  want_paths != 0 additionally reserves packed
  * traceback storage.  rect_off (int32 [n+1]) / rects (int32 [rect_off[n]][4] = y0,y1,x0,x1
  * inclusive DP coordinates) give per-pair zero rectangles (the Waterman-Eggert masks of
- * praline/component/preprofile.py:247-255); both may be NULL. */
+ * praline/component/preprofile.py:247-255); both may be NULL.  Any number of rectangles per pair: up to 4 per pair
+ * run on the split-strip kernels (masks held in registers); plans in which some pair has more take the
+ * PRALINE_MATCH_REFERENCE path with per-row column masks prepared on the device (correct, an order of magnitude
+ * slower - more than five Waterman-Eggert iterations are rare). */
 int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pairs,
                         int want_paths, const int32_t *rect_off, const int32_t *rects,
                         praline_plan **out);
@@ -225,7 +230,8 @@ int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float g
  * m (float32 [L1][L2], host) of the arena pair (one, two) exactly as the kernels evaluate it:
  * kind 0 = fp32 MFMA chain (k-ordered fmaf chain, used by the traceback plans and
  * praline_build_scores), kind 1 = f16 hi/lo split on the matrix pipe (used by scores-only plans;
- * identical to kind 0 whenever all operands are f16-representable, e.g. one-hot x integer matrix).
+ * identical to kind 0 whenever all operands are f16-representable, e.g. one-hot x integer matrix),
+ * kind 2 = the reference's own summation order (PRALINE_MATCH_REFERENCE plans, arenas with > 32 active symbols).
  * praline_plan_match_kind tells which of the two a plan's praline_plan_run uses. */
 int praline_arena_match_scores(praline_arena *arena, int32_t one, int32_t two, int kind, float *m);
 int praline_arena_info(const praline_arena *arena, int32_t *n_active, int32_t *mfma_steps_f32,

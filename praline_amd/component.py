@@ -437,22 +437,11 @@ class LocalMasterSlaveAligner(Component):
         rects = [[] for _ in slave_sequences]
         results = [[] for _ in slave_sequences]   # per slave: (score, path) per iteration
         for it in range(iterations):
-            if it > native.MAX_RECTS:
-                # more masked rectangles than the batched kernels carry per pair: dense masks through the
-                # raw path, one pair at a time (same results, rarely needed: the default is 2 iterations)
-                scores, paths = [], []
-                raw = PairwiseAligner(self.manager, aligner_env, self.tag)
-                for j, s in enumerate(slave_sequences):
-                    zero = [(y, x) for (y0, y1, x0, x1) in rects[j] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
-                    out = raw._execute_raw("local", master_sequence, s, track_id_sets, track_id_sets, zero,
-                                           score_matrices, _normalise_gap_series(gap_series))
-                    scores.append(out['score'])
-                    paths.append(np.array(out['alignment'].path, dtype=int))
-            else:
-                batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, gap_series)
-                for j, s in enumerate(slave_sequences):
-                    batch.add("local", master_sequence, s, list(rects[j]))
-                scores, paths = batch.run(want_paths=True)
+            # one device submission per iteration, whatever the number of masked rectangles per pair
+            batch = PairwiseBatch(track_id_sets, track_id_sets, score_matrices, gap_series)
+            for j, s in enumerate(slave_sequences):
+                batch.add("local", master_sequence, s, list(rects[j]))
+            scores, paths = batch.run(want_paths=True)
             for j in range(len(slave_sequences)):
                 p = np.array(paths[j], dtype=int)
                 results[j].append((scores[j], p))
@@ -510,9 +499,6 @@ def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_seri
     with one exchange step.  Every rank returns all N tracks."""
     if mode not in ("global", "local"):
         raise ComponentError("the preprofile stage aligns in 'global' or 'local' mode, not '{0}'".format(mode))
-    if mode == "local" and waterman_eggert_iterations > native.MAX_RECTS + 1:
-        raise ComponentError("build_preprofiles carries at most {0} masked rectangles per pair ({1} Waterman-Eggert "
-                             "iterations); use LocalMasterSlaveAligner for more".format(native.MAX_RECTS, native.MAX_RECTS + 1))
     tracks = [seq.get_track(track_id) for seq in sequences]
     for t in tracks:
         if t.tid != PlainTrack.tid:

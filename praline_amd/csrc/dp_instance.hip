@@ -7,7 +7,7 @@
 #define PRALINE_CAT2(a, b) a##b
 #define PRALINE_CAT(a, b) PRALINE_CAT2(a, b)
 
-int PRALINE_CAT(praline_launch_dp_, PRALINE_NSTEP_INST)(const LaunchArgs &la, int tp, bool local, int out, bool mask)
+int PRALINE_CAT(praline_launch_dp_, PRALINE_NSTEP_INST)(const LaunchArgs &la, int tp, bool local, int out, int mask)
 {
     return launch_nstep<PRALINE_NSTEP_INST>(la, tp, local, out, mask);
 }

@@ -52,6 +52,10 @@ struct RunParams {
 struct RectList {
     const int32_t *rect_off;  // [n_pairs + 1] or nullptr
     const int32_t *rects;     // [.][4] y0,y1,x0,x1 inclusive DP coordinates
+    // plans in which some pair has more than PRALINE_MAX_RECTS rectangles (k_dp_batch MASK = 2): per pair, strip and
+    // DP row the 32-bit mask of the strip's zeroed columns, prepared by k_build_zmask
+    const unsigned *zmask = nullptr;
+    const int64_t *zm_off = nullptr;   // [n_pairs]
 };
 
 __device__ __forceinline__ bool mode_free_one(int mode) { return mode == 2 || mode == 3; }
@@ -276,7 +280,9 @@ __device__ __forceinline__ float select32(const float (&v)[32], int idx)
 // MSRC = 1 (reference-order audit mode, PRALINE_MATCH_REFERENCE): the match scores are not formed by MFMAs but read
 // from dense per-pair matrices mref + m_off[pair] ([L1][L2] float32) that k_match_ref wrote in the reference's own
 // summation order; TP must be 1.  Everything after the match scores is the same code.
-template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK, int MSRC = 0>
+// MASK: 0 no zero rectangles, 1 up to PRALINE_MAX_RECTS per pair held in registers, 2 any number per pair, walked in
+// memory for every row (plans in which some pair has more than PRALINE_MAX_RECTS: many Waterman-Eggert iterations).
+template <int NSTEP, int TP, bool LOCAL, int OUT, int MASK, int MSRC = 0>
 __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__restrict__ tasks,
                                                  const int32_t *__restrict__ lane_one,
                                                  const int32_t *__restrict__ lane_pair,
@@ -329,7 +335,12 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
 
     // ---- zero rectangles (Waterman-Eggert masks, praline/component/preprofile.py:247-255) ----
     int rect[PRALINE_MAX_RECTS][4];
-    if constexpr (MASK) {
+    // MASK == 2: one 32-bit column mask per (strip, row) of this pair, uint32 [nstrips][L1 + 1] at zmask + zm_off[pair]
+    const unsigned *my_zm = nullptr;
+    if constexpr (MASK == 2) {
+        if (my_pair >= 0 && rl.zmask != nullptr) my_zm = rl.zmask + rl.zm_off[my_pair];
+    }
+    if constexpr (MASK == 1) {
         int n_rects = 0, r0 = 0;
         if (my_pair >= 0 && rl.rect_off != nullptr) {
             r0 = rl.rect_off[my_pair];
@@ -418,6 +429,13 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
         }
 
         for (int y = 1; y <= tk.max_l1; ++y) {
+            // MASK == 2: bit c of zrow = cell (y, x0 + c + 1) lies in one of this pair's rectangles; the words were
+            // prepared by k_build_zmask (walking the rectangle list here, in a loop, miscompiled the LOCAL instance with
+            // ROCm 7.2: wrong scores even with empty lists)
+            unsigned zrow = 0;
+            if constexpr (MASK == 2) {
+                if (my_zm != nullptr && y <= L1 && s < my_strips) zrow = my_zm[(int64_t)s * (L1 + 1) + y];
+            }
             float m[32];
             if constexpr (MSRC == 1) {
                 // dense reference-order match scores of this lane's own pair
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
 
             if (strip_act && y <= L1) {
                 bool row_in[PRALINE_MAX_RECTS];
-                if constexpr (MASK) {
+                if constexpr (MASK == 1) {
 #pragma unroll
                     for (int r = 0; r < PRALINE_MAX_RECTS; ++r) row_in[r] = y >= rect[r][0] && y <= rect[r][1];
                 }
@@ -481,12 +499,15 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
                         if (LOCAL) M = __builtin_fmaxf(M, 0.0f);   // cext.c:208-209
                         float U = Uc[c];
                         float Lc = lrun;
-                        if constexpr (MASK) {
+                        if constexpr (MASK == 1) {
                             bool z = false;
 #pragma unroll
                             for (int r = 0; r < PRALINE_MAX_RECTS; ++r)
                                 z = z || (row_in[r] && (x0 + c + 1) >= rect[r][2] && (x0 + c + 1) <= rect[r][3]);
                             if (z) { M = 0.0f; U = 0.0f; Lc = 0.0f; }  // cext.c:141-149
+                        }
+                        if constexpr (MASK == 2) {
+                            if ((zrow >> c) & 1u) { M = 0.0f; U = 0.0f; Lc = 0.0f; }
                         }
                         const float H = max3f(M, U, Lc);
                         if (LOCAL) best = __builtin_fmaxf(best, H);
@@ -519,12 +540,15 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
                         bool isMM = sMM == M;
                         bool isMU = !isMM && sMU == M;
                         bool isML = !isMM && !isMU && sML == M;
-                        if constexpr (MASK) {
+                        if constexpr (MASK == 1) {
                             bool z = false;
 #pragma unroll
                             for (int r = 0; r < PRALINE_MAX_RECTS; ++r)
                                 z = z || (row_in[r] && (x0 + c + 1) >= rect[r][2] && (x0 + c + 1) <= rect[r][3]);
                             if (z) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }
+                        }
+                        if constexpr (MASK == 2) {
+                            if ((zrow >> c) & 1u) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }
                         }
                         w_mlo |= (isMM || isML) ? (1u << c) : 0u;
                         w_mhi |= (isMU || isML) ? (1u << c) : 0u;
@@ -896,6 +920,31 @@ __global__ void k_path_bounds(const int32_t *__restrict__ paths, const int64_t *
     bounds[4 * p + 3] = rows > 0 ? path[2 * (rows - 1) + 1] : -1;
 }
 
+
+// Column masks of the zero rectangles for k_dp_batch MASK = 2: one block per pair, entry (strip s, row y) = bit c set
+// when cell (y, 32 s + c + 1) lies in one of the pair's rectangles (cext.c:141-149 skips those cells).
+__global__ __launch_bounds__(256) void k_build_zmask(const int32_t *__restrict__ pairs, const int32_t *__restrict__ len,
+                                                     const int32_t *__restrict__ rect_off, const int32_t *__restrict__ rects,
+                                                     const int64_t *__restrict__ zm_off, unsigned *__restrict__ zmask)
+{
+    const int p = blockIdx.x;
+    const int L1 = len[pairs[2 * p]], L2 = len[pairs[2 * p + 1]];
+    const int nstrips = (L2 + 31) >> 5;
+    const int r0 = rect_off[p], n = rect_off[p + 1] - r0;
+    unsigned *out = zmask + zm_off[p];
+    for (int e = threadIdx.x; e < nstrips * (L1 + 1); e += blockDim.x) {
+        const int s = e / (L1 + 1), y = e % (L1 + 1);
+        unsigned z = 0;
+        for (int r = 0; r < n; ++r) {
+            const int32_t *q = rects + (int64_t)(r0 + r) * 4;
+            if (y >= q[0] && y <= q[1]) {
+                const int lo = max(q[2] - (32 * s + 1), 0), hi = min(q[3] - (32 * s + 1), 31);
+                if (lo <= hi) z |= (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo);
+            }
+        }
+        out[e] = z;
+    }
+}
 
 // --------------------------------------------------------------------------------------------
 // Reference-order match scores (audit mode PRALINE_MATCH_REFERENCE).

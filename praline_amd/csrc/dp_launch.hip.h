@@ -45,16 +45,16 @@ void praline_launch_split_f16(const float *src, int KP, int KS, int n_active, in
 int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int one, int two, int L1, int L2, float *m,
                                  hipStream_t stream);
 // k_dp_batch on dense reference-order match scores (dp_ref_instance.hip)
-int praline_launch_dp_ref(const LaunchArgs &la, bool local, int out, bool mask);
+int praline_launch_dp_ref(const LaunchArgs &la, bool local, int out, int mask);
 // k_dp_batch instances (dp_instance.hip)
-int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, bool mask);
-int praline_launch_dp_8(const LaunchArgs &la, int tp, bool local, int out, bool mask);
-int praline_launch_dp_10(const LaunchArgs &la, int tp, bool local, int out, bool mask);
-int praline_launch_dp_12(const LaunchArgs &la, int tp, bool local, int out, bool mask);
-int praline_launch_dp_14(const LaunchArgs &la, int tp, bool local, int out, bool mask);
-int praline_launch_dp_16(const LaunchArgs &la, int tp, bool local, int out, bool mask);
+int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, int mask);
+int praline_launch_dp_8(const LaunchArgs &la, int tp, bool local, int out, int mask);
+int praline_launch_dp_10(const LaunchArgs &la, int tp, bool local, int out, int mask);
+int praline_launch_dp_12(const LaunchArgs &la, int tp, bool local, int out, int mask);
+int praline_launch_dp_14(const LaunchArgs &la, int tp, bool local, int out, int mask);
+int praline_launch_dp_16(const LaunchArgs &la, int tp, bool local, int out, int mask);
 
-template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK> static void launch_one(const LaunchArgs &la)
+template <int NSTEP, int TP, bool LOCAL, int OUT, int MASK> static void launch_one(const LaunchArgs &la)
 {
     hipLaunchKernelGGL((k_dp_batch<NSTEP, TP, LOCAL, OUT, MASK>), dim3(la.n_tasks), dim3(64), 0, la.stream, la.ar,
                        la.tasks, la.lane_one, la.lane_pair, la.bnd, la.tb, la.aux, la.rl, la.scores, la.end_cells, la.rp);
@@ -62,18 +62,19 @@ template <int NSTEP, int TP, bool LOCAL, int OUT, bool MASK> static void launch_
 
 // Instantiated variants: scores-only (TP 1/2, local or not); traceback (TP 1, local or not, with or
 // without zero rectangles).
-template <int NSTEP> static int launch_nstep(const LaunchArgs &la, int tp, bool local, int out, bool mask)
+template <int NSTEP> static int launch_nstep(const LaunchArgs &la, int tp, bool local, int out, int mask)
 {
     if (la.split) return PRALINE_ERR_UNSUPPORTED;  // handled by praline_launch_split_N
     if (out == 0) {
         if (mask) return PRALINE_ERR_UNSUPPORTED;
-        if (tp == 2) { if (local) launch_one<NSTEP, 2, true, 0, false>(la); else launch_one<NSTEP, 2, false, 0, false>(la); }
-        else if (tp == 1) { if (local) launch_one<NSTEP, 1, true, 0, false>(la); else launch_one<NSTEP, 1, false, 0, false>(la); }
+        if (tp == 2) { if (local) launch_one<NSTEP, 2, true, 0, 0>(la); else launch_one<NSTEP, 2, false, 0, 0>(la); }
+        else if (tp == 1) { if (local) launch_one<NSTEP, 1, true, 0, 0>(la); else launch_one<NSTEP, 1, false, 0, 0>(la); }
         else return PRALINE_ERR_UNSUPPORTED;
     } else {
         if (tp != 1) return PRALINE_ERR_UNSUPPORTED;
-        if (local) { if (mask) launch_one<NSTEP, 1, true, 1, true>(la); else launch_one<NSTEP, 1, true, 1, false>(la); }
-        else { if (mask) launch_one<NSTEP, 1, false, 1, true>(la); else launch_one<NSTEP, 1, false, 1, false>(la); }
+        if (mask == 2) return PRALINE_ERR_UNSUPPORTED;   // column-mask plans run on the dense-match-score instances (dp_ref_instance.hip)
+        if (local) { if (mask) launch_one<NSTEP, 1, true, 1, 1>(la); else launch_one<NSTEP, 1, true, 1, 0>(la); }
+        else { if (mask) launch_one<NSTEP, 1, false, 1, 1>(la); else launch_one<NSTEP, 1, false, 1, 0>(la); }
     }
     return PRALINE_OK;
 }

@@ -277,6 +277,7 @@ struct praline_arena {
     DevBuf<int32_t> d_set_lo;
     DevBuf<unsigned char> d_nzidx, d_nzcnt;
     bool ref_ready = false;
+    bool wide = false;       // more than 32 active symbols: no MFMA operand layouts; every plan runs the reference-order path
     Arena16Dev view16() const
     {
         Arena16Dev v;
@@ -298,6 +299,7 @@ struct praline_arena {
 
 static int arena_launch_premultiply(praline_arena *a, bool check_f16 = false)
 {
+    if (a->wide) return PRALINE_OK;   // no packed operands: plans on this arena read the raw profiles (k_match_ref)
     if (!check_f16) {   // the recurring call: everything in one launch
         hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)(a->rows_pad / 32)), dim3(64), 0, g_rt.stream, a->d_raw.p, a->d_S.p,
                            a->d_seq_of_rowp.p, a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, a->d_active.p, a->n_active,
@@ -402,14 +404,14 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     a->nstep = 0;
     for (int c : kNstepChoices) if (c >= need) { a->nstep = c; break; }
     if (!a->nstep) {
-        const int n_act = a->n_active;
-        delete a;
-        return fail(PRALINE_ERR_UNSUPPORTED, "%d active symbols (symbols with mass in some profile and a non-zero score row); "
-                    "the kernels handle up to 32", n_act);
+        // more active symbols than the MFMA operand layouts hold (32): the arena keeps the raw profiles only and its
+        // plans evaluate the match scores on the vector ALU in the reference's order (k_match_ref, any alphabet <= 254)
+        a->wide = true;
+        a->nstep = 2;
     }
     a->KS = (a->nstep + 3) / 4 * 4;
     a->KP = 2 * a->KS;
-    a->nr16 = a->n_active <= 16 ? 1 : (a->n_active <= 32 ? 2 : 0);
+    a->nr16 = a->wide ? 0 : (a->n_active <= 16 ? 1 : 2);
 
     // one-hot arenas (every row: a single 1, zeros elsewhere): active-symbol bytes for the one-hot operand table
     std::vector<unsigned char> sym8;
@@ -439,7 +441,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         (rc = a->d_len.upload(a->len, st)) || (rc = a->d_row_off_pad.upload(a->row_off_pad, st)) ||
         (rc = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
         (rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
-        (rc = a->d_P.alloc((size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc((size_t)a->rows_pad * a->KP)) ||
+        (rc = a->d_P.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) ||
         (rc = a->d_flag16.alloc(1)) || (a->onehot && (rc = a->d_sym8.upload(sym8, st))) || (rc = a->d_sym_raw.upload(sym_raw, st)) ||
         (a->nr16 > 0 && ((rc = a->d_P16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)) ||
                          (rc = a->d_Q16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)))) ||
@@ -513,6 +515,7 @@ struct praline_plan {
     int64_t path_cap = 0;
     bool want_paths = false;
     bool has_rects = false;
+    int mask_kind = 0;   // 0 none, 1 <= PRALINE_MAX_RECTS rectangles per pair (registers), 2 any number (k_dp_batch MASK = 2)
     int tp = 1;
     bool split = false;  // k_dp_split task layout
     std::vector<WaveTask> tasks;
@@ -546,6 +549,9 @@ struct praline_plan {
     DevBuf<int64_t> d_m_off;
     DevBuf<int32_t> d_chunk_pairs;
     DevBuf<float> d_mref;
+    // mask_kind 2: column masks per (pair, strip, row) for k_dp_batch MASK = 2 (k_build_zmask)
+    DevBuf<unsigned> d_zmask;
+    DevBuf<int64_t> d_zm_off;
     std::string last_kernel;        // the DP kernel instance the last run launched (as rocprofv3 names it)
     float *last_scores = nullptr;   // where the last praline_plan_run wrote the scores (own buffer or the caller's)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last run's launches, on the launch stream
@@ -586,18 +592,20 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         return fail(PRALINE_ERR_UNSUPPORTED, "zero rectangles are only supported together with want_paths");
     RC(ensure_runtime(-1));
     const praline_arena &a = *arena;
+    bool many_rects = false;   // some pair carries more rectangles than the register-resident mask code holds
     for (int64_t p = 0; p < n_pairs; ++p) {
         const int32_t o = pairs[2 * p], t = pairs[2 * p + 1];
         if (o < 0 || o >= a.n_seqs || t < 0 || t >= a.n_seqs)
             return fail(PRALINE_ERR_ARG, "pair %lld = (%d, %d) out of range", (long long)p, o, t);
-        if (rect_off && rect_off[p + 1] - rect_off[p] > PRALINE_MAX_RECTS)
-            return fail(PRALINE_ERR_UNSUPPORTED, "pair %lld has more than %d zero rectangles", (long long)p, PRALINE_MAX_RECTS);
+        if (rect_off && rect_off[p + 1] < rect_off[p]) return fail(PRALINE_ERR_ARG, "rect_off is not ascending at pair %lld", (long long)p);
+        many_rects = many_rects || (rect_off && rect_off[p + 1] - rect_off[p] > PRALINE_MAX_RECTS);
     }
     praline_plan *pl = new praline_plan();
     pl->arena = arena;
     pl->n_pairs = n_pairs;
     pl->want_paths = want_paths != 0;
     pl->has_rects = rect_off && rect_off[n_pairs] > 0;
+    pl->mask_kind = !pl->has_rects ? 0 : (many_rects ? 2 : 1);
 
     // ---- host scheduling (sched.cpp): tasks, launch order, workgroup descriptors ----
     SchedOptions opt;
@@ -607,7 +615,11 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     opt.split_layout = a.nr16 > 0 || !want_paths;
     if (const char *env = getenv("PRALINE_KERNEL")) { if (!strcmp(env, "batch")) opt.split_layout = false; }
     if (const char *env = getenv("PRALINE_TP")) opt.tp = atoi(env);
-    pl->ref = match_mode() == PRALINE_MATCH_REFERENCE;
+    // the split-strip kernels hold PRALINE_MAX_RECTS rectangles per pair in registers; plans with more per pair (many
+    // Waterman-Eggert iterations: rare) take the dense-match-score path with per-row column masks (k_build_zmask).
+    // (The MFMA-fed k_dp_batch instance with those masks gave wrong LOCAL scores under ROCm 7.2 - codegen-sensitive,
+    // not understood - so it is not used.)
+    pl->ref = match_mode() == PRALINE_MATCH_REFERENCE || a.wide || many_rects;
     if (pl->ref) { opt.split_layout = false; opt.tp = 1; }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
     if (const char *env = getenv("PRALINE_NO_W2")) opt.shared_waves = env[0] != '1';
@@ -658,6 +670,17 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             std::vector<int32_t> ro(rect_off, rect_off + n_pairs + 1), rv(rects, rects + (size_t)rect_off[n_pairs] * 4);
             if ((rc = pl->d_rect_off.upload(ro, st)) || (rc = pl->d_rects.upload(rv, st))) { delete pl; return rc; }
         }
+        if (pl->mask_kind == 2) {
+            std::vector<int64_t> zo((size_t)n_pairs);
+            int64_t tot = 0;
+            for (int64_t p = 0; p < n_pairs; ++p) {
+                zo[(size_t)p] = tot;
+                tot += (int64_t)((a.len[pairs[2 * p + 1]] + 31) / 32) * (a.len[pairs[2 * p]] + 1);
+            }
+            if ((rc = pl->d_zm_off.upload(zo, st)) || (rc = pl->d_zmask.alloc((size_t)tot))) { delete pl; return rc; }
+            hipLaunchKernelGGL(k_build_zmask, dim3((unsigned)n_pairs), dim3(256), 0, st, pl->d_pairs.p, a.d_len.p, pl->d_rect_off.p,
+                               pl->d_rects.p, pl->d_zm_off.p, pl->d_zmask.p);
+        }
     }
     hipError_t e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
@@ -697,7 +720,7 @@ extern "C" void *praline_plan_device_scores(praline_plan *plan) { return plan ? 
 // --------------------------------------------------------------------------------------------
 // kernel dispatch: one translation unit per MFMA step count (dp_instance.hip), see dp_launch.hip.h
 // --------------------------------------------------------------------------------------------
-static int launch_dp(int nstep, const LaunchArgs &la, int tp, bool local, int out, bool mask)
+static int launch_dp(int nstep, const LaunchArgs &la, int tp, bool local, int out, int mask)
 {
     int rc = PRALINE_ERR_UNSUPPORTED;
     if (la.split) {
@@ -824,7 +847,7 @@ static int plan_run_ref(praline_plan &pl, LaunchArgs la, int mode, bool local)
         la.n_tasks = (unsigned)(t1 - t0);
         la.mref = pl.d_mref.p;
         la.m_off = pl.d_m_off.p;
-        int rc = praline_launch_dp_ref(la, local, pl.want_paths ? 1 : 0, pl.has_rects);
+        int rc = praline_launch_dp_ref(la, local, pl.want_paths ? 1 : 0, pl.mask_kind);
         if (rc != PRALINE_OK) return fail(rc, "no reference-order kernel instance (paths=%d mask=%d)", (int)pl.want_paths, (int)pl.has_rects);
         HIPCHK(hipGetLastError());
         if (pl.want_paths) RC(launch_traceback(pl, la, t0, t1, mode));
@@ -853,6 +876,8 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     la.bnd = pl.d_bnd.p;
     la.rl.rect_off = pl.has_rects ? pl.d_rect_off.p : nullptr;
     la.rl.rects = pl.has_rects ? pl.d_rects.p : nullptr;
+    la.rl.zmask = pl.mask_kind == 2 ? pl.d_zmask.p : nullptr;
+    la.rl.zm_off = pl.mask_kind == 2 ? pl.d_zm_off.p : nullptr;
     la.scores = d_scores ? (float *)d_scores : pl.d_scores.p;
     la.end_cells = pl.d_end_cells.p;
     la.rp.mode = mode;
@@ -873,9 +898,9 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
 
     {
         char kn[160];
-        const char *lb = local ? "true" : "false", *mb = pl.has_rects ? "true" : "false";
-        if (pl.ref) snprintf(kn, sizeof(kn), "k_dp_batch<2, 1, %s, %d, %s, 1>", lb, pl.want_paths ? 1 : 0, mb);
-        else if (!pl.split) snprintf(kn, sizeof(kn), "k_dp_batch<%d, %d, %s, %d, %s, 0>", a.nstep, pl.want_paths ? 1 : pl.tp, lb, pl.want_paths ? 1 : 0, mb);
+        const char *lb = local ? "true" : "false";
+        if (pl.ref) snprintf(kn, sizeof(kn), "k_dp_batch<2, 1, %s, %d, %d, 1>", lb, pl.want_paths ? 1 : 0, pl.mask_kind);
+        else if (!pl.split) snprintf(kn, sizeof(kn), "k_dp_batch<%d, %d, %s, %d, %d, 0>", a.nstep, pl.want_paths ? 1 : pl.tp, lb, pl.want_paths ? 1 : 0, pl.mask_kind);
         else if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // refined below (nterm, chain)
         else if (la.a16 == nullptr) snprintf(kn, sizeof(kn), "k_dp_split<%d, %s>", a.nstep, lb);
         else {
@@ -916,7 +941,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             la.n_wg = (unsigned)pl.wg_singles.size();
         }
         HIPCHK(hipEventRecord(pl.ev0, st));
-        RC(launch_dp(a.nstep, la, pl.tp, local, 0, false));
+        RC(launch_dp(a.nstep, la, pl.tp, local, 0, 0));
         HIPCHK(hipEventRecord(pl.ev1, st));
         HIPCHK(hipGetLastError());
         return PRALINE_OK;
@@ -1015,7 +1040,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16_tb instance for nr=%d nterm=%d", a.nr16, tb_nterm);
         } else {
             la.split = 0;
-            RC(launch_dp(a.nstep, la, 1, local, 1, pl.has_rects));
+            RC(launch_dp(a.nstep, la, 1, local, 1, pl.mask_kind));
         }
         HIPCHK(hipGetLastError());
         RC(launch_traceback(pl, la, t0, t1, mode));
@@ -1223,7 +1248,28 @@ extern "C" int praline_build_scores(int num_sets, const praline_array *i1s, cons
     RC(praline_arena_create(2, lens, (int32_t)A, prof.data(), S.data(), &ar));
     DevBuf<float> d_m;
     int rc = d_m.alloc((size_t)(L1 * L2));
-    if (rc == PRALINE_OK) {
+    if (rc == PRALINE_OK && (ar->wide || match_mode() == PRALINE_MATCH_REFERENCE)) {
+        // the reference's own summation order (per track set), any alphabet: bit-identical to cext_build_scores
+        std::vector<int32_t> sizes;
+        for (int n = 0; n < num_sets; ++n) sizes.push_back((int32_t)std::max(i1s[n].dim[1], i2s[n].dim[1]));
+        rc = praline_arena_set_track_sets(ar, num_sets, sizes.data());
+        if (rc == PRALINE_OK) rc = arena_ensure_ref(ar);
+        DevBuf<int32_t> d_pair, d_chunk;
+        DevBuf<int64_t> d_off;
+        if (rc == PRALINE_OK) rc = d_pair.upload(std::vector<int32_t>{0, 1}, g_rt.stream);
+        if (rc == PRALINE_OK) rc = d_chunk.upload(std::vector<int32_t>{0}, g_rt.stream);
+        if (rc == PRALINE_OK) rc = d_off.upload(std::vector<int64_t>{0}, g_rt.stream);
+        if (rc == PRALINE_OK) {
+            hipLaunchKernelGGL(k_match_ref, dim3(1, (unsigned)((L1 + PRALINE_REF_ROWS - 1) / PRALINE_REF_ROWS)), dim3(256), 0,
+                               g_rt.stream, ar->d_raw.p, ar->d_S.p, ar->A, ar->d_row_off_raw.p, ar->d_len.p, ar->d_nzidx.p,
+                               ar->d_nzcnt.p, ar->d_set_lo.p, (int)ar->set_lo.size() - 1, d_pair.p, d_chunk.p, d_off.p, d_m.p);
+            std::vector<float> hm((size_t)(L1 * L2));
+            hipError_t e = hipMemcpyAsync(hm.data(), d_m.p, hm.size() * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(g_rt.stream);
+            if (e != hipSuccess) rc = fail(PRALINE_ERR_DEVICE, "build_scores: %s", hipGetErrorString(e));
+            else scatter2<float>(hm, *m);
+        }
+    } else if (rc == PRALINE_OK) {
         dim3 grid((unsigned)((L2 + 31) / 32), (unsigned)((L1 + 31) / 32));
         hipLaunchKernelGGL(k_scores_tile, grid, dim3(64), 0, g_rt.stream, ar->view(), 0, 1, ar->nstep, d_m.p);
         std::vector<float> hm((size_t)(L1 * L2));
@@ -1391,6 +1437,23 @@ extern "C" int praline_arena_match_scores(praline_arena *arena, int32_t one, int
     const int L1 = arena->len[one], L2 = arena->len[two];
     DevBuf<float> d_m;
     RC(d_m.alloc((size_t)L1 * L2));
+    if (kind == 2) {   // the reference's summation order (what PRALINE_MATCH_REFERENCE plans and wide arenas use)
+        RC(arena_ensure_ref(arena));
+        DevBuf<int32_t> d_pair, d_chunk;
+        DevBuf<int64_t> d_off;
+        RC(d_pair.upload(std::vector<int32_t>{one, two}, g_rt.stream));
+        RC(d_chunk.upload(std::vector<int32_t>{0}, g_rt.stream));
+        RC(d_off.upload(std::vector<int64_t>{0}, g_rt.stream));
+        hipLaunchKernelGGL(k_match_ref, dim3(1, (unsigned)((L1 + PRALINE_REF_ROWS - 1) / PRALINE_REF_ROWS)), dim3(256), 0,
+                           g_rt.stream, arena->d_raw.p, arena->d_S.p, arena->A, arena->d_row_off_raw.p, arena->d_len.p,
+                           arena->d_nzidx.p, arena->d_nzcnt.p, arena->d_set_lo.p, (int)arena->set_lo.size() - 1, d_pair.p,
+                           d_chunk.p, d_off.p, d_m.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(m, d_m.p, (size_t)L1 * L2 * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
+        HIPCHK(hipStreamSynchronize(g_rt.stream));
+        return PRALINE_OK;
+    }
+    if (arena->wide) return fail(PRALINE_ERR_UNSUPPORTED, "this arena has more than 32 active symbols: only kind 2 (reference order) exists");
     if (kind == 0) {
         dim3 grid((unsigned)((L2 + 31) / 32), (unsigned)((L1 + 31) / 32));
         hipLaunchKernelGGL(k_scores_tile, grid, dim3(64), 0, g_rt.stream, arena->view(), one, two, arena->nstep, d_m.p);
@@ -1398,7 +1461,7 @@ extern "C" int praline_arena_match_scores(praline_arena *arena, int32_t one, int
         if (arena->nr16 == 0) return fail(PRALINE_ERR_UNSUPPORTED, "no f16 operands for this arena");
         int rc = praline_launch_scores_tile16(arena->view16(), arena->nr16, arena->nterm16, one, two, L1, L2, d_m.p, g_rt.stream);
         if (rc != PRALINE_OK) return fail(rc, "no k_scores_tile16 instance");
-    } else return fail(PRALINE_ERR_ARG, "kind must be 0 (fp32 MFMA chain) or 1 (f16 split)");
+    } else return fail(PRALINE_ERR_ARG, "kind must be 0 (fp32 MFMA chain), 1 (f16 split) or 2 (reference order)");
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(m, d_m.p, (size_t)L1 * L2 * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
     HIPCHK(hipStreamSynchronize(g_rt.stream));

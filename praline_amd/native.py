@@ -19,7 +19,8 @@ MODES = {"global": 0, "local": 1, "semiglobal_both": 2, "semiglobal_one": 3,
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
 
-MAX_RECTS = 4   # zero rectangles per pair the batched kernels carry (PRALINE_MAX_RECTS, dp_kernels.hip.h)
+MAX_RECTS = 4   # zero rectangles per pair the split-strip kernels hold in registers (PRALINE_MAX_RECTS); plans with more
+                # per pair run on k_dp_batch with the rectangle list walked in memory (no limit)
 
 
 class NativeError(RuntimeError):
@@ -262,7 +263,7 @@ class Arena(object):
 
     def match_scores(self, one, two, kind=0):
         """Dense match-score matrix of a pair exactly as the kernels evaluate it (diagnostics):
-        kind 0 = fp32 MFMA chain, kind 1 = f16 hi/lo split on the matrix pipe."""
+        kind 0 = fp32 MFMA chain, kind 1 = f16 hi/lo split on the matrix pipe, kind 2 = reference order."""
         m = np.zeros((int(self.lens[one]), int(self.lens[two])), dtype=np.float32)
         _check(lib().praline_arena_match_scores(self._h, int(one), int(two), int(kind), m.ctypes.data))
         return m

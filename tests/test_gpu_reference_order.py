@@ -212,3 +212,80 @@ def test_c2_float_profile_alignments_vs_reference_order(nat, bba):
     print("C2 float-profile path parity:", json.dumps(stats))
     # the fast mode is allowed to differ only on rounding-level ties, and rarely
     assert stats["paths_differing_total"] <= 0.02 * stats["alignments"], stats
+
+
+def test_wide_alphabets_take_the_reference_order_path(nat):
+    """More than 32 active symbols (the reference has no such limit, cext.c:389-420): the arena keeps the raw profiles
+    and its plans run the reference-order path - scores and paths bit-identical to the oracle, every mode, float
+    profiles over a 60-symbol alphabet, with rectangles; praline_build_scores likewise."""
+    rng = np.random.default_rng(31)
+    A = 60
+    S = rng.normal(0, 3, (A, A)).astype(np.float32)
+    lens = [35, 51, 8, 40]
+    profs = []
+    for L in lens:
+        c = np.zeros((L, A), dtype=np.float32)
+        for _ in range(5):
+            c[np.arange(L), rng.integers(0, A, L)] += rng.integers(1, 4, L)
+        profs.append((c / c.sum(axis=1, keepdims=True)).astype(np.float32))
+    arena = nat.Arena(profs, S)
+    assert arena.info()["n_active"] > 32
+    pairs = np.array([(i, j) for i in range(4) for j in range(4) if i != j], dtype=np.int32)
+    rects = [[(2, 5, 1, 6)] if k % 2 else [] for k in range(len(pairs))]
+    res = run_device(nat, arena, pairs, MODES)
+    res_l = run_device(nat, arena, pairs, ["local"], rects=rects)
+    res0 = run_device(nat, arena, pairs, ["global"], want_paths=False)
+    for k, (i, j) in enumerate(pairs):
+        for mode in MODES:
+            assert res[mode][2] == 2
+            s_or, p_or = orc.pairwise_align(mode, [profs[i]], [profs[j]], [S], (GO, GE))
+            assert res[mode][0][k] == np.float32(s_or), (mode, i, j)
+            assert np.array_equal(res[mode][1][k], p_or), (mode, i, j)
+        zero = [(y, x) for (y0, y1, x0, x1) in rects[k] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)
+                if y <= lens[i] and x <= lens[j]]
+        s_or, p_or = orc.pairwise_align("local", [profs[i]], [profs[j]], [S], (GO, GE), zero_idxs=zero or None)
+        assert res_l["local"][0][k] == np.float32(s_or) and np.array_equal(res_l["local"][1][k], p_or), (i, j)
+    assert np.array_equal(bits(res0["global"][0]), bits(res["global"][0]))
+    m_dev = arena.match_scores(0, 1, kind=2)
+    m_ref = np.zeros_like(m_dev)
+    orc.cext_build_scores([profs[0]], [profs[1]], [orc.build_nonzero_matrix(profs[0])], [orc.build_nonzero_matrix(profs[1])], [S], m_ref)
+    assert np.array_equal(bits(m_dev), bits(m_ref))
+    arena.close()
+    m = np.zeros((lens[0], lens[1]), dtype=np.float32)
+    nat.cext_build_scores([profs[0]], [profs[1]], None, None, [S], m)       # the drop-in twin on a wide alphabet
+    assert np.array_equal(bits(m), bits(m_ref))
+
+
+def test_many_rectangles_per_pair(nat, bba):
+    """More zero rectangles per pair than the split-strip kernels hold in registers (Waterman-Eggert with many
+    iterations, preprofile.py:247-255): one batched submission on the reference-order path with per-row column masks;
+    scores and paths bit-identical to the oracle's, one-hot and float profiles."""
+    rng = np.random.default_rng(37)
+    lens = [60, 75, 48, 66, 90]
+    onehots = [one_hot(rng.integers(0, 20, L), 27) for L in lens]
+    floats = [synth_profile(rng, L)[0] for L in lens]
+    pairs = np.array([(i, j) for i in range(5) for j in range(5) if i != j], dtype=np.int32)
+    rects = []
+    for k, (i, j) in enumerate(pairs):
+        n = [0, 3, 7, 12][k % 4]
+        rl = []
+        for _ in range(n):
+            y0, x0 = int(rng.integers(1, lens[i])), int(rng.integers(1, lens[j]))
+            rl.append((y0, min(lens[i], y0 + int(rng.integers(0, 9))), x0, min(lens[j], x0 + int(rng.integers(0, 9)))))
+        rects.append(rl)
+    assert max(len(r) for r in rects) > nat.MAX_RECTS
+    for profs in (onehots, floats):
+        arena = nat.Arena(profs, bba["S"])
+        for mode in MODES:
+            plan = nat.Plan(arena, pairs, want_paths=True, rects=rects)
+            kind = plan.match_kind()
+            plan.run(mode, GO, GE)
+            sc, paths = plan.scores(), plan.paths()
+            plan.close()
+            for k, (i, j) in enumerate(pairs):
+                zero = [(y, x) for (y0, y1, x0, x1) in rects[k] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
+                assert kind == 2                         # such plans evaluate the match scores in the reference's order
+                s_or, p_or = orc.pairwise_align(mode, [profs[i]], [profs[j]], [bba["S"]], (GO, GE), zero_idxs=zero or None)
+                assert sc[k] == np.float32(s_or), (mode, i, j, len(rects[k]))
+                assert np.array_equal(paths[k], p_or), (mode, i, j, len(rects[k]))
+        arena.close()
