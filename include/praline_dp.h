@@ -164,6 +164,20 @@ int praline_arena_destroy(praline_arena *arena);
  * Only PRALINE_MATCH_REFERENCE needs it: the reference keeps one running sum per set and adds the sets in list
  * order (cext.c:389-420).  Default: one set of size A. */
 int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets, const int32_t *sizes);
+
+/* Resident progressive alignment (the N - 1 merge steps of TreeMultipleSequenceAligner / AdHocMultipleSequenceAligner,
+ * praline/component/msa.py:124-237,250-558).  praline_arena_set_counts hands the arena the INTEGER counts behind its
+ * profile rows (int32 [sum of lengths][A]: one-hot counts for plain tracks, ProfileTrack.counts otherwise,
+ * msa.py:71-98) and reserves room for reserve_seqs further sequences of reserve_rows rows in total (it grows by itself
+ * beyond that).  praline_arena_append_merged merges the two sequences of pair `pair_index` of a path plan that has been
+ * run (global or semiglobal mode) along that pair's device path - ProfileTrack.merge for every track set
+ * (praline/container/sequence.py:205-239), profile rows as ProfileTrack.profile forms them (sequence.py:192-203) - and
+ * appends the result to the arena as a NEW sequence (packed operands included): the growing clusters never leave the
+ * GPU; only the path itself is needed on the host, for the bookkeeping of Alignment.merge
+ * (praline/container/align.py:30-61).  After the first append the arena is no longer one-hot. */
+int praline_arena_set_counts(praline_arena *arena, const int32_t *counts, int64_t reserve_seqs, int64_t reserve_rows);
+int praline_arena_append_merged(praline_arena *arena, praline_plan *plan, int64_t pair_index, int32_t *new_index,
+                                int32_t *new_len);
 /* Re-runs the device-side packing + pre-multiply from the resident raw profiles (the part of
  * cext_build_scores that is per sequence, not per pair); asynchronous on praline_stream(). */
 int praline_arena_premultiply(praline_arena *arena);

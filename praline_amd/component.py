@@ -731,6 +731,90 @@ def _merge_clusters(one, two, track_id_sets, path):
         one.add_track(trid, track)
 
 
+class _Len(object):
+    """Stands in for a cluster where only its length is asked for (auto_align_mode)."""
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+class ResidentClusters(object):
+    """The growing clusters of a progressive alignment RESIDENT ON THE GPU: one arena holds every initial
+    cluster - integer counts and packed profile operands - and every merge step appends the merged cluster in place
+    (native.Arena.append_merged: ProfileTrack.merge, praline/container/sequence.py:205-239, on the device path).  Per
+    step only the alignment path travels to the host, where Alignment.merge (praline/container/align.py:30-61) keeps
+    the sequence-level bookkeeping; no count track is merged or re-uploaded on the host."""
+
+    def __init__(self, sequences, track_id_sets, score_matrices, gap_series):
+        for seq in sequences:
+            _validate_track_sets(seq, seq, track_id_sets, track_id_sets, score_matrices)
+        self.gap_open, self.gap_extend = _normalise_gap_series(gap_series)
+        S, sizes = _block_diagonal(score_matrices)
+        counts, profiles = [], []
+        for i, seq in enumerate(sequences):
+            cluster = _count_cluster(i, seq, track_id_sets)          # msa.py:71-98: every aligned track as integer counts
+            cparts, pparts = [], []
+            for ids, sz in zip(track_id_sets, sizes):
+                track = cluster.get_track(ids[0])
+                c = np.asarray(track.counts, dtype=np.int32)
+                p = _track_profile(track)
+                if c.shape[1] < sz:
+                    c = np.pad(c, ((0, 0), (0, sz - c.shape[1])))
+                    p = np.pad(p, ((0, 0), (0, sz - p.shape[1])))
+                cparts.append(c)
+                pparts.append(p)
+            counts.append(np.concatenate(cparts, axis=1) if len(cparts) > 1 else cparts[0])
+            profiles.append(np.concatenate(pparts, axis=1) if len(pparts) > 1 else pparts[0])
+        self.arena = native.Arena(profiles, S, set_sizes=sizes)
+        n, longest = len(sequences), max(len(c) for c in counts)
+        self.arena.set_counts(np.concatenate(counts, axis=0), reserve_seqs=n - 1, reserve_rows=(n - 1) * 2 * longest)
+        self.index = {i: i for i in range(n)}                      # cluster id -> arena sequence
+        self.length = {i: len(counts[i]) for i in range(n)}
+
+    def cluster(self, cid):
+        return _Len(self.length[cid])
+
+    def scores(self, requests):
+        """Scores only of (mode, cluster a, cluster b) requests: one device submission per mode."""
+        out = [None] * len(requests)
+        for mode in MODES:
+            sel = [k for k, r in enumerate(requests) if r[0] == mode]
+            if not sel:
+                continue
+            pairs = np.array([(self.index[requests[k][1]], self.index[requests[k][2]]) for k in sel], dtype=np.int32)
+            plan = native.Plan(self.arena, pairs, want_paths=False)
+            try:
+                plan.run(mode, self.gap_open, self.gap_extend)
+                sc = plan.scores()
+            finally:
+                plan.close()
+            for q, k in enumerate(sel):
+                out[k] = float(sc[q])
+        return out
+
+    def align_and_merge(self, mode, a, b):
+        """Align clusters a and b, merge b into a along the path on the device; returns (score, path int [rows, 2])."""
+        pairs = np.array([(self.index[a], self.index[b])], dtype=np.int32)
+        plan = native.Plan(self.arena, pairs, want_paths=True)
+        try:
+            plan.run(mode, self.gap_open, self.gap_extend)
+            score = float(plan.scores()[0])
+            path = np.array(plan.paths()[0], dtype=int)
+            idx, ln = self.arena.append_merged(plan, 0)
+        finally:
+            plan.close()
+        self.index[a] = idx
+        self.length[a] = ln
+        del self.index[b]
+        del self.length[b]
+        return score, path
+
+    def close(self):
+        self.arena.close()
+
+
 class TreeMultipleSequenceAligner(Component):
     """praline/component/msa.py:18-248: N-1 profile-profile alignments in guide-tree order; after each
     one the two clusters' count tracks and sub-alignments are merged along the path
@@ -751,10 +835,31 @@ class TreeMultipleSequenceAligner(Component):
         merge_mode = self.environment['merge_mode']
         if merge_mode not in ("global", "semiglobal", "semiglobal_auto"):
             raise ComponentError("unknown merge mode '{0}'".format(merge_mode))
-        aligner = self.manager.index.resolve(self.environment['aligner'])
+        aligner, aligner_env = _resolve_aligner(self)
         alignments = {i: _identity_alignment(seq) for i, seq in enumerate(sequences)}
-        clusters = {i: _count_cluster(i, seq, track_id_sets) for i, seq in enumerate(sequences)}
         steps = list(guide_tree.merge_orders)
+        self.steps = []      # (mode, score, path) of every merge step, in order (diagnostics / tests)
+        if _is_device_aligner(aligner) and isinstance(self.manager, BatchManager) and steps:
+            # resident path: the clusters live and grow on the GPU, a step brings back only its path
+            resident = ResidentClusters(sequences, track_id_sets, score_matrices, aligner_env['gap_series'])
+            try:
+                for done, (i, j) in enumerate(steps):
+                    if merge_mode == "global":
+                        mode = "global"
+                    elif merge_mode == "semiglobal":
+                        mode = "semiglobal_both"
+                    else:
+                        mode = auto_align_mode(resident.cluster(i), resident.cluster(j))
+                    score, path = resident.align_and_merge(mode, i, j)
+                    self.steps.append((mode, score, path))
+                    alignments[i] = alignments[i].merge(alignments[j], path)
+                    del alignments[j]
+                    yield ProgressMessage((done + 1) / float(len(steps)))
+            finally:
+                resident.close()
+            yield CompleteMessage(outputs={'alignment': list(alignments.values())[0]})
+            return
+        clusters = {i: _count_cluster(i, seq, track_id_sets) for i, seq in enumerate(sequences)}
         for done, (i, j) in enumerate(steps):
             one, two = clusters[i], clusters[j]
             if merge_mode == "global":
@@ -771,6 +876,7 @@ class TreeMultipleSequenceAligner(Component):
             for message in execution.run():
                 yield message
             path = np.array(execution.outputs[0]['alignment'].path)
+            self.steps.append((mode, execution.outputs[0]['score'], path))
             _merge_clusters(one, two, track_id_sets, path)
             alignments[i] = alignments[i].merge(alignments[j], path)
             del clusters[j]
@@ -836,9 +942,41 @@ class AdHocMultipleSequenceAligner(Component):
         if dist_mode not in ("global", "semiglobal", "semiglobal_auto"):
             raise ComponentError("unknown distance mode '{0}'".format(dist_mode))
         alignments = {i: _identity_alignment(seq) for i, seq in enumerate(sequences)}
-        clusters = {i: _count_cluster(i, seq, track_id_sets) for i, seq in enumerate(sequences)}
         known = {}      # (cluster id a, cluster id b), a before b in cluster order -> score (float32)
         changed = None  # the cluster that grew in the previous round: its scores are stale
+        aligner, aligner_env = _resolve_aligner(self)
+        if _is_device_aligner(aligner) and isinstance(self.manager, BatchManager) and len(sequences) > 1:
+            # resident path: clusters on the GPU; a round = one scores-only submission over the stale pairs (msa.py:
+            # 504-540 with its cache) + one alignment whose merge happens on the device path
+            resident = ResidentClusters(sequences, track_id_sets, score_matrices, aligner_env['gap_series'])
+            try:
+                ids = list(range(len(sequences)))
+                total = max(len(ids) - 1, 1)
+                done = 0
+                while len(ids) > 1:
+                    pending = [(a, b) for x, a in enumerate(ids) for b in ids[x + 1:] if changed is None or changed in (a, b)]
+                    scores = resident.scores([(self._align_mode(dist_mode, resident.cluster(a), resident.cluster(b)), a, b)
+                                              for a, b in pending])
+                    for (a, b), sc in zip(pending, scores):
+                        known[(a, b)] = np.float32(sc)
+                    s = np.full((len(ids), len(ids)), -(2 ** 32), dtype=np.float32)
+                    for x, a in enumerate(ids):
+                        for y in range(x + 1, len(ids)):
+                            s[x, y] = s[y, x] = known[(a, ids[y])]
+                    x, y = np.unravel_index(s.argmax(), s.shape)     # first maximum in row-major order (msa.py:552)
+                    i, j = ids[x], ids[y]
+                    _, path = resident.align_and_merge(self._align_mode(merge_mode, resident.cluster(i), resident.cluster(j)), i, j)
+                    alignments[i] = alignments[i].merge(alignments[j], path)
+                    del alignments[j]
+                    ids.remove(j)
+                    changed = i
+                    done += 1
+                    yield ProgressMessage(done / float(total))
+            finally:
+                resident.close()
+            yield CompleteMessage(outputs={'alignment': list(alignments.values())[0]})
+            return
+        clusters = {i: _count_cluster(i, seq, track_id_sets) for i, seq in enumerate(sequences)}
         total = max(len(clusters) - 1, 1)
         done = 0
         while len(clusters) > 1:

@@ -197,9 +197,9 @@ __global__ __launch_bounds__(64) void k_prepare_rows(const float *__restrict__ r
                                                       const int32_t *__restrict__ len,
                                                       const int32_t *__restrict__ active, int n_active, int A, int KP, int KS,
                                                       int64_t rows_pad, float *__restrict__ P, float *__restrict__ Q, int NR,
-                                                      _Float16 *__restrict__ P16, _Float16 *__restrict__ Q16)
+                                                      _Float16 *__restrict__ P16, _Float16 *__restrict__ Q16, int64_t block0 = 0)
 {
-    const int64_t rowp0 = (int64_t)blockIdx.x * 32;
+    const int64_t rowp0 = ((int64_t)blockIdx.x + block0) * 32;   // block0: first 32-row block (appended sequences only)
     for (int i = threadIdx.x; i < 32 * KP; i += 64)
         pack_entry(rowp0 * KP + i, raw, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, P);
     for (int c0 = 0; c0 < KP; c0 += 32)
@@ -920,6 +920,45 @@ __global__ void k_path_bounds(const int32_t *__restrict__ paths, const int64_t *
     bounds[4 * p + 3] = rows > 0 ? path[2 * (rows - 1) + 1] : -1;
 }
 
+
+// Resident progressive alignment: merge two clusters of the arena along the device path of their
+// alignment into a NEW sequence at the arena's end - ProfileTrack.merge (praline/container/sequence.py:205-239) for
+// every track set: alignment column c sums the integer counts of the positions that advance in it (the reference sums
+// in float32 and truncates to int: the same integers), and the profile row PairwiseAligner will read is
+// float32(float64(count) / float64(float32(rowsum))), the rowsum per track set (sequence.py:192-203, align.py:171-172).
+// One 64-thread block per alignment column.
+__global__ __launch_bounds__(64) void k_merge_clusters(const int32_t *__restrict__ path, int cols, int32_t *cnt, float *raw,
+                                                        int A, int64_t row_one, int64_t row_two, int64_t row_new,
+                                                        const int32_t *__restrict__ set_lo, int n_sets)
+{
+    __shared__ int32_t v[256];
+    const int c = blockIdx.x;
+    if (c >= cols) return;
+    const int y0 = path[2 * c], x0 = path[2 * c + 1], y1 = path[2 * c + 2], x1 = path[2 * c + 3];
+    const bool adv0 = y1 > y0, adv1 = x1 > x0;
+    for (int a = threadIdx.x; a < A; a += 64) {
+        int32_t t = 0;
+        if (adv0) t += cnt[(row_one + y1 - 1) * A + a];
+        if (adv1) t += cnt[(row_two + x1 - 1) * A + a];
+        v[a] = t;
+        cnt[(row_new + c) * A + a] = t;
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < A; a += 64) {
+        int s = 0;
+        while (s + 1 < n_sets && a >= set_lo[s + 1]) ++s;
+        long long sum = 0;
+        for (int k = set_lo[s]; k < set_lo[s + 1]; ++k) sum += v[k];
+        const float total = (float)sum;
+        raw[(row_new + c) * A + a] = (float)((double)v[a] / (double)total);
+    }
+}
+
+__global__ void k_fill_i32(int32_t *dst, int64_t n, int32_t value)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
 
 // Column masks of the zero rectangles for k_dp_batch MASK = 2: one block per pair, entry (strip s, row y) = bit c set
 // when cell (y, 32 s + c + 1) lies in one of the pair's rectangles (cext.c:141-149 skips those cells).

@@ -277,6 +277,11 @@ struct praline_arena {
     DevBuf<int32_t> d_set_lo;
     DevBuf<unsigned char> d_nzidx, d_nzcnt;
     bool ref_ready = false;
+    // resident progressive alignment (praline_arena_append_merged): integer counts of every row, capacities
+    DevBuf<int32_t> d_cnt;
+    bool have_cnt = false;
+    int64_t cap_rows_raw = 0, cap_rows_pad = 0, cap_seqs = 0;   // 0: the buffers hold exactly what is in use
+    int64_t rp_end = 0;       // padded rows taken by sequences (the zero tail follows)
     bool wide = false;       // more than 32 active symbols: no MFMA operand layouts; every plan runs the reference-order path
     Arena16Dev view16() const
     {
@@ -355,6 +360,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         if (rp > (int64_t)1 << 30) { delete a; return fail(PRALINE_ERR_ARG, "arena too large"); }
     }
     a->rows_raw = rr;
+    a->rp_end = rp;
     // tail padding: the kernels prefetch one row past the longest sequence and read whole strips
     a->rows_pad = rp + (a->max_len + 31) / 32 * 32 + 64;
 
@@ -496,6 +502,70 @@ static int arena_ensure_ref(praline_arena *a)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     a->ref_ready = true;
+    return PRALINE_OK;
+}
+
+// ---- resident progressive alignment: clusters merged on the device, appended to the arena in place ----------
+template <typename T> static int grow_buf(DevBuf<T> &b, size_t old_n, size_t new_n, int fill_byte, hipStream_t st)
+{
+    if (!b.p || new_n <= old_n) return PRALINE_OK;
+    DevBuf<T> nb;
+    RC(nb.alloc(new_n));
+    HIPCHK(hipMemcpyAsync(nb.p, b.p, old_n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemsetAsync(nb.p + old_n, fill_byte, (new_n - old_n) * sizeof(T), st));
+    HIPCHK(hipStreamSynchronize(st));   // the old block goes back to the pool
+    std::swap(b.p, nb.p);
+    std::swap(b.n, nb.n);
+    std::swap(b.cap_bytes, nb.cap_bytes);
+    return PRALINE_OK;
+}
+
+static int arena_reserve(praline_arena *a, int64_t need_seqs, int64_t need_rows_raw, int64_t need_rows_pad)
+{
+    hipStream_t st = g_rt.stream;
+    const int64_t cur_seqs = a->cap_seqs ? a->cap_seqs : a->n_seqs, cur_raw = a->cap_rows_raw ? a->cap_rows_raw : a->rows_raw,
+                  cur_pad = a->cap_rows_pad ? a->cap_rows_pad : a->rows_pad;
+    if (need_seqs > cur_seqs) {
+        const int64_t n = std::max(need_seqs, 2 * cur_seqs);
+        RC(grow_buf(a->d_len, (size_t)cur_seqs, (size_t)n, 0, st));
+        RC(grow_buf(a->d_row_off_pad, (size_t)cur_seqs, (size_t)n, 0, st));
+        RC(grow_buf(a->d_row_off_raw, (size_t)cur_seqs, (size_t)n, 0, st));
+        a->cap_seqs = n;
+    }
+    if (need_rows_raw > cur_raw) {
+        const int64_t n = std::max(need_rows_raw, 2 * cur_raw);
+        RC(grow_buf(a->d_raw, (size_t)cur_raw * a->A, (size_t)n * a->A, 0, st));
+        RC(grow_buf(a->d_cnt, (size_t)cur_raw * a->A, (size_t)n * a->A, 0, st));
+        a->cap_rows_raw = n;
+    }
+    if (need_rows_pad > cur_pad) {
+        const int64_t n = std::max(need_rows_pad, 2 * cur_pad);
+        RC(grow_buf(a->d_seq_of_rowp, (size_t)cur_pad, (size_t)n, 0xff, st));   // -1: no sequence
+        if (!a->wide) {
+            RC(grow_buf(a->d_P, (size_t)cur_pad * a->KP, (size_t)n * a->KP, 0, st));
+            RC(grow_buf(a->d_Q, (size_t)cur_pad * a->KP, (size_t)n * a->KP, 0, st));
+            if (a->nr16 > 0) {
+                RC(grow_buf(a->d_P16, (size_t)cur_pad * 4 * a->nr16 * 16, (size_t)n * 4 * a->nr16 * 16, 0, st));
+                RC(grow_buf(a->d_Q16, (size_t)cur_pad * 4 * a->nr16 * 16, (size_t)n * 4 * a->nr16 * 16, 0, st));
+            }
+        }
+        a->cap_rows_pad = n;
+    }
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_set_counts(praline_arena *arena, const int32_t *counts, int64_t reserve_seqs, int64_t reserve_rows)
+{
+    if (!arena || !counts) return fail(PRALINE_ERR_ARG, "NULL argument");
+    RC(ensure_runtime(-1));
+    praline_arena *a = arena;
+    RC(a->d_cnt.alloc((size_t)a->rows_raw * a->A));
+    HIPCHK(hipMemcpyAsync(a->d_cnt.p, counts, (size_t)a->rows_raw * a->A * sizeof(int32_t), hipMemcpyHostToDevice, g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream));
+    a->have_cnt = true;
+    if (reserve_seqs > 0 || reserve_rows > 0)
+        RC(arena_reserve(a, a->n_seqs + std::max<int64_t>(reserve_seqs, 0), a->rows_raw + std::max<int64_t>(reserve_rows, 0),
+                         a->rows_pad + std::max<int64_t>(reserve_rows, 0) + 32 * std::max<int64_t>(reserve_seqs, 0)));
     return PRALINE_OK;
 }
 
@@ -1154,6 +1224,67 @@ extern "C" int praline_plan_path_bounds(praline_plan *plan, int32_t *bounds)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(bounds, d_bounds.p, (size_t)plan->n_pairs * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, g_rt.stream));
     HIPCHK(hipStreamSynchronize(g_rt.stream));
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_append_merged(praline_arena *arena, praline_plan *plan, int64_t pair_index, int32_t *new_index,
+                                           int32_t *new_len)
+{
+    if (!arena || !plan || !new_index || !new_len) return fail(PRALINE_ERR_ARG, "NULL argument");
+    if (plan->arena != arena) return fail(PRALINE_ERR_ARG, "the plan belongs to another arena");
+    if (!plan->want_paths || plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "the plan has no paths (want_paths + praline_plan_run first)");
+    if (plan->last_mode == PRALINE_MODE_LOCAL) return fail(PRALINE_ERR_UNSUPPORTED, "clusters are merged along global / semiglobal paths");
+    if (pair_index < 0 || pair_index >= plan->n_pairs) return fail(PRALINE_ERR_ARG, "pair index out of range");
+    praline_arena *a = arena;
+    if (!a->have_cnt) return fail(PRALINE_ERR_ARG, "praline_arena_set_counts has not been called");
+    hipStream_t st = g_rt.stream;
+    int64_t start = 0;
+    int32_t rows = 0, pr[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&start, plan->d_path_start.p + pair_index, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&rows, plan->d_path_rows.p + pair_index, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(pr, plan->d_pairs.p + 2 * pair_index, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int cols = rows - 1;
+    if (cols <= 0) return fail(PRALINE_ERR_DEVICE, "empty alignment path");
+    const int64_t idx = a->n_seqs, pad = (cols + 31) / 32 * 32;
+    const int new_max = std::max(a->max_len, cols);
+    const int64_t new_rp = a->rp_end + pad, new_rows_pad = new_rp + (new_max + 31) / 32 * 32 + 64;
+    RC(arena_reserve(a, idx + 1, a->rows_raw + cols, new_rows_pad));
+    const int32_t off_raw = (int32_t)a->rows_raw, off_pad = (int32_t)a->rp_end, len32 = cols;
+    HIPCHK(hipMemcpyAsync(a->d_len.p + idx, &len32, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(a->d_row_off_raw.p + idx, &off_raw, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(a->d_row_off_pad.p + idx, &off_pad, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, st, a->d_seq_of_rowp.p + a->rp_end, pad, (int32_t)idx);
+    if (!a->d_set_lo.p) RC(a->d_set_lo.upload(a->set_lo, st));
+    hipLaunchKernelGGL(k_merge_clusters, dim3((unsigned)cols), dim3(64), 0, st, plan->d_paths.p + 2 * start, cols, a->d_cnt.p, a->d_raw.p,
+                       a->A, (int64_t)a->row_off_raw[pr[0]], (int64_t)a->row_off_raw[pr[1]], (int64_t)off_raw, a->d_set_lo.p,
+                       (int)a->set_lo.size() - 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));   // the three host words above
+    a->len.push_back(cols);
+    a->row_off_raw.push_back(off_raw);
+    a->row_off_pad.push_back(off_pad);
+    a->n_seqs = idx + 1;
+    a->rows_raw += cols;
+    a->rp_end = new_rp;
+    a->max_len = new_max;
+    a->rows_pad = new_rows_pad;
+    // a merged cluster is no plain sequence: the one-hot shortcuts of this arena end here
+    a->onehot = false;
+    a->all_onehot = false;
+    if (a->nr16 > 0) a->nterm16 = 3;
+    a->ref_ready = false;
+    a->d_counts.release();
+    a->counts_ext = nullptr;
+    if (!a->wide) {   // packed operands of the new rows only
+        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)(pad / 32)), dim3(64), 0, st, a->d_raw.p, a->d_S.p, a->d_seq_of_rowp.p,
+                           a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, a->d_active.p, a->n_active, a->A, a->KP, a->KS,
+                           a->rows_pad, a->d_P.p, a->d_Q.p, a->nr16, (_Float16 *)a->d_P16.p, (_Float16 *)a->d_Q16.p,
+                           (int64_t)(off_pad / 32));
+        HIPCHK(hipGetLastError());
+    }
+    *new_index = (int32_t)idx;
+    *new_len = cols;
     return PRALINE_OK;
 }
 

@@ -64,6 +64,8 @@ def lib():
     L.praline_arena_create.argtypes = [i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
     L.praline_arena_destroy.argtypes = [vp]
     L.praline_arena_set_track_sets.argtypes = [vp, i32, vp]
+    L.praline_arena_set_counts.argtypes = [vp, vp, i64, i64]
+    L.praline_arena_append_merged.argtypes = [vp, vp, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.praline_set_match_mode.argtypes = [i32]
     L.praline_arena_premultiply.argtypes = [vp]
     L.praline_plan_create.argtypes = [vp, i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
@@ -257,6 +259,23 @@ class Arena(object):
         if set_sizes is not None and len(set_sizes) > 1:
             sz = np.ascontiguousarray(set_sizes, dtype=np.int32)
             _check(lib().praline_arena_set_track_sets(h, len(sz), sz.ctypes.data))
+
+    def set_counts(self, counts, reserve_seqs=0, reserve_rows=0):
+        """The integer counts behind the profile rows, int32 [sum L, A] (praline_arena_set_counts): makes the arena
+        growable by append_merged."""
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        if c.shape != (int(self.lens.sum()), self.A):
+            raise ValueError("counts must have shape (%d, %d)" % (int(self.lens.sum()), self.A))
+        _check(lib().praline_arena_set_counts(self._h, c.ctypes.data, int(reserve_seqs), int(reserve_rows)))
+
+    def append_merged(self, plan, pair_index=0):
+        """Merge the two sequences of a path plan's pair along its device path into a NEW arena sequence
+        (praline_arena_append_merged); returns (index, length)."""
+        idx, ln = ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(lib().praline_arena_append_merged(self._h, plan._h, int(pair_index), ctypes.byref(idx), ctypes.byref(ln)))
+        self.lens = np.append(self.lens, np.int32(ln.value))
+        self.n_seqs += 1
+        return int(idx.value), int(ln.value)
 
     def premultiply(self):
         _check(lib().praline_arena_premultiply(self._h))

@@ -358,3 +358,103 @@ def test_adhoc_msa_against_reference(env, seqs):
             for o in (out, out_b):
                 assert [s.name for s in o['alignment'].items] == [str(x) for x in d[key + "names"]], key
                 assert np.array_equal(np.asarray(o['alignment'].path), d[key + "path"]), key
+
+
+def _run_component(manager, cls, keys, **inputs):
+    """Run a component instance directly (so that its diagnostics stay reachable); returns (instance, outputs)."""
+    env_ = core.Environment({}).collapse(cls, core.Environment(dict(keys or {})))
+    inst = cls(manager, env_, "root")
+    for name, port in cls.inputs.items():
+        inputs.setdefault(name, None)
+    outputs = None
+    for msg in inst.execute(**inputs):
+        if msg.kind == core.MESSAGE_KIND_COMPLETE and msg.tag is None:
+            outputs = msg.outputs
+    return inst, outputs
+
+
+def test_resident_msa_merges_on_the_device(env, seqs, monkeypatch):
+    """under the batching manager the clusters of TreeMultipleSequenceAligner / AdHocMultipleSequenceAligner
+    live and grow on the GPU (ResidentClusters): ONE arena, merged clusters appended in place, NO host-side count-track
+    merge (ProfileTrack.merge is made to fail).  Every merge step's mode, score (1e-5) and path and the final alignment
+    against the real reference's run, preprofile (float) and input (integer) tracks, all merge modes."""
+    d = load_golden("treemsa.npz")
+    da = load_golden("adhoc.npz")
+    pp = load_golden("profile_profile.npz")
+
+    def no_host_merge(self, track, path):
+        raise AssertionError("a count track was merged on the host")
+    monkeypatch.setattr(ct.ProfileTrack, "merge", no_host_merge)
+    arenas = []
+    orig_arena = comp.native.Arena
+
+    class CountingArena(orig_arena):
+        def __init__(self, *a, **kw):
+            arenas.append(1)
+            orig_arena.__init__(self, *a, **kw)
+    monkeypatch.setattr(comp.native, "Arena", CountingArena)
+    pre = [ct.Sequence(s.name, [(ct.TRACK_ID_INPUT, s.get_track(ct.TRACK_ID_INPUT)),
+                                (ct.TRACK_ID_PREPROFILE, ct.ProfileTrack(pp["counts%d" % i], ct.ALPHABET_AA))])
+           for i, s in enumerate(seqs)]
+    for tag, sset, tracks in (("pre", pre, [[ct.TRACK_ID_PREPROFILE]]), ("in", seqs, T_IN)):
+        order = pp["merge_order"] if tag == "pre" else d["merge_order_input"]
+        tree = ct.SequenceTree(sset, [tuple(int(v) for v in x) for x in order])
+        for merge_mode in ("semiglobal", "global", "semiglobal_auto"):
+            key = "%s_%s_" % (tag, merge_mode)
+            del arenas[:]
+            inst, out = _run_component(env["batch"], comp.TreeMultipleSequenceAligner, {"merge_mode": merge_mode},
+                                       sequences=sset, guide_tree=tree, track_id_sets=tracks, score_matrices=[env["blosum"]])
+            assert len(arenas) == 1, key                      # one arena for the whole progressive alignment
+            assert len(inst.steps) == int(d[key + "n_steps"])
+            for c, (mode, score, path) in enumerate(inst.steps):
+                assert mode == str(d[key + "step%d_mode" % c]), (key, c)
+                ref = float(d[key + "step%d_score" % c])
+                assert abs(score - ref) <= 1e-5 * abs(ref), (key, c)
+                assert np.array_equal(path, d[key + "step%d_path" % c]), (key, c)
+            assert [s.name for s in out['alignment'].items] == [str(x) for x in d[key + "names"]]
+            assert np.array_equal(np.asarray(out['alignment'].path), d[key + "path"]), key
+        for merge_mode, dist_mode in (("semiglobal", "global"), ("global", "global"),
+                                      ("semiglobal_auto", "semiglobal_auto"), ("global", "semiglobal")):
+            key = "%s_%s_%s_" % (tag, merge_mode, dist_mode)
+            del arenas[:]
+            out = run_one(env["batch"], comp.AdHocMultipleSequenceAligner, {"merge_mode": merge_mode, "dist_mode": dist_mode},
+                          sequences=sset, track_id_sets=tracks, score_matrices=[env["blosum"]])
+            assert len(arenas) == 1, key
+            assert [s.name for s in out['alignment'].items] == [str(x) for x in da[key + "names"]], key
+            assert np.array_equal(np.asarray(out['alignment'].path), da[key + "path"]), key
+
+
+def test_resident_msa_larger_set_equals_host_path(env):
+    """The resident path against the component-by-component host path (serial manager: one PairwiseAligner execution
+    and host merges per step) on 24 synthetic sequences with two track sets (amino acids + a 3-letter track): equal
+    merge steps (scores to 1e-6: the host path re-derives every cluster's profile from the merged counts like the
+    device does) and equal final alignment; the arena grows past its reservation."""
+    rng = np.random.default_rng(5)
+    n = 24
+    base = rng.integers(0, 20, 90)
+    seqs2 = []
+    for i in range(n):
+        L = int(rng.integers(40, 90))
+        v = base[:L].copy()
+        flip = rng.random(L) < 0.25
+        v[flip] = rng.integers(0, 20, int(flip.sum()))
+        ss = rng.integers(0, 4, L)
+        seqs2.append(ct.Sequence("q%02d" % i, [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=v)),
+                                                ("ss", ct.PlainTrack(None, ct.ALPHABET_RNA, raw_indices=ss))]))
+    tracks = [[ct.TRACK_ID_INPUT], ["ss"]]
+    ss_matrix = ct.ScoreMatrix(None, [ct.ALPHABET_RNA, ct.ALPHABET_RNA],
+                               matrix=(np.eye(4, dtype=np.float32) * 3 - 1).astype(np.float32))
+    mats = [env["blosum"], ss_matrix]
+    tree = run_one(env["batch"], comp.GuideTreeBuilder, sequences=seqs2, track_id_sets=tracks, score_matrices=mats)['guide_tree']
+    for merge_mode in ("semiglobal", "global", "semiglobal_auto"):
+        host, out_h = _run_component(env["serial"], comp.TreeMultipleSequenceAligner, {"merge_mode": merge_mode},
+                                     sequences=seqs2, guide_tree=tree, track_id_sets=tracks, score_matrices=mats)
+        dev, out_d = _run_component(env["batch"], comp.TreeMultipleSequenceAligner, {"merge_mode": merge_mode},
+                                    sequences=seqs2, guide_tree=tree, track_id_sets=tracks, score_matrices=mats)
+        assert len(host.steps) == len(dev.steps) == n - 1
+        for (m1, s1, p1), (m2, s2, p2) in zip(host.steps, dev.steps):
+            assert m1 == m2 and abs(s1 - s2) <= 1e-6 * max(1.0, abs(s1)) and np.array_equal(p1, p2)
+        assert np.array_equal(np.asarray(out_h['alignment'].path), np.asarray(out_d['alignment'].path))
+    out_h = run_one(env["serial"], comp.AdHocMultipleSequenceAligner, sequences=seqs2[:10], track_id_sets=tracks, score_matrices=mats)
+    out_d = run_one(env["batch"], comp.AdHocMultipleSequenceAligner, sequences=seqs2[:10], track_id_sets=tracks, score_matrices=mats)
+    assert np.array_equal(np.asarray(out_h['alignment'].path), np.asarray(out_d['alignment'].path))
