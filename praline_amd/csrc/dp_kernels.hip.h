@@ -1056,6 +1056,99 @@ __global__ __launch_bounds__(256) void k_match_ref(const float *__restrict__ raw
     }
 }
 
+// The same sums with the y-independent half of every term prepared per arena row: for a row x used as sequence TWO,
+//     T[x][i][b] = fl(p2[x][j_b] * S[i][j_b])        j_b = b-th nonzero of row x, zero past its end
+// (zero too where j_b lies in another track set than i: S is block diagonal and the reference's inner loop of set s
+// only visits set s).  A cell is then  acc = fl(acc + fl(T[x][i_a][b] * p1[y][i_a]))  over the nonzeros a of row y
+// (outer, ascending) and b = 0 .. TB-1 (inner): exactly the reference's terms in the reference's order, the added
+// zero terms leave the float32 sum unchanged (x + (+0) = x).  One multiply and one add per term, no index chasing in
+// the inner loop; the T rows of a pair (L2 x A x TB floats) stay in L2 across the rows of sequence one.  Layout
+// T[i][row][b]: the 64 lanes of a wave (consecutive x, the same y and hence the same i) read one contiguous run.
+// The nonzero list of each of the block's rows y - wave-uniform - is staged in LDS once.
+__global__ void k_build_reft(const float *__restrict__ raw, const float *__restrict__ S, int A, int64_t rows,
+                             const unsigned char *__restrict__ nzidx, const unsigned char *__restrict__ nzcnt,
+                             const int32_t *__restrict__ set_lo, int n_sets, int TB, float *__restrict__ T)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (row, i)
+    if (e >= rows * A) return;
+    const int64_t r = e / A;
+    const int i = (int)(e % A);
+    int s = 0;
+    while (s + 1 < n_sets && i >= set_lo[s + 1]) ++s;
+    const int lo = set_lo[s], hi = set_lo[s + 1];
+    const int n = nzcnt[r];
+    const unsigned char *idx = nzidx + r * A;
+    const float *p2 = raw + r * A, *srow = S + (int64_t)i * A;
+    float *out = T + ((int64_t)i * rows + r) * TB;   // symbol-major: for one symbol, consecutive rows are contiguous
+    for (int b = 0; b < TB; ++b) {
+        float t = 0.0f;
+        if (b < n) {
+            const int j = idx[b];
+            if (j >= lo && j < hi) t = __fmul_rn(p2[j], srow[j]);
+        }
+        out[b] = t;
+    }
+}
+
+template <int TB>
+__global__ __launch_bounds__(256) void k_match_reft(const float *__restrict__ raw, int A, const float *__restrict__ T, int64_t rows,
+                                                    const int32_t *__restrict__ row_off_raw, const int32_t *__restrict__ len,
+                                                    const unsigned char *__restrict__ nzidx,
+                                                    const unsigned char *__restrict__ nzcnt,
+                                                    const int32_t *__restrict__ set_lo, int n_sets,
+                                                    const int32_t *__restrict__ pairs, const int32_t *__restrict__ chunk_pairs,
+                                                    const int64_t *__restrict__ m_off, float *__restrict__ mref)
+{
+    const int p = chunk_pairs[blockIdx.x];
+    const int one = pairs[2 * p], two = pairs[2 * p + 1];
+    const int L1 = len[one], L2 = len[two];
+    const int y0 = blockIdx.y * PRALINE_REF_ROWS;
+    if (y0 >= L1) return;
+    const int ny = min(PRALINE_REF_ROWS, L1 - y0);
+    const int64_t r1 = row_off_raw[one], r2 = row_off_raw[two];
+    float *out = mref + m_off[p];
+    // nonzero lists of this block's rows: (symbol, value) pairs, at most 32 per row kept here (longer rows: global)
+    __shared__ int s_n[PRALINE_REF_ROWS];
+    __shared__ int s_i[PRALINE_REF_ROWS][32];
+    __shared__ float s_v[PRALINE_REF_ROWS][32];
+    for (int e = threadIdx.x; e < ny * 32; e += blockDim.x) {
+        const int yy = e >> 5, a = e & 31;
+        const int n1 = nzcnt[r1 + y0 + yy];
+        if (a == 0) s_n[yy] = n1;
+        if (a < n1) {
+            const int i = nzidx[(r1 + y0 + yy) * A + a];
+            s_i[yy][a] = i;
+            s_v[yy][a] = raw[(r1 + y0 + yy) * A + i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ny * L2; c += blockDim.x) {
+        const int yy = c / L2, y = y0 + yy, x = c % L2;
+        const float *p1 = raw + (r1 + y) * A;
+        const unsigned char *i1 = nzidx + (r1 + y) * A;
+        const int n1 = s_n[yy];
+        const float *Tx = T + (r2 + x) * (int64_t)TB;
+        float score = 0.0f, acc = 0.0f;
+        int s = 0;
+        for (int a = 0; a < n1; ++a) {
+            const int i = a < 32 ? s_i[yy][a] : (int)i1[a];
+            while (s + 1 < n_sets && i >= set_lo[s + 1]) { score = __fadd_rn(score, acc); acc = 0.0f; ++s; }
+            const float v1 = a < 32 ? s_v[yy][a] : p1[i];
+            const float4 *t4 = reinterpret_cast<const float4 *>(Tx + (int64_t)i * rows * TB);
+#pragma unroll
+            for (int q = 0; q < TB / 4; ++q) {
+                const float4 t = t4[q];
+                acc = __fadd_rn(acc, __fmul_rn(t.x, v1));
+                acc = __fadd_rn(acc, __fmul_rn(t.y, v1));
+                acc = __fadd_rn(acc, __fmul_rn(t.z, v1));
+                acc = __fadd_rn(acc, __fmul_rn(t.w, v1));
+            }
+        }
+        for (; s < n_sets; ++s) { score = __fadd_rn(score, acc); acc = 0.0f; }
+        out[(int64_t)y * L2 + x] = score;
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // Raw parity kernels: the reference's buffers (contiguous copies on the device).
 // --------------------------------------------------------------------------------------------

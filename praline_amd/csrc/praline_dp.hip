@@ -276,6 +276,8 @@ struct praline_arena {
     std::vector<int32_t> set_lo;     // n_sets + 1 boundaries, default {0, A}
     DevBuf<int32_t> d_set_lo;
     DevBuf<unsigned char> d_nzidx, d_nzcnt;
+    DevBuf<float> d_reft;    // T[row][i][b] (k_build_reft), ref_tb floats per (row, symbol); ref_tb = 0: not built
+    int ref_tb = 0;
     bool ref_ready = false;
     // resident progressive alignment (praline_arena_append_merged): integer counts of every row, capacities
     DevBuf<int32_t> d_cnt;
@@ -489,6 +491,33 @@ extern "C" int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets
     return PRALINE_OK;
 }
 
+static int arena_ensure_ref(praline_arena *a);
+
+// reference-order match scores of the pairs chunk_pairs[0 .. n_chunk) into mref + m_off[pair]
+static int launch_match_ref(praline_arena *a, const int32_t *d_pairs, const int32_t *d_chunk_pairs, size_t n_chunk, int max_l1,
+                            const int64_t *d_m_off, float *d_mref)
+{
+    RC(arena_ensure_ref(a));
+    hipStream_t st = g_rt.stream;
+    const dim3 grid((unsigned)n_chunk, (unsigned)((max_l1 + PRALINE_REF_ROWS - 1) / PRALINE_REF_ROWS)), block(256);
+    const int n_sets = (int)a->set_lo.size() - 1;
+#define PRALINE_REFT(TB)                                                                                               \
+    hipLaunchKernelGGL((k_match_reft<TB>), grid, block, 0, st, a->d_raw.p, a->A, a->d_reft.p, a->rows_raw, a->d_row_off_raw.p, a->d_len.p,  \
+                       a->d_nzidx.p, a->d_nzcnt.p, a->d_set_lo.p, n_sets, d_pairs, d_chunk_pairs, d_m_off, d_mref)
+    switch (a->ref_tb) {
+        case 4: PRALINE_REFT(4); break;
+        case 8: PRALINE_REFT(8); break;
+        case 16: PRALINE_REFT(16); break;
+        case 32: PRALINE_REFT(32); break;
+        default:
+            hipLaunchKernelGGL(k_match_ref, grid, block, 0, st, a->d_raw.p, a->d_S.p, a->A, a->d_row_off_raw.p, a->d_len.p, a->d_nzidx.p,
+                               a->d_nzcnt.p, a->d_set_lo.p, n_sets, d_pairs, d_chunk_pairs, d_m_off, d_mref);
+    }
+#undef PRALINE_REFT
+    HIPCHK(hipGetLastError());
+    return PRALINE_OK;
+}
+
 // nonzero lists + set boundaries for k_match_ref, built on first use
 static int arena_ensure_ref(praline_arena *a)
 {
@@ -500,7 +529,27 @@ static int arena_ensure_ref(praline_arena *a)
     hipLaunchKernelGGL(k_build_nz, dim3((unsigned)((a->rows_raw + 255) / 256)), dim3(256), 0, st, a->d_raw.p, a->rows_raw, a->A,
                        a->d_nzidx.p, a->d_nzcnt.p);
     HIPCHK(hipGetLastError());
+    // the per-row tables of k_match_reft (half of every term prepared once per arena row) when they fit
+    std::vector<unsigned char> cnt((size_t)a->rows_raw);
+    HIPCHK(hipMemcpyAsync(cnt.data(), a->d_nzcnt.p, cnt.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    int max_nz = 1;
+    for (unsigned char c : cnt) max_nz = std::max(max_nz, (int)c);
+    a->ref_tb = max_nz <= 4 ? 4 : (max_nz <= 8 ? 8 : (max_nz <= 16 ? 16 : (max_nz <= 32 ? 32 : 0)));
+    size_t table_limit = (size_t)16 << 30;
+    if (const char *env = getenv("PRALINE_REF_TABLE_MB")) table_limit = (size_t)atoll(env) << 20;
+    const size_t t_elems = (size_t)a->rows_raw * a->A * (size_t)a->ref_tb;
+    if (a->ref_tb > 0 && t_elems * sizeof(float) <= table_limit) {
+        RC(a->d_reft.alloc(t_elems));
+        const int64_t n = a->rows_raw * a->A;
+        hipLaunchKernelGGL(k_build_reft, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->d_raw.p, a->d_S.p, a->A, a->rows_raw,
+                           a->d_nzidx.p, a->d_nzcnt.p, a->d_set_lo.p, (int)a->set_lo.size() - 1, a->ref_tb, a->d_reft.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+    } else {
+        a->ref_tb = 0;
+        a->d_reft.release();
+    }
     a->ref_ready = true;
     return PRALINE_OK;
 }
@@ -904,10 +953,7 @@ static int plan_run_ref(praline_plan &pl, LaunchArgs la, int mode, bool local)
         HIPCHK(hipMemcpyAsync(pl.d_m_off.p, pl.h_m_off.data(), (size_t)pl.n_pairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
         if (!chunk.empty()) {
             HIPCHK(hipMemcpyAsync(pl.d_chunk_pairs.p, chunk.data(), chunk.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_match_ref, dim3((unsigned)chunk.size(), (unsigned)((max_l1 + PRALINE_REF_ROWS - 1) / PRALINE_REF_ROWS)),
-                               dim3(256), 0, st, a.d_raw.p, a.d_S.p, a.A, a.d_row_off_raw.p, a.d_len.p, a.d_nzidx.p, a.d_nzcnt.p,
-                               a.d_set_lo.p, (int)a.set_lo.size() - 1, pl.d_pairs.p, pl.d_chunk_pairs.p, pl.d_m_off.p, pl.d_mref.p);
-            HIPCHK(hipGetLastError());
+            RC(launch_match_ref(&a, pl.d_pairs.p, pl.d_chunk_pairs.p, chunk.size(), max_l1, pl.d_m_off.p, pl.d_mref.p));
         }
         la.tasks = pl.d_tasks.p + t0;
         la.lane_one = pl.d_lane_one.p + t0 * 64;
@@ -1390,10 +1436,8 @@ extern "C" int praline_build_scores(int num_sets, const praline_array *i1s, cons
         if (rc == PRALINE_OK) rc = d_pair.upload(std::vector<int32_t>{0, 1}, g_rt.stream);
         if (rc == PRALINE_OK) rc = d_chunk.upload(std::vector<int32_t>{0}, g_rt.stream);
         if (rc == PRALINE_OK) rc = d_off.upload(std::vector<int64_t>{0}, g_rt.stream);
+        if (rc == PRALINE_OK) rc = launch_match_ref(ar, d_pair.p, d_chunk.p, 1, (int)L1, d_off.p, d_m.p);
         if (rc == PRALINE_OK) {
-            hipLaunchKernelGGL(k_match_ref, dim3(1, (unsigned)((L1 + PRALINE_REF_ROWS - 1) / PRALINE_REF_ROWS)), dim3(256), 0,
-                               g_rt.stream, ar->d_raw.p, ar->d_S.p, ar->A, ar->d_row_off_raw.p, ar->d_len.p, ar->d_nzidx.p,
-                               ar->d_nzcnt.p, ar->d_set_lo.p, (int)ar->set_lo.size() - 1, d_pair.p, d_chunk.p, d_off.p, d_m.p);
             std::vector<float> hm((size_t)(L1 * L2));
             hipError_t e = hipMemcpyAsync(hm.data(), d_m.p, hm.size() * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream);
             if (e == hipSuccess) e = hipStreamSynchronize(g_rt.stream);
@@ -1575,11 +1619,7 @@ extern "C" int praline_arena_match_scores(praline_arena *arena, int32_t one, int
         RC(d_pair.upload(std::vector<int32_t>{one, two}, g_rt.stream));
         RC(d_chunk.upload(std::vector<int32_t>{0}, g_rt.stream));
         RC(d_off.upload(std::vector<int64_t>{0}, g_rt.stream));
-        hipLaunchKernelGGL(k_match_ref, dim3(1, (unsigned)((L1 + PRALINE_REF_ROWS - 1) / PRALINE_REF_ROWS)), dim3(256), 0,
-                           g_rt.stream, arena->d_raw.p, arena->d_S.p, arena->A, arena->d_row_off_raw.p, arena->d_len.p,
-                           arena->d_nzidx.p, arena->d_nzcnt.p, arena->d_set_lo.p, (int)arena->set_lo.size() - 1, d_pair.p,
-                           d_chunk.p, d_off.p, d_m.p);
-        HIPCHK(hipGetLastError());
+        RC(launch_match_ref(arena, d_pair.p, d_chunk.p, 1, L1, d_off.p, d_m.p));
         HIPCHK(hipMemcpyAsync(m, d_m.p, (size_t)L1 * L2 * sizeof(float), hipMemcpyDeviceToHost, g_rt.stream));
         HIPCHK(hipStreamSynchronize(g_rt.stream));
         return PRALINE_OK;
