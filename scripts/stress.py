@@ -21,13 +21,26 @@ def dp_on_m(mode, m, rects=None):
         zero = [(y, x) for (y0, y1, x0, x1) in rects for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
     return orc.raw_pairwise_align(mode, np.ascontiguousarray(m), g1, g2, zero)
 while time.time() < t_end:
-    kind = rng.choice(["onehot", "profile", "dna"])
+    kind = rng.choice(["onehot", "profile", "dna", "wide"])
+    # a quarter of the batches in the reference-order match-score mode (PRALINE_MATCH_REFERENCE); wide alphabets and
+    # plans with many rectangles take that path by themselves
+    ref_mode = rng.random() < 0.25
+    nat.set_match_mode("ref" if ref_mode else None)
     N = int(rng.choice([64, 128, 200, 300])) if os.environ.get("STRESS_BIG") == "1" else int(rng.choice([2, 3, 5, 9, 17, 33, 48]))
     mu = int(rng.choice([3, 20, 40, 70, 130, 260, 520])) if kind != "dna" else int(rng.choice([50, 300, 900]))
     lens = np.maximum(1, rng.integers(max(1, mu // 2), mu * 3 // 2 + 1, N))
     if kind == "dna":
         S, A = nucleotide_matrix(), 15
         profs = [np.eye(A, dtype=np.float32)[rng.integers(0, 4, int(L))] for L in lens]
+    elif kind == "wide":
+        A = int(rng.integers(34, 70))
+        S = rng.normal(0, 3, (A, A)).astype(np.float32)
+        profs = []
+        for L in lens:
+            c = np.zeros((int(L), A), dtype=np.float32)
+            for _ in range(int(rng.integers(1, 6))):
+                c[np.arange(int(L)), rng.integers(0, A, int(L))] += rng.integers(1, 4, int(L))
+            profs.append((c / c.sum(axis=1, keepdims=True)).astype(np.float32))
     elif kind == "onehot":
         S, A = blosum62_matrix(), 27
         profs = [np.eye(A, dtype=np.float32)[rng.integers(0, 20, int(L))] for L in lens]
@@ -44,7 +57,7 @@ while time.time() < t_end:
     if want_paths and mode == "local" and rng.random() < 0.5:
         rects = []
         for (i, j) in pairs:
-            k = int(rng.integers(0, 3))
+            k = int(rng.integers(0, 3)) if rng.random() < 0.8 else int(rng.integers(0, 9))
             rr = []
             for _ in range(k):
                 y0 = int(rng.integers(1, lens[i] + 1)); x0 = int(rng.integers(1, lens[j] + 1))
@@ -66,10 +79,16 @@ while time.time() < t_end:
             print("MISMATCH kind=%s N=%d mu=%d mode=%s paths=%s rects=%s pair=(%d,%d) lens=(%d,%d) dev=%r oracle=%r" % (
                 kind, N, mu, mode, want_paths, rects[k] if rects else None, i, j, lens[i], lens[j], sc[k], s_or), flush=True)
             sys.exit(1)
-        if kind != "profile" and rects is None and k % 3 == 0:
+        if kind not in ("profile", "wide") and rects is None and k % 3 == 0:
             ref = orc.pairwise_score_fast(mode, profs[i], profs[j], S, -11.0, -1.0)
             assert sc[k] == np.float32(ref), ("reference order", kind, mode, i, j)
+        if mk == 2 and k % 2 == 0:
+            # the device's reference-order match scores are the reference's, bit for bit
+            m_ref = np.zeros_like(m)
+            orc.cext_build_scores([profs[i]], [profs[j]], [orc.build_nonzero_matrix(profs[i])], [orc.build_nonzero_matrix(profs[j])], [S], m_ref)
+            assert np.array_equal(m.view(np.uint32), m_ref.view(np.uint32)), ("reference-order match scores", kind, mode, i, j)
         n_pairs_checked += 1
     arena.close()
     n_cases += 1
+nat.set_match_mode(None)
 print("stress ok: %d random batches, %d pairs checked against the oracle" % (n_cases, n_pairs_checked))
