@@ -74,7 +74,7 @@ int praline_shutdown(void);                   /* release streams and cached devi
 int praline_synchronize(void);                /* wait for all work submitted by this library */
 const char *praline_last_error(void);         /* message of the last failure on this thread */
 /* Scratch buffers (strip boundaries, traceback planes, paths) are recycled through a pool of released device
- * blocks (cap: PRALINE_POOL_KEEP_MB, default 16384).  praline_pool_trim waits for the library's work and returns
+ * blocks (cap: PRALINE_POOL_KEEP_MB, default 65536).  praline_pool_trim waits for the library's work and returns
  * every cached block to the driver - call it before handing the GPU's memory to another allocator. */
 int praline_pool_trim(void);
 int64_t praline_pool_cached_bytes(void);

@@ -44,6 +44,16 @@ void praline_launch_split_f16(const float *src, int KP, int KS, int n_active, in
                               hipStream_t stream);
 int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int one, int two, int L1, int L2, float *m,
                                  hipStream_t stream);
+// two-pass alignments with paths (dp_tb2_instance.hip): flag-free forward fill, then block recompute + traceback
+struct Trace2Args {
+    const int64_t *slot_off;
+    int32_t *paths;
+    int64_t *path_start;
+    int32_t *path_rows;
+};
+int praline_launch_tb2_forward(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, bool mask);
+int praline_launch_tb2_backward(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, int nr, int nterm, bool local,
+                                bool mask);
 // k_dp_batch on dense reference-order match scores (dp_ref_instance.hip)
 int praline_launch_dp_ref(const LaunchArgs &la, bool local, int out, int mask);
 // k_dp_batch instances (dp_instance.hip)

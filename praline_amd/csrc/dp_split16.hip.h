@@ -809,6 +809,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
 // src: P or Q in the fp32 layout [rowp][hh][KS] (k = 2 s + hh).  dst: [rowp][hh][piece][r][8 halves],
 // slot (piece, r) element jj holds k = 16 r + 8 hh + jj.  flag[0] is set when any value needs a
 // non-zero lo piece (i.e. the exact single-term mode is not applicable).
+#ifdef PRALINE_SPLIT16_AUX   // non-template kernel: defined in dp_split16_instance.hip's translation unit only
 __global__ void k_split_f16(const float *__restrict__ src, int KP, int KS, int n_active, int NR, int64_t rows_pad,
                             _Float16 *__restrict__ dst, int *__restrict__ flag)
 {
@@ -821,6 +822,7 @@ __global__ void k_split_f16(const float *__restrict__ src, int KP, int KS, int n
         if (__ballot(inexact) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
     }
 }
+#endif
 
 // Dense match-score matrix of one pair with EXACTLY the arithmetic of k_dp_split16 (diagnostics /
 // tests: the DP is verified bit-for-bit on these values).  One wave per 32x32 tile.

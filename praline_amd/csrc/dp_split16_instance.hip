@@ -1,5 +1,6 @@
 // dp_split16_instance.hip -- k_dp_split16 / k_split_f16 / k_scores_tile16 instances; compiled with
 // -mllvm -amdgpu-mfma-vgpr-form.
+#define PRALINE_SPLIT16_AUX 1
 #include "dp_launch.hip.h"
 #include "dp_split16.hip.h"
 #include "dp_split16_tb.hip.h"

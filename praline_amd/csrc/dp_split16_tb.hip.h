@@ -81,7 +81,15 @@ struct TbCarry {
 // (aop: rows the lower half receives, aopH: the upper half's) and the accumulator takes mfma(aop, row t+1) +
 // mfma(aopH, row t); see split16_step in dp_split16.hip.h.  BOLD holds row t and is refilled with row t+3 once its
 // MFMAs are issued (three operand sets rotate); without DM, BOLD is BOPS itself.
-template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool DM = false>
+// SINK: where the per-row flag words go.  0: the traceback planes in global memory (single pass);
+//   1: nowhere - the flag-free FORWARD fill of the two-pass scheme (see k_trace_recompute below): no flag is formed,
+//      instead the three states of every 32nd row are written to ckpt (float [block][3][16][64] per strip);
+//   2: an LDS row of the recompute kernel, lds_flags + (row index) * 512 + lane * 8 (no end-cell bookkeeping).
+// BSRC = 1 (one-hot arenas, single-term instances): the operand row of the refill is not loaded from the arena - 64
+// lanes reading 64 different rows per step cost the CU's L1 one tag cycle per lane, which the flag-free forward fill
+// (150 VALU per step instead of 350) no longer hides - but looked up in the one-hot operand table in LDS
+// (dp_split16.hip.h) by the row's symbol, byte SB of symw.
+template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool DM = false, int SINK = 0, int BSRC = 0, int SB = 0>
 __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                                 float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
                                                 float4 (&BOLD)[(NTERM == 1 ? 1 : 2) * NR],
@@ -93,7 +101,9 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
                                                 float &cdM, float &cdU, float &cdL, float &best_run, int &best_y,
                                                 int &best_x, int &best_k, float go, float ge, int xb,
                                                 const int (&rect)[PRALINE_MAX_RECTS][4], const int *chain_in = nullptr,
-                                                int *chain_seen = nullptr, int load_row = 0)
+                                                int *chain_seen = nullptr, int load_row = 0, float *ckpt = nullptr,
+                                                char *lds_flags = nullptr, int lds_row = 0, const char *onehot_lane = nullptr,
+                                                unsigned symw = 0)
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NM = NTERM * NR;
@@ -166,10 +176,12 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             // All three are shifted in like the extend bits below: no compare, no VCC write -> v_cndmask wait
             // states, no scalar mask logic.  The maximum is finite in every interior cell (one state of each
             // boundary cell is), so no NaN here.
-            w_nm = shift_in_sign(w_nm, sMM, Mref);
-            w_nu = shift_in_sign(w_nu, sMU, Mref);
+            if constexpr (SINK != 1) {
+                w_nm = shift_in_sign(w_nm, sMM, Mref);
+                w_nu = shift_in_sign(w_nu, sMU, Mref);
+            }
             if constexpr (LOCAL) {
-                w_stop = __builtin_amdgcn_alignbit(w_stop, __builtin_bit_cast(unsigned, M), 31);
+                if constexpr (SINK != 1) w_stop = __builtin_amdgcn_alignbit(w_stop, __builtin_bit_cast(unsigned, M), 31);
                 M = __builtin_fmaxf(M, 0.0f);                                    // cext.c:208-209
             }
             if constexpr (MK) {
@@ -178,8 +190,10 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             // "from extend" bits = sign of (open - extend), shifted in with one v_alignbit each: no compare, so
             // no VCC write -> v_cndmask wait states (the compare form cost ~35 s_nop per step).  Column c lands
             // in bit 15 - c; reversed once per row below.  (-inf) - (-inf) only happens in cells no path enters.
-            w_u = shift_in_sign(w_u, uo, ue);
-            w_l = shift_in_sign(w_l, lo, le);
+            if constexpr (SINK != 1) {
+                w_u = shift_in_sign(w_u, uo, ue);
+                w_l = shift_in_sign(w_l, lo, le);
+            }
             md = Mp[c]; ud = Up[c]; ld = Lp[c];
             Mp[c] = M; Up[c] = U; Lp[c] = Lc;
             mleft = M; lleft = Lc;
@@ -194,13 +208,18 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         row_cells(std::false_type{});
     }
     PREV = acc;
-    {
+    if constexpr (BSRC == 1) {
+        const unsigned sym = (symw >> (8 * SB)) & 0xffu;
+        const float4 *bsrc = reinterpret_cast<const float4 *>(onehot_lane + sym * onehot_stride(NR));
+#pragma unroll
+        for (int q = 0; q < NR; ++q) BOLD[q] = bsrc[q];
+    } else {
         const float4 *bsrc = reinterpret_cast<const float4 *>(b_next);
 #pragma unroll
         for (int q = 0; q < NP * NR; ++q) BOLD[q] = bsrc[q];   // (BOLD is BOPS without DM)
     }
     b_next += b_stride;
-    if (LOCAL) {
+    if (LOCAL && SINK != 2) {
         // local end cell = first maximum of o in C order (y, x, k) (align.py:402).  The state arrays now hold
         // this row's values: take the row maximum (2 ops per cell) and compare ONCE per row; the column and
         // state are located only inside the update block, which a wave-level vote skips almost always.
@@ -252,12 +271,27 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 
     if constexpr (CHAIN) {
         if (h) chain_store_row(bnd_st, Mp[15], Up[15], Lp[15]);
-    } else {
+    } else if constexpr (SINK != 2) {   // (the recompute kernel reads the kept columns, it writes none)
         if (h) *reinterpret_cast<float4 *>(bnd_st) = make_float4(Mp[15], Up[15], Lp[15], 0.0f);
     }
     bnd_st += 32 * sizeof(float4);
+    if constexpr (SINK == 1) {
+        // forward fill of the two-pass scheme: the states of every 32nd row are the recompute kernel's starting points
+#ifndef PRALINE_TB2_ABLATE
+#define PRALINE_TB2_ABLATE 0   // timing experiments only: 1 no checkpoint stores, 2 no kept boundary columns
+#endif
+        if (!(PRALINE_TB2_ABLATE & 1) && yy >= 32 && (yy & 31) == 0) {
+            float *q = ckpt + (int64_t)(yy >> 5) * (3 * 16 * 64);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                __builtin_nontemporal_store(Mp[c], q + c * 64);
+                __builtin_nontemporal_store(Up[c], q + (16 + c) * 64);
+                __builtin_nontemporal_store(Lp[c], q + (32 + c) * 64);
+            }
+        }
+    }
     // match source as two bit planes, code = lo | hi << 1: 1 MM / 2 MU / 3 ML / 0 stop (masked cell, or the clamp won)
-    {
+    if constexpr (SINK != 1) {
         const unsigned r_nm = __builtin_bitreverse32(w_nm) >> 16, r_nu = __builtin_bitreverse32(w_nu) >> 16;
         unsigned go_on = 0xffffu;
         if constexpr (LOCAL) go_on &= ~(__builtin_bitreverse32(w_stop) >> 16);
@@ -270,7 +304,8 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         // much later - they must not push the strip-boundary columns and the operand rows out of L2 (global /
         // semiglobal with paths +11 %).  Not in chain mode: there the producer drains its stores before every
         // publish and a streaming store takes longer to retire.
-        if constexpr (CHAIN) *reinterpret_cast<unsigned long long *>(tb_st) = w64;
+        if constexpr (SINK == 2) *reinterpret_cast<unsigned long long *>(lds_flags + lds_row * 512) = w64;
+        else if constexpr (CHAIN) *reinterpret_cast<unsigned long long *>(tb_st) = w64;
         else __builtin_nontemporal_store(w64, reinterpret_cast<unsigned long long *>(tb_st));
     }
     tb_st += 64;
@@ -282,8 +317,16 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #ifndef PRALINE_TB_DM
 #define PRALINE_TB_DM 1
 #endif
-template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false>
-__global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+// TWOPASS (task mode only): the FORWARD fill of the two-pass scheme - no flags, no traceback planes; instead every
+// strip keeps its own boundary column (bnd: float4 [nstrips + 1][max_l1 + PRALINE_TB2_PAD][32] per task) and the
+// states of every 32nd row go to ckpt (float [nstrips][(max_l1 + 8) / 32 + 1][3][16][64] per task, at tk.tb_off):
+// k_trace_recompute rebuilds the flags of just the 32 x 32 blocks each path crosses.  End cells as in the single pass.
+#define PRALINE_TB2_PAD 72
+#ifndef PRALINE_TB2_WAVES_PER_SIMD
+#define PRALINE_TB2_WAVES_PER_SIMD 2
+#endif
+template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool TWOPASS = false, int BSRC = 0>
+__global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one,
                                                        const int32_t *__restrict__ lane_pair, float4 *bnd,
                                                        uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,
@@ -295,6 +338,20 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
     constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0);   // see split16_tb_step
+    constexpr int SINK = TWOPASS ? 1 : 0;
+    static_assert(!(CHAIN && TWOPASS), "the two-pass fill is a task-mode kernel");
+    static_assert(BSRC == 0 || (BSRC == 1 && TWOPASS && DM), "the one-hot table feeds the single-term forward fill");
+    __shared__ __attribute__((aligned(16))) char onehot_tab[BSRC == 1 ? onehot_bytes(NR) : 16];
+    if constexpr (BSRC == 1) {
+        _Float16 *tab = reinterpret_cast<_Float16 *>(onehot_tab);
+        constexpr int per_row = onehot_stride(NR) / 2;  // halves per table row (the last 8 are padding)
+        for (int i = threadIdx.x; i < (16 * NR + 1) * per_row; i += blockDim.x) {
+            const int sym = i / per_row, e = i % per_row;
+            const int hh = e / (8 * NR), r = (e / 8) % NR, jj = e % 8;
+            tab[i] = (e < 16 * NR && 16 * r + 8 * hh + jj == sym) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
+        __syncthreads();
+    }
     // CHAIN: one wave per block; block b = strip-major (strip, task): producers are dispatched before consumers
     const int task = CHAIN ? (int)(blockIdx.x % n_tasks) : (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chain_strip = CHAIN ? (int)(blockIdx.x / n_tasks) : 0;
@@ -326,10 +383,14 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
     const int b_stride = ar.row_bytes;
     const int acol = 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
     const char *qA = ar.Q16 + ((int64_t)ar.row_off[two] + acol) * ar.row_bytes + h * ar.half_bytes;
+    const unsigned *pSym = (BSRC == 1) ? reinterpret_cast<const unsigned *>(ar.sym8 + (have_pair ? ar.row_off[my_one] : 0)) : nullptr;
+    const char *onehot_lane = onehot_tab + h * (16 * NR);
 
     if (CHAIN && chain_strip >= nstrips) return;
     // boundary columns: float4 [y][32]; chain mode keeps one per strip boundary, [strip][y][32]
-    const int64_t chain_col = CHAIN ? (int64_t)(max_l1 + 24) * 32 : 0;
+    const int64_t chain_col = CHAIN ? (int64_t)(max_l1 + 24) * 32 : (TWOPASS ? (int64_t)(max_l1 + PRALINE_TB2_PAD) * 32 : 0);
+    const int ckpt_blocks = (max_l1 + 8) / 32 + 1;
+    float *my_ckpt = TWOPASS ? reinterpret_cast<float *>(tb) + tk.tb_off + lane : nullptr;   // [strip][block][3][16][64]
     char *my_bnd = reinterpret_cast<char *>(bnd + tk.bnd_off + chain_col * chain_strip + j);          // read by this wave
     char *my_bnd_out = reinterpret_cast<char *>(bnd + tk.bnd_off + chain_col * (chain_strip + 1) + j);  // written (CHAIN)
     constexpr int BROW = 32 * (int)sizeof(float4);
@@ -436,11 +497,18 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         float4 bX[NOP], bY[NOP], bZ[NOP];   // bZ: DM only (rows t, t+1, t+2 rotate through three sets)
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
+        unsigned sw0 = 0;   // BSRC == 1: the symbols of rows 1 .. 4
         {
             float4 b1[NOP];
             const float4 *s1 = reinterpret_cast<const float4 *>(pB);
             const float4 *s2 = reinterpret_cast<const float4 *>(pB + b_stride);
             const float4 *s3 = reinterpret_cast<const float4 *>(pB + 2 * b_stride);
+            if constexpr (BSRC == 1) {
+                sw0 = pSym[0];
+                s1 = reinterpret_cast<const float4 *>(onehot_lane + (sw0 & 0xffu) * onehot_stride(NR));
+                s2 = reinterpret_cast<const float4 *>(onehot_lane + ((sw0 >> 8) & 0xffu) * onehot_stride(NR));
+                s3 = reinterpret_cast<const float4 *>(onehot_lane + ((sw0 >> 16) & 0xffu) * onehot_stride(NR));
+            }
 #pragma unroll
             for (int q = 0; q < NOP; ++q) { b1[q] = s1[q]; bX[q] = s2[q]; bY[q] = s3[q]; bZ[q] = s1[q]; }
 #pragma unroll
@@ -455,23 +523,32 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         const char *b_next = pB + 3 * b_stride;
         // boundary states three rows ahead, in three rotating registers (one row = 0.7 us at one wave per SIMD is
         // not enough for a load that misses L2; measured with the 1-deep version: 27 % of the cycles waiting)
-        const char *bnd_ld = my_bnd + 4 * BROW;
-        char *bnd_st = CHAIN ? my_bnd_out : my_bnd;                          // upper half stores row yy = t - 1 (row 0: dummy)
+        // TWOPASS: strip s reads column s and writes column s + 1 (all of them stay for the recompute kernel)
+        const char *col_in = (TWOPASS && !(PRALINE_TB2_ABLATE & 2)) ? my_bnd + (int64_t)s * chain_col * (int64_t)sizeof(float4) : my_bnd;
+        const char *bnd_ld = col_in + 4 * BROW;
+        char *bnd_st = CHAIN ? my_bnd_out : ((TWOPASS && !(PRALINE_TB2_ABLATE & 2)) ? my_bnd + (int64_t)(s + 1) * chain_col * (int64_t)sizeof(float4) : my_bnd);   // upper half stores row yy = t - 1 (row 0: dummy)
+        float *ckpt_strip = TWOPASS ? my_ckpt + (int64_t)s * ckpt_blocks * (3 * 16 * 64) : nullptr;
         if constexpr (CHAIN) {
             if (chain_in != nullptr) chain_seen = chain_wait(chain_in, 3, chain_seen);
         }
-        float4 bnd_prefA = *reinterpret_cast<const float4 *>(my_bnd + BROW);      // row 1
-        float4 bnd_prefB = *reinterpret_cast<const float4 *>(my_bnd + 2 * BROW);  // row 2
-        float4 bnd_prefC = *reinterpret_cast<const float4 *>(my_bnd + 3 * BROW);  // row 3
+        float4 bnd_prefA = *reinterpret_cast<const float4 *>(col_in + BROW);      // row 1
+        float4 bnd_prefB = *reinterpret_cast<const float4 *>(col_in + 2 * BROW);  // row 2
+        float4 bnd_prefC = *reinterpret_cast<const float4 *>(col_in + 3 * BROW);  // row 3
         uint2 *tb_st = my_tb + (int64_t)s * tb_rows * 64 + (h ? 0 : 64);     // row yy = t - h of step t = 1
 
         // BUSE holds operand row T + 1; BOLD row T (DM; otherwise BUSE again); PREF the boundary states of row T
 #define PRALINE_TB_STEP(T, CUR, PREV, BUSE, BOLD, PREF)                                                              \
-        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, DM>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, BOLD, aop, aopH,     \
+        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, DM, SINK>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, BOLD, aop, aopH, \
                                                 b_next, b_stride,                                                           \
                                                 bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl, cpxm, cpxu, cpxl,   \
                                                 cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge, xb, srect,         \
-                                                chain_in, &chain_seen, (T) + 3)
+                                                chain_in, &chain_seen, (T) + 3, ckpt_strip)
+        // one-hot table: the refill (operand row T + 3) takes its symbol from byte SBYTE of SYMW
+#define PRALINE_TB_STEP_OH(T, CUR, PREV, BUSE, BOLD, PREF, SYMW, SBYTE)                                                \
+        split16_tb_step<NR, NTERM, LOCAL, MASK, false, true, SINK, 1, SBYTE>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, BOLD, aop, \
+                                                aopH, b_next, b_stride, bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu,  \
+                                                cxl, cpxm, cpxu, cpxl, cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, \
+                                                ge, xb, srect, nullptr, nullptr, 0, ckpt_strip, nullptr, 0, onehot_lane, SYMW)
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
             const int yy_ = (T) - h;                                                                                 \
@@ -494,7 +571,8 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         {
             const float best_s = best_run;
             const int by = best_y, bx = best_x, bk = best_k;
-            if constexpr (DM) PRALINE_TB_STEP(1, accA, accB, bX, bZ, bnd_prefA);
+            if constexpr (BSRC == 1) PRALINE_TB_STEP_OH(1, accA, accB, bX, bZ, bnd_prefA, sw0, 3);
+            else if constexpr (DM) PRALINE_TB_STEP(1, accA, accB, bX, bZ, bnd_prefA);
             else PRALINE_TB_STEP(1, accA, accB, bX, bX, bnd_prefA);
             if (h) {
 #pragma unroll
@@ -509,6 +587,42 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
         // DM - the operand sets rotate with period 3 (without DM two operand sets alternate); the steps past
         // max_l1 + 1 compute rows that nobody reports
         int chain_next = chain_every;
+        if constexpr (BSRC == 1) {
+            // twelve steps per iteration: the step at T refills operand row T + 3, symbol byte T + 2 of the sequence;
+            // T = 2 (mod 12), so the twelve symbols are exactly the dwords 1 + 3 k, 2 + 3 k, 3 + 3 k (loaded one
+            // iteration ahead)
+            const unsigned *pn = pSym + 1;
+            unsigned d1 = pn[0], d2 = pn[1], d3 = pn[2];
+            for (int t = 2; t <= max_l1 + 1; t += 12) {
+                pn += 3;
+                const unsigned n1 = pn[0], n2 = pn[1], n3 = pn[2];
+                PRALINE_TB_STEP_OH(t, accB, accA, bY, bX, bnd_prefB, d1, 0);
+                PRALINE_TB_TAILS(t)
+                PRALINE_TB_STEP_OH(t + 1, accA, accB, bZ, bY, bnd_prefC, d1, 1);
+                PRALINE_TB_TAILS(t + 1)
+                PRALINE_TB_STEP_OH(t + 2, accB, accA, bX, bZ, bnd_prefA, d1, 2);
+                PRALINE_TB_TAILS(t + 2)
+                PRALINE_TB_STEP_OH(t + 3, accA, accB, bY, bX, bnd_prefB, d1, 3);
+                PRALINE_TB_TAILS(t + 3)
+                PRALINE_TB_STEP_OH(t + 4, accB, accA, bZ, bY, bnd_prefC, d2, 0);
+                PRALINE_TB_TAILS(t + 4)
+                PRALINE_TB_STEP_OH(t + 5, accA, accB, bX, bZ, bnd_prefA, d2, 1);
+                PRALINE_TB_TAILS(t + 5)
+                PRALINE_TB_STEP_OH(t + 6, accB, accA, bY, bX, bnd_prefB, d2, 2);
+                PRALINE_TB_TAILS(t + 6)
+                PRALINE_TB_STEP_OH(t + 7, accA, accB, bZ, bY, bnd_prefC, d2, 3);
+                PRALINE_TB_TAILS(t + 7)
+                PRALINE_TB_STEP_OH(t + 8, accB, accA, bX, bZ, bnd_prefA, d3, 0);
+                PRALINE_TB_TAILS(t + 8)
+                PRALINE_TB_STEP_OH(t + 9, accA, accB, bY, bX, bnd_prefB, d3, 1);
+                PRALINE_TB_TAILS(t + 9)
+                PRALINE_TB_STEP_OH(t + 10, accB, accA, bZ, bY, bnd_prefC, d3, 2);
+                PRALINE_TB_TAILS(t + 10)
+                PRALINE_TB_STEP_OH(t + 11, accA, accB, bX, bZ, bnd_prefA, d3, 3);
+                PRALINE_TB_TAILS(t + 11)
+                d1 = n1; d2 = n2; d3 = n3;
+            }
+        } else
         for (int t = 2; t <= max_l1 + 1; t += 6) {
             if constexpr (CHAIN) {
                 // the steps up to t - 1 have stored the boundary rows up to t - 2.  Every publish drains the wave's
@@ -545,6 +659,7 @@ __global__ __launch_bounds__(256, PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_t
             }
         }
 #undef PRALINE_TB_STEP
+#undef PRALINE_TB_STEP_OH
 #undef PRALINE_TB_TAILS
         if constexpr (CHAIN) chain_publish(chain_out, PRALINE_CHAIN_DONE, lane);
     }

@@ -1,0 +1,63 @@
+// dp_tb2_instance.hip -- the two-pass alignments-with-paths kernels: k_dp_split16_tb<..., TWOPASS> (flag-free forward
+// fill with kept boundary columns and row checkpoints) and k_trace_recompute (dp_trace2.hip.h); compiled with
+// -mllvm -amdgpu-mfma-vgpr-form like the other split16 kernels.
+#include "dp_launch.hip.h"
+#include "dp_trace2.hip.h"
+
+template <int NR, int NTERM> static void launch_fwd(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask)
+{
+    const dim3 grid(la.n_tasks), block(64);
+#define PRALINE_FWD(LOC, MSK)                                                                                            \
+    hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, LOC, MSK, false, true>), grid, block, 0, la.stream, a16, la.tasks,      \
+                       la.lane_one, la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells,  \
+                       la.rp, (int)la.n_tasks)
+    if constexpr (NTERM == 1) {
+        if (a16.sym8 != nullptr) {   // one-hot arena: operand rows from the one-hot table in LDS
+#define PRALINE_FWD_OH(LOC, MSK)                                                                                         \
+    hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, LOC, MSK, false, true, 1>), grid, block, 0, la.stream, a16, la.tasks,   \
+                       la.lane_one, la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells,  \
+                       la.rp, (int)la.n_tasks)
+            if (local) { if (mask) PRALINE_FWD_OH(true, true); else PRALINE_FWD_OH(true, false); }
+            else { if (mask) PRALINE_FWD_OH(false, true); else PRALINE_FWD_OH(false, false); }
+#undef PRALINE_FWD_OH
+            return;
+        }
+    }
+    if (local) { if (mask) PRALINE_FWD(true, true); else PRALINE_FWD(true, false); }
+    else { if (mask) PRALINE_FWD(false, true); else PRALINE_FWD(false, false); }
+#undef PRALINE_FWD
+}
+
+template <int NR, int NTERM> static void launch_bwd(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, bool local,
+                                                    bool mask)
+{
+    const dim3 grid(la.n_tasks), block(64);
+#define PRALINE_BWD(LOC, MSK)                                                                                            \
+    hipLaunchKernelGGL((k_trace_recompute<NR, NTERM, LOC, MSK>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,    \
+                       la.lane_pair, (const float4 *)la.bnd, (const float *)la.tb, la.rl, la.end_cells, ta.slot_off,       \
+                       ta.paths, ta.path_start, ta.path_rows, la.rp, (int)la.n_tasks)
+    if (local) { if (mask) PRALINE_BWD(true, true); else PRALINE_BWD(true, false); }
+    else { if (mask) PRALINE_BWD(false, true); else PRALINE_BWD(false, false); }
+#undef PRALINE_BWD
+}
+
+int praline_launch_tb2_forward(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, bool mask)
+{
+    if (nr == 1 && nterm == 1) launch_fwd<1, 1>(la, a16, local, mask);
+    else if (nr == 1 && nterm == 3) launch_fwd<1, 3>(la, a16, local, mask);
+    else if (nr == 2 && nterm == 1) launch_fwd<2, 1>(la, a16, local, mask);
+    else if (nr == 2 && nterm == 3) launch_fwd<2, 3>(la, a16, local, mask);
+    else return PRALINE_ERR_UNSUPPORTED;
+    return PRALINE_OK;
+}
+
+int praline_launch_tb2_backward(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, int nr, int nterm, bool local,
+                                bool mask)
+{
+    if (nr == 1 && nterm == 1) launch_bwd<1, 1>(la, a16, ta, local, mask);
+    else if (nr == 1 && nterm == 3) launch_bwd<1, 3>(la, a16, ta, local, mask);
+    else if (nr == 2 && nterm == 1) launch_bwd<2, 1>(la, a16, ta, local, mask);
+    else if (nr == 2 && nterm == 3) launch_bwd<2, 3>(la, a16, ta, local, mask);
+    else return PRALINE_ERR_UNSUPPORTED;
+    return PRALINE_OK;
+}

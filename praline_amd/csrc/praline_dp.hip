@@ -149,14 +149,15 @@ extern "C" void *praline_stream(void) { return g_rt.ready ? (void *)g_rt.stream 
 struct PoolBlock { void *p; size_t bytes; };
 static std::vector<PoolBlock> g_pool;
 static size_t g_pool_bytes = 0;
-// Cap of the cached (released, not yet freed) bytes: PRALINE_POOL_KEEP_MB, default 16 GiB - enough for the scratch
-// of a C3-size path plan, small next to what torch / RCCL may want on the same GPU.  praline_pool_trim() returns
-// every cached block to the driver.  The pool, like the rest of the library, is for one host thread per device.
+// Cap of the cached (released, not yet freed) bytes: PRALINE_POOL_KEEP_MB, default 64 GiB of the 288 - two launch
+// chunks' worth of path-plan scratch (24 GiB each, PRALINE_TB_BUDGET_MB): with a smaller cap every C3-size plan paid
+// seconds of hipMalloc / hipFree.  praline_pool_trim() returns every cached block to the driver (call it before
+// another allocator needs the memory).  The pool, like the rest of the library, is for one host thread per device.
 static size_t pool_keep_bytes()
 {
     static size_t keep = (size_t)-1;
     if (keep == (size_t)-1) {
-        keep = (size_t)16 << 30;
+        keep = (size_t)64 << 30;
         if (const char *env = getenv("PRALINE_POOL_KEEP_MB")) keep = (size_t)atoll(env) << 20;
     }
     return keep;
@@ -653,6 +654,8 @@ struct praline_plan {
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
     DevBuf<char> d_bnd;
+    DevBuf<float4> d_bnd2;      // two-pass mode: every strip's boundary column, kept for the recompute kernel
+    std::vector<int64_t> bnd_off0;
     DevBuf<char> d_bnd_chain;   // chain mode: one boundary column per strip boundary
     DevBuf<int> d_chain_flags;  // chain mode: rows published per (task, strip)
     DevBuf<float4> d_chain_cand;  // chain mode, local: first-argmax candidate per (task, strip, pair)
@@ -691,6 +694,8 @@ static int64_t chain_max_tasks()
     if (const char *env = getenv("PRALINE_CHAIN_MAX_TASKS")) return atoll(env);
     return 2304;   // measured crossover with task mode (scripts/exp_chain.py); within +-5 % of it up to ~4000 tasks
 }
+
+#define PRALINE_TB2_PAD_ROWS 72   // = PRALINE_TB2_PAD of dp_split16_tb.hip.h (rows per kept boundary column beyond max_l1)
 
 // traceback scratch budget per launch chunk (bytes)
 static size_t tb_budget_bytes()
@@ -1089,6 +1094,84 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     size_t t0 = 0;
     const size_t nt = pl.tasks.size();
     HIPCHK(hipEventRecord(pl.ev0, st));
+    // ---- two passes (dp_trace2.hip.h) for plans too large for chain mode: a flag-free forward fill that keeps the
+    // strip boundary columns and (M, U, L) of every 32nd row, then k_trace_recompute rebuilds the flags of only the
+    // 32 x 32 blocks each path crosses.  PRALINE_TB_TWOPASS=0 keeps the single pass.
+    {
+        int64_t single_bytes = 0;
+        int all_strips = 0;
+        for (size_t t = 0; t < nt; ++t) { single_bytes += pl.tb_elems[t] * (int64_t)tb_elem_bytes; all_strips = std::max(all_strips, (int)pl.tasks[t].nstrips); }
+        const bool would_chain = pl.split && la.a16 != nullptr && all_strips >= 2 && (size_t)single_bytes <= budget &&
+                                 (int64_t)nt <= chain_max_tasks() && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
+        // Default: LOCAL plans only.  Measured on C3 (1 047 552 alignments of ~250 aa, one-hot): local 60.1 -> 47.3 ms,
+        // global 54.7 -> 53.7 ms (the forward fill's extra stores and a recompute of ~half the cells eat the saving when
+        // every path spans the whole matrix).  PRALINE_TB_TWOPASS=1: every mode, =2: also instead of chain mode, =0: never.
+        const char *tp = getenv("PRALINE_TB_TWOPASS");
+        const int tpv = tp ? atoi(tp) : -1;
+        const bool twopass = pl.split && la.a16 != nullptr && tpv != 0 && (tpv == 2 || (!would_chain && (local || tpv == 1)));
+        if (twopass) {
+            char kn[160];
+            snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, %d, %s, %s, false, true>", a.nr16, tb_nterm, local ? "true" : "false",
+                     pl.has_rects ? "true" : "false");
+            pl.last_kernel = kn;
+            if (pl.bnd_off0.size() != nt) { pl.bnd_off0.resize(nt); for (size_t t = 0; t < nt; ++t) pl.bnd_off0[t] = pl.tasks[t].bnd_off; }
+            if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
+            int rc2 = PRALINE_OK;
+            while (t0 < nt && rc2 == PRALINE_OK) {
+                size_t t1 = t0;
+                int64_t ck_e = 0, bnd_e = 0, aux_e = 0;   // floats, float4s, floats
+                while (t1 < nt) {
+                    const WaveTask &wt = pl.tasks[t1];
+                    const int64_t ck_add = (int64_t)wt.nstrips * ((wt.max_l1 + 8) / 32 + 1) * (3 * 16 * 64);
+                    const int64_t bnd_add = (int64_t)(wt.nstrips + 1) * (wt.max_l1 + PRALINE_TB2_PAD_ROWS) * 32;
+                    if (t1 > t0 && (size_t)((ck_e + ck_add) * 4 + (bnd_e + bnd_add) * 16) > budget) break;
+                    pl.tasks[t1].tb_off = ck_e;
+                    pl.tasks[t1].bnd_off = bnd_e;
+                    pl.tasks[t1].aux_off = aux_e;
+                    ck_e += ck_add;
+                    bnd_e += bnd_add;
+                    aux_e += semiglobal ? pl.aux_elems[t1] : 0;
+                    ++t1;
+                }
+                if (pl.d_tb.n < (size_t)ck_e * 4) rc2 = pl.d_tb.alloc((size_t)ck_e * 4);
+                if (rc2 == PRALINE_OK && pl.d_bnd2.n < (size_t)bnd_e) rc2 = pl.d_bnd2.alloc((size_t)bnd_e);
+                if (rc2 == PRALINE_OK && pl.d_aux.n < (size_t)std::max<int64_t>(aux_e, 1)) rc2 = pl.d_aux.alloc((size_t)std::max<int64_t>(aux_e, 1));
+                if (rc2 != PRALINE_OK) break;
+                hipError_t e = hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, st);
+                if (e != hipSuccess) { rc2 = fail(PRALINE_ERR_DEVICE, "task upload: %s", hipGetErrorString(e)); break; }
+                la.tasks = pl.d_tasks.p + t0;
+                la.lane_one = pl.d_lane_one.p + t0 * 32;
+                la.lane_pair = pl.d_lane_pair.p + t0 * 32;
+                la.tb = (uint4 *)pl.d_tb.p;
+                la.bnd = pl.d_bnd2.p;
+                la.aux = pl.d_aux.p;
+                la.n_tasks = (unsigned)(t1 - t0);
+                rc2 = praline_launch_tb2_forward(la, a16, a.nr16, tb_nterm, local, pl.has_rects);
+                if (rc2 != PRALINE_OK) { rc2 = fail(rc2, "no two-pass forward instance for nr=%d nterm=%d", a.nr16, tb_nterm); break; }
+                if (semiglobal) {
+                    const int64_t lanes = (int64_t)(t1 - t0) * 32;
+                    hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar, pl.d_tasks.p,
+                                       pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, pl.d_aux.p, pl.d_end_cells.p, la.scores,
+                                       la.rp, (int32_t)t0, (int32_t)t1, 1);
+                }
+                Trace2Args ta;
+                ta.slot_off = pl.d_slot_off.p;
+                ta.paths = pl.d_paths.p;
+                ta.path_start = pl.d_path_start.p;
+                ta.path_rows = pl.d_path_rows.p;
+                rc2 = praline_launch_tb2_backward(la, a16, ta, a.nr16, tb_nterm, local, pl.has_rects);
+                if (rc2 != PRALINE_OK) { rc2 = fail(rc2, "no two-pass backward instance for nr=%d nterm=%d", a.nr16, tb_nterm); break; }
+                if (hipGetLastError() != hipSuccess) { rc2 = fail(PRALINE_ERR_DEVICE, "two-pass launch failed"); break; }
+                t0 = t1;
+            }
+            // the single pass and chain mode address the plan's shared boundary buffer through the scheduler's offsets
+            for (size_t t = 0; t < nt; ++t) pl.tasks[t].bnd_off = pl.bnd_off0[t];
+            if (rc2 != PRALINE_OK) return rc2;
+            // (d_tasks holds two-pass offsets now: the next single-pass run uploads its own)
+            HIPCHK(hipEventRecord(pl.ev1, st));
+            return PRALINE_OK;
+        }
+    }
     while (t0 < nt) {
         size_t t1 = t0;
         int64_t tb_e = 0, aux_e = 0;

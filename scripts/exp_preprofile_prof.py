@@ -7,7 +7,7 @@ from praline_amd import native as nat, component as comp, container as ct
 from bench import synth_lengths
 nat.init(0)
 blosum = ct.blosum62()
-N = 512
+N = int(os.environ.get("N", "512"))
 rng = np.random.default_rng(3)
 lens = synth_lengths(rng, N, 250)
 seqs = [ct.Sequence("s%d" % i, [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=rng.integers(0, 20, int(L))))])

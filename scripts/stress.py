@@ -63,6 +63,8 @@ while time.time() < t_end:
                 y0 = int(rng.integers(1, lens[i] + 1)); x0 = int(rng.integers(1, lens[j] + 1))
                 rr.append((y0, min(int(lens[i]), y0 + int(rng.integers(0, 12))), x0, min(int(lens[j]), x0 + int(rng.integers(0, 12)))))
             rects.append(rr)
+    # path plans: a third through the two-pass scheme (forward fill + block recompute) whatever their size
+    os.environ["PRALINE_TB_TWOPASS"] = "2" if rng.random() < 0.33 else "0"
     arena = nat.Arena(profs, S)
     plan = nat.Plan(arena, pairs, want_paths=want_paths, rects=rects)
     mk = plan.match_kind()

@@ -640,3 +640,39 @@ def test_premultiply_relaunch_is_idempotent(nat, bba, kind):
         assert np.array_equal(bits(arena.match_scores(2, 6, k)), bits(m_before[k]))
     plan.close()
     arena.close()
+
+
+def test_two_pass_paths_equal_single_pass(nat, bba, monkeypatch):
+    """The two-pass scheme for alignments with paths (flag-free forward fill with kept strip boundaries and row
+    checkpoints + k_trace_recompute, dp_trace2.hip.h) against the single pass and the oracle: identical scores and
+    paths in every mode, with Waterman-Eggert rectangles, one-hot (one-hot table operands) and float profiles, lengths
+    that straddle the 32-row blocks and the 32-column strips."""
+    rng = np.random.default_rng(41)
+    lens = [1, 31, 32, 33, 64, 65, 97, 130, 200, 47]
+    sets = {"onehot": [one_hot(rng.integers(0, 20, L), 27) for L in lens],
+            "float": [synth_profile(rng, L)[0] for L in lens]}
+    pairs = np.array([(i, j) for i in range(len(lens)) for j in range(len(lens)) if i != j], dtype=np.int32)
+    rects = [[(3, 40, 2, 37)] if k % 3 == 0 else ([(50, 70, 20, 90), (1, 5, 60, 64)] if k % 3 == 1 else []) for k in range(len(pairs))]
+    for kind, profs in sets.items():
+        arena = nat.Arena(profs, bba["S"])
+        for mode in MODES:
+            for use_rects in ((False, True) if mode == "local" else (False,)):
+                res = {}
+                for two in ("0", "2"):
+                    monkeypatch.setenv("PRALINE_TB_TWOPASS", two)
+                    plan = nat.Plan(arena, pairs, want_paths=True, rects=rects if use_rects else None)
+                    mk = plan.match_kind()
+                    plan.run(mode, *GAPS)
+                    res[two] = (plan.scores().copy(), [p.copy() for p in plan.paths()], plan.kernel_name())
+                    plan.close()
+                assert res["0"][2] != res["2"][2] and res["2"][2].endswith("true>"), res["2"][2]
+                assert np.array_equal(bits(res["0"][0]), bits(res["2"][0])), (kind, mode, use_rects)
+                for k, (i, j) in enumerate(pairs):
+                    assert np.array_equal(res["0"][1][k], res["2"][1][k]), (kind, mode, use_rects, i, j)
+                for k in range(0, len(pairs), 7):
+                    i, j = pairs[k]
+                    zero = [(y, x) for (y0, y1, x0, x1) in (rects[k] if use_rects else []) for y in range(y0, min(y1, lens[i]) + 1)
+                            for x in range(x0, min(x1, lens[j]) + 1)]
+                    s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(i, j, mk), zero_idxs=zero or None)
+                    assert res["2"][0][k] == np.float32(s_or) and np.array_equal(res["2"][1][k], p_or), (kind, mode, i, j)
+        arena.close()
