@@ -234,6 +234,10 @@ int praline_arena_counts_bind(praline_arena *arena, void *d_counts);
 int praline_plan_add_counts(praline_plan *plan, int use_threshold, float threshold, int local);
 int praline_arena_counts_read(praline_arena *arena, int32_t *counts);
 int praline_plan_path_bounds(praline_plan *plan, int32_t *bounds);
+/* Waterman-Eggert without a host round trip: the bounding box of every pair's current path (of the last
+ * praline_plan_run) becomes one more zero rectangle of that pair, on the device, and the SAME plan - its schedule and
+ * scratch - runs the next iteration.  Up to 4 per pair this way (plans created without rectangle lists only). */
+int praline_plan_mask_path_bounds(praline_plan *plan);
 
 /* Convenience: arena-resident one-shot (plan + run + copy back). */
 int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float gap_extend,

@@ -461,8 +461,21 @@ def _preprofile_slave_counts(profiles, S, pairs, mode, gap_open, gap_extend, sco
         if counts_out is not None:
             arena.counts_bind(counts_out.data_ptr())
         arena.counts_reset()
+        if len(pairs) and iterations <= native.MAX_RECTS + 1:
+            # ONE plan for all Waterman-Eggert iterations: the path bounding boxes become the next iteration's masks on
+            # the device (no second schedule, no bounds / rectangle traffic over PCIe)
+            plan = native.Plan(arena, pairs, want_paths=True)
+            try:
+                for it in range(iterations):
+                    plan.run(mode, gap_open, gap_extend)
+                    plan.add_counts(score_threshold, local=(mode == "local"))
+                    if it + 1 < iterations:
+                        plan.mask_path_bounds()
+            finally:
+                plan.close()
+            iterations = 0
         rects = None
-        for it in range(iterations if len(pairs) else 0):
+        for it in range(iterations if len(pairs) else 0):     # more rectangles per pair than the slots hold
             plan = native.Plan(arena, pairs, want_paths=True, rects=rects)
             try:
                 plan.run(mode, gap_open, gap_extend)

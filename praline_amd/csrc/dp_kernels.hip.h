@@ -921,6 +921,23 @@ __global__ void k_path_bounds(const int32_t *__restrict__ paths, const int64_t *
 }
 
 
+// Waterman-Eggert on the device: the bounding box of every pair's path becomes that pair's zero rectangle number `slot`
+// (rects: int32 [n_pairs][PRALINE_MAX_RECTS][4]; unused slots hold the empty rectangle) - no host round trip between
+// the iterations (praline/component/preprofile.py:247-255).
+__global__ void k_path_bounds_to_rects(const int32_t *__restrict__ paths, const int64_t *__restrict__ path_start,
+                                       const int32_t *__restrict__ path_rows, int64_t n_pairs, int slot, int32_t *__restrict__ rects)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int rows = path_rows[p];
+    const int32_t *path = paths + path_start[p] * 2;
+    int32_t *q = rects + (p * PRALINE_MAX_RECTS + slot) * 4;
+    q[0] = rows > 0 ? path[0] : (1 << 30);
+    q[1] = rows > 0 ? path[2 * (rows - 1)] : -1;
+    q[2] = rows > 0 ? path[1] : (1 << 30);
+    q[3] = rows > 0 ? path[2 * (rows - 1) + 1] : -1;
+}
+
 // Resident progressive alignment: merge two clusters of the arena along the device path of their
 // alignment into a NEW sequence at the arena's end - ProfileTrack.merge (praline/container/sequence.py:205-239) for
 // every track set: alignment column c sums the integer counts of the positions that advance in it (the reference sums

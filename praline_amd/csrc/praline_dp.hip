@@ -54,6 +54,10 @@ struct Runtime {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    // path plans that run in several launch chunks alternate between the main stream and this one (two scratch sets):
+    // the traceback and the tail of chunk k overlap the fill of chunk k + 1
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 static Runtime g_rt;
 
@@ -73,6 +77,9 @@ static int ensure_runtime(int device)
     if (device >= n) return fail(PRALINE_ERR_ARG, "device %d out of range (%d visible)", device, n);
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&g_rt.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&g_rt.stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&g_rt.ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&g_rt.ev_join, hipEventDisableTiming));
     g_rt.device = device;
     g_rt.ready = true;
     return PRALINE_OK;
@@ -98,7 +105,11 @@ extern "C" int praline_shutdown(void)
 {
     if (!g_rt.ready) return PRALINE_OK;
     (void)hipStreamSynchronize(g_rt.stream);
+    (void)hipStreamSynchronize(g_rt.stream2);
     pool_clear();
+    (void)hipEventDestroy(g_rt.ev_fork);
+    (void)hipEventDestroy(g_rt.ev_join);
+    (void)hipStreamDestroy(g_rt.stream2);
     (void)hipStreamDestroy(g_rt.stream);
     g_rt = Runtime();
     return PRALINE_OK;
@@ -167,7 +178,10 @@ static void *pool_alloc(size_t bytes, size_t *got)
 {
     size_t best = (size_t)-1;
     for (size_t i = 0; i < g_pool.size(); ++i)
-        if (g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + (1 << 20) &&
+        // smallest cached block that fits; a request of a GiB or more takes ANY block that fits (a first hipMalloc of a
+        // 24 GiB scratch block costs the better part of a second - more than the C3 stage it serves), smaller ones
+        // only blocks of up to twice their size
+        if (g_pool[i].bytes >= bytes && (bytes >= ((size_t)1 << 30) || g_pool[i].bytes <= 2 * bytes + (1 << 20)) &&
             (best == (size_t)-1 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
     if (best != (size_t)-1) {
         PoolBlock b = g_pool[best];
@@ -635,6 +649,7 @@ struct praline_plan {
     int64_t path_cap = 0;
     bool want_paths = false;
     bool has_rects = false;
+    int slot_rects = -1;  // >= 0: the rectangles live in fixed slots on the device (praline_plan_mask_path_bounds), this many used
     int mask_kind = 0;   // 0 none, 1 <= PRALINE_MAX_RECTS rectangles per pair (registers), 2 any number (k_dp_batch MASK = 2)
     int tp = 1;
     bool split = false;  // k_dp_split task layout
@@ -660,6 +675,10 @@ struct praline_plan {
     DevBuf<int> d_chain_flags;  // chain mode: rows published per (task, strip)
     DevBuf<float4> d_chain_cand;  // chain mode, local: first-argmax candidate per (task, strip, pair)
     DevBuf<char> d_tb;
+    // second scratch set of chunked path plans (chunks alternate between two streams)
+    DevBuf<char> d_tb_b;
+    DevBuf<float> d_aux_b;
+    DevBuf<float4> d_bnd2_b;
     DevBuf<int64_t> d_slot_off, d_path_start;
     std::vector<int64_t> slot_off;
     float last_kernel_ms = 0.0f;
@@ -701,7 +720,9 @@ static int64_t chain_max_tasks()
 static size_t tb_budget_bytes()
 {
     if (const char *env = getenv("PRALINE_TB_BUDGET_MB")) return (size_t)atoll(env) << 20;
-    return (size_t)24 << 30;
+    // 8 GiB (two sets of 4 GiB once a plan needs several chunks): with the chunks alternating between two streams the
+    // rate is within 3 % of a 24 GiB budget (C3), and a first-use hipMalloc of the scratch costs 0.2 s instead of 0.8
+    return (size_t)8 << 30;
 }
 
 extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, int want_paths,
@@ -880,18 +901,18 @@ static int launch_dp(int nstep, const LaunchArgs &la, int tp, bool local, int ou
 // end cells of the semiglobal modes + device traceback for the tasks [t0, t1) of a path plan (after their fill)
 static int launch_traceback(praline_plan &pl, const LaunchArgs &la, size_t t0, size_t t1, int mode)
 {
-    hipStream_t st = g_rt.stream;
+    hipStream_t st = la.stream;
     // k_traceback runs over all pairs and skips those whose task is outside [t0, t1)
     const int threads = 64;
     const int64_t blocks = (pl.n_pairs + threads - 1) / threads;
     if (mode >= PRALINE_MODE_SEMIGLOBAL_BOTH) {   // end cells of the semiglobal modes, scanned per task
         const int64_t lanes = (int64_t)(t1 - t0) * (pl.split ? 32 : 64);
         hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar,
-                           pl.d_tasks.p, pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, pl.d_aux.p,
+                           pl.d_tasks.p, pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, la.aux,
                            pl.d_end_cells.p, la.scores, la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
     }
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)blocks), dim3(threads), 0, st, la.ar, pl.d_tasks.p,
-                       pl.d_loc.p, pl.d_pairs.p, (const uint4 *)pl.d_tb.p, pl.d_aux.p, la.rl, pl.d_end_cells.p,
+                       pl.d_loc.p, pl.d_pairs.p, (const uint4 *)la.tb, la.aux, la.rl, pl.d_end_cells.p,
                        la.scores, pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs,
                        la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
     HIPCHK(hipGetLastError());
@@ -1117,14 +1138,38 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             if (pl.bnd_off0.size() != nt) { pl.bnd_off0.resize(nt); for (size_t t = 0; t < nt; ++t) pl.bnd_off0[t] = pl.tasks[t].bnd_off; }
             if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
             int rc2 = PRALINE_OK;
+            // plans that need several chunks: half the budget per chunk, two scratch sets, alternating streams
+            size_t chunk_budget = budget;
+            {
+                int64_t all = 0;
+                for (size_t t = 0; t < nt; ++t)
+                    all += (int64_t)pl.tasks[t].nstrips * ((pl.tasks[t].max_l1 + 8) / 32 + 1) * (3 * 16 * 64) * 4 +
+                           (int64_t)(pl.tasks[t].nstrips + 1) * (pl.tasks[t].max_l1 + PRALINE_TB2_PAD_ROWS) * 32 * 16;
+                if ((size_t)all > budget) chunk_budget = budget / 2;
+            }
+            int chunk_no = 0;
+            bool forked = false;
             while (t0 < nt && rc2 == PRALINE_OK) {
+                const int set = chunk_no & 1;
+                hipStream_t cs = set ? g_rt.stream2 : st;
+                if (set && !forked) {
+                    if (hipEventRecord(g_rt.ev_fork, st) != hipSuccess || hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0) != hipSuccess) {
+                        rc2 = fail(PRALINE_ERR_DEVICE, "stream fork failed");
+                        break;
+                    }
+                    forked = true;
+                }
+                DevBuf<char> &d_ck = set ? pl.d_tb_b : pl.d_tb;
+                DevBuf<float4> &d_bk = set ? pl.d_bnd2_b : pl.d_bnd2;
+                DevBuf<float> &d_ax = set ? pl.d_aux_b : pl.d_aux;
+                la.stream = cs;
                 size_t t1 = t0;
                 int64_t ck_e = 0, bnd_e = 0, aux_e = 0;   // floats, float4s, floats
                 while (t1 < nt) {
                     const WaveTask &wt = pl.tasks[t1];
                     const int64_t ck_add = (int64_t)wt.nstrips * ((wt.max_l1 + 8) / 32 + 1) * (3 * 16 * 64);
                     const int64_t bnd_add = (int64_t)(wt.nstrips + 1) * (wt.max_l1 + PRALINE_TB2_PAD_ROWS) * 32;
-                    if (t1 > t0 && (size_t)((ck_e + ck_add) * 4 + (bnd_e + bnd_add) * 16) > budget) break;
+                    if (t1 > t0 && (size_t)((ck_e + ck_add) * 4 + (bnd_e + bnd_add) * 16) > chunk_budget) break;
                     pl.tasks[t1].tb_off = ck_e;
                     pl.tasks[t1].bnd_off = bnd_e;
                     pl.tasks[t1].aux_off = aux_e;
@@ -1133,25 +1178,25 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                     aux_e += semiglobal ? pl.aux_elems[t1] : 0;
                     ++t1;
                 }
-                if (pl.d_tb.n < (size_t)ck_e * 4) rc2 = pl.d_tb.alloc((size_t)ck_e * 4);
-                if (rc2 == PRALINE_OK && pl.d_bnd2.n < (size_t)bnd_e) rc2 = pl.d_bnd2.alloc((size_t)bnd_e);
-                if (rc2 == PRALINE_OK && pl.d_aux.n < (size_t)std::max<int64_t>(aux_e, 1)) rc2 = pl.d_aux.alloc((size_t)std::max<int64_t>(aux_e, 1));
+                if (d_ck.n < (size_t)ck_e * 4) rc2 = d_ck.alloc((size_t)ck_e * 4);
+                if (rc2 == PRALINE_OK && d_bk.n < (size_t)bnd_e) rc2 = d_bk.alloc((size_t)bnd_e);
+                if (rc2 == PRALINE_OK && d_ax.n < (size_t)std::max<int64_t>(aux_e, 1)) rc2 = d_ax.alloc((size_t)std::max<int64_t>(aux_e, 1));
                 if (rc2 != PRALINE_OK) break;
-                hipError_t e = hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, st);
+                hipError_t e = hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, cs);
                 if (e != hipSuccess) { rc2 = fail(PRALINE_ERR_DEVICE, "task upload: %s", hipGetErrorString(e)); break; }
                 la.tasks = pl.d_tasks.p + t0;
                 la.lane_one = pl.d_lane_one.p + t0 * 32;
                 la.lane_pair = pl.d_lane_pair.p + t0 * 32;
-                la.tb = (uint4 *)pl.d_tb.p;
-                la.bnd = pl.d_bnd2.p;
-                la.aux = pl.d_aux.p;
+                la.tb = (uint4 *)d_ck.p;
+                la.bnd = d_bk.p;
+                la.aux = d_ax.p;
                 la.n_tasks = (unsigned)(t1 - t0);
                 rc2 = praline_launch_tb2_forward(la, a16, a.nr16, tb_nterm, local, pl.has_rects);
                 if (rc2 != PRALINE_OK) { rc2 = fail(rc2, "no two-pass forward instance for nr=%d nterm=%d", a.nr16, tb_nterm); break; }
                 if (semiglobal) {
                     const int64_t lanes = (int64_t)(t1 - t0) * 32;
-                    hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar, pl.d_tasks.p,
-                                       pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, pl.d_aux.p, pl.d_end_cells.p, la.scores,
+                    hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, cs, la.ar, pl.d_tasks.p,
+                                       pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, d_ax.p, pl.d_end_cells.p, la.scores,
                                        la.rp, (int32_t)t0, (int32_t)t1, 1);
                 }
                 Trace2Args ta;
@@ -1163,7 +1208,11 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                 if (rc2 != PRALINE_OK) { rc2 = fail(rc2, "no two-pass backward instance for nr=%d nterm=%d", a.nr16, tb_nterm); break; }
                 if (hipGetLastError() != hipSuccess) { rc2 = fail(PRALINE_ERR_DEVICE, "two-pass launch failed"); break; }
                 t0 = t1;
+                ++chunk_no;
             }
+            la.stream = st;
+            if (forked && (hipEventRecord(g_rt.ev_join, g_rt.stream2) != hipSuccess || hipStreamWaitEvent(st, g_rt.ev_join, 0) != hipSuccess))
+                rc2 = fail(PRALINE_ERR_DEVICE, "stream join failed");
             // the single pass and chain mode address the plan's shared boundary buffer through the scheduler's offsets
             for (size_t t = 0; t < nt; ++t) pl.tasks[t].bnd_off = pl.bnd_off0[t];
             if (rc2 != PRALINE_OK) return rc2;
@@ -1172,27 +1221,47 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             return PRALINE_OK;
         }
     }
+    // plans that need several chunks: half the budget per chunk, two scratch sets, alternating streams (the traceback
+    // and the tail of chunk k overlap the fill of chunk k + 1)
+    size_t chunk_budget = budget;
+    {
+        int64_t all = 0;
+        for (size_t t = 0; t < nt; ++t) all += pl.tb_elems[t] * (int64_t)tb_elem_bytes;
+        if ((size_t)all > budget) chunk_budget = budget / 2;
+    }
+    int chunk_no = 0;
+    bool forked = false;
     while (t0 < nt) {
+        const int set = chunk_no & 1;
+        hipStream_t cs = set ? g_rt.stream2 : st;
+        if (set && !forked) {
+            HIPCHK(hipEventRecord(g_rt.ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0));
+            forked = true;
+        }
+        DevBuf<char> &d_tbs = set ? pl.d_tb_b : pl.d_tb;
+        DevBuf<float> &d_ax = set ? pl.d_aux_b : pl.d_aux;
+        la.stream = cs;
         size_t t1 = t0;
         int64_t tb_e = 0, aux_e = 0;
         while (t1 < nt) {
             const int64_t add = pl.tb_elems[t1];
-            if (t1 > t0 && (size_t)(tb_e + add) * tb_elem_bytes > budget) break;
+            if (t1 > t0 && (size_t)(tb_e + add) * tb_elem_bytes > chunk_budget) break;
             pl.tasks[t1].tb_off = tb_e;
             pl.tasks[t1].aux_off = aux_e;
             tb_e += add;
             aux_e += semiglobal ? pl.aux_elems[t1] : 0;
             ++t1;
         }
-        if (pl.d_tb.n < (size_t)tb_e * tb_elem_bytes) RC(pl.d_tb.alloc((size_t)tb_e * tb_elem_bytes));
-        if (pl.d_aux.n < (size_t)std::max<int64_t>(aux_e, 1)) RC(pl.d_aux.alloc((size_t)std::max<int64_t>(aux_e, 1)));
+        if (d_tbs.n < (size_t)tb_e * tb_elem_bytes) RC(d_tbs.alloc((size_t)tb_e * tb_elem_bytes));
+        if (d_ax.n < (size_t)std::max<int64_t>(aux_e, 1)) RC(d_ax.alloc((size_t)std::max<int64_t>(aux_e, 1)));
         if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
-        HIPCHK(hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, cs));
         la.tasks = pl.d_tasks.p + t0;
         la.lane_one = pl.d_lane_one.p + t0 * lanes_per_task;
         la.lane_pair = pl.d_lane_pair.p + t0 * lanes_per_task;
-        la.tb = (uint4 *)pl.d_tb.p;
-        la.aux = pl.d_aux.p;
+        la.tb = (uint4 *)d_tbs.p;
+        la.aux = d_ax.p;
         la.n_tasks = (unsigned)(t1 - t0);
         // Chain mode for small plans (single alignments, the merge steps of the progressive MSA): one wave per
         // (task, strip), pipelined across workgroups (dp_split16_tb.hip.h); the plan must be one chunk.
@@ -1244,6 +1313,12 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         HIPCHK(hipGetLastError());
         RC(launch_traceback(pl, la, t0, t1, mode));
         t0 = t1;
+        ++chunk_no;
+    }
+    la.stream = st;
+    if (forked) {
+        HIPCHK(hipEventRecord(g_rt.ev_join, g_rt.stream2));
+        HIPCHK(hipStreamWaitEvent(st, g_rt.ev_join, 0));
     }
     HIPCHK(hipEventRecord(pl.ev1, st));
     return PRALINE_OK;
@@ -1414,6 +1489,40 @@ extern "C" int praline_arena_append_merged(praline_arena *arena, praline_plan *p
     }
     *new_index = (int32_t)idx;
     *new_len = cols;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_mask_path_bounds(praline_plan *plan)
+{
+    if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
+    if (!plan->want_paths || plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "the plan has no paths (want_paths + praline_plan_run first)");
+    if (plan->ref) return fail(PRALINE_ERR_UNSUPPORTED, "reference-order plans take their rectangles at creation");
+    if (plan->has_rects && plan->slot_rects < 0)
+        return fail(PRALINE_ERR_UNSUPPORTED, "the plan was created with its own rectangle lists");
+    if (plan->n_pairs == 0) return PRALINE_OK;
+    hipStream_t st = g_rt.stream;
+    if (plan->slot_rects < 0) {
+        // fixed slots: PRALINE_MAX_RECTS per pair, all empty to start with
+        std::vector<int32_t> ro((size_t)plan->n_pairs + 1);
+        for (int64_t p = 0; p <= plan->n_pairs; ++p) ro[(size_t)p] = (int32_t)(p * PRALINE_MAX_RECTS);
+        RC(plan->d_rect_off.upload(ro, st));
+        RC(plan->d_rects.alloc((size_t)plan->n_pairs * PRALINE_MAX_RECTS * 4));
+        const int32_t empty[4] = {1 << 30, -1, 1 << 30, -1};
+        std::vector<int32_t> rv((size_t)plan->n_pairs * PRALINE_MAX_RECTS * 4);
+        for (size_t i = 0; i < rv.size(); ++i) rv[i] = empty[i & 3];
+        RC(plan->d_rects.upload(rv.data(), rv.size(), st));
+        HIPCHK(hipStreamSynchronize(st));
+        plan->slot_rects = 0;
+    }
+    if (plan->slot_rects >= PRALINE_MAX_RECTS)
+        return fail(PRALINE_ERR_UNSUPPORTED, "more than %d rectangles per pair: create a plan with explicit rectangle lists", PRALINE_MAX_RECTS);
+    const int64_t blocks = (plan->n_pairs + 255) / 256;
+    hipLaunchKernelGGL(k_path_bounds_to_rects, dim3((unsigned)blocks), dim3(256), 0, st, plan->d_paths.p, plan->d_path_start.p,
+                       plan->d_path_rows.p, plan->n_pairs, plan->slot_rects, plan->d_rects.p);
+    HIPCHK(hipGetLastError());
+    plan->slot_rects += 1;
+    plan->has_rects = true;
+    plan->mask_kind = 1;
     return PRALINE_OK;
 }
 

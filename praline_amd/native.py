@@ -77,6 +77,7 @@ def lib():
     L.praline_plan_add_counts.argtypes = [vp, ctypes.c_int, f32, ctypes.c_int]
     L.praline_arena_counts_read.argtypes = [vp, vp]
     L.praline_plan_path_bounds.argtypes = [vp, vp]
+    L.praline_plan_mask_path_bounds.argtypes = [vp]
     for name in ("praline_arena_counts_reset", "praline_plan_add_counts", "praline_arena_counts_read",
                  "praline_plan_path_bounds"):
         getattr(L, name).restype = ctypes.c_int
@@ -390,6 +391,11 @@ class Plan(object):
         (praline_plan_add_counts): compress_path + extend_path_local + merge + get_frequencies."""
         _check(lib().praline_plan_add_counts(self._h, 0 if threshold is None else 1,
                                              0.0 if threshold is None else float(threshold), 1 if local else 0))
+
+    def mask_path_bounds(self):
+        """Add every pair's current path bounding box to its zero rectangles ON THE DEVICE (the next Waterman-Eggert
+        iteration runs on this same plan; praline_plan_mask_path_bounds)."""
+        _check(lib().praline_plan_mask_path_bounds(self._h))
 
     def path_bounds(self):
         """int32 [n, 4]: (y0, y1, x0, x1) of every path - the next Waterman-Eggert mask rectangle."""
