@@ -523,15 +523,17 @@ def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_seri
     profiles = [_track_profile(t) for t in tracks]
     lens = np.array([len(t.values) for t in tracks], dtype=np.int64)
     row_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
-    ii, jj = np.divmod(np.arange(n * n, dtype=np.int64), n)      # every ordered pair (master i, slave j != i), i outer
-    keep = ii != jj
+    # every ordered pair (master i, slave j != i), i outer, j ascending - for this rank's masters
+    masters = np.arange(n, dtype=np.int32)
     iterations = waterman_eggert_iterations if mode == "local" else 1
     if world > 1:
         from . import allpairs
-        mine = np.zeros(n, dtype=bool)
-        mine[allpairs.shard_masters(lens, world)[rank]] = True
-        keep &= mine[ii]
-    pairs = np.stack([ii[keep], jj[keep]], axis=1).astype(np.int32)
+        masters = allpairs.shard_masters(lens, world)[rank].astype(np.int32)
+    pairs = np.empty((len(masters) * max(n - 1, 0), 2), dtype=np.int32)
+    if n > 1:
+        pairs[:, 0] = np.repeat(masters, n - 1)
+        slave = np.tile(np.arange(n - 1, dtype=np.int32), len(masters))
+        pairs[:, 1] = slave + (slave >= pairs[:, 0])          # skip j == i
     counts = _preprofile_counts_exchange(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations,
                                          world, group).astype(int)
     out = []

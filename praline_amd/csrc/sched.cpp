@@ -32,21 +32,32 @@ HalfTask empty_half(int32_t two)
 // step 1: group by sequence two, sort by len(one) descending, cut into 32-lane half tasks
 std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs)
 {
-    // order = pair indices by (sequence two ascending, length of sequence one descending, index ascending): a counting
-    // sort into the groups of equal sequence two (ascending index inside a group), then a stable sort by length per
-    // group - one comparison sort over the whole list cost 15 of the 19 ms of a 261 632-pair plan
+    // order = pair indices by (sequence two ascending, length of sequence one descending, index ascending): two stable
+    // counting sorts, least significant key first - by length (descending), then by sequence two.  (A comparison sort of
+    // the whole list cost 15 of the 19 ms of a 261 632-pair plan, per-group std::stable_sort still 40 of the 98 ms of
+    // C3's 1 047 552 pairs; this is linear.)
     std::vector<int64_t> order((size_t)n_pairs);
     {
-        int32_t max_two = -1;
-        for (int64_t i = 0; i < n_pairs; ++i) max_two = std::max(max_two, pairs[2 * i + 1]);
+        int32_t max_two = -1, max_len = 0;
+        for (int64_t i = 0; i < n_pairs; ++i) {
+            max_two = std::max(max_two, pairs[2 * i + 1]);
+            max_len = std::max(max_len, lens[pairs[2 * i]]);
+        }
+        std::vector<int32_t> by_len((size_t)n_pairs);
+        {
+            // bucket b = max_len - len: longer first
+            std::vector<int64_t> start((size_t)max_len + 2, 0);
+            for (int64_t i = 0; i < n_pairs; ++i) ++start[(size_t)(max_len - lens[pairs[2 * i]]) + 1];
+            for (size_t t = 1; t < start.size(); ++t) start[t] += start[t - 1];
+            for (int64_t i = 0; i < n_pairs; ++i) by_len[(size_t)start[(size_t)(max_len - lens[pairs[2 * i]])]++] = (int32_t)i;
+        }
         std::vector<int64_t> start((size_t)max_two + 2, 0);
         for (int64_t i = 0; i < n_pairs; ++i) ++start[(size_t)pairs[2 * i + 1] + 1];
         for (size_t t = 1; t < start.size(); ++t) start[t] += start[t - 1];
-        std::vector<int64_t> fill(start.begin(), start.end() - 1);
-        for (int64_t i = 0; i < n_pairs; ++i) order[(size_t)fill[(size_t)pairs[2 * i + 1]]++] = i;
-        for (size_t t = 0; t + 1 < start.size(); ++t)
-            std::stable_sort(order.begin() + start[t], order.begin() + start[t + 1],
-                             [&](int64_t x, int64_t y) { return lens[pairs[2 * x]] > lens[pairs[2 * y]]; });
+        for (int64_t q = 0; q < n_pairs; ++q) {
+            const int64_t i = by_len[(size_t)q];
+            order[(size_t)start[(size_t)pairs[2 * i + 1]]++] = i;
+        }
     }
     std::vector<HalfTask> halves;
     for (int64_t i = 0; i < n_pairs;) {
@@ -61,13 +72,20 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
         }
         halves.push_back(h);
     }
-    // longest work first; equal-shaped halves end up adjacent (paired into one wave when TP = 2)
-    std::stable_sort(halves.begin(), halves.end(), [&](const HalfTask &x, const HalfTask &y) {
+    // longest work first; equal-shaped halves end up adjacent (paired into one wave when TP = 2).  Sort indices, not
+    // the 264-byte structs.
+    std::vector<int32_t> idx(halves.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
+        const HalfTask &x = halves[(size_t)a], &y = halves[(size_t)b];
         const int sx = (lens[x.two] + 31) / 32, sy = (lens[y.two] + 31) / 32;
         if (sx != sy) return sx > sy;
         return x.max_l1 > y.max_l1;
     });
-    return halves;
+    std::vector<HalfTask> sorted;
+    sorted.reserve(halves.size());
+    for (int32_t i : idx) sorted.push_back(halves[(size_t)i]);
+    return sorted;
 }
 
 // step 2: XCD-aware placement.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with a
