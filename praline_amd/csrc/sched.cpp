@@ -162,46 +162,87 @@ std::vector<WgDesc> share_waves(const std::vector<WaveTask> &tasks, const SchedO
     int64_t lo = 1, hi = cand[0].cost;  // smallest c* whose workgroups fit
     while (lo < hi) {
         const int64_t mid = (lo + hi) / 2;
-        if (slots_for(mid) <= opt.wave_slots) hi = mid; else lo = mid + 1;
+        if (slots_for(mid) <= opt.wave_slots - (opt.wg_xcd ? 48 : 0)) hi = mid; else lo = mid + 1;   // (per-XCD rounding of the workgroups)
     }
-    std::vector<const Cand *> by_w[5];
-    for (const Cand &c : cand) by_w[waves_for(c, lo)].push_back(&c);
-    if (by_w[2].empty() && by_w[4].empty()) return out;
-
+    {
+        bool any = false;
+        for (const Cand &c : cand) any = any || waves_for(c, lo) > 1;
+        if (!any) return out;
+    }
     struct Built { int64_t cost; WgDesc d; };
-    std::vector<Built> built;
     auto blank = [](int share) { WgDesc d; d.task[0] = d.task[1] = d.task[2] = d.task[3] = -1; d.share = share; d.barriers = 0; d.pad[0] = d.pad[1] = 0; return d; };
-    for (const Cand *c : by_w[4]) {
-        Built b; b.cost = wave_cost(*c, 4); b.d = blank(4);
-        b.d.task[0] = c->task; b.d.barriers = barriers_of(*c, 4);
-        built.push_back(b);
+    // workgroups of one set of candidates (cost-descending): share 4 alone, share 2 in pairs, singles in fours
+    auto build = [&](const std::vector<const Cand *> &set) {
+        std::vector<const Cand *> by_w[5];
+        for (const Cand *c : set) by_w[waves_for(*c, lo)].push_back(c);
+        std::vector<Built> built;
+        for (const Cand *c : by_w[4]) {
+            Built b; b.cost = wave_cost(*c, 4); b.d = blank(4);
+            b.d.task[0] = c->task; b.d.barriers = barriers_of(*c, 4);
+            built.push_back(b);
+        }
+        for (size_t i = 0; i < by_w[2].size(); i += 2) {
+            const Cand *c0 = by_w[2][i], *c1 = i + 1 < by_w[2].size() ? by_w[2][i + 1] : nullptr;
+            Built b; b.cost = wave_cost(*c0, 2); b.d = blank(2);
+            b.d.task[0] = c0->task; b.d.task[2] = c1 ? c1->task : -1;
+            b.d.barriers = std::max(barriers_of(*c0, 2), c1 ? barriers_of(*c1, 2) : 0);
+            built.push_back(b);
+        }
+        for (size_t i = 0; i < by_w[1].size(); i += 4) {
+            Built b; b.cost = by_w[1][i]->cost; b.d = blank(1);
+            for (int q = 0; q < 4; ++q) b.d.task[q] = i + q < by_w[1].size() ? by_w[1][i + q]->task : -1;
+            built.push_back(b);
+        }
+        std::stable_sort(built.begin(), built.end(), [](const Built &x, const Built &y) { return x.cost > y.cost; });
+        return built;
+    };
+    // Launch order.  A CU holds two of these workgroups and the dispatcher deals the blocks round-robin - block b to XCD
+    // b % 8 and, inside the XCD, to CU (b / 8) % 32 - so blocks b and b + 256 end up on the same CU (same SIMDs;
+    // confirmed with the trace build): the longest go first in descending order, then the SHORTEST in ascending order
+    // (the longest shares its SIMDs with the shortest), then whatever is left in the middle.
+    auto snake = [&](const std::vector<Built> &built, size_t round) {
+        std::vector<WgDesc> order;
+        const size_t nb = built.size();
+        if (opt.snake && nb > round) {
+            const size_t tail = std::min<size_t>(round, nb - round);
+            for (size_t i = 0; i < round; ++i) order.push_back(built[i].d);
+            for (size_t i = 0; i < tail; ++i) order.push_back(built[nb - 1 - i].d);
+            for (size_t i = round; i < nb - tail; ++i) order.push_back(built[i].d);
+        } else {
+            for (const Built &b : built) order.push_back(b.d);
+        }
+        return order;
+    };
+    if (!opt.wg_xcd) {
+        std::vector<const Cand *> all;
+        for (const Cand &c : cand) all.push_back(&c);
+        return snake(build(all), 256);
     }
-    for (size_t i = 0; i < by_w[2].size(); i += 2) {
-        const Cand *c0 = by_w[2][i], *c1 = i + 1 < by_w[2].size() ? by_w[2][i + 1] : nullptr;
-        Built b; b.cost = wave_cost(*c0, 2); b.d = blank(2);
-        b.d.task[0] = c0->task; b.d.task[2] = c1 ? c1->task : -1;
-        b.d.barriers = std::max(barriers_of(*c0, 2), c1 ? barriers_of(*c1, 2) : 0);
-        built.push_back(b);
+    // XCD-aware: every XCD has its own 4 MB L2, and all these workgroups are resident at once, so WHERE a task runs
+    // decides whether the operand rows it streams are already in that L2.  Tasks of neighbouring sequences two have
+    // nearly the same partners (the all-pairs stage: {i < j}), so the sequences two are cut into eight contiguous runs
+    // of equal cost, one per XCD; each XCD's workgroups are formed and snake-ordered on their own and the eight lists
+    // are interleaved (launch index 8 q + x runs on XCD x).  Placement only affects speed, never results.
+    int32_t max_two = 0;
+    for (const Cand &c : cand) max_two = std::max(max_two, tasks[(size_t)c.task].two[0]);
+    std::vector<int64_t> col_cost((size_t)max_two + 1, 0);
+    int64_t total = 0;
+    for (const Cand &c : cand) { col_cost[(size_t)tasks[(size_t)c.task].two[0]] += c.cost; total += c.cost; }
+    std::vector<int> col_xcd((size_t)max_two + 1, 0);
+    {
+        int64_t run = 0;
+        for (size_t t = 0; t < col_cost.size(); ++t) {
+            col_xcd[t] = (int)std::min<int64_t>(7, (run + col_cost[t] / 2) * 8 / std::max<int64_t>(total, 1));
+            run += col_cost[t];
+        }
     }
-    for (size_t i = 0; i < by_w[1].size(); i += 4) {
-        Built b; b.cost = by_w[1][i]->cost; b.d = blank(1);
-        for (int q = 0; q < 4; ++q) b.d.task[q] = i + q < by_w[1].size() ? by_w[1][i + q]->task : -1;
-        built.push_back(b);
-    }
-    std::stable_sort(built.begin(), built.end(), [](const Built &x, const Built &y) { return x.cost > y.cost; });
-    // Launch order.  A CU holds two of these workgroups and the dispatcher deals them round-robin, so blocks b and
-    // b + 256 end up on the same CU (same SIMDs; confirmed with the trace build): the 256 longest go first in
-    // descending order, then the SHORTEST 256 in ascending order (the longest shares its SIMDs with the
-    // shortest), then whatever is left in the middle.
-    const size_t nb = built.size();
-    if (opt.snake && nb > 256) {
-        const size_t tail = std::min<size_t>(256, nb - 256);
-        for (size_t i = 0; i < 256; ++i) out.push_back(built[i].d);
-        for (size_t i = 0; i < tail; ++i) out.push_back(built[nb - 1 - i].d);
-        for (size_t i = 256; i < nb - tail; ++i) out.push_back(built[i].d);
-    } else {
-        for (const Built &b : built) out.push_back(b.d);
-    }
+    std::vector<const Cand *> per_xcd[8];
+    for (const Cand &c : cand) per_xcd[col_xcd[(size_t)tasks[(size_t)c.task].two[0]]].push_back(&c);   // (cand is cost-descending)
+    std::vector<WgDesc> lists[8];
+    size_t longest = 0;
+    for (int x = 0; x < 8; ++x) { lists[x] = snake(build(per_xcd[x]), 32); longest = std::max(longest, lists[x].size()); }
+    for (size_t q = 0; q < longest; ++q)
+        for (int x = 0; x < 8; ++x) out.push_back(q < lists[x].size() ? lists[x][q] : blank(1));
     return out;
 }
 

@@ -13,6 +13,7 @@ struct SchedOptions {
     bool shared_waves = true;     // build the four-wave workgroup lists
     int64_t wave_slots = 2048;    // resident wave slots assumed by the share search (256 CUs x 4 SIMDs x 2)
     bool snake = true;            // launch order: longest workgroups share a CU with the shortest
+    bool wg_xcd = true;           // shared-wave workgroups: sequences two in eight contiguous runs, one per XCD
 };
 
 struct Schedule {

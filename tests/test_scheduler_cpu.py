@@ -110,7 +110,12 @@ def test_shared_wave_descriptors(sched):
             assert len(wf) == 0 and ns > 0
             continue
         assert len(wf) > 0 and ns == 0
-        assert 4 * len(wf) <= slots                                          # every workgroup resident
+        busy = [(d[:4] >= 0).any() for d in wf]                              # (idle padding workgroups exit at once)
+        assert 4 * sum(busy) <= slots                                        # every working workgroup resident
+        for q in range(0, len(wf), 8):                                       # padding only at the end of an XCD's list
+            for x in range(8):
+                if not busy[q + x]:
+                    assert not any(busy[q + x::8])
         leaders = []
         for task4, share, nbar in zip(wf[:, :4], wf[:, 4], wf[:, 5]):
             assert share in (1, 2, 4)
