@@ -243,6 +243,12 @@ int praline_plan_mask_path_bounds(praline_plan *plan);
 int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float gap_extend,
                          int64_t n_pairs, const int32_t *pairs, float *scores);
 
+/* Guide-tree clustering (host code, no device needed): the merge order of the agglomerative clustering of
+ * praline/util/cluster.py:27-114 on an n x n float64 distance matrix (row-major; (i, j) and (j, i) are read separately
+ * as in the reference) - repeatedly the first minimum of the cluster linkage table in cluster-id order, the merged
+ * cluster keeping the id of the first.  linkage: 0 single, 1 complete, 2 average.  order: int32 [n - 1][2]. */
+int praline_merge_order(int64_t n, const double *dist, int linkage, int32_t *order);
+
 /* Diagnostics / audits.  praline_plan_match_kind: 0 fp32 MFMA chain, 1 f16 split, 2 reference order.
  * praline_arena_match_scores writes the dense match-score matrix
  * m (float32 [L1][L2], host) of the arena pair (one, two) exactly as the kernels evaluate it:

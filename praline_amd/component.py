@@ -564,6 +564,9 @@ def _preprofile_counts_exchange(profiles, S, pairs, mode, gap_open, gap_extend, 
 
 
 # ---- callers: guide tree (all-pairs distance stage) ----------------------------------------------
+native_clustering = True   # merge_order of 64 clusters and more runs in libpraline_dp.so's host code
+
+
 def merge_order(distance_matrix, linkage):
     """Agglomerative clustering merge order (praline/util/cluster.py:27-114): repeatedly merge the two
     clusters with the smallest linkage distance (first minimum in cluster-id order, both (i, j) and (j, i)
@@ -585,6 +588,10 @@ def merge_order(distance_matrix, linkage):
         raise KeyError(linkage)
     if n < 2:
         return []
+    if n >= 64 and native_clustering:
+        # the same algorithm in the library's host code (csrc/cluster.cpp): N = 4096 in tens of milliseconds instead
+        # of 2.9 s of numpy calls; tests/test_host_logic.py compares the two
+        return native.merge_order(d, linkage)
     link = d.copy()
     np.fill_diagonal(link, np.inf)
     sums, size = (d, np.ones(n)) if linkage == 'average' else (None, None)

@@ -97,6 +97,7 @@ def lib():
     L.praline_arena_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                      ctypes.POINTER(i32)]
     L.praline_plan_match_kind.argtypes = [vp]
+    L.praline_merge_order.argtypes = [i64, vp, i32, vp]
     L.praline_plan_kernel_name.argtypes = [vp, ctypes.c_char_p, i64]
     if L.praline_abi_version() != 1:
         raise NativeError(ERR_ARG, "ABI version mismatch")
@@ -139,6 +140,17 @@ def set_match_mode(kind):
 
 def get_match_mode():
     return {v: k for k, v in MATCH_MODES.items()}[int(lib().praline_get_match_mode())]
+
+
+def merge_order(dist, linkage):
+    """Clustering merge order on the host side of the library (praline_merge_order, csrc/cluster.cpp)."""
+    d = np.ascontiguousarray(dist, dtype=np.float64)
+    n = d.shape[0]
+    out = np.zeros((max(n - 1, 0), 2), dtype=np.int32)
+    rc = lib().praline_merge_order(n, d.ctypes.data, {'single': 0, 'complete': 1, 'average': 2}[linkage], out.ctypes.data)
+    if rc != OK:
+        raise NativeError(rc, "praline_merge_order: bad arguments")
+    return [tuple(int(v) for v in row) for row in out]
 
 
 def pool_trim():

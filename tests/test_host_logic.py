@@ -400,3 +400,30 @@ def test_entry_point_metadata_registers_the_components(tmp_path):
             "assert idx.resolve('praline.component.PairwiseAligner') is component.PairwiseAligner\n"
             "assert len(idx._types) == 9\n" % (str(tmp_path), root))
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_native_merge_order_equals_numpy_version():
+    """praline_merge_order (csrc/cluster.cpp, host code of the library) against component.merge_order's numpy statement
+    of the same incremental algorithm: every linkage, tie-heavy integer distances (integer scoring), float distances,
+    asymmetric matrices; and the guide-tree golden of the real reference."""
+    from praline_amd import native
+    rng = np.random.default_rng(5)
+    saved = comp.native_clustering
+    try:
+        for n in (2, 3, 17, 64, 130, 257):
+            for kind in ("ties", "float", "asym"):
+                m = rng.integers(0, 9, (n, n)).astype(np.float64) if kind == "ties" else rng.random((n, n)) * 100
+                if kind != "asym":
+                    m = m + m.T
+                np.fill_diagonal(m, 0)
+                m = m.astype(np.float32)        # the guide tree hands over float32 distances (tree.py:147)
+                for linkage in ("single", "complete", "average"):
+                    comp.native_clustering = False
+                    want = comp.merge_order(m, linkage)
+                    assert native.merge_order(m, linkage) == want, (n, kind, linkage)
+                    comp.native_clustering = True
+                    assert comp.merge_order(m, linkage) == want
+    finally:
+        comp.native_clustering = saved
+    d = load_golden("profile_profile.npz")
+    assert native.merge_order(d["dist"], "average") == [tuple(x) for x in d["merge_order"]]
