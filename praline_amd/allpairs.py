@@ -83,11 +83,24 @@ def shard_masters(lens, world):
     return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world)]
 
 
+def _require_torch_gpu():
+    """torch must have been imported BEFORE libpraline_dp.so was loaded (it ships its own HIP runtime; loaded second, it
+    reports no GPU): fail with that explanation rather than with torch's."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("torch sees no GPU - import torch before praline_amd.native loads libpraline_dp.so "
+                           "(torch.distributed programs do: the process group comes first)")
+    return torch
+
+
 def _group_device(group):
     """Tensors of a collective live where the group's backend wants them: cuda for nccl (= RCCL), cpu for gloo."""
     import torch
     import torch.distributed as dist
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    if dist.get_backend(group) != "nccl":
+        return torch.device("cpu")
+    _require_torch_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 def all_gather_scores(local, shards, rank, world, group=None):
@@ -133,7 +146,7 @@ def scores_to_distance(n, pairs, scores):
 def device_scorer(profiles, score_matrix, mode, gap_open, gap_extend):
     """The product scorer: align a slice of the pair list on this rank's GPU (scores stay in HBM).
     Returns a function pairs -> torch.cuda.FloatTensor."""
-    import torch
+    torch = _require_torch_gpu()
     from . import native
 
     arena = native.Arena(profiles, score_matrix)

@@ -14,6 +14,14 @@ MODES = ["global", "local", "semiglobal_both", "semiglobal_one", "semiglobal_two
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Load order matters where torch and libpraline_dp.so share a process: torch brings its own HIP runtime, and
+    # torch.cuda.is_available() turns False when another copy (the system one libpraline_dp.so links) was loaded first.
+    # The multi-GPU tests use torch, so it goes first here - as in bench.py and in any torch.distributed program, where
+    # the process group exists before the library is touched.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

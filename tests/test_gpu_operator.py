@@ -458,3 +458,42 @@ def test_resident_msa_larger_set_equals_host_path(env):
     out_h = run_one(env["serial"], comp.AdHocMultipleSequenceAligner, sequences=seqs2[:10], track_id_sets=tracks, score_matrices=mats)
     out_d = run_one(env["batch"], comp.AdHocMultipleSequenceAligner, sequences=seqs2[:10], track_id_sets=tracks, score_matrices=mats)
     assert np.array_equal(np.asarray(out_h['alignment'].path), np.asarray(out_d['alignment'].path))
+
+
+def test_preprofile_counts_through_rccl_in_place(env, seqs):
+    """The multi-GPU branch of build_preprofiles on hardware: the counts are accumulated straight into a torch-owned
+    device tensor (praline_arena_counts_bind) and all-reduced in place over RCCL.  One process owns one GPU here, so the
+    group has a single rank and the all-reduce is the identity: the tracks must equal the single-rank call's (the
+    sharding itself is covered by the gloo world-2/3 tests)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    torch.cuda.set_device(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from praline_amd import allpairs
+        want = comp.build_preprofiles(seqs, ct.TRACK_ID_INPUT, env["blosum"], mode="local", waterman_eggert_iterations=2)
+        profiles = [comp._track_profile(s.get_track(ct.TRACK_ID_INPUT)) for s in seqs]
+        S = np.ascontiguousarray(env["blosum"].matrix, dtype=np.float32)
+        n = len(seqs)
+        pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32)
+        counts = comp._preprofile_counts_exchange(profiles, S, pairs, "local", -11.0, -1.0, None, 2, world=2, group=None)
+        off = 0
+        for i, s in enumerate(seqs):
+            L = len(s)
+            c = counts[off:off + L].astype(int).copy()
+            c[np.arange(L), np.asarray(s.get_track(ct.TRACK_ID_INPUT).values)] += 1
+            assert np.array_equal(c, np.asarray(want[i].counts)), i
+            off += L
+        # and the score exchange helper on the same one-rank group
+        sc = allpairs.all_gather_scores(np.arange(5, dtype=np.float32), [np.arange(5)], 0, 1, None)
+        assert np.array_equal(sc, np.arange(5, dtype=np.float32))
+    finally:
+        if created:
+            dist.destroy_process_group()
