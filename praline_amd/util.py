@@ -98,11 +98,13 @@ def auto_align_mode(one, two):
     return "semiglobal_one" if len(one) > len(two) else "semiglobal_two"
 
 
-def zero_idxs_to_rectangles(zero_idxs, max_rects=4):
+def zero_idxs_to_rectangles(zero_idxs, max_rects=1024):
     """The Waterman-Eggert masks the reference builds are full rectangles appended one after the
     other, enumerated first-coordinate-major (praline/component/preprofile.py:247-255).  Parse such a
-    list back into inclusive rectangles (y0, y1, x0, x1); returns None if the list is anything else
-    (the caller then falls back to the full-mask raw path)."""
+    list back into inclusive rectangles (y0, y1, x0, x1) - any cell list decomposes into row-run
+    rectangles, the batched plans take any number of them (up to 4 in registers, more through per-row
+    column masks); returns None only beyond max_rects (the caller then falls back to the dense-mask
+    raw path)."""
     idx = np.asarray(list(zero_idxs), dtype=np.int64).reshape(-1, 2)
     rects = []
     i, n = 0, idx.shape[0]

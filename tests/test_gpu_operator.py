@@ -203,7 +203,7 @@ def test_raw_pairwise_aligner_and_arbitrary_zero_idxs(env, seqs):
                       match_score_model=ct.MatchScoreModel(a, b, m), gap_score_model_one=ct.GapScoreModel(a, d[p + "g1"]),
                       gap_score_model_two=ct.GapScoreModel(b, d[p + "g2"]), zero_idxs=zi)
         assert out['score'] == float(d[p + "score"]) and np.array_equal(np.array(out['alignment'].path), d[p + "path"]), n
-    # PairwiseAligner with a scattered (non-rectangular) mask goes through the dense-mask path
+    # PairwiseAligner with a scattered (non-rectangular) mask: 60 one-cell rectangles through the batched path
     rng = np.random.default_rng(4)
     zi = [(int(rng.integers(1, 100)), int(rng.integers(1, 100))) for _ in range(60)]
     out = run_one(env["serial"], comp.PairwiseAligner, mode="local", sequence_one=seqs[4], sequence_two=seqs[3],

@@ -179,7 +179,8 @@ def test_extend_path_semiglobal_matches_oracle():
 def test_zero_idxs_rectangles():
     zi = [(y, x) for y in range(3, 7) for x in range(10, 15)] + [(y, x) for y in range(1, 3) for x in range(2, 4)]
     assert util.zero_idxs_to_rectangles(zi) == [(3, 6, 10, 14), (1, 2, 2, 3)]
-    assert util.zero_idxs_to_rectangles([(1, 1), (3, 3), (5, 5), (7, 7), (9, 9), (11, 11)]) is None
+    assert util.zero_idxs_to_rectangles([(1, 1), (3, 3), (5, 5)]) == [(1, 1, 1, 1), (3, 3, 3, 3), (5, 5, 5, 5)]
+    assert util.zero_idxs_to_rectangles([(1, 1), (3, 3), (5, 5), (7, 7), (9, 9), (11, 11)], max_rects=4) is None
     assert util.zero_idxs_to_rectangles([]) == []
     # a parsed rectangle list always reproduces the same mask
     rng = np.random.default_rng(1)
