@@ -328,7 +328,8 @@ def main():
                             "source": ctr.get("source")} if ctr else None),
         "mfma": {"achieved": alg_flops / ksec / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                  "frac": alg_flops / ksec / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                 "dtype": "f16 hi/lo split (%d terms)" % info["f16_terms"],
+                 "dtype": {1: "f16, exact single term", 2: "f16 hi/lo split (3 terms K-packed into 4 MFMAs per step)",
+                           3: "f16 hi/lo split (3 terms, 6 MFMAs per step)"}.get(info["f16_terms"], "f16"),
                  "frac_of_fp32_mfma_peak": alg_flops / ksec / 1e12 / PEAK_F32_MFMA_TFLOPS,
                  "f16_terms": info["f16_terms"], "f16_ranges": info["f16_ranges"]},
         # what actually bounds the recurrence: VALU issue.  valu_per_step is the PMC-measured dynamic count

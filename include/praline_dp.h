@@ -258,6 +258,8 @@ int praline_merge_order(int64_t n, const double *dist, int linkage, int32_t *ord
  * kind 2 = the reference's own summation order (PRALINE_MATCH_REFERENCE plans, arenas with > 32 active symbols).
  * praline_plan_match_kind tells which of the two a plan's praline_plan_run uses. */
 int praline_arena_match_scores(praline_arena *arena, int32_t one, int32_t two, int kind, float *m);
+/* f16_terms: 1 = every operand is exactly f16-representable (single term, bit-exact), 3 = hi/lo split in three terms
+ * of f16_ranges MFMAs each, 2 = the same three terms K-packed into four MFMAs (at most 21 active symbols). */
 int praline_arena_info(const praline_arena *arena, int32_t *n_active, int32_t *mfma_steps_f32,
                        int32_t *f16_ranges, int32_t *f16_terms);
 int praline_plan_match_kind(const praline_plan *plan);

@@ -95,6 +95,33 @@ __device__ __forceinline__ bool split_f16_entry(const float *__restrict__ src, i
     return (float)lo != 0.0f || (float)hi + (float)lo != v;
 }
 
+// The K-PACKED form of the three-term split (arenas with at most 21 active symbols, NR = 2): the three partial products
+//     q_lo . p_hi  +  q_hi . p_lo  +  q_hi . p_hi          (dp_split16.hip.h)
+// are laid out one after the other along the MFMA's k axis - 3 n <= 63 of the 64 k slots of FOUR 32x32x16 MFMAs
+// instead of six (two 16-wide ranges per term, 12 of every 32 slots padding).  Measured on C2: the six MFMAs of a step
+// cost 21 % of the scores kernel (an ablation build without them: 2.22 -> 1.76 ms) although the matrix pipe is only a
+// third busy - fewer of them is the one lever left on a kernel that sits on its VALU floor.
+// Packed slot q (0..3) of half hh, element jj holds packed index kp = 16 q + 8 hh + jj: term kp / n, symbol kp % n.
+//   side 0 (A operand, Q = P . S^T): terms take lo, hi, hi;   side 1 (B operand, P): hi, lo, hi.
+__device__ __forceinline__ void split_f16_entry_packed(const float *__restrict__ src, int KP, int KS, int n_active, int side,
+                                                       int64_t idx, _Float16 *__restrict__ dst)
+{
+    const int64_t rowp = idx / 64;
+    const int rem = (int)(idx % 64);
+    const int hh = rem / 32, q = (rem / 8) % 4, jj = rem % 8;
+    const int kp = 16 * q + 8 * hh + jj;
+    _Float16 out = (_Float16)0.0f;
+    if (kp < 3 * n_active) {
+        const int term = kp / n_active, k = kp % n_active;
+        const float v = src[rowp * KP + (k & 1) * KS + (k >> 1)];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const bool want_lo = side == 0 ? term == 0 : term == 1;
+        out = want_lo ? lo : hi;
+    }
+    dst[(rowp * 2 + hh) * 32 + q * 8 + jj] = out;
+}
+
 #ifdef PRALINE_AUX_KERNELS  // non-template kernels: defined in praline_dp.hip's translation unit only
 // --------------------------------------------------------------------------------------------
 // Arena packing + the profile x matrix pre-multiply
@@ -197,7 +224,8 @@ __global__ __launch_bounds__(64) void k_prepare_rows(const float *__restrict__ r
                                                       const int32_t *__restrict__ len,
                                                       const int32_t *__restrict__ active, int n_active, int A, int KP, int KS,
                                                       int64_t rows_pad, float *__restrict__ P, float *__restrict__ Q, int NR,
-                                                      _Float16 *__restrict__ P16, _Float16 *__restrict__ Q16, int64_t block0 = 0)
+                                                      _Float16 *__restrict__ P16, _Float16 *__restrict__ Q16, int64_t block0 = 0,
+                                                      int packed = 0)
 {
     const int64_t rowp0 = ((int64_t)blockIdx.x + block0) * 32;   // block0: first 32-row block (appended sequences only)
     for (int i = threadIdx.x; i < 32 * KP; i += 64)
@@ -206,6 +234,13 @@ __global__ __launch_bounds__(64) void k_prepare_rows(const float *__restrict__ r
         premultiply_block(rowp0, c0, raw, S, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, rows_pad, Q);
     if (NR > 0) {
         __syncthreads();   // this wave's P and Q rows are visible to all its lanes
+        if (packed) {   // K-packed three-term layout (NR = 2, n_active <= 21): 64 halves per row and side
+            for (int i = threadIdx.x; i < 32 * 64; i += 64) {
+                split_f16_entry_packed(P, KP, KS, n_active, 1, rowp0 * 64 + i, P16);
+                split_f16_entry_packed(Q, KP, KS, n_active, 0, rowp0 * 64 + i, Q16);
+            }
+            return;
+        }
         const int per_row = 2 * NR * 8;
         for (int i = threadIdx.x; i < 32 * per_row; i += 64) {
             split_f16_entry(P, KP, KS, n_active, NR, rowp0 * per_row + i, P16);

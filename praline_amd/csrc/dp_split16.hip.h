@@ -241,8 +241,8 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         // order: (qlo, phi) r.., (qhi, plo) r.., then (qhi, phi) r..   [small terms first]
         const int term = (NTERM == 1) ? 2 : k / NR;
         const int r = k % NR;
-        const int ia = (term == 0) ? NR + r : r;          // A piece: lo for term 0, hi otherwise
-        const int ib = (term == 1) ? NR + r : r;          // B piece: lo for term 1, hi otherwise
+        const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);          // A piece: lo for term 0, hi otherwise
+        const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);          // B piece: lo for term 1, hi otherwise
 #if !(PRALINE_S16_ABLATE & 4)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
         if constexpr (DM) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aopH[ia]), as_half8(BPREV[ib]), acc, 0, 0, 0);
@@ -584,8 +584,8 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
             for (int k = 0; k < NTERM * NR; ++k) {
                 const int term = (NTERM == 1) ? 2 : k / NR;
                 const int r = k % NR;
-                const int ia = (term == 0) ? NR + r : r;
-                const int ib = (term == 1) ? NR + r : r;
+                const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);
+                const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(br1[ib]), accA, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -620,8 +620,8 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
             for (int k = 0; k < NTERM * NR; ++k) {
                 const int term = (NTERM == 1) ? 2 : k / NR;
                 const int r = k % NR;
-                const int ia = (term == 0) ? NR + r : r;
-                const int ib = (term == 1) ? NR + r : r;
+                const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);
+                const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(br1[ib]), accA, 0, 0, 0);
             }
             p0 = *reinterpret_cast<const float2 *>(my_bnd + BROW);      // row 1
@@ -844,8 +844,8 @@ __global__ __launch_bounds__(64) void k_scores_tile16(Arena16Dev ar, int one, in
     for (int k = 0; k < NTERM * NR; ++k) {
         const int term = (NTERM == 1) ? 2 : k / NR;
         const int r = k % NR;
-        const int ia = (term == 0) ? NR + r : r;
-        const int ib = (term == 1) ? NR + r : r;
+        const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);
+        const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(a[ia]), as_half8(b[ib]), acc, 0, 0, 0);
     }
     // D[i][jcol]: lane holds column jcol = j (row y0 + j of the DP), i = x within the strip

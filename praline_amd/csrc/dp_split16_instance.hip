@@ -46,6 +46,7 @@ int praline_launch_split16(const LaunchArgs &la, const Arena16Dev &a16, int nr, 
     else if (nr == 1 && nterm == 3) launch16<1, 3>(la, a16, local, wpb);
     else if (nr == 2 && nterm == 1) launch16<2, 1>(la, a16, local, wpb);
     else if (nr == 2 && nterm == 3) launch16<2, 3>(la, a16, local, wpb);
+    else if (nr == 2 && nterm == 2) launch16<2, 2>(la, a16, local, wpb);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }
@@ -66,6 +67,7 @@ int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int o
     else if (nr == 1 && nterm == 3) hipLaunchKernelGGL((k_scores_tile16<1, 3>), grid, dim3(64), 0, stream, a16, one, two, m);
     else if (nr == 2 && nterm == 1) hipLaunchKernelGGL((k_scores_tile16<2, 1>), grid, dim3(64), 0, stream, a16, one, two, m);
     else if (nr == 2 && nterm == 3) hipLaunchKernelGGL((k_scores_tile16<2, 3>), grid, dim3(64), 0, stream, a16, one, two, m);
+    else if (nr == 2 && nterm == 2) hipLaunchKernelGGL((k_scores_tile16<2, 2>), grid, dim3(64), 0, stream, a16, one, two, m);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }
@@ -103,6 +105,7 @@ int praline_launch_split16_tb_chain(const LaunchArgs &la, const Arena16Dev &a16,
     else if (nr == 1 && nterm == 3) launch16_tb_chain<1, 3>(la, a16, local, mask, max_strips, flags, cand, every);
     else if (nr == 2 && nterm == 1) launch16_tb_chain<2, 1>(la, a16, local, mask, max_strips, flags, cand, every);
     else if (nr == 2 && nterm == 3) launch16_tb_chain<2, 3>(la, a16, local, mask, max_strips, flags, cand, every);
+    else if (nr == 2 && nterm == 2) launch16_tb_chain<2, 2>(la, a16, local, mask, max_strips, flags, cand, every);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }
@@ -115,6 +118,7 @@ int praline_launch_split16_tb(const LaunchArgs &la, const Arena16Dev &a16, int n
     else if (nr == 1 && nterm == 3) launch16_tb<1, 3>(la, a16, local, mask, wpb);
     else if (nr == 2 && nterm == 1) launch16_tb<2, 1>(la, a16, local, mask, wpb);
     else if (nr == 2 && nterm == 3) launch16_tb<2, 3>(la, a16, local, mask, wpb);
+    else if (nr == 2 && nterm == 2) launch16_tb<2, 2>(la, a16, local, mask, wpb);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }

@@ -143,8 +143,8 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     for (int k = 0; k < NM; ++k) {
         const int term = (NTERM == 1) ? 2 : k / NR;
         const int r = k % NR;
-        const int ia = (term == 0) ? NR + r : r;
-        const int ib = (term == 1) ? NR + r : r;
+        const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);
+        const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
         if constexpr (DM) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aopH[ia]), as_half8(BOLD[ib]), acc, 0, 0, 0);
         // pin the MFMA at the START of its chunk: left alone the scheduler sinks it to the end of the step and
@@ -515,8 +515,8 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
             for (int k = 0; k < NTERM * NR; ++k) {
                 const int term = (NTERM == 1) ? 2 : k / NR;
                 const int r = k % NR;
-                const int ia = (term == 0) ? NR + r : r;
-                const int ib = (term == 1) ? NR + r : r;
+                const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);
+                const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);
                 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(b1[ib]), accA, 0, 0, 0);
             }
         }

@@ -47,6 +47,7 @@ int praline_launch_tb2_forward(const LaunchArgs &la, const Arena16Dev &a16, int 
     else if (nr == 1 && nterm == 3) launch_fwd<1, 3>(la, a16, local, mask);
     else if (nr == 2 && nterm == 1) launch_fwd<2, 1>(la, a16, local, mask);
     else if (nr == 2 && nterm == 3) launch_fwd<2, 3>(la, a16, local, mask);
+    else if (nr == 2 && nterm == 2) launch_fwd<2, 2>(la, a16, local, mask);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }
@@ -58,6 +59,7 @@ int praline_launch_tb2_backward(const LaunchArgs &la, const Arena16Dev &a16, con
     else if (nr == 1 && nterm == 3) launch_bwd<1, 3>(la, a16, ta, local, mask);
     else if (nr == 2 && nterm == 1) launch_bwd<2, 1>(la, a16, ta, local, mask);
     else if (nr == 2 && nterm == 3) launch_bwd<2, 3>(la, a16, ta, local, mask);
+    else if (nr == 2 && nterm == 2) launch_bwd<2, 2>(la, a16, ta, local, mask);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(64) void k_trace_recompute(Arena16Dev ar, const Wav
                 for (int kk = 0; kk < NTERM * NR; ++kk) {
                     const int term = (NTERM == 1) ? 2 : kk / NR;
                     const int r = kk % NR;
-                    const int ia = (term == 0) ? NR + r : r;
-                    const int ib = (term == 1) ? NR + r : r;
+                    const int ia = (NTERM == 2) ? kk : ((term == 0) ? NR + r : r);
+                    const int ib = (NTERM == 2) ? kk : ((term == 1) ? NR + r : r);
                     accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(b1[ib]), accA, 0, 0, 0);
                 }
             }

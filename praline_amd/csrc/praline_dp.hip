@@ -273,7 +273,8 @@ struct praline_arena {
     DevBuf<int32_t> d_len, d_row_off_pad, d_row_off_raw, d_seq_of_rowp, d_active;
     // f16 split operands for k_dp_split16 (matrix-pipe MFMA)
     int nr16 = 0;          // 16-wide k ranges (1 or 2); 0 = not available (> 32 active symbols)
-    int nterm16 = 3;       // 1: every operand is exactly representable in f16, 3: hi/lo split
+    int nterm16 = 3;       // 1: every operand is exactly representable in f16, 3: hi/lo split in six MFMAs per step (NR = 2),
+                           // 2: the same three terms K-packed into four MFMAs (at most 21 active symbols; dp_kernels.hip.h)
     DevBuf<char> d_P16, d_Q16;
     DevBuf<int> d_flag16;
     // one-hot arenas (ordinary sequences): active-symbol index per padded row; see k_dp_split16<.., ONEHOT>
@@ -326,7 +327,7 @@ static int arena_launch_premultiply(praline_arena *a, bool check_f16 = false)
         hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)(a->rows_pad / 32)), dim3(64), 0, g_rt.stream, a->d_raw.p, a->d_S.p,
                            a->d_seq_of_rowp.p, a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, a->d_active.p, a->n_active,
                            a->A, a->KP, a->KS, a->rows_pad, a->d_P.p, a->d_Q.p, a->nr16, (_Float16 *)a->d_P16.p,
-                           (_Float16 *)a->d_Q16.p);
+                           (_Float16 *)a->d_Q16.p, (int64_t)0, a->nterm16 == 2 ? 1 : 0);
         HIPCHK(hipGetLastError());
         return PRALINE_OK;
     }
@@ -479,6 +480,14 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         e = hipMemcpy(&flag, a->d_flag16.p, sizeof(int), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena flag: %s", hipGetErrorString(e)); }
         a->nterm16 = flag ? 3 : 1;
+        // at most 21 active symbols: the three terms fit the 64 k slots of four MFMAs (PRALINE_PACKED3=0: keep six)
+        const char *pk = getenv("PRALINE_PACKED3");
+        if (a->nterm16 == 3 && a->nr16 == 2 && 3 * a->n_active <= 63 && !(pk && pk[0] == '0')) {
+            a->nterm16 = 2;
+            rc = arena_launch_premultiply(a);   // re-split in the packed layout
+            if (rc == PRALINE_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(PRALINE_ERR_DEVICE, "arena re-split failed");
+            if (rc != PRALINE_OK) { delete a; return rc; }
+        }
     }
     *out = a;
     return PRALINE_OK;
@@ -1477,7 +1486,7 @@ extern "C" int praline_arena_append_merged(praline_arena *arena, praline_plan *p
     // a merged cluster is no plain sequence: the one-hot shortcuts of this arena end here
     a->onehot = false;
     a->all_onehot = false;
-    if (a->nr16 > 0) a->nterm16 = 3;
+    if (a->nr16 > 0 && a->nterm16 == 1) a->nterm16 = 3;   // (an exact arena keeps the standard layout; its new rows need the lo pieces)
     a->ref_ready = false;
     a->d_counts.release();
     a->counts_ext = nullptr;
@@ -1485,7 +1494,7 @@ extern "C" int praline_arena_append_merged(praline_arena *arena, praline_plan *p
         hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)(pad / 32)), dim3(64), 0, st, a->d_raw.p, a->d_S.p, a->d_seq_of_rowp.p,
                            a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, a->d_active.p, a->n_active, a->A, a->KP, a->KS,
                            a->rows_pad, a->d_P.p, a->d_Q.p, a->nr16, (_Float16 *)a->d_P16.p, (_Float16 *)a->d_Q16.p,
-                           (int64_t)(off_pad / 32));
+                           (int64_t)(off_pad / 32), a->nterm16 == 2 ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     *new_index = (int32_t)idx;

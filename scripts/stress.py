@@ -14,6 +14,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 n_cases = n_pairs_checked = 0
+t_progress = time.time()
 def dp_on_m(mode, m, rects=None):
     g1, g2 = orc.gap_arrays(m.shape[0], m.shape[1], (-11.0, -1.0))
     zero = None
@@ -92,5 +93,8 @@ while time.time() < t_end:
         n_pairs_checked += 1
     arena.close()
     n_cases += 1
+    if time.time() - t_progress > 60:      # (a silent GPU job is taken to be hung after a few minutes)
+        t_progress = time.time()
+        print("  ... %d batches, %d pairs checked" % (n_cases, n_pairs_checked), flush=True)
 nat.set_match_mode(None)
 print("stress ok: %d random batches, %d pairs checked against the oracle" % (n_cases, n_pairs_checked))
