@@ -33,6 +33,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4n __attribute__((ext_vector_type(4)));
 
 // One-hot operand table (LDS): row `sym` holds the B operand slots of a profile row with all its mass
 // on active symbol sym, [hh][r][8 halves]; row 16 NR is the all-zero row (padding rows, symbols that
@@ -175,7 +176,24 @@ __device__ __forceinline__ void stage_issue_bnd(unsigned long long curN, unsigne
 // the extra products are exact zeros (x + 0 = x), the order of the real terms is unchanged -> same bits.
 // Used in exact mode only (NTERM = 1: two MFMAs per step instead of one, +4 % on C2 one-hot); with the three-term
 // split the six dependent MFMAs per step outweigh the selects (measured: 2224 -> 2050 GCUPS on C2 float profiles).
-template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int SB = 0, bool DM = false, bool SNAPBR = false>
+// KEEP (the forward fill of the two-pass alignments-with-paths scheme on THIS kernel, see dp_trace2.hip.h): besides
+// its own (H, L) boundary hand-off the step writes what k_trace_recompute starts from -
+//   * every strip's boundary column as three states: float4 (M, U, L, 0) of the cell (yy, last column of the strip),
+//     [strip + 1][row][32 pairs] (the recurrence itself only carries H = max(M, U, L));
+//   * KEEP == 2 (the two steps in 32 in which a half is at a row yy = 32 i): the (M, U, L) states of that row,
+//     float4 [yy / 32][3][4][64] per strip (state, group of four columns, lane);
+//   * global mode: M and U of the corner cell (the end state k is the first of M, U, L that equals the score).
+// The states are the recurrence's own intermediates (M before the maximum, U and L on entry to the cell): no extra
+// arithmetic, and fl(max3(Mp, Up, Lp) + m) = max3 of the three rounded sums, so they are bit for bit the values the
+// three-state kernels carry.
+struct KeepState {
+    char *st = nullptr;       // kept boundary column being written: this lane's float4 of the row this step stores
+    f4n *ckpt = nullptr;      // this strip's checkpoint blocks (+ lane)
+    float snap_m = 0.0f, snap_u = 0.0f;
+};
+#define PRALINE_CKPT_BLOCK_F4 (3 * 4 * 64)   // float4 elements per checkpoint block
+
+template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int SB = 0, bool DM = false, bool SNAPBR = false, int KEEP = 0>
 __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                              float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
                                              const float4 (&aop)[(NTERM == 1 ? 1 : 2) * NR],
@@ -192,9 +210,11 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
                                              const char *stage_lds = nullptr,
                                              const unsigned *stage_rd = nullptr, unsigned stage_rd_bnd = 0,
                                              const unsigned (*stage_gofs)[4] = nullptr, unsigned long long *stage_cur = nullptr,
-                                             unsigned stage_lds_addr = 0, unsigned stage_gofs_n = 0, bool may_snap = true)
+                                             unsigned stage_lds_addr = 0, unsigned stage_gofs_n = 0, bool may_snap = true,
+                                             KeepState *ks = nullptr)
 {
     static_assert(!DM || BSRC == 2 || BSRC == 1, "the double-MFMA tile is wired for the staged stream and the one-hot table");
+    static_assert(KEEP == 0 || !DM, "the kept states are taken from the non-DM tile");
     constexpr bool ONEHOT = BSRC == 1;
     // bnd_pref: this step's boundary value on entry; refilled with the value 3 rows ahead.
     // BOPS: B operands of row t+1 on entry; refilled with row t+4 (3-deep rings, the caller rotates
@@ -232,6 +252,19 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     const float hd_out = Hs[16];  // H[y-1] of this lane's last column: diagonal input of the next lane / strip
     const f2 go2 = {go, go}, ge2 = {ge, ge};
     f2 hs = {Hs[0], Hs[1]};  // previous-row H left of the next column pair (read BEFORE that pair's slots are rewritten)
+    bool ck_mine = false;
+    f4n ckM, ckU, ckL;         // KEEP == 2: the states of four columns, stored once complete
+    float kM = 0.0f, kU = 0.0f, kL = 0.0f;   // KEEP: states of this lane's last column
+    if constexpr (KEEP != 0) {
+        ck_mine = yy >= 32 && (yy & 31) == 0;
+        if (!LOCAL && may_snap && have_pair && yy == L1 && last_owner) {   // the corner cell is in this row
+            float hw[16], mw[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { hw[c] = Hs[c]; mw[c] = (c & 1) ? m2[c >> 1].y : m2[c >> 1].x; }
+            ks->snap_m = select16(hw, cidx) + select16(mw, cidx);
+            ks->snap_u = select16(Uc, cidx);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- MFMAs of row t+1 on the matrix pipe, interleaved with the recurrence of this row ----
@@ -259,9 +292,28 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
             const f2 Ug = pk_add(U, ge2);
             // column 2cp
             const float H0 = max3f(M.x, U.x, lrun);
+            const float lin0 = lrun;
             lrun = __builtin_fmaxf(Mo.x, lrun + ge);      // L[y][x+1]   (cext.c:169-183,276-283)
             // column 2cp + 1
             const float H1 = max3f(M.y, U.y, lrun);
+            if constexpr (KEEP != 0) {
+                if (cp == 7) { kM = M.y; kU = U.y; kL = lrun; }
+            }
+            if constexpr (KEEP == 2) {
+                if ((cp & 1) == 0) { ckM.x = M.x; ckM.y = M.y; ckU.x = U.x; ckU.y = U.y; ckL.x = lin0; ckL.y = lrun; }
+                else {
+                    ckM.z = M.x; ckM.w = M.y; ckU.z = U.x; ckU.w = U.y; ckL.z = lin0; ckL.w = lrun;
+#ifndef PRALINE_KEEP_ABLATE
+#define PRALINE_KEEP_ABLATE 0   // timing experiments only: 1 no checkpoint stores, 2 no kept boundary columns
+#endif
+                    if (ck_mine && !(PRALINE_KEEP_ABLATE & 1)) {
+                        f4n *q = ks->ckpt + (int64_t)(yy >> 5) * PRALINE_CKPT_BLOCK_F4 + (cp >> 1) * 64;
+                        __builtin_nontemporal_store(ckM, q);
+                        __builtin_nontemporal_store(ckU, q + 4 * 64);
+                        __builtin_nontemporal_store(ckL, q + 8 * 64);
+                    }
+                }
+            }
             lrun = __builtin_fmaxf(Mo.y, lrun + ge);
             if (LOCAL) best_run = max3f(best_run, H0, H1);
             Uc[2 * cp] = __builtin_fmaxf(Mo.x, Ug.x);        // U[y+1][x]   (cext.c:152-166,247-254)
@@ -313,6 +365,13 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
 #endif
 #endif
     bnd_st += 32 * sizeof(float2);
+    if constexpr (KEEP != 0) {
+        if (h && !(PRALINE_KEEP_ABLATE & 2)) {
+            const f4n kv = {kM, kU, kL, 0.0f};
+            __builtin_nontemporal_store(kv, reinterpret_cast<f4n *>(ks->st));
+        }
+        ks->st += 32 * sizeof(float4);
+    }
     if (semiglobal && last_owner) col_run = __builtin_fmaxf(col_run, select16s(Hs, cidx));
     // may_snap (wave-uniform): this step can be some lane's last row (the task's pairs are sorted by length, so
     // for most of a strip it cannot, and a scalar branch replaces the per-lane test)
@@ -361,13 +420,18 @@ __device__ unsigned long long *praline_trace_buf = nullptr;
 // (producer and consumer are >= 2 iterations = 24 rows apart in every direction, and the per-step
 // counted vmcnt retires every store older than three steps).  share == 1: four
 // independent tasks, no barriers.
-template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int WPG = 1>
-__global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+// KEEP: the forward fill of the two-pass alignments with paths (see KeepState): kept boundary columns at
+// keep_bnd + tk.aux_off (float4 [nstrips + 1][max_l1 + PRALINE_TB2_PAD][32]), row checkpoints at ckpt + tk.tb_off
+// (floats), end cells (global: the corner and its first maximal state) to end_cells.
+template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int WPG = 1, bool KEEP = false>
+__global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ lane_one,
                                                     const int32_t *__restrict__ lane_pair, float2 *bnd,
                                                     float *__restrict__ scores, RunParams rp, int n_tasks,
-                                                    const WgDesc *__restrict__ wg = nullptr)
+                                                    const WgDesc *__restrict__ wg = nullptr, float4 *keep_bnd = nullptr,
+                                                    float *ckpt = nullptr, int32_t *__restrict__ end_cells = nullptr)
 {
+    static_assert(!KEEP || (BSRC == 2 && !LOCAL), "the kept-state forward fill runs on the staged stream (global / semiglobal recurrences)");
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
     static_assert(WPG == 1 || (WPG == 4 && BSRC == 2), "four-wave workgroups use the staged stream");
@@ -482,6 +546,17 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     if (h == 0 && rank == 0)
         for (int y = 1; y <= max_l1 + 2; ++y)
             *reinterpret_cast<float2 *>(my_bnd + (int64_t)y * BROW) = make_float2(boundary_value(y, go, ge, free_one), PRALINE_NEG_INF);
+    KeepState ks;
+    const int64_t keep_col = (int64_t)(max_l1 + PRALINE_TB2_PAD) * 32 * (int64_t)sizeof(float4);   // bytes per kept column
+    char *keep_base = nullptr;
+    if constexpr (KEEP) {
+        keep_base = reinterpret_cast<char *>(keep_bnd + tk.aux_off + j);
+        // strip 0's column: states of (y, 0) = (-inf, o[y,0,1], -inf)
+        if (h == 0 && rank == 0)
+            for (int y = 1; y <= max_l1 + 4; ++y)
+                *reinterpret_cast<float4 *>(keep_base + (int64_t)y * 32 * sizeof(float4)) =
+                    make_float4(PRALINE_NEG_INF, boundary_value(y, go, ge, free_one), PRALINE_NEG_INF, 0.0f);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
 
@@ -549,6 +624,10 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         float hd_x = PRALINE_NEG_INF, l_x = PRALINE_NEG_INF;
         float best_run = out_best;
         float col_run = out_colmax;
+        if constexpr (KEEP) {
+            ks.st = keep_base + (int64_t)(s + 1) * keep_col;   // upper half stores row yy = t - 1 (row 0: dummy)
+            ks.ckpt = reinterpret_cast<f4n *>(ckpt + tk.tb_off) + (int64_t)s * PRALINE_TB2_CKPT_BLOCKS(max_l1) * PRALINE_CKPT_BLOCK_F4 + lane;
+        }
 
         // pipeline prologue: B operands of rows 1..4, MFMAs of row 1, boundary column of rows 1..3
         float4 b0[NOP], b1[NOP], b2[NOP], b3[NOP];   // b3: one-hot table with DM (four sets: rows t .. t+3)
@@ -649,7 +728,21 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, 0u, \
                                        stage_lds, stage_rd, stage_rd_bnd, &stage_gofs, stage_cur, stage_lds_addr, stage_gofs_n, \
                                        (T) >= min_l1)
-#define PRALINE_STEP16S(T, CUR, PREV, BUSE, BFILL, PH) PRALINE_STEP16Y(T, CUR, PREV, BUSE, BFILL, PH, BUSE, false)
+#define PRALINE_STEP16K(T, CUR, PREV, BUSE, BFILL, PH, KP)                                                            \
+        split16_step<NR, NTERM, LOCAL, 2, PH, false, SNAPBR, KP>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BUSE, BFILL, b_next, b_stride, bnd_ld,  \
+                                       bnd_st, p0, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,     \
+                                       out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, 0u, \
+                                       stage_lds, stage_rd, stage_rd_bnd, &stage_gofs, stage_cur, stage_lds_addr, stage_gofs_n, \
+                                       (T) >= min_l1, &ks)
+        // KEEP: the two steps in 32 whose rows (lower half T, upper half T - 1) include a checkpoint row take the
+        // instance with the checkpoint stores (wave-uniform test)
+#define PRALINE_STEP16S(T, CUR, PREV, BUSE, BFILL, PH)                                                                \
+        do {                                                                                                          \
+            if constexpr (KEEP) {                                                                                     \
+                if ((T) >= 32 && ((T) & 31) <= 1) PRALINE_STEP16K(T, CUR, PREV, BUSE, BFILL, PH, 2);                   \
+                else PRALINE_STEP16K(T, CUR, PREV, BUSE, BFILL, PH, 1);                                               \
+            } else PRALINE_STEP16Y(T, CUR, PREV, BUSE, BFILL, PH, BUSE, false);                                       \
+        } while (0)
         // step 1: only the lower half has a row; the upper half's garbage is undone right after
         {
             float Hsave[17];
@@ -755,6 +848,7 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         }
 #undef PRALINE_STEP16
 #undef PRALINE_STEP16S
+#undef PRALINE_STEP16K
 #undef PRALINE_STEP16D
 #undef PRALINE_STEP16Y
 #undef PRALINE_STEP16X
@@ -773,6 +867,13 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
     }
 #endif
 
+    if constexpr (KEEP) {
+        // global end state: the first of (M, U, L) of the corner cell that equals its maximum (np.argmax, praline/component/align.py:428-430);
+        // only the half (and rank) that owns the corner holds a finite out_corner - the others report 0
+        float kf = 0.0f;
+        if (out_corner != PRALINE_NEG_INF) kf = (ks.snap_m == out_corner) ? 0.0f : ((ks.snap_u == out_corner) ? 1.0f : 2.0f);
+        out_best = kf;   // (not LOCAL: the slot is free; folded with max like the other results)
+    }
     float corner_all = __builtin_fmaxf(out_corner, partner_value(out_corner, h));
     float rowmax_all = __builtin_fmaxf(out_rowmax, partner_value(out_rowmax, h));
     float colmax_all = __builtin_fmaxf(out_colmax, partner_value(out_colmax, h));
@@ -802,6 +903,10 @@ __global__ __launch_bounds__(256) void k_dp_split16(Arena16Dev ar, const WaveTas
         else if (semiglobal) score = (rowmax_all > colmax_all && free_two) ? rowmax_all : colmax_all;
         else score = corner_all;
         scores[lane_pair[base + j]] = score;
+        if constexpr (KEEP) {
+            int32_t *ec = end_cells + (int64_t)lane_pair[base + j] * 4;
+            ec[0] = L1; ec[1] = L2; ec[2] = (int)best_all; ec[3] = 0;
+        }
     }
 }
 

@@ -83,7 +83,7 @@ struct TbCarry {
 // MFMAs are issued (three operand sets rotate); without DM, BOLD is BOPS itself.
 // SINK: where the per-row flag words go.  0: the traceback planes in global memory (single pass);
 //   1: nowhere - the flag-free FORWARD fill of the two-pass scheme (see k_trace_recompute below): no flag is formed,
-//      instead the three states of every 32nd row are written to ckpt (float [block][3][16][64] per strip);
+//      instead the three states of every 32nd row are written to ckpt (float4 [block][3][4][64] per strip);
 //   2: an LDS row of the recompute kernel, lds_flags + (row index) * 512 + lane * 8 (no end-cell bookkeeping).
 // BSRC = 1 (one-hot arenas, single-term instances): the operand row of the refill is not loaded from the arena - 64
 // lanes reading 64 different rows per step cost the CU's L1 one tag cycle per lane, which the flag-free forward fill
@@ -281,12 +281,15 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #define PRALINE_TB2_ABLATE 0   // timing experiments only: 1 no checkpoint stores, 2 no kept boundary columns
 #endif
         if (!(PRALINE_TB2_ABLATE & 1) && yy >= 32 && (yy & 31) == 0) {
-            float *q = ckpt + (int64_t)(yy >> 5) * (3 * 16 * 64);
+            f4n *q = reinterpret_cast<f4n *>(ckpt + (int64_t)(yy >> 5) * PRALINE_TB2_CKPT_FLOATS);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                __builtin_nontemporal_store(Mp[c], q + c * 64);
-                __builtin_nontemporal_store(Up[c], q + (16 + c) * 64);
-                __builtin_nontemporal_store(Lp[c], q + (32 + c) * 64);
+            for (int g = 0; g < 4; ++g) {
+                const f4n vm = {Mp[4 * g], Mp[4 * g + 1], Mp[4 * g + 2], Mp[4 * g + 3]};
+                const f4n vu = {Up[4 * g], Up[4 * g + 1], Up[4 * g + 2], Up[4 * g + 3]};
+                const f4n vl = {Lp[4 * g], Lp[4 * g + 1], Lp[4 * g + 2], Lp[4 * g + 3]};
+                __builtin_nontemporal_store(vm, q + g * 64);
+                __builtin_nontemporal_store(vu, q + (4 + g) * 64);
+                __builtin_nontemporal_store(vl, q + (8 + g) * 64);
             }
         }
     }
@@ -319,9 +322,8 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #endif
 // TWOPASS (task mode only): the FORWARD fill of the two-pass scheme - no flags, no traceback planes; instead every
 // strip keeps its own boundary column (bnd: float4 [nstrips + 1][max_l1 + PRALINE_TB2_PAD][32] per task) and the
-// states of every 32nd row go to ckpt (float [nstrips][(max_l1 + 8) / 32 + 1][3][16][64] per task, at tk.tb_off):
+// states of every 32nd row go to ckpt (float4 [nstrips][PRALINE_TB2_CKPT_BLOCKS][3][4][64] per task, at tk.tb_off):
 // k_trace_recompute rebuilds the flags of just the 32 x 32 blocks each path crosses.  End cells as in the single pass.
-#define PRALINE_TB2_PAD 72
 #ifndef PRALINE_TB2_WAVES_PER_SIMD
 #define PRALINE_TB2_WAVES_PER_SIMD 2
 #endif
@@ -389,8 +391,8 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
     if (CHAIN && chain_strip >= nstrips) return;
     // boundary columns: float4 [y][32]; chain mode keeps one per strip boundary, [strip][y][32]
     const int64_t chain_col = CHAIN ? (int64_t)(max_l1 + 24) * 32 : (TWOPASS ? (int64_t)(max_l1 + PRALINE_TB2_PAD) * 32 : 0);
-    const int ckpt_blocks = (max_l1 + 8) / 32 + 1;
-    float *my_ckpt = TWOPASS ? reinterpret_cast<float *>(tb) + tk.tb_off + lane : nullptr;   // [strip][block][3][16][64]
+    const int ckpt_blocks = PRALINE_TB2_CKPT_BLOCKS(max_l1);
+    float *my_ckpt = TWOPASS ? reinterpret_cast<float *>(tb) + tk.tb_off + 4 * lane : nullptr;   // float4 [strip][block][3][4][64]
     char *my_bnd = reinterpret_cast<char *>(bnd + tk.bnd_off + chain_col * chain_strip + j);          // read by this wave
     char *my_bnd_out = reinterpret_cast<char *>(bnd + tk.bnd_off + chain_col * (chain_strip + 1) + j);  // written (CHAIN)
     constexpr int BROW = 32 * (int)sizeof(float4);
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
         const char *col_in = (TWOPASS && !(PRALINE_TB2_ABLATE & 2)) ? my_bnd + (int64_t)s * chain_col * (int64_t)sizeof(float4) : my_bnd;
         const char *bnd_ld = col_in + 4 * BROW;
         char *bnd_st = CHAIN ? my_bnd_out : ((TWOPASS && !(PRALINE_TB2_ABLATE & 2)) ? my_bnd + (int64_t)(s + 1) * chain_col * (int64_t)sizeof(float4) : my_bnd);   // upper half stores row yy = t - 1 (row 0: dummy)
-        float *ckpt_strip = TWOPASS ? my_ckpt + (int64_t)s * ckpt_blocks * (3 * 16 * 64) : nullptr;
+        float *ckpt_strip = TWOPASS ? my_ckpt + (int64_t)s * ckpt_blocks * PRALINE_TB2_CKPT_FLOATS : nullptr;
         if constexpr (CHAIN) {
             if (chain_in != nullptr) chain_seen = chain_wait(chain_in, 3, chain_seen);
         }

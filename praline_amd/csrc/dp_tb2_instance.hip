@@ -29,13 +29,13 @@ template <int NR, int NTERM> static void launch_fwd(const LaunchArgs &la, const 
 }
 
 template <int NR, int NTERM> static void launch_bwd(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, bool local,
-                                                    bool mask)
+                                                    bool mask, int keep_in_aux)
 {
     const dim3 grid(la.n_tasks), block(64);
 #define PRALINE_BWD(LOC, MSK)                                                                                            \
     hipLaunchKernelGGL((k_trace_recompute<NR, NTERM, LOC, MSK>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,    \
                        la.lane_pair, (const float4 *)la.bnd, (const float *)la.tb, la.rl, la.end_cells, ta.slot_off,       \
-                       ta.paths, ta.path_start, ta.path_rows, la.rp, (int)la.n_tasks)
+                       ta.paths, ta.path_start, ta.path_rows, la.rp, (int)la.n_tasks, keep_in_aux)
     if (local) { if (mask) PRALINE_BWD(true, true); else PRALINE_BWD(true, false); }
     else { if (mask) PRALINE_BWD(false, true); else PRALINE_BWD(false, false); }
 #undef PRALINE_BWD
@@ -53,13 +53,30 @@ int praline_launch_tb2_forward(const LaunchArgs &la, const Arena16Dev &a16, int 
 }
 
 int praline_launch_tb2_backward(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, int nr, int nterm, bool local,
-                                bool mask)
+                                bool mask, int keep_in_aux)
 {
-    if (nr == 1 && nterm == 1) launch_bwd<1, 1>(la, a16, ta, local, mask);
-    else if (nr == 1 && nterm == 3) launch_bwd<1, 3>(la, a16, ta, local, mask);
-    else if (nr == 2 && nterm == 1) launch_bwd<2, 1>(la, a16, ta, local, mask);
-    else if (nr == 2 && nterm == 3) launch_bwd<2, 3>(la, a16, ta, local, mask);
-    else if (nr == 2 && nterm == 2) launch_bwd<2, 2>(la, a16, ta, local, mask);
+    if (nr == 1 && nterm == 1) launch_bwd<1, 1>(la, a16, ta, local, mask, keep_in_aux);
+    else if (nr == 1 && nterm == 3) launch_bwd<1, 3>(la, a16, ta, local, mask, keep_in_aux);
+    else if (nr == 2 && nterm == 1) launch_bwd<2, 1>(la, a16, ta, local, mask, keep_in_aux);
+    else if (nr == 2 && nterm == 3) launch_bwd<2, 3>(la, a16, ta, local, mask, keep_in_aux);
+    else if (nr == 2 && nterm == 2) launch_bwd<2, 2>(la, a16, ta, local, mask, keep_in_aux);
+    else return PRALINE_ERR_UNSUPPORTED;
+    return PRALINE_OK;
+}
+
+template <int NR, int NTERM> static void launch_keep(const LaunchArgs &la, const Arena16Dev &a16, void *keep_bnd, float *ckpt)
+{
+    hipLaunchKernelGGL((k_dp_split16<NR, NTERM, false, 2, 4, true>), dim3(la.n_wg), dim3(256), 0, la.stream, a16, la.tasks,
+                       la.lane_one, la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg, (float4 *)keep_bnd,
+                       ckpt, la.end_cells);
+}
+
+int praline_launch_keep_forward(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, void *keep_bnd, float *ckpt)
+{
+    if (!a16.stage || la.wg == nullptr) return PRALINE_ERR_UNSUPPORTED;
+    if (nr == 1 && nterm == 3) launch_keep<1, 3>(la, a16, keep_bnd, ckpt);
+    else if (nr == 2 && nterm == 3) launch_keep<2, 3>(la, a16, keep_bnd, ckpt);
+    else if (nr == 2 && nterm == 2) launch_keep<2, 2>(la, a16, keep_bnd, ckpt);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }

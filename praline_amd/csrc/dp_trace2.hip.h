@@ -16,18 +16,23 @@
 #pragma once
 #include "dp_split16_tb.hip.h"
 
+#ifndef PRALINE_TB2_BWD_WAVES
+#define PRALINE_TB2_BWD_WAVES 2
+#endif
 #define PRALINE_TB2_ROWS 40   // LDS flag rows per block: 32 + the pipeline's overshoot
 
 template <int NR, int NTERM, bool LOCAL, bool MASK>
-__global__ __launch_bounds__(64) void k_trace_recompute(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(64, MASK ? 1 : PRALINE_TB2_BWD_WAVES) void k_trace_recompute(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                         const int32_t *__restrict__ lane_one,
                                                         const int32_t *__restrict__ lane_pair, const float4 *__restrict__ bnd,
                                                         const float *__restrict__ ckpt, RectList rl,
                                                         const int32_t *__restrict__ end_cells,
                                                         const int64_t *__restrict__ slot_off, int32_t *__restrict__ paths,
                                                         int64_t *__restrict__ path_start, int32_t *__restrict__ path_rows,
-                                                        RunParams rp, int n_tasks)
+                                                        RunParams rp, int n_tasks, int keep_in_aux = 0)
 {
+    // keep_in_aux: the forward fill was k_dp_split16<..., KEEP> - the kept columns sit at tk.aux_off (tk.bnd_off is
+    // that kernel's own (H, L) hand-off column)
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
     constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0);
@@ -58,10 +63,10 @@ __global__ __launch_bounds__(64) void k_trace_recompute(Arena16Dev ar, const Wav
     const char *qA = ar.Q16 + ((int64_t)ar.row_off[two] + acol) * ar.row_bytes + h * ar.half_bytes;
 
     const int64_t col_elems = (int64_t)(max_l1 + PRALINE_TB2_PAD) * 32;   // float4 elements per boundary column
-    const char *my_bnd = reinterpret_cast<const char *>(bnd + tk.bnd_off + j);
+    const char *my_bnd = reinterpret_cast<const char *>(bnd + (keep_in_aux ? tk.aux_off : tk.bnd_off) + j);
     constexpr int BROW = 32 * (int)sizeof(float4);
-    const int ckpt_blocks = (max_l1 + 8) / 32 + 1;
-    const float *my_ckpt = ckpt + tk.tb_off + lane;
+    const int ckpt_blocks = PRALINE_TB2_CKPT_BLOCKS(max_l1);
+    const float4 *my_ckpt = reinterpret_cast<const float4 *>(ckpt + tk.tb_off) + lane;   // float4 [strip][block][3][4][64]
     char *lds_flags = lds_flags_all + lane * 8;
 
     int rect[PRALINE_MAX_RECTS][4];
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(64) void k_trace_recompute(Arena16Dev ar, const Wav
             }
         }
         const char *col_in = my_bnd + (int64_t)s * col_elems * (int64_t)sizeof(float4);
-        const float *ckpt_strip = my_ckpt + (int64_t)s * ckpt_blocks * (3 * 16 * 64);
+        const float4 *ckpt_strip = my_ckpt + (int64_t)s * ckpt_blocks * (PRALINE_TB2_CKPT_FLOATS / 4);
 
         for (;;) {
             const bool act = !stopped && y >= 1 && x > x0;      // (x <= x0 + 32 holds: the strips are walked downwards)
@@ -155,9 +160,14 @@ __global__ __launch_bounds__(64) void k_trace_recompute(Arena16Dev ar, const Wav
                         Mp[c] = PRALINE_NEG_INF; Up[c] = PRALINE_NEG_INF; Lp[c] = boundary_value(xb + c + 1, go, ge, free_two);
                     }
                 } else {
-                    const float *q = ckpt_strip + (int64_t)(yb0 >> 5) * (3 * 16 * 64);
+                    const float4 *q = ckpt_strip + (int64_t)(yb0 >> 5) * (PRALINE_TB2_CKPT_FLOATS / 4);
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) { Mp[c] = q[c * 64]; Up[c] = q[(16 + c) * 64]; Lp[c] = q[(32 + c) * 64]; }
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 vm = q[g * 64], vu = q[(4 + g) * 64], vl = q[(8 + g) * 64];
+                        Mp[4 * g] = vm.x; Mp[4 * g + 1] = vm.y; Mp[4 * g + 2] = vm.z; Mp[4 * g + 3] = vm.w;
+                        Up[4 * g] = vu.x; Up[4 * g + 1] = vu.y; Up[4 * g + 2] = vu.z; Up[4 * g + 3] = vu.w;
+                        Lp[4 * g] = vl.x; Lp[4 * g + 1] = vl.y; Lp[4 * g + 2] = vl.z; Lp[4 * g + 3] = vl.w;
+                    }
                 }
             };
             load_top();

@@ -24,5 +24,11 @@ struct WgDesc {
     int32_t pad[2];
 };
 
+// two-pass alignments with paths: rows per kept boundary column beyond max_l1, and checkpoint blocks per strip (one
+// per 32 rows; the unrolled loops compute rows up to max_l1 + 12; block 0 is never written)
+#define PRALINE_TB2_PAD 72
+#define PRALINE_TB2_CKPT_BLOCKS(max_l1) (((max_l1) + 12) / 32 + 1)
+#define PRALINE_TB2_CKPT_FLOATS (3 * 16 * 64)   // floats per checkpoint block: float4 [state][four-column group][64 lanes]
+
 #define PRALINE_MAX_RECTS 4   // zero rectangles per pair carried by the batched kernels
 #define PRALINE_MW_LAG 2      // 12-row iterations between consecutive ranks of a shared task

@@ -723,7 +723,7 @@ static int64_t chain_max_tasks()
     return 2304;   // measured crossover with task mode (scripts/exp_chain.py); within +-5 % of it up to ~4000 tasks
 }
 
-#define PRALINE_TB2_PAD_ROWS 72   // = PRALINE_TB2_PAD of dp_split16_tb.hip.h (rows per kept boundary column beyond max_l1)
+#define PRALINE_TB2_PAD_ROWS PRALINE_TB2_PAD
 
 // traceback scratch budget per launch chunk (bytes)
 static size_t tb_budget_bytes()
@@ -1139,6 +1139,71 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         // every path spans the whole matrix).  PRALINE_TB_TWOPASS=1: every mode, =2: also instead of chain mode, =0: never.
         const char *tp = getenv("PRALINE_TB_TWOPASS");
         const int tpv = tp ? atoi(tp) : -1;
+        // ---- two passes with the forward fill on the staged SCORES kernel (k_dp_split16<..., KEEP>: LDS-DMA operand
+        // stream, shared-wave workgroups, 9 instead of ~20 VALU operations per cell) - float-profile arenas, global
+        // mode, plans of one chunk.  PRALINE_TB_KEEP=1 enables it.
+        {
+            const char *kp = getenv("PRALINE_TB_KEEP");
+            const int kpv = kp ? atoi(kp) : -1;
+            bool keep = pl.split && la.a16 != nullptr && a16.stage && kpv != 0 && tpv != 0 && mode == PRALINE_MODE_GLOBAL &&
+                        !pl.has_rects && a.nterm16 != 1 && (!pl.wg.empty() || !pl.wg_singles.empty()) &&
+                        kpv == 1;   // opt-in while it is being tuned (C2: 5.8 ms against 5.9 in chain mode)
+            if (getenv("PRALINE_DEBUG_KEEP"))
+                fprintf(stderr, "keep=%d split=%d a16=%d stage=%d kpv=%d tpv=%d mode=%d rects=%d nterm=%d wg=%zu singles=%zu nt=%zu\n", (int)keep,
+                        (int)pl.split, la.a16 != nullptr, a16.stage, kpv, tpv, mode, (int)pl.has_rects, a.nterm16, pl.wg.size(), pl.wg_singles.size(), nt);
+            int64_t ck_e = 0, bnd_e = 0;   // floats, float4s
+            if (keep) {
+                for (size_t t = 0; t < nt; ++t) {
+                    const WaveTask &wt = pl.tasks[t];
+                    ck_e += (int64_t)wt.nstrips * PRALINE_TB2_CKPT_BLOCKS(wt.max_l1) * PRALINE_TB2_CKPT_FLOATS;
+                    bnd_e += (int64_t)(wt.nstrips + 1) * (wt.max_l1 + PRALINE_TB2_PAD_ROWS) * 32;
+                }
+                keep = (size_t)(ck_e * 4 + bnd_e * 16) <= budget;
+            }
+            if (keep) {
+                char kn[160];
+                snprintf(kn, sizeof(kn), "k_dp_split16<%d, %d, false, 2, 4, true>", a.nr16, a.nterm16);
+                pl.last_kernel = kn;
+                ck_e = 0; bnd_e = 0;
+                for (size_t t = 0; t < nt; ++t) {
+                    WaveTask &wt = pl.tasks[t];
+                    wt.tb_off = ck_e;
+                    wt.aux_off = bnd_e;
+                    ck_e += (int64_t)wt.nstrips * PRALINE_TB2_CKPT_BLOCKS(wt.max_l1) * PRALINE_TB2_CKPT_FLOATS;
+                    bnd_e += (int64_t)(wt.nstrips + 1) * (wt.max_l1 + PRALINE_TB2_PAD_ROWS) * 32;
+                }
+                if (pl.d_tb.n < (size_t)ck_e * 4) RC(pl.d_tb.alloc((size_t)ck_e * 4));
+                if (pl.d_bnd2.n < (size_t)bnd_e) RC(pl.d_bnd2.alloc((size_t)bnd_e));
+                if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
+                HIPCHK(hipMemcpyAsync(pl.d_tasks.p, pl.tasks.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));
+                la.tasks = pl.d_tasks.p;
+                la.n_tasks = (unsigned)nt;
+                la.aux = nullptr;
+                if (!pl.wg.empty()) {
+                    if (!pl.d_wg.p) { RC(pl.d_wg.upload(pl.wg, st)); }
+                    la.wg = pl.d_wg.p;
+                    la.n_wg = (unsigned)pl.wg.size();
+                } else {
+                    if (!pl.d_wg_singles.p) { RC(pl.d_wg_singles.upload(pl.wg_singles, st)); }
+                    la.wg = pl.d_wg_singles.p;
+                    la.n_wg = (unsigned)pl.wg_singles.size();
+                }
+                int rc2 = praline_launch_keep_forward(la, a16, a.nr16, a.nterm16, pl.d_bnd2.p, (float *)pl.d_tb.p);
+                if (rc2 != PRALINE_OK) return fail(rc2, "no kept-state forward instance for nr=%d nterm=%d", a.nr16, a.nterm16);
+                Trace2Args ta;
+                ta.slot_off = pl.d_slot_off.p;
+                ta.paths = pl.d_paths.p;
+                ta.path_start = pl.d_path_start.p;
+                ta.path_rows = pl.d_path_rows.p;
+                la.tb = (uint4 *)pl.d_tb.p;
+                la.bnd = pl.d_bnd2.p;
+                rc2 = praline_launch_tb2_backward(la, a16, ta, a.nr16, a.nterm16, false, false, 1);
+                if (rc2 != PRALINE_OK) return fail(rc2, "no two-pass backward instance for nr=%d nterm=%d", a.nr16, a.nterm16);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(pl.ev1, st));
+                return PRALINE_OK;
+            }
+        }
         const bool twopass = pl.split && la.a16 != nullptr && tpv != 0 && (tpv == 2 || (!would_chain && (local || tpv == 1)));
         if (twopass) {
             char kn[160];
@@ -1153,7 +1218,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             {
                 int64_t all = 0;
                 for (size_t t = 0; t < nt; ++t)
-                    all += (int64_t)pl.tasks[t].nstrips * ((pl.tasks[t].max_l1 + 8) / 32 + 1) * (3 * 16 * 64) * 4 +
+                    all += (int64_t)pl.tasks[t].nstrips * PRALINE_TB2_CKPT_BLOCKS(pl.tasks[t].max_l1) * PRALINE_TB2_CKPT_FLOATS * 4 +
                            (int64_t)(pl.tasks[t].nstrips + 1) * (pl.tasks[t].max_l1 + PRALINE_TB2_PAD_ROWS) * 32 * 16;
                 if ((size_t)all > budget) chunk_budget = budget / 2;
             }
@@ -1177,7 +1242,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                 int64_t ck_e = 0, bnd_e = 0, aux_e = 0;   // floats, float4s, floats
                 while (t1 < nt) {
                     const WaveTask &wt = pl.tasks[t1];
-                    const int64_t ck_add = (int64_t)wt.nstrips * ((wt.max_l1 + 8) / 32 + 1) * (3 * 16 * 64);
+                    const int64_t ck_add = (int64_t)wt.nstrips * PRALINE_TB2_CKPT_BLOCKS(wt.max_l1) * PRALINE_TB2_CKPT_FLOATS;
                     const int64_t bnd_add = (int64_t)(wt.nstrips + 1) * (wt.max_l1 + PRALINE_TB2_PAD_ROWS) * 32;
                     if (t1 > t0 && (size_t)((ck_e + ck_add) * 4 + (bnd_e + bnd_add) * 16) > chunk_budget) break;
                     pl.tasks[t1].tb_off = ck_e;

@@ -331,7 +331,8 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
 
     out.wg.clear();
     out.wg_singles.clear();
-    if (out.split && !opt.want_paths && opt.shared_waves) {
+    // (path plans too: the forward fill of their two-pass scheme can run on the scores kernel's workgroups)
+    if (out.split && opt.shared_waves) {
         out.wg = share_waves(out.tasks, opt);
         if (out.wg.empty()) out.wg_singles = four_singles(out.tasks);
     }

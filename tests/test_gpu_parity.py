@@ -676,3 +676,34 @@ def test_two_pass_paths_equal_single_pass(nat, bba, monkeypatch):
                     s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(i, j, mk), zero_idxs=zero or None)
                     assert res["2"][0][k] == np.float32(s_or) and np.array_equal(res["2"][1][k], p_or), (kind, mode, i, j)
         arena.close()
+
+
+def test_two_pass_forward_on_the_scores_kernel(nat, bba, monkeypatch):
+    """PRALINE_TB_KEEP=1: the forward fill of the two-pass scheme runs on the staged scores kernel (k_dp_split16<..., KEEP>:
+    H recurrence, LDS-DMA operand stream, shared-wave workgroups) and keeps the three states the recompute kernel starts
+    from.  Identical scores, end states and paths as the single pass and as the oracle on the device's match scores:
+    lengths around the 32-row checkpoint blocks and the 32-column strips, tasks with one wave and with shared waves,
+    corner cells whose maximum is a gap state (very different lengths)."""
+    rng = np.random.default_rng(43)
+    for lens in ([1, 31, 32, 33, 64, 65, 97, 130, 200, 47, 85, 86, 300], [390, 412, 7, 640, 96, 128, 129, 1000]):
+        profs = [synth_profile(rng, L)[0] for L in lens]
+        pairs = np.array([(i, j) for i in range(len(lens)) for j in range(len(lens)) if i != j], dtype=np.int32)
+        arena = nat.Arena(profs, bba["S"])
+        res = {}
+        for keep in ("0", "1"):
+            monkeypatch.setenv("PRALINE_TB_KEEP", keep)
+            monkeypatch.setenv("PRALINE_TB_TWOPASS", "0" if keep == "0" else "-1")
+            plan = nat.Plan(arena, pairs, want_paths=True)
+            mk = plan.match_kind()
+            plan.run("global", *GAPS)
+            res[keep] = (plan.scores().copy(), [p.copy() for p in plan.paths()], plan.kernel_name())
+            plan.close()
+        assert "k_dp_split16<" in res["1"][2] and res["1"][2].endswith("true>"), res["1"][2]
+        assert np.array_equal(bits(res["0"][0]), bits(res["1"][0]))
+        for k, (i, j) in enumerate(pairs):
+            assert np.array_equal(res["0"][1][k], res["1"][1][k]), (i, j)
+        for k in range(0, len(pairs), 5):
+            i, j = pairs[k]
+            s_or, p_or = oracle_dp_on_m("global", arena.match_scores(i, j, mk))
+            assert res["1"][0][k] == np.float32(s_or) and np.array_equal(res["1"][1][k], p_or), (i, j)
+        arena.close()
