@@ -924,7 +924,10 @@ __global__ void k_split_f16(const float *__restrict__ src, int KP, int KS, int n
     const bool inexact = split_f16_entry(src, KP, KS, n_active, NR, idx, dst);
     // flag == nullptr: the representability check was already done when the arena was created
     if (flag != nullptr) {
-        if (__ballot(inexact) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+        // (one atomic per arena, not one per wave: with float profiles every wave has something to report, and 50 000
+        // atomics on one word took 0.55 ms per call - a quarter of C2's host-to-host time)
+        if (__ballot(inexact) != 0ull && (threadIdx.x & 63) == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            atomicOr(flag, 1);
     }
 }
 #endif
