@@ -65,7 +65,9 @@ while time.time() < t_end:
                 rr.append((y0, min(int(lens[i]), y0 + int(rng.integers(0, 12))), x0, min(int(lens[j]), x0 + int(rng.integers(0, 12)))))
             rects.append(rr)
     # path plans: a third through the two-pass scheme (forward fill + block recompute) whatever their size
+    # (of those, the float-profile global plans with their forward fill on the scores kernel, PRALINE_TB_KEEP)
     os.environ["PRALINE_TB_TWOPASS"] = "2" if rng.random() < 0.33 else "0"
+    os.environ["PRALINE_TB_KEEP"] = "1" if rng.random() < 0.5 else "0"
     arena = nat.Arena(profs, S)
     plan = nat.Plan(arena, pairs, want_paths=want_paths, rects=rects)
     mk = plan.match_kind()
