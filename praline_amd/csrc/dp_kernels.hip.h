@@ -776,6 +776,9 @@ __global__ __launch_bounds__(64) void k_semiglobal_end(ArenaDev ar, const WaveTa
 // + extend_path_semiglobal (praline/util/align.py:268-297).  Paths are written backwards from the
 // end of the pair's slot, so they come out in start->end order: rows [path_start, slot_end).
 // --------------------------------------------------------------------------------------------
+#ifndef PRALINE_TBW
+#define PRALINE_TBW 8   // rows per lane in k_traceback's flag-word window
+#endif
 __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
                             const PairLoc *__restrict__ loc, const int32_t *__restrict__ pairs,
                             const uint4 *__restrict__ tb, const float *__restrict__ aux, RectList rl,
@@ -818,9 +821,21 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
         // k_dp_split16_tb planes: the interior walk as a short loop without a branch per state - the lanes of a wave
         // are at different cells and states, every divergent branch is paid by all of them (and a single alignment
         // pays the instruction count of one lane: ~120 instructions per step before)
+        // Small plans (at most one wave of pairs - the merge steps of the progressive MSA): the walk is one dependent load
+        // per path row, for a single alignment as long as a fifth of its chain-mode fill.  Every lane then keeps a WINDOW
+        // of flag words in LDS - PRALINE_TBW rows upwards from its cell, for its 16-column group and the group to its
+        // left (a step moves at most one row up and one column left) - refilled with 2 x PRALINE_TBW independent loads
+        // when any lane of the wave has left its window: one memory latency per ~PRALINE_TBW rows.  Measured, single
+        // alignments: 400 x 400 0.69 -> 0.61 ms, 3000 x 3000 5.1 -> 4.4 ms.  Not for large plans: with full waves some lane
+        // leaves its window almost every step, and the 16 words per refill are more traffic than the direct loads (no gain
+        // measured on C2 with paths).
         const int64_t rows = tk.max_l1 + 8;
         int guard = L1 + L2 + 2;
         bool stopped = false;
+        __shared__ uint2 win_s[2 * PRALINE_TBW][64];
+        const bool windowed = n_pairs <= 64;
+        const int tid = threadIdx.x & 63;
+        int wy = -1, wg = -(1 << 30);   // the window holds rows wy .. wy - PRALINE_TBW + 1 of the groups wg and wg - 1
         while (y > 0 && x > 0 && guard-- > 0) {
             bool masked = false;
             for (int r = 0; r < n_rects; ++r) {
@@ -828,7 +843,29 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
                 masked = masked || (y >= q[0] && y <= q[1] && x >= q[2] && x <= q[3]);
             }
             const int c = (x - 1) & 31, bit = c & 15;
-            const uint2 word = my_tb2[((int64_t)((x - 1) >> 5) * rows + y) * 64 + 32 * (c >> 4)];
+            uint2 word;
+            if (windowed) {
+                const int g = (x - 1) >> 4;   // 16-column group: strip g / 2, lane half g % 2
+                const bool miss = !((g == wg || g == wg - 1) && y <= wy && y > wy - PRALINE_TBW);
+                if (__ballot(miss) != 0ull) {
+                    uint2 t0[PRALINE_TBW], t1[PRALINE_TBW];
+                    const int gl = g > 0 ? g - 1 : 0;
+                    const uint2 *b0 = my_tb2 + (int64_t)(g >> 1) * rows * 64 + 32 * (g & 1);
+                    const uint2 *b1 = my_tb2 + (int64_t)(gl >> 1) * rows * 64 + 32 * (gl & 1);
+#pragma unroll
+                    for (int i = 0; i < PRALINE_TBW; ++i) {
+                        const int64_t r = y - i > 0 ? y - i : 0;
+                        t0[i] = b0[r * 64];
+                        t1[i] = b1[r * 64];
+                    }
+#pragma unroll
+                    for (int i = 0; i < PRALINE_TBW; ++i) { win_s[i][tid] = t0[i]; win_s[PRALINE_TBW + i][tid] = t1[i]; }
+                    wy = y; wg = g;
+                }
+                word = win_s[(g == wg ? 0 : PRALINE_TBW) + (wy - y)][tid];
+            } else {
+                word = my_tb2[((int64_t)((x - 1) >> 5) * rows + y) * 64 + 32 * (c >> 4)];
+            }
             // word.x: match source as two bit planes (low bits | high bits << 16); word.y: U-extend | L-extend << 16
             const int code = (int)(((word.x >> bit) & 1u) | (((word.x >> (16 + bit)) & 1u) << 1));
             const int ub = (int)((word.y >> bit) & 1u), lb = (int)((word.y >> (16 + bit)) & 1u);
