@@ -178,6 +178,11 @@ int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets, const int
 int praline_arena_set_counts(praline_arena *arena, const int32_t *counts, int64_t reserve_seqs, int64_t reserve_rows);
 int praline_arena_append_merged(praline_arena *arena, praline_plan *plan, int64_t pair_index, int32_t *new_index,
                                 int32_t *new_len);
+/* The same for n pairs of one plan (pair_index[n] -> new_index[n], new_len[n]): merge steps of DIFFERENT subtrees of the
+ * guide tree do not depend on each other, so a whole level of the tree is one path plan and one call here (one round
+ * trip for the path locations, the merge kernels of all pairs, one packing launch over the new rows). */
+int praline_arena_append_merged_many(praline_arena *arena, praline_plan *plan, int64_t n, const int64_t *pair_index,
+                                     int32_t *new_index, int32_t *new_len);
 /* Re-runs the device-side packing + pre-multiply from the resident raw profiles (the part of
  * cext_build_scores that is per sequence, not per pair); asynchronous on praline_stream(). */
 int praline_arena_premultiply(praline_arena *arena);

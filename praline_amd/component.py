@@ -833,8 +833,52 @@ class ResidentClusters(object):
         del self.length[b]
         return score, path
 
+    def align_and_merge_many(self, requests):
+        """(mode, a, b) requests whose clusters are pairwise distinct - merge steps of different subtrees of the guide
+        tree: one device submission per mode, then every b is merged into its a on the device.  Returns the (score, path)
+        of every request, in order."""
+        out = [None] * len(requests)
+        merged = {}
+        for mode in MODES:
+            sel = [k for k, r in enumerate(requests) if r[0] == mode]
+            if not sel:
+                continue
+            pairs = np.array([(self.index[requests[k][1]], self.index[requests[k][2]]) for k in sel], dtype=np.int32)
+            plan = native.Plan(self.arena, pairs, want_paths=True)
+            try:
+                plan.run(mode, self.gap_open, self.gap_extend)
+                sc = plan.scores()
+                paths = plan.paths()
+                for q, k in enumerate(sel):
+                    out[k] = (float(sc[q]), np.array(paths[q], dtype=int))
+                for k, m in zip(sel, self.arena.append_merged_many(plan, np.arange(len(sel)))):
+                    merged[k] = m
+            finally:
+                plan.close()
+        for k, (_, a, b) in enumerate(requests):
+            self.index[a], self.length[a] = merged[k]
+            del self.index[b]
+            del self.length[b]
+        return out
+
     def close(self):
         self.arena.close()
+
+
+def merge_levels(steps):
+    """Group the merge steps (i, j) of a guide tree (cluster j is merged into cluster i) into levels of mutually
+    independent steps: a step's level is one more than the latest level that produced one of its two clusters.  Steps
+    of one level touch disjoint clusters, so they can run as one batch; the result of every step - and therefore the
+    final alignment - does not depend on the order in which independent steps are carried out."""
+    last, levels = {}, []
+    for k, (i, j) in enumerate(steps):
+        lvl = max(last.get(i, 0), last.get(j, 0))
+        if lvl == len(levels):
+            levels.append([])
+        levels[lvl].append(k)
+        last[i] = lvl + 1
+        last.pop(j, None)
+    return levels
 
 
 class TreeMultipleSequenceAligner(Component):
@@ -864,19 +908,35 @@ class TreeMultipleSequenceAligner(Component):
         if _is_device_aligner(aligner) and isinstance(self.manager, BatchManager) and steps:
             # resident path: the clusters live and grow on the GPU, a step brings back only its path
             resident = ResidentClusters(sequences, track_id_sets, score_matrices, aligner_env['gap_series'])
+            # Steps of different subtrees do not depend on each other: every LEVEL of the guide tree (merge_levels) is
+            # one device submission per mode instead of one per step - the same alignments, scores and paths (each step
+            # sees exactly the clusters it would see in the reference's serial order, msa.py:124-237), in far fewer
+            # latency-bound round trips.
+            self.steps = [None] * len(steps)
+            self.levels = merge_levels(steps)
+            done = 0
             try:
-                for done, (i, j) in enumerate(steps):
-                    if merge_mode == "global":
-                        mode = "global"
-                    elif merge_mode == "semiglobal":
-                        mode = "semiglobal_both"
+                for level in self.levels:
+                    requests = []
+                    for k in level:
+                        i, j = steps[k]
+                        if merge_mode == "global":
+                            mode = "global"
+                        elif merge_mode == "semiglobal":
+                            mode = "semiglobal_both"
+                        else:
+                            mode = auto_align_mode(resident.cluster(i), resident.cluster(j))
+                        requests.append((mode, i, j))
+                    if len(requests) == 1:
+                        results = [resident.align_and_merge(*requests[0])]
                     else:
-                        mode = auto_align_mode(resident.cluster(i), resident.cluster(j))
-                    score, path = resident.align_and_merge(mode, i, j)
-                    self.steps.append((mode, score, path))
-                    alignments[i] = alignments[i].merge(alignments[j], path)
-                    del alignments[j]
-                    yield ProgressMessage((done + 1) / float(len(steps)))
+                        results = resident.align_and_merge_many(requests)
+                    for k, (mode, i, j), (score, path) in zip(level, requests, results):
+                        self.steps[k] = (mode, score, path)
+                        alignments[i] = alignments[i].merge(alignments[j], path)
+                        del alignments[j]
+                        done += 1
+                        yield ProgressMessage(done / float(len(steps)))
             finally:
                 resident.close()
             yield CompleteMessage(outputs={'alignment': list(alignments.values())[0]})

@@ -1506,46 +1506,65 @@ extern "C" int praline_plan_path_bounds(praline_plan *plan, int32_t *bounds)
     return PRALINE_OK;
 }
 
-extern "C" int praline_arena_append_merged(praline_arena *arena, praline_plan *plan, int64_t pair_index, int32_t *new_index,
-                                           int32_t *new_len)
+extern "C" int praline_arena_append_merged_many(praline_arena *arena, praline_plan *plan, int64_t n, const int64_t *pair_index,
+                                                int32_t *new_index, int32_t *new_len)
 {
-    if (!arena || !plan || !new_index || !new_len) return fail(PRALINE_ERR_ARG, "NULL argument");
+    if (!arena || !plan || !new_index || !new_len || (n > 0 && !pair_index)) return fail(PRALINE_ERR_ARG, "NULL argument");
     if (plan->arena != arena) return fail(PRALINE_ERR_ARG, "the plan belongs to another arena");
     if (!plan->want_paths || plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "the plan has no paths (want_paths + praline_plan_run first)");
     if (plan->last_mode == PRALINE_MODE_LOCAL) return fail(PRALINE_ERR_UNSUPPORTED, "clusters are merged along global / semiglobal paths");
-    if (pair_index < 0 || pair_index >= plan->n_pairs) return fail(PRALINE_ERR_ARG, "pair index out of range");
+    if (n <= 0) return PRALINE_OK;
+    for (int64_t q = 0; q < n; ++q)
+        if (pair_index[q] < 0 || pair_index[q] >= plan->n_pairs) return fail(PRALINE_ERR_ARG, "pair index out of range");
     praline_arena *a = arena;
     if (!a->have_cnt) return fail(PRALINE_ERR_ARG, "praline_arena_set_counts has not been called");
     hipStream_t st = g_rt.stream;
-    int64_t start = 0;
-    int32_t rows = 0, pr[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(&start, plan->d_path_start.p + pair_index, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&rows, plan->d_path_rows.p + pair_index, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(pr, plan->d_pairs.p + 2 * pair_index, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // where the paths are: one round trip for the whole plan (a level of the guide tree is one plan)
+    const int64_t np = plan->n_pairs;
+    std::vector<int64_t> start((size_t)np);
+    std::vector<int32_t> rows((size_t)np), pr((size_t)np * 2);
+    HIPCHK(hipMemcpyAsync(start.data(), plan->d_path_start.p, (size_t)np * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(rows.data(), plan->d_path_rows.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(pr.data(), plan->d_pairs.p, (size_t)np * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const int cols = rows - 1;
-    if (cols <= 0) return fail(PRALINE_ERR_DEVICE, "empty alignment path");
-    const int64_t idx = a->n_seqs, pad = (cols + 31) / 32 * 32;
-    const int new_max = std::max(a->max_len, cols);
-    const int64_t new_rp = a->rp_end + pad, new_rows_pad = new_rp + (new_max + 31) / 32 * 32 + 64;
-    RC(arena_reserve(a, idx + 1, a->rows_raw + cols, new_rows_pad));
-    const int32_t off_raw = (int32_t)a->rows_raw, off_pad = (int32_t)a->rp_end, len32 = cols;
-    HIPCHK(hipMemcpyAsync(a->d_len.p + idx, &len32, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(a->d_row_off_raw.p + idx, &off_raw, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(a->d_row_off_pad.p + idx, &off_pad, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, st, a->d_seq_of_rowp.p + a->rp_end, pad, (int32_t)idx);
+    const int64_t idx0 = a->n_seqs;
+    int64_t rows_raw = a->rows_raw, rp = a->rp_end;
+    int new_max = a->max_len;
+    for (int64_t q = 0; q < n; ++q) {
+        const int cols = rows[(size_t)pair_index[q]] - 1;
+        if (cols <= 0) return fail(PRALINE_ERR_DEVICE, "empty alignment path");
+        rows_raw += cols;
+        rp += (cols + 31) / 32 * 32;
+        new_max = std::max(new_max, cols);
+    }
+    const int64_t new_rows_pad = rp + (new_max + 31) / 32 * 32 + 64;
+    RC(arena_reserve(a, idx0 + n, rows_raw, new_rows_pad));
     if (!a->d_set_lo.p) RC(a->d_set_lo.upload(a->set_lo, st));
-    hipLaunchKernelGGL(k_merge_clusters, dim3((unsigned)cols), dim3(64), 0, st, plan->d_paths.p + 2 * start, cols, a->d_cnt.p, a->d_raw.p,
-                       a->A, (int64_t)a->row_off_raw[pr[0]], (int64_t)a->row_off_raw[pr[1]], (int64_t)off_raw, a->d_set_lo.p,
-                       (int)a->set_lo.size() - 1);
+    const int64_t rp0 = a->rp_end;
+    for (int64_t q = 0; q < n; ++q) {
+        const int64_t p = pair_index[q];
+        const int cols = rows[(size_t)p] - 1;
+        const int64_t pad = (cols + 31) / 32 * 32;
+        const int32_t off_raw = (int32_t)a->rows_raw, off_pad = (int32_t)a->rp_end;
+        const int64_t idx = a->n_seqs;
+        hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, st, a->d_seq_of_rowp.p + a->rp_end, pad, (int32_t)idx);
+        hipLaunchKernelGGL(k_merge_clusters, dim3((unsigned)cols), dim3(64), 0, st, plan->d_paths.p + 2 * start[(size_t)p], cols, a->d_cnt.p,
+                           a->d_raw.p, a->A, (int64_t)a->row_off_raw[pr[(size_t)(2 * p)]], (int64_t)a->row_off_raw[pr[(size_t)(2 * p + 1)]],
+                           (int64_t)off_raw, a->d_set_lo.p, (int)a->set_lo.size() - 1);
+        a->len.push_back(cols);
+        a->row_off_raw.push_back(off_raw);
+        a->row_off_pad.push_back(off_pad);
+        a->n_seqs = idx + 1;
+        a->rows_raw += cols;
+        a->rp_end += pad;
+        new_index[q] = (int32_t)idx;
+        new_len[q] = cols;
+    }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));   // the three host words above
-    a->len.push_back(cols);
-    a->row_off_raw.push_back(off_raw);
-    a->row_off_pad.push_back(off_pad);
-    a->n_seqs = idx + 1;
-    a->rows_raw += cols;
-    a->rp_end = new_rp;
+    // the descriptors of the new sequences (the host vectors are final now)
+    HIPCHK(hipMemcpyAsync(a->d_len.p + idx0, a->len.data() + idx0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(a->d_row_off_raw.p + idx0, a->row_off_raw.data() + idx0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(a->d_row_off_pad.p + idx0, a->row_off_pad.data() + idx0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     a->max_len = new_max;
     a->rows_pad = new_rows_pad;
     // a merged cluster is no plain sequence: the one-hot shortcuts of this arena end here
@@ -1555,16 +1574,21 @@ extern "C" int praline_arena_append_merged(praline_arena *arena, praline_plan *p
     a->ref_ready = false;
     a->d_counts.release();
     a->counts_ext = nullptr;
-    if (!a->wide) {   // packed operands of the new rows only
-        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)(pad / 32)), dim3(64), 0, st, a->d_raw.p, a->d_S.p, a->d_seq_of_rowp.p,
+    if (!a->wide) {   // packed operands of the new rows only (they are contiguous in the padded row space)
+        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)((a->rp_end - rp0) / 32)), dim3(64), 0, st, a->d_raw.p, a->d_S.p, a->d_seq_of_rowp.p,
                            a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, a->d_active.p, a->n_active, a->A, a->KP, a->KS,
                            a->rows_pad, a->d_P.p, a->d_Q.p, a->nr16, (_Float16 *)a->d_P16.p, (_Float16 *)a->d_Q16.p,
-                           (int64_t)(off_pad / 32), a->nterm16 == 2 ? 1 : 0);
+                           (int64_t)(rp0 / 32), a->nterm16 == 2 ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
-    *new_index = (int32_t)idx;
-    *new_len = cols;
+    HIPCHK(hipStreamSynchronize(st));   // the descriptor uploads read the host vectors
     return PRALINE_OK;
+}
+
+extern "C" int praline_arena_append_merged(praline_arena *arena, praline_plan *plan, int64_t pair_index, int32_t *new_index,
+                                           int32_t *new_len)
+{
+    return praline_arena_append_merged_many(arena, plan, 1, &pair_index, new_index, new_len);
 }
 
 extern "C" int praline_plan_mask_path_bounds(praline_plan *plan)

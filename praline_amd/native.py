@@ -66,6 +66,7 @@ def lib():
     L.praline_arena_set_track_sets.argtypes = [vp, i32, vp]
     L.praline_arena_set_counts.argtypes = [vp, vp, i64, i64]
     L.praline_arena_append_merged.argtypes = [vp, vp, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    L.praline_arena_append_merged_many.argtypes = [vp, vp, i64, vp, vp, vp]
     L.praline_set_match_mode.argtypes = [i32]
     L.praline_arena_premultiply.argtypes = [vp]
     L.praline_plan_create.argtypes = [vp, i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
@@ -289,6 +290,17 @@ class Arena(object):
         self.lens = np.append(self.lens, np.int32(ln.value))
         self.n_seqs += 1
         return int(idx.value), int(ln.value)
+
+    def append_merged_many(self, plan, pair_indices):
+        """append_merged for several pairs of one plan (praline_arena_append_merged_many): list of (index, length)."""
+        pi = np.ascontiguousarray(pair_indices, dtype=np.int64)
+        n = int(pi.shape[0])
+        idx = np.zeros(n, dtype=np.int32)
+        ln = np.zeros(n, dtype=np.int32)
+        _check(lib().praline_arena_append_merged_many(self._h, plan._h, n, pi.ctypes.data, idx.ctypes.data, ln.ctypes.data))
+        self.lens = np.append(self.lens, ln)
+        self.n_seqs += n
+        return [(int(i), int(l)) for i, l in zip(idx, ln)]
 
     def premultiply(self):
         _check(lib().praline_arena_premultiply(self._h))

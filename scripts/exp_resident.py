@@ -41,3 +41,5 @@ for name, manager in (("resident", batch), ("host", serial), ("resident", batch)
     print("%-8s TreeMSA: %.1f ms total, %.2f ms per merge step (%d steps, final alignment %d columns)" % (
         name, dt * 1e3, dt * 1e3 / (N - 1), N - 1, res[name].shape[0] - 1))
 print("equal alignments:", np.array_equal(res["resident"], res["host"]))
+lv = comp.merge_levels(list(tree.merge_orders))
+print("guide tree levels: %d for %d steps (largest level %d steps)" % (len(lv), N - 1, max(len(x) for x in lv)))

@@ -452,6 +452,7 @@ def test_resident_msa_larger_set_equals_host_path(env):
         dev, out_d = _run_component(env["batch"], comp.TreeMultipleSequenceAligner, {"merge_mode": merge_mode},
                                     sequences=seqs2, guide_tree=tree, track_id_sets=tracks, score_matrices=mats)
         assert len(host.steps) == len(dev.steps) == n - 1
+        assert sum(len(lv) for lv in dev.levels) == n - 1 and len(dev.levels) < n - 1   # independent steps were batched
         for (m1, s1, p1), (m2, s2, p2) in zip(host.steps, dev.steps):
             assert m1 == m2 and abs(s1 - s2) <= 1e-6 * max(1.0, abs(s1)) and np.array_equal(p1, p2)
         assert np.array_equal(np.asarray(out_h['alignment'].path), np.asarray(out_d['alignment'].path))

@@ -428,3 +428,32 @@ def test_native_merge_order_equals_numpy_version():
         comp.native_clustering = saved
     d = load_golden("profile_profile.npz")
     assert native.merge_order(d["dist"], "average") == [tuple(x) for x in d["merge_order"]]
+
+
+def test_merge_levels_groups_independent_steps():
+    """component.merge_levels: the merge steps of a guide tree grouped into levels of mutually independent steps (the
+    resident TreeMSA path submits one batch per level): every step comes after the steps that produced its clusters, no
+    two steps of a level share a cluster, a caterpillar tree degenerates to one step per level."""
+    from praline_amd.component import merge_levels
+    assert merge_levels([(0, 1), (0, 2), (0, 3), (0, 4)]) == [[0], [1], [2], [3]]
+    assert merge_levels([(2, 3), (0, 1), (4, 5), (0, 2), (6, 7), (4, 6), (0, 4)]) == [[0, 1, 2, 4], [3, 5], [6]]
+    rng = np.random.default_rng(3)
+    for n in (2, 3, 17, 100):
+        alive = list(range(n))
+        steps = []
+        while len(alive) > 1:
+            a, b = sorted(rng.choice(len(alive), 2, replace=False))
+            steps.append((alive[a], alive[b]))
+            del alive[b]
+        levels = merge_levels(steps)
+        assert sorted(k for lv in levels for k in lv) == list(range(n - 1))
+        level_of = {k: q for q, lv in enumerate(levels) for k in lv}
+        made = {}                                  # cluster -> step that last produced it
+        for k, (i, j) in enumerate(steps):
+            for c in (i, j):
+                if c in made:
+                    assert level_of[made[c]] < level_of[k]
+            made[i] = k
+        for lv in levels:
+            used = [c for k in lv for c in steps[k]]
+            assert len(used) == len(set(used))
