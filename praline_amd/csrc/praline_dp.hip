@@ -780,6 +780,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     if (const char *env = getenv("PRALINE_W_SLOTS")) opt.wave_slots = atoll(env);
     if (const char *env = getenv("PRALINE_W_SNAKE")) opt.snake = atoi(env) != 0;
     if (const char *env = getenv("PRALINE_WG_XCD")) opt.wg_xcd = atoi(env) != 0;
+    if (const char *env = getenv("PRALINE_WG_BALANCE")) opt.balance = atoi(env) != 0;
     Schedule sch;
     build_schedule(a.len.data(), n_pairs, pairs, opt, sch);
     pl->tp = sch.tp;

@@ -9,6 +9,8 @@
 #include "sched.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 
 namespace {
@@ -135,6 +137,145 @@ int barriers_of(const Cand &c, int W)   // barriers every wave of the share grou
     return total;
 }
 
+// busy steps of rank r of a task shared by W waves (its strips r, r + W, ...)
+int64_t rank_steps(const Cand &c, int W, int r)
+{
+    const int nr = c.nstrips > r ? (c.nstrips - r + W - 1) / W : 0;
+    return (int64_t)nr * (12 * c.iter + 1);
+}
+
+struct Built { int64_t cost; WgDesc d; int64_t w[4]; int64_t crit; };   // w: busy steps of the four waves; crit: longest start delay + work
+
+WgDesc blank_wg(int share)
+{
+    WgDesc d;
+    d.task[0] = d.task[1] = d.task[2] = d.task[3] = -1;
+    d.share = share;
+    d.barriers = 0;
+    d.pad[0] = d.pad[1] = 0;
+    return d;
+}
+
+Built blank_built()
+{
+    Built b;
+    b.cost = 0;
+    b.d = blank_wg(1);
+    b.w[0] = b.w[1] = b.w[2] = b.w[3] = 0;
+    b.crit = 0;
+    return b;
+}
+
+// workgroups of one set of candidates (cost-descending) under the wave counts W: share 4 alone, share 2 in pairs,
+// singles in fours; sorted by cost, longest first
+std::vector<Built> build_wgs(const std::vector<Cand> &cand, const std::vector<int> &set, const std::vector<int> &W)
+{
+    std::vector<int> by_w[5];
+    for (int i : set) by_w[W[(size_t)i]].push_back(i);
+    std::vector<Built> built;
+    built.reserve(by_w[4].size() + by_w[2].size() / 2 + by_w[1].size() / 4 + 2);
+    for (int i : by_w[4]) {
+        const Cand &c = cand[(size_t)i];
+        Built b = blank_built();
+        b.cost = wave_cost(c, 4); b.d = blank_wg(4);
+        b.d.task[0] = c.task; b.d.barriers = barriers_of(c, 4);
+        for (int r = 0; r < 4; ++r) b.w[r] = rank_steps(c, 4, r);
+        b.crit = (int64_t)b.d.barriers * 12;
+        built.push_back(b);
+    }
+    for (size_t k = 0; k < by_w[2].size(); k += 2) {
+        const Cand &c0 = cand[(size_t)by_w[2][k]];
+        const Cand *c1 = k + 1 < by_w[2].size() ? &cand[(size_t)by_w[2][k + 1]] : nullptr;
+        Built b = blank_built();
+        b.cost = wave_cost(c0, 2); b.d = blank_wg(2);
+        b.d.task[0] = c0.task; b.d.task[2] = c1 ? c1->task : -1;
+        b.d.barriers = std::max(barriers_of(c0, 2), c1 ? barriers_of(*c1, 2) : 0);
+        b.w[0] = rank_steps(c0, 2, 0); b.w[1] = rank_steps(c0, 2, 1);
+        if (c1) { b.w[2] = rank_steps(*c1, 2, 0); b.w[3] = rank_steps(*c1, 2, 1); }
+        b.crit = (int64_t)b.d.barriers * 12;
+        built.push_back(b);
+    }
+    for (size_t k = 0; k < by_w[1].size(); k += 4) {
+        Built b = blank_built();
+        b.cost = cand[(size_t)by_w[1][k]].cost;
+        for (int q = 0; q < 4; ++q)
+            if (k + q < by_w[1].size()) {
+                const Cand &c = cand[(size_t)by_w[1][k + q]];
+                b.d.task[q] = c.task;
+                b.w[q] = c.cost;
+            }
+        b.crit = b.cost;
+        built.push_back(b);
+    }
+    std::stable_sort(built.begin(), built.end(), [](const Built &x, const Built &y) { return x.cost > y.cost; });
+    return built;
+}
+
+// Launch order.  A CU holds two of these workgroups and the dispatcher deals the blocks round-robin - block b to XCD
+// b % 8 and, inside the XCD, to CU (b / 8) % 32 - so blocks b and b + 256 end up on the same CU (same SIMDs;
+// confirmed with the trace build): the longest go first in descending order, then the SHORTEST in ascending order
+// (the longest shares its SIMDs with the shortest), then whatever is left in the middle.
+std::vector<Built> snake_order(const std::vector<Built> &built, size_t round, bool on)
+{
+    std::vector<Built> order;
+    const size_t nb = built.size();
+    order.reserve(nb);
+    if (on && nb > round) {
+        const size_t tail = std::min<size_t>(round, nb - round);
+        for (size_t i = 0; i < round; ++i) order.push_back(built[i]);
+        for (size_t i = 0; i < tail; ++i) order.push_back(built[nb - 1 - i]);
+        for (size_t i = round; i < nb - tail; ++i) order.push_back(built[i]);
+    } else {
+        order = built;
+    }
+    return order;
+}
+
+// The launch list for the wave counts W, and what it costs.  Model (checked against the C2 launch: 2.09 ms predicted,
+// 2.08 measured): all workgroups are resident at once, two per CU (launch positions b and b + 256), wave i of both on
+// SIMD i; a SIMD issues one wave's VALU work at a time, so it is busy for the SUM of its two waves' steps, and the
+// launch lasts as long as the busiest SIMD (or the longest chain of start delays + work).  Returns the modelled
+// makespan in steps, -1 when the workgroups do not fit the resident slots.
+int64_t assemble(const std::vector<Cand> &cand, const std::vector<int> &W, const std::vector<int> (&per_xcd)[8], const SchedOptions &opt,
+                 std::vector<WgDesc> *out)
+{
+    const size_t per_xcd_slots = (size_t)(opt.wave_slots / 32);   // resident workgroups per XCD (2 per CU)
+    std::vector<Built> order;
+    bool fits = true;   // (a list that does not fit is still a valid launch list: its tail starts when slots free up)
+    if (!opt.wg_xcd) {
+        std::vector<int> all;
+        all.reserve(cand.size());
+        for (size_t i = 0; i < cand.size(); ++i) all.push_back((int)i);
+        order = snake_order(build_wgs(cand, all, W), 256, opt.snake);
+        fits = order.size() <= 8 * per_xcd_slots;
+    } else {
+        std::vector<Built> lists[8];
+        size_t longest = 0;
+        for (int x = 0; x < 8; ++x) {
+            lists[x] = snake_order(build_wgs(cand, per_xcd[x], W), 32, opt.snake);
+            longest = std::max(longest, lists[x].size());
+        }
+        fits = longest <= per_xcd_slots;
+        order.reserve(8 * longest);
+        for (size_t q = 0; q < longest; ++q)
+            for (int x = 0; x < 8; ++x) order.push_back(q < lists[x].size() ? lists[x][q] : blank_built());
+    }
+    int64_t makespan = 0;
+    const size_t nb = order.size();
+    for (size_t b = 0; b < nb && b < 256; ++b)
+        for (int i = 0; i < 4; ++i) {
+            const int64_t sum = order[b].w[i] + (b + 256 < nb ? order[b + 256].w[i] : 0);
+            makespan = std::max(makespan, sum);
+        }
+    for (const Built &b : order) makespan = std::max(makespan, b.crit);
+    if (out) {
+        out->clear();
+        out->reserve(nb);
+        for (const Built &b : order) out->push_back(b.d);
+    }
+    return fits ? makespan : -1;
+}
+
 std::vector<WgDesc> share_waves(const std::vector<WaveTask> &tasks, const SchedOptions &opt)
 {
     std::vector<Cand> cand;
@@ -154,95 +295,116 @@ std::vector<WgDesc> share_waves(const std::vector<WaveTask> &tasks, const SchedO
     std::vector<WgDesc> out;
     if (cand.empty() || (int64_t)cand.size() >= opt.wave_slots) return out;
     std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.cost != y.cost ? x.cost > y.cost : x.task < y.task; });
-    auto slots_for = [&](int64_t cstar) {
-        int64_t n1 = 0, n2 = 0, n4 = 0;
-        for (const Cand &c : cand) { const int W = waves_for(c, cstar); (W == 1 ? n1 : W == 2 ? n2 : n4)++; }
-        return 4 * (n4 + (n2 + 1) / 2 + (n1 + 3) / 4);
-    };
-    int64_t lo = 1, hi = cand[0].cost;  // smallest c* whose workgroups fit
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) / 2;
-        if (slots_for(mid) <= opt.wave_slots - (opt.wg_xcd ? 48 : 0)) hi = mid; else lo = mid + 1;   // (per-XCD rounding of the workgroups)
-    }
-    {
-        bool any = false;
-        for (const Cand &c : cand) any = any || waves_for(c, lo) > 1;
-        if (!any) return out;
-    }
-    struct Built { int64_t cost; WgDesc d; };
-    auto blank = [](int share) { WgDesc d; d.task[0] = d.task[1] = d.task[2] = d.task[3] = -1; d.share = share; d.barriers = 0; d.pad[0] = d.pad[1] = 0; return d; };
-    // workgroups of one set of candidates (cost-descending): share 4 alone, share 2 in pairs, singles in fours
-    auto build = [&](const std::vector<const Cand *> &set) {
-        std::vector<const Cand *> by_w[5];
-        for (const Cand *c : set) by_w[waves_for(*c, lo)].push_back(c);
-        std::vector<Built> built;
-        for (const Cand *c : by_w[4]) {
-            Built b; b.cost = wave_cost(*c, 4); b.d = blank(4);
-            b.d.task[0] = c->task; b.d.barriers = barriers_of(*c, 4);
-            built.push_back(b);
-        }
-        for (size_t i = 0; i < by_w[2].size(); i += 2) {
-            const Cand *c0 = by_w[2][i], *c1 = i + 1 < by_w[2].size() ? by_w[2][i + 1] : nullptr;
-            Built b; b.cost = wave_cost(*c0, 2); b.d = blank(2);
-            b.d.task[0] = c0->task; b.d.task[2] = c1 ? c1->task : -1;
-            b.d.barriers = std::max(barriers_of(*c0, 2), c1 ? barriers_of(*c1, 2) : 0);
-            built.push_back(b);
-        }
-        for (size_t i = 0; i < by_w[1].size(); i += 4) {
-            Built b; b.cost = by_w[1][i]->cost; b.d = blank(1);
-            for (int q = 0; q < 4; ++q) b.d.task[q] = i + q < by_w[1].size() ? by_w[1][i + q]->task : -1;
-            built.push_back(b);
-        }
-        std::stable_sort(built.begin(), built.end(), [](const Built &x, const Built &y) { return x.cost > y.cost; });
-        return built;
-    };
-    // Launch order.  A CU holds two of these workgroups and the dispatcher deals the blocks round-robin - block b to XCD
-    // b % 8 and, inside the XCD, to CU (b / 8) % 32 - so blocks b and b + 256 end up on the same CU (same SIMDs;
-    // confirmed with the trace build): the longest go first in descending order, then the SHORTEST in ascending order
-    // (the longest shares its SIMDs with the shortest), then whatever is left in the middle.
-    auto snake = [&](const std::vector<Built> &built, size_t round) {
-        std::vector<WgDesc> order;
-        const size_t nb = built.size();
-        if (opt.snake && nb > round) {
-            const size_t tail = std::min<size_t>(round, nb - round);
-            for (size_t i = 0; i < round; ++i) order.push_back(built[i].d);
-            for (size_t i = 0; i < tail; ++i) order.push_back(built[nb - 1 - i].d);
-            for (size_t i = round; i < nb - tail; ++i) order.push_back(built[i].d);
-        } else {
-            for (const Built &b : built) order.push_back(b.d);
-        }
-        return order;
-    };
-    if (!opt.wg_xcd) {
-        std::vector<const Cand *> all;
-        for (const Cand &c : cand) all.push_back(&c);
-        return snake(build(all), 256);
-    }
+    const size_t n = cand.size();
+
     // XCD-aware: every XCD has its own 4 MB L2, and all these workgroups are resident at once, so WHERE a task runs
     // decides whether the operand rows it streams are already in that L2.  Tasks of neighbouring sequences two have
     // nearly the same partners (the all-pairs stage: {i < j}), so the sequences two are cut into eight contiguous runs
     // of equal cost, one per XCD; each XCD's workgroups are formed and snake-ordered on their own and the eight lists
     // are interleaved (launch index 8 q + x runs on XCD x).  Placement only affects speed, never results.
-    int32_t max_two = 0;
-    for (const Cand &c : cand) max_two = std::max(max_two, tasks[(size_t)c.task].two[0]);
-    std::vector<int64_t> col_cost((size_t)max_two + 1, 0);
-    int64_t total = 0;
-    for (const Cand &c : cand) { col_cost[(size_t)tasks[(size_t)c.task].two[0]] += c.cost; total += c.cost; }
-    std::vector<int> col_xcd((size_t)max_two + 1, 0);
-    {
+    std::vector<int> per_xcd[8];
+    if (opt.wg_xcd) {
+        int32_t max_two = 0;
+        for (const Cand &c : cand) max_two = std::max(max_two, tasks[(size_t)c.task].two[0]);
+        std::vector<int64_t> col_cost((size_t)max_two + 1, 0);
+        int64_t total = 0;
+        for (const Cand &c : cand) { col_cost[(size_t)tasks[(size_t)c.task].two[0]] += c.cost; total += c.cost; }
+        std::vector<int> col_xcd((size_t)max_two + 1, 0);
         int64_t run = 0;
         for (size_t t = 0; t < col_cost.size(); ++t) {
             col_xcd[t] = (int)std::min<int64_t>(7, (run + col_cost[t] / 2) * 8 / std::max<int64_t>(total, 1));
             run += col_cost[t];
         }
+        for (size_t i = 0; i < n; ++i) per_xcd[col_xcd[(size_t)tasks[(size_t)cand[i].task].two[0]]].push_back((int)i);   // (cost-descending)
     }
-    std::vector<const Cand *> per_xcd[8];
-    for (const Cand &c : cand) per_xcd[col_xcd[(size_t)tasks[(size_t)c.task].two[0]]].push_back(&c);   // (cand is cost-descending)
-    std::vector<WgDesc> lists[8];
-    size_t longest = 0;
-    for (int x = 0; x < 8; ++x) { lists[x] = snake(build(per_xcd[x]), 32); longest = std::max(longest, lists[x].size()); }
-    for (size_t q = 0; q < longest; ++q)
-        for (int x = 0; x < 8; ++x) out.push_back(q < lists[x].size() ? lists[x][q] : blank(1));
+
+    // (a) every task gets W = 1, 2 or 4 waves - the smallest W that brings its per-wave cost under c*, c* the smallest
+    // value for which all workgroups fit the wave slots
+    auto slots_for = [&](int64_t cstar) {
+        int64_t n1 = 0, n2 = 0, n4 = 0;
+        for (const Cand &c : cand) { const int w = waves_for(c, cstar); (w == 1 ? n1 : w == 2 ? n2 : n4)++; }
+        return 4 * (n4 + (n2 + 1) / 2 + (n1 + 3) / 4);
+    };
+    int64_t lo = 1, hi = cand[0].cost;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (slots_for(mid) <= opt.wave_slots - (opt.wg_xcd ? 48 : 0)) hi = mid; else lo = mid + 1;   // (per-XCD rounding of the workgroups)
+    }
+    std::vector<int> W(n), best_W;
+    bool any = false;
+    for (size_t i = 0; i < n; ++i) { W[i] = waves_for(cand[i], lo); any = any || W[i] > 1; }
+    if (!any) return out;
+    bool balance = opt.balance;
+    if (const char *env = getenv("PRALINE_WG_BALANCE")) balance = atoi(env) != 0;   // (also read here: the CPU test library has no plan options)
+    if (!balance) {
+        assemble(cand, W, per_xcd, opt, &out);
+        return out;
+    }
+    int64_t best = assemble(cand, W, per_xcd, opt, nullptr);
+    best_W = W;
+
+    // (b) EXPERIMENT (opt.balance / PRALINE_WG_BALANCE=1; off by default).  The threshold minimises the longest WAVE; what a
+    // launch lasts is the busiest SIMD - the sum of the two waves it hosts (see assemble).  With more tasks than half the
+    // slots the threshold leaves the cheaper tasks whole (long waves) beside the halves of the expensive ones: C2's
+    // busiest SIMD carries 7 519 steps against a mean of 6 080.  A whole task wants a SHORT partner on its SIMD: quartering
+    // a window of z mid-cost tasks provides them (the snake order pairs the longest workgroups with the shortest), the
+    // cheapest tasks stay whole as far as the slots demand and the halves of the rest pair with each other; z and the
+    // window's place are searched on the model, per XCD list.  Modelled on C2: 7 519 -> 6 869 steps (-8.6 %; an
+    // exhaustive search of this family without the XCD split: 6 640).  MEASURED: no gain (2.14 ms against 2.07-2.14) -
+    // the sum model misses what the quartered tasks cost (four waves in lock step on four SIMDs, each beside a wave of
+    // another task; a wave left alone on its SIMD no longer hides its own latencies), so the threshold stays the default.
+    {
+        std::vector<int> all_idx;
+        if (!opt.wg_xcd) for (size_t i = 0; i < n; ++i) all_idx.push_back((int)i);
+        const int n_sets = opt.wg_xcd ? 8 : 1;
+        const int64_t set_wgs = opt.wg_xcd ? opt.wave_slots / 32 : opt.wave_slots / 4;   // resident workgroups per set
+        auto try_one = [&](int dz, int place) -> int64_t {   // place: start of the window, in 16ths of the quarterable tasks
+            for (int x = 0; x < n_sets; ++x) {
+                const std::vector<int> &set = opt.wg_xcd ? per_xcd[x] : all_idx;   // cost-descending
+                const int64_t m = (int64_t)set.size();
+                std::vector<int> can4;
+                int64_t n2 = 0;
+                for (int i : set) { if (cand[(size_t)i].wmax == 4) can4.push_back(i); n2 += cand[(size_t)i].wmax >= 2; }
+                const int64_t z0 = std::max<int64_t>(0, (2 * n2 + (m - n2) - 4 * set_wgs) / 2);
+                const int64_t step = std::max<int64_t>(1, m / 96);
+                const int64_t z = std::min<int64_t>((int64_t)can4.size(), std::max<int64_t>(0, z0 + dz * step));
+                const int64_t first = std::min<int64_t>((int64_t)can4.size() - z, (int64_t)can4.size() * place / 16);
+                for (int i : set) W[(size_t)i] = std::min(2, cand[(size_t)i].wmax);
+                for (int64_t k = 0; k < z; ++k) W[(size_t)can4[(size_t)(first + k)]] = 4;
+                int64_t c1 = 0, c2 = 0, c4 = 0;
+                for (int i : set) (W[(size_t)i] == 1 ? c1 : W[(size_t)i] == 2 ? c2 : c4)++;
+                // the cheapest halves stay whole until the workgroups fit
+                for (int64_t t = m - 1; t >= 0 && c4 + (c2 + 1) / 2 + (c1 + 3) / 4 > set_wgs; --t)
+                    if (W[(size_t)set[(size_t)t]] == 2) { W[(size_t)set[(size_t)t]] = 1; --c2; ++c1; }
+                if (c4 + (c2 + 1) / 2 + (c1 + 3) / 4 > set_wgs) return -1;
+            }
+            const int64_t ms = assemble(cand, W, per_xcd, opt, nullptr);
+            if (getenv("PRALINE_SCHED_DEBUG")) fprintf(stderr, "balance: dz=%d place=%d/16 -> makespan %lld (best %lld)\n", dz, place, (long long)ms, (long long)best);
+            if (ms >= 0 && (best < 0 || ms < best)) { best = ms; best_W = W; }
+            return ms;
+        };
+        if (const char *env = getenv("PRALINE_WG_BALANCE_FORCE")) {   // experiments: "dz,place" - take exactly this member of the family
+            int dz = 0, place = 4;
+            if (sscanf(env, "%d,%d", &dz, &place) == 2) {
+                best = -1;
+                try_one(dz, place);
+                if (best >= 0) { assemble(cand, best_W, per_xcd, opt, &out); return out; }
+            }
+        }
+        int best_dz = 0;
+        int64_t best_here = -1;
+        for (int dz = -4; dz <= 0; dz += 2) {
+            const int64_t ms = try_one(dz, 4);
+            if (ms >= 0 && (best_here < 0 || ms < best_here)) { best_here = ms; best_dz = dz; }
+        }
+        try_one(best_dz, 2);
+        try_one(best_dz, 6);
+    }
+    if (best < 0) {
+        // (cannot happen with the reserve above; keep the threshold list whatever the model says)
+        for (size_t i = 0; i < n; ++i) best_W[i] = waves_for(cand[i], lo);
+    }
+    assemble(cand, best_W, per_xcd, opt, &out);
     return out;
 }
 
