@@ -1,5 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of
 libpraline_dp.so; the CPU oracle and the committed golden vectors are the checkers."""
+import os
+
 import numpy as np
 import pytest
 
@@ -665,6 +667,8 @@ def test_two_pass_paths_equal_single_pass(nat, bba, monkeypatch):
                     plan.run(mode, *GAPS)
                     res[two] = (plan.scores().copy(), [p.copy() for p in plan.paths()], plan.kernel_name())
                     plan.close()
+                if not res["2"][2].endswith("true>") and (os.environ.get("PRALINE_KERNEL") == "batch" or os.environ.get("PRALINE_MM")):
+                    pytest.skip("the two-pass kernels need the f16 operand layouts (switched off by the environment)")
                 assert res["0"][2] != res["2"][2] and res["2"][2].endswith("true>"), res["2"][2]
                 assert np.array_equal(bits(res["0"][0]), bits(res["2"][0])), (kind, mode, use_rects)
                 for k, (i, j) in enumerate(pairs):
@@ -698,6 +702,8 @@ def test_two_pass_forward_on_the_scores_kernel(nat, bba, monkeypatch):
             plan.run("global", *GAPS)
             res[keep] = (plan.scores().copy(), [p.copy() for p in plan.paths()], plan.kernel_name())
             plan.close()
+        if "k_dp_split16<" not in res["1"][2] and any(os.environ.get(k) for k in ("PRALINE_KERNEL", "PRALINE_MM", "PRALINE_NO_STAGE", "PRALINE_NO_W2")):
+            pytest.skip("the kept-state forward fill needs the staged scores kernel (switched off by the environment)")
         assert "k_dp_split16<" in res["1"][2] and res["1"][2].endswith("true>"), res["1"][2]
         assert np.array_equal(bits(res["0"][0]), bits(res["1"][0]))
         for k, (i, j) in enumerate(pairs):

@@ -184,7 +184,7 @@ def test_c2_float_profile_alignments_vs_reference_order(nat, bba):
     worst_rel = 0.0
     for q, mode in enumerate(MODES):
         sc, paths, kind = fast[mode]
-        assert kind == 1
+        assert kind == (0 if os.environ.get("PRALINE_KERNEL") == "batch" else 1)   # (k_dp_batch has no f16 layouts)
         rel = np.abs(sc - sc_ref[:, q]) / np.maximum(1.0, np.abs(sc_ref[:, q]))
         assert rel.max() <= 1e-5, (mode, rel.max())
         worst_rel = max(worst_rel, float(rel.max()))
