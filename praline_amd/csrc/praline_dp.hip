@@ -1223,22 +1223,13 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                            (int64_t)(pl.tasks[t].nstrips + 1) * (pl.tasks[t].max_l1 + PRALINE_TB2_PAD_ROWS) * 32 * 16;
                 if ((size_t)all > budget) chunk_budget = budget / 2;
             }
-            int chunk_no = 0;
-            bool forked = false;
-            while (t0 < nt && rc2 == PRALINE_OK) {
-                const int set = chunk_no & 1;
-                hipStream_t cs = set ? g_rt.stream2 : st;
-                if (set && !forked) {
-                    if (hipEventRecord(g_rt.ev_fork, st) != hipSuccess || hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0) != hipSuccess) {
-                        rc2 = fail(PRALINE_ERR_DEVICE, "stream fork failed");
-                        break;
-                    }
-                    forked = true;
-                }
-                DevBuf<char> &d_ck = set ? pl.d_tb_b : pl.d_tb;
-                DevBuf<float4> &d_bk = set ? pl.d_bnd2_b : pl.d_bnd2;
-                DevBuf<float> &d_ax = set ? pl.d_aux_b : pl.d_aux;
-                la.stream = cs;
+            // The chunks are cut first and each scratch set is allocated ONCE, for its largest chunk: a buffer that grew
+            // in the middle of the loop would hand its old block back to the pool while the kernels of an earlier chunk
+            // may still be using it - and the pool could give it to the OTHER set, which runs on the other stream
+            // (seen with 45 000 alignments of ~1 000 x 1 300: thousands of wrong paths, different from run to run).
+            struct Chunk2 { size_t t0, t1; int64_t ck_e, bnd_e, aux_e; };
+            std::vector<Chunk2> chunks;
+            while (t0 < nt) {
                 size_t t1 = t0;
                 int64_t ck_e = 0, bnd_e = 0, aux_e = 0;   // floats, float4s, floats
                 while (t1 < nt) {
@@ -1254,26 +1245,62 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                     aux_e += semiglobal ? pl.aux_elems[t1] : 0;
                     ++t1;
                 }
-                if (d_ck.n < (size_t)ck_e * 4) rc2 = d_ck.alloc((size_t)ck_e * 4);
-                if (rc2 == PRALINE_OK && d_bk.n < (size_t)bnd_e) rc2 = d_bk.alloc((size_t)bnd_e);
-                if (rc2 == PRALINE_OK && d_ax.n < (size_t)std::max<int64_t>(aux_e, 1)) rc2 = d_ax.alloc((size_t)std::max<int64_t>(aux_e, 1));
-                if (rc2 != PRALINE_OK) break;
-                hipError_t e = hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, cs);
-                if (e != hipSuccess) { rc2 = fail(PRALINE_ERR_DEVICE, "task upload: %s", hipGetErrorString(e)); break; }
-                la.tasks = pl.d_tasks.p + t0;
-                la.lane_one = pl.d_lane_one.p + t0 * 32;
-                la.lane_pair = pl.d_lane_pair.p + t0 * 32;
+                chunks.push_back({t0, t1, ck_e, bnd_e, aux_e});
+                t0 = t1;
+            }
+            {
+                int64_t need_ck[2] = {0, 0}, need_bk[2] = {0, 0}, need_ax[2] = {1, 1};
+                for (size_t c = 0; c < chunks.size(); ++c) {
+                    need_ck[c & 1] = std::max(need_ck[c & 1], chunks[c].ck_e * 4);
+                    need_bk[c & 1] = std::max(need_bk[c & 1], chunks[c].bnd_e);
+                    need_ax[c & 1] = std::max(need_ax[c & 1], chunks[c].aux_e);
+                }
+                const bool grow = pl.d_tb.n < (size_t)need_ck[0] || pl.d_tb_b.n < (size_t)need_ck[1] || pl.d_bnd2.n < (size_t)need_bk[0] ||
+                                  pl.d_bnd2_b.n < (size_t)need_bk[1] || pl.d_aux.n < (size_t)need_ax[0] || pl.d_aux_b.n < (size_t)need_ax[1];
+                if (grow) {   // (an earlier run's kernels may still be reading the blocks that are about to be replaced)
+                    HIPCHK(hipStreamSynchronize(st));
+                    HIPCHK(hipStreamSynchronize(g_rt.stream2));
+                }
+                if (pl.d_tb.n < (size_t)need_ck[0]) RC(pl.d_tb.alloc((size_t)need_ck[0]));
+                if (pl.d_bnd2.n < (size_t)need_bk[0]) RC(pl.d_bnd2.alloc((size_t)need_bk[0]));
+                if (pl.d_aux.n < (size_t)need_ax[0]) RC(pl.d_aux.alloc((size_t)need_ax[0]));
+                if (chunks.size() > 1) {
+                    if (pl.d_tb_b.n < (size_t)need_ck[1]) RC(pl.d_tb_b.alloc((size_t)need_ck[1]));
+                    if (pl.d_bnd2_b.n < (size_t)need_bk[1]) RC(pl.d_bnd2_b.alloc((size_t)need_bk[1]));
+                    if (pl.d_aux_b.n < (size_t)need_ax[1]) RC(pl.d_aux_b.alloc((size_t)need_ax[1]));
+                }
+            }
+            HIPCHK(hipMemcpyAsync(pl.d_tasks.p, pl.tasks.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));   // (before the fork)
+            bool forked = false;
+            for (size_t c = 0; c < chunks.size() && rc2 == PRALINE_OK; ++c) {
+                const int set = (int)(c & 1);
+                hipStream_t cs = set ? g_rt.stream2 : st;
+                if (set && !forked) {
+                    if (hipEventRecord(g_rt.ev_fork, st) != hipSuccess || hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0) != hipSuccess) {
+                        rc2 = fail(PRALINE_ERR_DEVICE, "stream fork failed");
+                        break;
+                    }
+                    forked = true;
+                }
+                DevBuf<char> &d_ck = set ? pl.d_tb_b : pl.d_tb;
+                DevBuf<float4> &d_bk = set ? pl.d_bnd2_b : pl.d_bnd2;
+                DevBuf<float> &d_ax = set ? pl.d_aux_b : pl.d_aux;
+                la.stream = cs;
+                const size_t c0 = chunks[c].t0, t1 = chunks[c].t1;
+                la.tasks = pl.d_tasks.p + c0;
+                la.lane_one = pl.d_lane_one.p + c0 * 32;
+                la.lane_pair = pl.d_lane_pair.p + c0 * 32;
                 la.tb = (uint4 *)d_ck.p;
                 la.bnd = d_bk.p;
                 la.aux = d_ax.p;
-                la.n_tasks = (unsigned)(t1 - t0);
+                la.n_tasks = (unsigned)(t1 - c0);
                 rc2 = praline_launch_tb2_forward(la, a16, a.nr16, tb_nterm, local, pl.has_rects);
                 if (rc2 != PRALINE_OK) { rc2 = fail(rc2, "no two-pass forward instance for nr=%d nterm=%d", a.nr16, tb_nterm); break; }
                 if (semiglobal) {
-                    const int64_t lanes = (int64_t)(t1 - t0) * 32;
+                    const int64_t lanes = (int64_t)(t1 - c0) * 32;
                     hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, cs, la.ar, pl.d_tasks.p,
                                        pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, d_ax.p, pl.d_end_cells.p, la.scores,
-                                       la.rp, (int32_t)t0, (int32_t)t1, 1);
+                                       la.rp, (int32_t)c0, (int32_t)t1, 1);
                 }
                 Trace2Args ta;
                 ta.slot_off = pl.d_slot_off.p;
@@ -1283,8 +1310,6 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                 rc2 = praline_launch_tb2_backward(la, a16, ta, a.nr16, tb_nterm, local, pl.has_rects);
                 if (rc2 != PRALINE_OK) { rc2 = fail(rc2, "no two-pass backward instance for nr=%d nterm=%d", a.nr16, tb_nterm); break; }
                 if (hipGetLastError() != hipSuccess) { rc2 = fail(PRALINE_ERR_DEVICE, "two-pass launch failed"); break; }
-                t0 = t1;
-                ++chunk_no;
             }
             la.stream = st;
             if (forked && (hipEventRecord(g_rt.ev_join, g_rt.stream2) != hipSuccess || hipStreamWaitEvent(st, g_rt.ev_join, 0) != hipSuccess))
@@ -1305,19 +1330,10 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         for (size_t t = 0; t < nt; ++t) all += pl.tb_elems[t] * (int64_t)tb_elem_bytes;
         if ((size_t)all > budget) chunk_budget = budget / 2;
     }
-    int chunk_no = 0;
-    bool forked = false;
+    // (cut first, allocate each scratch set once for its largest chunk - see the two-pass loop above)
+    struct Chunk1 { size_t t0, t1; int64_t tb_e, aux_e; };
+    std::vector<Chunk1> chunks;
     while (t0 < nt) {
-        const int set = chunk_no & 1;
-        hipStream_t cs = set ? g_rt.stream2 : st;
-        if (set && !forked) {
-            HIPCHK(hipEventRecord(g_rt.ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0));
-            forked = true;
-        }
-        DevBuf<char> &d_tbs = set ? pl.d_tb_b : pl.d_tb;
-        DevBuf<float> &d_ax = set ? pl.d_aux_b : pl.d_aux;
-        la.stream = cs;
         size_t t1 = t0;
         int64_t tb_e = 0, aux_e = 0;
         while (t1 < nt) {
@@ -1329,10 +1345,44 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             aux_e += semiglobal ? pl.aux_elems[t1] : 0;
             ++t1;
         }
-        if (d_tbs.n < (size_t)tb_e * tb_elem_bytes) RC(d_tbs.alloc((size_t)tb_e * tb_elem_bytes));
-        if (d_ax.n < (size_t)std::max<int64_t>(aux_e, 1)) RC(d_ax.alloc((size_t)std::max<int64_t>(aux_e, 1)));
-        if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
-        HIPCHK(hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, cs));
+        chunks.push_back({t0, t1, tb_e, aux_e});
+        t0 = t1;
+    }
+    {
+        size_t need_tb[2] = {0, 0}, need_ax[2] = {1, 1};
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            need_tb[c & 1] = std::max(need_tb[c & 1], (size_t)chunks[c].tb_e * tb_elem_bytes);
+            need_ax[c & 1] = std::max(need_ax[c & 1], (size_t)chunks[c].aux_e);
+        }
+        const bool grow = pl.d_tb.n < need_tb[0] || pl.d_aux.n < need_ax[0] ||
+                          (chunks.size() > 1 && (pl.d_tb_b.n < need_tb[1] || pl.d_aux_b.n < need_ax[1]));
+        if (grow) {   // (an earlier run's kernels may still be reading the blocks that are about to be replaced)
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipStreamSynchronize(g_rt.stream2));
+        }
+        if (pl.d_tb.n < need_tb[0]) RC(pl.d_tb.alloc(need_tb[0]));
+        if (pl.d_aux.n < need_ax[0]) RC(pl.d_aux.alloc(need_ax[0]));
+        if (chunks.size() > 1) {
+            if (pl.d_tb_b.n < need_tb[1]) RC(pl.d_tb_b.alloc(need_tb[1]));
+            if (pl.d_aux_b.n < need_ax[1]) RC(pl.d_aux_b.alloc(need_ax[1]));
+        }
+    }
+    if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
+    HIPCHK(hipMemcpyAsync(pl.d_tasks.p, pl.tasks.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));   // (before the fork)
+    bool forked = false;
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        const int set = (int)(c & 1);
+        hipStream_t cs = set ? g_rt.stream2 : st;
+        if (set && !forked) {
+            HIPCHK(hipEventRecord(g_rt.ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0));
+            forked = true;
+        }
+        DevBuf<char> &d_tbs = set ? pl.d_tb_b : pl.d_tb;
+        DevBuf<float> &d_ax = set ? pl.d_aux_b : pl.d_aux;
+        la.stream = cs;
+        t0 = chunks[c].t0;
+        const size_t t1 = chunks[c].t1;
         la.tasks = pl.d_tasks.p + t0;
         la.lane_one = pl.d_lane_one.p + t0 * lanes_per_task;
         la.lane_pair = pl.d_lane_pair.p + t0 * lanes_per_task;
@@ -1388,8 +1438,6 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         }
         HIPCHK(hipGetLastError());
         RC(launch_traceback(pl, la, t0, t1, mode));
-        t0 = t1;
-        ++chunk_no;
     }
     la.stream = st;
     if (forked) {

@@ -74,6 +74,7 @@ while time.time() < t_end:
     plan.run(mode, -11.0, -1.0)
     sc = plan.scores()
     paths = plan.paths() if want_paths else None
+    kname = plan.kernel_name()
     plan.close()
     check = rng.permutation(len(pairs))[:24]
     for k in check:
@@ -83,6 +84,20 @@ while time.time() < t_end:
         if sc[k] != np.float32(s_or) or (want_paths and not np.array_equal(paths[k], p_or)):
             print("MISMATCH kind=%s N=%d mu=%d mode=%s paths=%s rects=%s pair=(%d,%d) lens=(%d,%d) dev=%r oracle=%r" % (
                 kind, N, mu, mode, want_paths, rects[k] if rects else None, i, j, lens[i], lens[j], sc[k], s_or), flush=True)
+            print("  kernel %s  match kind %d  ref_mode %s  TWOPASS=%s KEEP=%s  pairs in plan %d  index %d" % (
+                kname, mk, ref_mode, os.environ.get("PRALINE_TB_TWOPASS"), os.environ.get("PRALINE_TB_KEEP"), len(pairs), k), flush=True)
+            if want_paths:
+                pd, po = np.asarray(paths[k]), np.asarray(p_or)
+                print("  path rows dev %d oracle %d" % (len(pd), len(po)), flush=True)
+                q = 1
+                while q <= min(len(pd), len(po)) and np.array_equal(pd[-q], po[-q]):
+                    q += 1
+                print("  first difference from the end at row -%d: dev %s oracle %s" % (q, pd[-q] if q <= len(pd) else None, po[-q] if q <= len(po) else None), flush=True)
+            out = os.path.join(ROOT, "gpurun_out", "stress_mismatch.npz")
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            np.savez_compressed(out, lens=lens, pairs=pairs, k=k, mode=mode, kind=kind, S=S, dev_path=np.asarray(paths[k]) if want_paths else 0,
+                                or_path=np.asarray(p_or) if want_paths else 0, p_i=profs[i], p_j=profs[j], m=m,
+                                profs=np.concatenate(profs, axis=0))
             sys.exit(1)
         if kind not in ("profile", "wide") and rects is None and k % 3 == 0:
             ref = orc.pairwise_score_fast(mode, profs[i], profs[j], S, -11.0, -1.0)

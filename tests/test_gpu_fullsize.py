@@ -1,6 +1,8 @@
 """GPU tests at BASELINE.json's full configuration sizes (all of C3 incl. the second Waterman-Eggert pass, one rank's
 share of C4, all of C5): properties that do not need the oracle at full size - the score recomputed from the returned path, mode ordering, symmetry
 and self-alignment under integer scoring - plus oracle spot checks on sampled pairs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,17 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 GO, GE = -11.0, -1.0
+GAPS = (GO, GE)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def oracle_dp_on_m(mode, m):
+    """The oracle's fill + end cell + traceback on a given match-score matrix (the device's own m)."""
+    g1, g2 = orc.gap_arrays(m.shape[0], m.shape[1], GAPS)
+    return orc.raw_pairwise_align(mode, np.ascontiguousarray(m), g1, g2, None)
 
 
 @pytest.fixture(scope="module")
@@ -266,4 +279,47 @@ def test_c5_long_dna_full_size(nat):
     plan.run("global", GO, GE)
     assert np.array_equal(plan.scores(), res["global"][sub])
     plan.close()
+    arena.close()
+
+
+def test_chunked_path_plans_on_two_streams(nat, monkeypatch):
+    """44 787 global alignments with paths of ~1 000 x 1 300 nucleotides (a batch `scripts/stress.py` drew): the scratch of
+    such a plan - tens of GB - runs in chunks that alternate between two streams and two scratch sets.  Regression test:
+    the sets used to be re-allocated inside the chunk loop, handing a block that an earlier chunk's kernels were still
+    reading back to the pool - and on to the other stream's set (thousands of wrong paths, different from run to run).
+    Single pass and two-pass scheme, default and smaller budgets, must give identical scores and paths, and sampled pairs
+    must equal the oracle."""
+    from praline_amd.matrices import nucleotide_matrix
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chunked_paths_dna.npz"))
+    lens, pairs, sym = d["lens"], d["pairs"], d["sym"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    profs = [np.eye(15, dtype=np.float32)[sym[off[i]:off[i + 1]]] for i in range(len(lens))]
+    S = nucleotide_matrix()
+    arena = nat.Arena(profs, S)
+
+    def run(two, budget):
+        monkeypatch.setenv("PRALINE_TB_TWOPASS", two)
+        if budget:
+            monkeypatch.setenv("PRALINE_TB_BUDGET_MB", budget)
+        else:
+            monkeypatch.delenv("PRALINE_TB_BUDGET_MB", raising=False)
+        plan = nat.Plan(arena, pairs, want_paths=True)
+        plan.run("global", *GAPS)
+        sc = plan.scores().copy()
+        buf, o, r = plan.paths_packed()
+        res = (sc, buf.copy(), o.copy(), r.copy(), plan.match_kind())
+        plan.close()
+        return res
+
+    ref = run("0", "160000")                       # one chunk
+    for two, budget in (("0", None), ("2", None), ("2", "3000"), ("0", "3000"), ("2", None)):
+        res = run(two, budget)
+        assert np.array_equal(bits(res[0]), bits(ref[0])), (two, budget)
+        assert np.array_equal(res[3], ref[3]) and np.array_equal(res[2], ref[2]) and np.array_equal(res[1], ref[1]), (two, budget)
+    rng = np.random.default_rng(7)
+    for k in rng.permutation(len(pairs))[:6]:
+        i, j = pairs[k]
+        s_or, p_or = oracle_dp_on_m("global", arena.match_scores(int(i), int(j), ref[4]))
+        assert ref[0][k] == np.float32(s_or)
+        assert np.array_equal(ref[1][ref[2][k]:ref[2][k] + ref[3][k]], p_or)
     arena.close()
