@@ -75,7 +75,38 @@ while time.time() < t_end:
     sc = plan.scores()
     paths = plan.paths() if want_paths else None
     kname = plan.kernel_name()
+    packed = plan.paths_packed() if want_paths else None
     plan.close()
+    if want_paths and rng.random() < 0.25:
+        # the same plan under another configuration (other pass scheme, other scratch budget = other chunking): EVERY
+        # score and path must be identical (races between chunks show up here, not in 24 sampled pairs)
+        keep_env = {k: os.environ.get(k) for k in ("PRALINE_TB_TWOPASS", "PRALINE_TB_BUDGET_MB")}
+        os.environ["PRALINE_TB_TWOPASS"] = "0" if os.environ.get("PRALINE_TB_TWOPASS") == "2" else "2"
+        bud = rng.choice(["", "40", "500", "3000"])
+        if bud:
+            os.environ["PRALINE_TB_BUDGET_MB"] = str(bud)
+        plan2 = nat.Plan(arena, pairs, want_paths=True, rects=rects)
+        plan2.run(mode, -11.0, -1.0)
+        sc2 = plan2.scores()
+        packed2 = plan2.paths_packed()
+        k2 = plan2.kernel_name()
+        plan2.close()
+        for kk, vv in keep_env.items():
+            if vv is None:
+                os.environ.pop(kk, None)
+            else:
+                os.environ[kk] = vv
+        same = np.array_equal(sc.view(np.uint32), sc2.view(np.uint32)) and np.array_equal(packed[2], packed2[2])
+        if same:   # (the buffers hold one slot of capacity L1 + L2 + 2 per pair: compare the rows in use)
+            for q in range(len(pairs)):
+                if not np.array_equal(packed[0][packed[1][q]:packed[1][q] + packed[2][q]], packed2[0][packed2[1][q]:packed2[1][q] + packed2[2][q]]):
+                    same = False
+                    print("  pair %d (%d, %d): paths differ" % (q, pairs[q][0], pairs[q][1]), flush=True)
+                    break
+        if not same:
+            print("CONFIGURATIONS DIFFER kind=%s N=%d mu=%d mode=%s pairs=%d: %s vs %s (budget %r): %d scores, %d path lengths differ" % (
+                kind, N, mu, mode, len(pairs), kname, k2, bud, int((sc != sc2).sum()), int((packed[2] != packed2[2]).sum())), flush=True)
+            sys.exit(1)
     check = rng.permutation(len(pairs))[:24]
     for k in check:
         i, j = pairs[k]
