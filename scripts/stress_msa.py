@@ -26,7 +26,7 @@ def run(manager, keys, **inputs):
 
 t_end = time.time() + budget
 t_print = time.time()
-n_cases = n_steps = n_levels = 0
+n_cases = n_steps = n_levels = n_adhoc = 0
 while time.time() < t_end:
     n = int(rng.choice([2, 3, 5, 9, 17, 33]))
     mu = int(rng.choice([12, 40, 90, 200]))
@@ -92,7 +92,22 @@ while time.time() < t_end:
         print("  sequences %s" % [s_.get_track(ct.TRACK_ID_INPUT).values.tolist() for s_ in seqs], flush=True)
         sys.exit(1)
     n_cases += 1; n_steps += n - 1; n_levels += len(dev.levels)
+    if n <= 17 and rng.random() < 0.3:
+        # AdHocMultipleSequenceAligner (msa.py:250-558): resident clusters + score cache under the batching manager against
+        # the serial manager - equal final alignments
+        mm, dm = [("semiglobal", "global"), ("global", "global"), ("semiglobal_auto", "semiglobal_auto"), ("global", "semiglobal")][int(rng.integers(0, 4))]
+        outs = []
+        for manager in (batch, serial):
+            ex = core.Execution(manager, "root")
+            ex.add_task(comp.AdHocMultipleSequenceAligner).environment(core.Environment({}), core.Environment({"merge_mode": mm, "dist_mode": dm})).inputs(
+                sequences=seqs, track_id_sets=T, score_matrices=mats)
+            outs.append(core.run(ex)[0]['alignment'])
+        if [x.name for x in outs[0].items] != [x.name for x in outs[1].items] or not np.array_equal(np.asarray(outs[0].path), np.asarray(outs[1].path)):
+            print("ADHOC MISMATCH n=%d mu=%d two_sets=%s merge_mode=%s dist_mode=%s" % (n, mu, two_sets, mm, dm), flush=True)
+            print("  sequences %s" % [s_.get_track(ct.TRACK_ID_INPUT).values.tolist() for s_ in seqs], flush=True)
+            sys.exit(1)
+        n_adhoc += 1
     if time.time() - t_print > 60:
         t_print = time.time()
         print("  ... %d alignments, %d merge steps in %d device levels" % (n_cases, n_steps, n_levels), flush=True)
-print("stress_msa ok: %d progressive alignments, %d merge steps in %d device levels, all equal to the serial host path" % (n_cases, n_steps, n_levels))
+print("stress_msa ok: %d progressive alignments, %d merge steps in %d device levels, all equal to the serial host path; %d ad-hoc alignments equal" % (n_cases, n_steps, n_levels, n_adhoc))
