@@ -41,6 +41,14 @@ typedef float f4n __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int onehot_stride(int NR) { return 32 * NR + 16; }
 __host__ __device__ constexpr int onehot_bytes(int NR) { return (16 * NR + 1) * onehot_stride(NR); }
 
+// Match-score LOOKUP (BSRC = 3; one-hot arenas in exact mode): with a one-hot sequence ONE the match score of a cell is
+// no contraction at all - m[y][x] = Q2[x][symbol of row y] - so the strip's 32 pre-multiplied rows are transposed into
+// an LDS table once per strip, lookup_tab[symbol][32 strip columns] (fp32; row 16 NR: zeros, for padding rows), and a
+// step reads its lane's 16 values with four ds_read_b128 instead of issuing two to four MFMAs: no MFMA, no accumulator
+// tiles, no operand registers.  The odd 16-byte row stride spreads the symbols' rows over the LDS banks.
+__host__ __device__ constexpr int lookup_stride() { return 128 + 16; }
+__host__ __device__ constexpr int lookup_bytes(int NR) { return (16 * NR + 1) * lookup_stride(); }
+
 // Measured: forcing v_pk_add_f32 for the three per-column adds made the kernel 13 % SLOWER (packed fp32
 // VALU beside MFMAs is an anti-lever on gfx950); plain scalar adds are used.
 __device__ __forceinline__ f2 pk_add(f2 a, f2 b)
@@ -216,16 +224,17 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     static_assert(!DM || BSRC == 2 || BSRC == 1, "the double-MFMA tile is wired for the staged stream and the one-hot table");
     static_assert(KEEP == 0 || !DM, "the kept states are taken from the non-DM tile");
     constexpr bool ONEHOT = BSRC == 1;
+    constexpr bool LOOKUP = BSRC == 3;   // CUR: this lane's 16 match scores of its row; PREV receives the next row's (symbol symw)
     // bnd_pref: this step's boundary value on entry; refilled with the value 3 rows ahead.
     // BOPS: B operands of row t+1 on entry; refilled with row t+4 (3-deep rings, the caller rotates
     // the register names through a 6x unrolled loop).
     constexpr int NP = (NTERM == 1) ? 1 : 2;   // pieces held per operand
-    constexpr int NM = NTERM * NR;             // MFMAs per step
+    constexpr int NM = LOOKUP ? 1 : NTERM * NR;   // MFMAs per step
     // ---- match scores of this lane's row: lower half row t (CUR), upper half row t-1 (PREV) ----
     f2 m2[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        if constexpr (DM) { m2[c].x = CUR[2 * c]; m2[c].y = CUR[2 * c + 1]; }
+        if constexpr (DM || LOOKUP) { m2[c].x = CUR[2 * c]; m2[c].y = CUR[2 * c + 1]; }
         else { m2[c].x = h ? PREV[2 * c] : CUR[2 * c]; m2[c].y = h ? PREV[2 * c + 1] : CUR[2 * c + 1]; }
     }
 
@@ -267,6 +276,13 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    if constexpr (LOOKUP) {
+        // the next row's match scores: this lane's 16 strip columns of the table row of that row's symbol
+        const float4 *q = reinterpret_cast<const float4 *>(onehot_lane + symw * lookup_stride());
+        const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+        PREV[0] = a0.x; PREV[1] = a0.y; PREV[2] = a0.z; PREV[3] = a0.w; PREV[4] = a1.x; PREV[5] = a1.y; PREV[6] = a1.z; PREV[7] = a1.w;
+        PREV[8] = a2.x; PREV[9] = a2.y; PREV[10] = a2.z; PREV[11] = a2.w; PREV[12] = a3.x; PREV[13] = a3.y; PREV[14] = a3.z; PREV[15] = a3.w;
+    }
     // ---- MFMAs of row t+1 on the matrix pipe, interleaved with the recurrence of this row ----
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -277,7 +293,7 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);          // A piece: lo for term 0, hi otherwise
         const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);          // B piece: lo for term 1, hi otherwise
 #if !(PRALINE_S16_ABLATE & 4)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+        if constexpr (!LOOKUP) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
         if constexpr (DM) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aopH[ia]), as_half8(BPREV[ib]), acc, 0, 0, 0);
 #else
         acc[k] += BOPS[ib].x * aop[ia].x;
@@ -324,8 +340,10 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    PREV = acc;
-    if constexpr (BSRC == 2) {
+    if constexpr (!LOOKUP) PREV = acc;
+    if constexpr (LOOKUP) {
+        // (nothing to refill: the table serves every row of the strip)
+    } else if constexpr (BSRC == 2) {
         // rows t+5 / t+4 go where rows t+1 / t lived (both consumed: their reads were waited for)
         constexpr int NOPB = ((NTERM == 1) ? 1 : 2) * NR;
         stage_issue<NOPB>(stage_cur[0], *stage_gofs, stage_lds_addr + 1024 + ((SB + 1) & 3) * stage_slot_bytes(NOPB),
@@ -423,8 +441,11 @@ __device__ unsigned long long *praline_trace_buf = nullptr;
 // KEEP: the forward fill of the two-pass alignments with paths (see KeepState): kept boundary columns at
 // keep_bnd + tk.aux_off (float4 [nstrips + 1][max_l1 + PRALINE_TB2_PAD][32]), row checkpoints at ckpt + tk.tb_off
 // (floats), end cells (global: the corner and its first maximal state) to end_cells.
+#ifndef PRALINE_LOOKUP_WAVES
+#define PRALINE_LOOKUP_WAVES 3   // waves per SIMD the lookup instances are compiled for (168 VGPRs)
+#endif
 template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int WPG = 1, bool KEEP = false>
-__global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES : 1)) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ lane_one,
                                                     const int32_t *__restrict__ lane_pair, float2 *bnd,
                                                     float *__restrict__ scores, RunParams rp, int n_tasks,
@@ -435,6 +456,8 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
     static_assert(WPG == 1 || (WPG == 4 && BSRC == 2), "four-wave workgroups use the staged stream");
+    constexpr bool LOOKUP = BSRC == 3;
+    static_assert(!LOOKUP || (NTERM == 1 && !KEEP), "the match-score lookup is an exact-mode path");
     constexpr bool MW = WPG > 1;
     constexpr bool SNAPBR = LOCAL && !MW;   // see split16_step
 #ifdef PRALINE_TRACE
@@ -445,6 +468,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
     constexpr bool DM = (STAGED || ONEHOT) && NTERM == 1 && (PRALINE_S16_DM != 0);   // one tile for both halves (see split16_step)
     static_assert(!ONEHOT || NTERM == 1, "the one-hot table path is an exact-mode path");
     __shared__ __attribute__((aligned(16))) char onehot_tab[ONEHOT ? onehot_bytes(NR) : 16];
+    __shared__ __attribute__((aligned(16))) char lookup_all[LOOKUP ? lookup_bytes(NR) : 16];   // (launched with one wave per block)
     __shared__ __attribute__((aligned(16))) char stage_lds_all[STAGED ? WPG * stage_lds_bytes(NP * NR) : 16];
     __shared__ float mw_out[MW ? WPG * 4 * 32 : 1];  // partial results of the waves sharing a task
     const int wv = MW ? (int)(threadIdx.x >> 6) : 0;
@@ -504,7 +528,8 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
     const char *pB = ar.P16 + (int64_t)(have_pair ? ar.row_off[my_one] : 0) * ar.row_bytes + h * ar.half_bytes;
     const int b_stride = ar.row_bytes;
     const unsigned *pSym = reinterpret_cast<const unsigned *>(ar.sym8 + (have_pair ? ar.row_off[my_one] : 0));
-    const char *onehot_lane = onehot_tab + h * (16 * NR);
+    char *lookup_tab = lookup_all;
+    const char *onehot_lane = LOOKUP ? lookup_tab + h * 64 : onehot_tab + h * (16 * NR);
     // STAGED: per-lane source offsets of the DMA pieces and LDS read addresses (see the comment above)
     unsigned stage_gofs[4] = {0, 0, 0, 0}, stage_rd[4] = {0, 0, 0, 0};
     const unsigned stage_rd_bnd = (unsigned)j * 8u;
@@ -593,7 +618,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
         const bool last_owner = (s == nstrips - 1) && own_last;
 
         float4 aop[NOP];
-        {
+        if constexpr (!LOOKUP) {
             const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.row_bytes);
 #pragma unroll
             for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
@@ -634,6 +659,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
         unsigned d1 = 0, d2 = 0, d3 = 0, d4 = 0;  // ONEHOT: symbols of the rows the next 12 steps refill
+        unsigned lw0 = 0, lw1 = 0, lw2 = 0, lw3 = 0;   // LOOKUP: the 16-byte symbol window
         float2 p0, p1, p2;
         const char *b_next = pB + 4 * b_stride;                   // first refill: row 5
         const char *bnd_ld = my_bnd + 4 * BROW;                   // first prefetch inside a step: row 4
@@ -677,6 +703,37 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
             cb += 64 * NR;
             stage_cur[0] = cb;  // next: operand row 6 (step 1)
             stage_cur[1] = cn;  // next: boundary row 5 (step 1)
+        } else if constexpr (LOOKUP) {
+            // this strip's table: lane (c = lane & 31, half hh) transposes the hi pieces of half hh of the pre-multiplied
+            // row x0 + c (exact mode: Q2 = hi exactly), k = 16 r + 8 hh + jj  ->  lookup_tab[k][c]
+            {
+                const char *src = ar.Q16 + ((int64_t)ar.row_off[two] + x0 + j) * ar.row_bytes + h * ar.half_bytes;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const half8 hv = as_half8(reinterpret_cast<const float4 *>(src)[r]);
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj)
+                        *reinterpret_cast<float *>(lookup_tab + (16 * r + 8 * h + jj) * lookup_stride() + j * 4) = (float)hv[jj];
+                }
+                if (h == 0) *reinterpret_cast<float *>(lookup_tab + (16 * NR) * lookup_stride() + j * 4) = 0.0f;   // padding rows: symbol 16 NR
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+            }
+            // symbols: byte r - 1 of the stream is the symbol of row r.  At step T the lower half fetches the scores of row
+            // T + 1 (byte T), the upper half those of row T (byte T - 1): the upper half works on the stream shifted by one
+            // byte, so both take byte T - 12 i of their 16-byte window (the window starts at byte 12 i).
+            lw0 = pSym[0]; lw1 = pSym[1]; lw2 = pSym[2]; lw3 = pSym[3];
+            {
+                const unsigned first = h ? (lw0 << 8) : lw0;
+                const float4 *q = reinterpret_cast<const float4 *>(onehot_lane + (first & 0xffu) * lookup_stride());
+                const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+                accA[0] = a0.x; accA[1] = a0.y; accA[2] = a0.z; accA[3] = a0.w; accA[4] = a1.x; accA[5] = a1.y; accA[6] = a1.z; accA[7] = a1.w;
+                accA[8] = a2.x; accA[9] = a2.y; accA[10] = a2.z; accA[11] = a2.w; accA[12] = a3.x; accA[13] = a3.y; accA[14] = a3.z; accA[15] = a3.w;
+            }
+            p0 = *reinterpret_cast<const float2 *>(my_bnd + BROW);      // row 1
+            p1 = *reinterpret_cast<const float2 *>(my_bnd + 2 * BROW);  // row 2
+            p2 = *reinterpret_cast<const float2 *>(my_bnd + 3 * BROW);  // row 3
         } else {
             float4 br1[NOP];
             const float4 *s1, *s2, *s3, *s4;
@@ -714,6 +771,12 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYMW, \
                                        nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
 #define PRALINE_STEP16(T, CUR, PREV, BSET, PSLOT) PRALINE_STEP16X(T, CUR, PREV, BSET, PSLOT, d1, 0)
+        // match-score lookup: CUR holds this row's scores, PREV receives the next row's (symbol SYM)
+#define PRALINE_STEP16L(T, CUR, PREV, PSLOT, SYM)                                                                     \
+        split16_step<NR, NTERM, LOCAL, 3, 0, false, SNAPBR>((T) - h, L1, have_pair, h, CUR, PREV, b0, aop, aop, b0, b0, b_next, b_stride, bnd_ld, \
+                                       bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
+                                       out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYM, \
+                                       nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
         // one-hot table with DM: BUSE holds row T+1, BOLD row T (refilled with row T+4 once its MFMAs are issued)
 #define PRALINE_STEP16XD(T, CUR, PREV, BUSE, BOLD, PSLOT, SYMW, SB)                                                   \
         split16_step<NR, NTERM, LOCAL, BSRC, SB, true, SNAPBR>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BOLD, BOLD, b_next, b_stride, bnd_ld, \
@@ -749,7 +812,8 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
 #pragma unroll
             for (int c = 0; c < 17; ++c) Hsave[c] = Hs[c];
             const float best_s = best_run, col_s = col_run;
-            if constexpr (DM && ONEHOT) PRALINE_STEP16XD(1, accA, accB, b0, b3, p0, d1, 0);
+            if constexpr (LOOKUP) PRALINE_STEP16L(1, accA, accB, p0, ((h ? (lw0 << 8) : lw0) >> 8) & 0xffu);
+            else if constexpr (DM && ONEHOT) PRALINE_STEP16XD(1, accA, accB, b0, b3, p0, d1, 0);
             else if constexpr (DM) PRALINE_STEP16D(1, accA, accB, b0, b1, 1, b2);
             else if constexpr (STAGED) PRALINE_STEP16S(1, accA, accB, b0, b1, 1);
             else PRALINE_STEP16(1, accA, accB, b0, p0);
@@ -799,6 +863,30 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
                 PRALINE_STEP16S(t + 11, accA, accB, b0, b1, 1);
                 }
             }
+        } else if constexpr (LOOKUP) {
+            const unsigned *pn = pSym + 4;
+            for (int t = 2; t <= max_l1 + 1; t += 12) {
+                const unsigned n1 = pn[0], n2 = pn[1], n3 = pn[2];   // the next window's new dwords
+                pn += 3;
+                // the upper half's window is the stream shifted by one byte (see above)
+                const unsigned W0 = h ? (lw0 << 8) : lw0;
+                const unsigned W1 = h ? __builtin_amdgcn_alignbit(lw1, lw0, 24) : lw1;
+                const unsigned W2 = h ? __builtin_amdgcn_alignbit(lw2, lw1, 24) : lw2;
+                const unsigned W3 = h ? __builtin_amdgcn_alignbit(lw3, lw2, 24) : lw3;
+                PRALINE_STEP16L(t, accB, accA, p1, (W0 >> 16) & 0xffu);
+                PRALINE_STEP16L(t + 1, accA, accB, p2, W0 >> 24);
+                PRALINE_STEP16L(t + 2, accB, accA, p0, W1 & 0xffu);
+                PRALINE_STEP16L(t + 3, accA, accB, p1, (W1 >> 8) & 0xffu);
+                PRALINE_STEP16L(t + 4, accB, accA, p2, (W1 >> 16) & 0xffu);
+                PRALINE_STEP16L(t + 5, accA, accB, p0, W1 >> 24);
+                PRALINE_STEP16L(t + 6, accB, accA, p1, W2 & 0xffu);
+                PRALINE_STEP16L(t + 7, accA, accB, p2, (W2 >> 8) & 0xffu);
+                PRALINE_STEP16L(t + 8, accB, accA, p0, (W2 >> 16) & 0xffu);
+                PRALINE_STEP16L(t + 9, accA, accB, p1, W2 >> 24);
+                PRALINE_STEP16L(t + 10, accB, accA, p2, W3 & 0xffu);
+                PRALINE_STEP16L(t + 11, accA, accB, p0, (W3 >> 8) & 0xffu);
+                lw0 = lw3; lw1 = n1; lw2 = n2; lw3 = n3;
+            }
         } else if constexpr (ONEHOT) {
             // twelve per iteration: the step at t refills the operands of row t + 4, i.e. symbol t + 3 of
             // the sequence; t = 2 (mod 12), so the twelve symbols are bytes 1..3 of d1, d2, d3 and byte 0
@@ -847,6 +935,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dp_split16(Arena16Dev ar,
             }
         }
 #undef PRALINE_STEP16
+#undef PRALINE_STEP16L
 #undef PRALINE_STEP16S
 #undef PRALINE_STEP16K
 #undef PRALINE_STEP16D

@@ -14,7 +14,15 @@ template <int NR, int NTERM> static void launch16(const LaunchArgs &la, const Ar
     hipLaunchKernelGGL((k_dp_split16<NR, NTERM, LOC, BSRC>), GRID, BLOCK, 0, la.stream, a16, la.tasks, la.lane_one,       \
                        la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks)
     if constexpr (NTERM == 1) {
-        if (a16.sym8 != nullptr) {  // one-hot arena: operand table in LDS
+        if (a16.sym8 != nullptr) {
+            // one-hot arena: the match scores are looked up (BSRC = 3: no MFMA at all); PRALINE_NO_LOOKUP=1 keeps the
+            // one-hot operand table feeding the MFMAs (BSRC = 1)
+            const char *nl = getenv("PRALINE_NO_LOOKUP");
+            if (!(nl && nl[0] == '1')) {
+                const dim3 g1((unsigned)la.n_tasks), b1(64);   // one wave (= its own table) per workgroup
+                if (local) PRALINE_LAUNCH16(true, 3, g1, b1); else PRALINE_LAUNCH16(false, 3, g1, b1);
+                return;
+            }
             if (local) PRALINE_LAUNCH16(true, 1, grid, block); else PRALINE_LAUNCH16(false, 1, grid, block);
             return;
         }

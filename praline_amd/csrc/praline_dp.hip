@@ -1060,7 +1060,9 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             const bool table = a.nterm16 == 1 && a16.sym8 != nullptr && !(!pl.wg.empty() && a16.stage);
             const bool four = a16.stage && !table && (!pl.wg.empty() || (!pl.wg_singles.empty() &&
                               !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')));
-            snprintf(kn, sizeof(kn), "k_dp_split16<%d, %d, %s, %d, %d, false>", a.nr16, a.nterm16, lb, table ? 1 : (a16.stage ? 2 : 0), four ? 4 : 1);
+            const char *nl = getenv("PRALINE_NO_LOOKUP");
+            snprintf(kn, sizeof(kn), "k_dp_split16<%d, %d, %s, %d, %d, false>", a.nr16, a.nterm16, lb,
+                     table ? ((nl && nl[0] == '1') ? 1 : 3) : (a16.stage ? 2 : 0), four ? 4 : 1);
         }
         pl.last_kernel = kn;
     }
