@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
     static_assert(!KEEP || (BSRC == 2 && !LOCAL), "the kept-state forward fill runs on the staged stream (global / semiglobal recurrences)");
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
-    static_assert(WPG == 1 || (WPG == 4 && BSRC == 2), "four-wave workgroups use the staged stream");
+    static_assert(WPG == 1 || (WPG == 4 && (BSRC == 2 || BSRC == 3)), "four-wave workgroups use the staged stream or the match-score lookup");
     constexpr bool LOOKUP = BSRC == 3;
     static_assert(!LOOKUP || (NTERM == 1 && !KEEP), "the match-score lookup is an exact-mode path");
     constexpr bool MW = WPG > 1;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
     constexpr bool DM = (STAGED || ONEHOT) && NTERM == 1 && (PRALINE_S16_DM != 0);   // one tile for both halves (see split16_step)
     static_assert(!ONEHOT || NTERM == 1, "the one-hot table path is an exact-mode path");
     __shared__ __attribute__((aligned(16))) char onehot_tab[ONEHOT ? onehot_bytes(NR) : 16];
-    __shared__ __attribute__((aligned(16))) char lookup_all[LOOKUP ? lookup_bytes(NR) : 16];   // (launched with one wave per block)
+    __shared__ __attribute__((aligned(16))) char lookup_all[LOOKUP ? WPG * lookup_bytes(NR) : 16];   // one table per wave
     __shared__ __attribute__((aligned(16))) char stage_lds_all[STAGED ? WPG * stage_lds_bytes(NP * NR) : 16];
     __shared__ float mw_out[MW ? WPG * 4 * 32 : 1];  // partial results of the waves sharing a task
     const int wv = MW ? (int)(threadIdx.x >> 6) : 0;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
     const char *pB = ar.P16 + (int64_t)(have_pair ? ar.row_off[my_one] : 0) * ar.row_bytes + h * ar.half_bytes;
     const int b_stride = ar.row_bytes;
     const unsigned *pSym = reinterpret_cast<const unsigned *>(ar.sym8 + (have_pair ? ar.row_off[my_one] : 0));
-    char *lookup_tab = lookup_all;
+    char *lookup_tab = lookup_all + (LOOKUP ? wv * lookup_bytes(NR) : 0);
     const char *onehot_lane = LOOKUP ? lookup_tab + h * 64 : onehot_tab + h * (16 * NR);
     // STAGED: per-lane source offsets of the DMA pieces and LDS read addresses (see the comment above)
     unsigned stage_gofs[4] = {0, 0, 0, 0}, stage_rd[4] = {0, 0, 0, 0};
@@ -866,6 +866,11 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
         } else if constexpr (LOOKUP) {
             const unsigned *pn = pSym + 4;
             for (int t = 2; t <= max_l1 + 1; t += 12) {
+                if constexpr (MW) {
+                    // shared task: the ranks meet here every 12 rows; the boundary rows this wave has stored are complete
+                    // (in L2) before the next rank, two iterations behind, can ask for them
+                    if (share > 1) { PRALINE_VMCNT(0); __builtin_amdgcn_s_barrier(); --mw_left; }
+                }
                 const unsigned n1 = pn[0], n2 = pn[1], n3 = pn[2];   // the next window's new dwords
                 pn += 3;
                 // the upper half's window is the stream shifted by one byte (see above)

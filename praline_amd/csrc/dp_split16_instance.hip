@@ -14,6 +14,16 @@ template <int NR, int NTERM> static void launch16(const LaunchArgs &la, const Ar
     hipLaunchKernelGGL((k_dp_split16<NR, NTERM, LOC, BSRC>), GRID, BLOCK, 0, la.stream, a16, la.tasks, la.lane_one,       \
                        la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks)
     if constexpr (NTERM == 1) {
+        if (a16.sym8 != nullptr && la.wg != nullptr) {   // one-hot arena, small batch: shared waves + match-score lookup
+            const dim3 g4(la.n_wg), b4(256);
+            if (local)
+                hipLaunchKernelGGL((k_dp_split16<NR, NTERM, true, 3, 4>), g4, b4, 0, la.stream, a16, la.tasks, la.lane_one,
+                                   la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
+            else
+                hipLaunchKernelGGL((k_dp_split16<NR, NTERM, false, 3, 4>), g4, b4, 0, la.stream, a16, la.tasks, la.lane_one,
+                                   la.lane_pair, (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
+            return;
+        }
         if (a16.sym8 != nullptr) {
             // one-hot arena: the match scores are looked up (BSRC = 3: no MFMA at all); PRALINE_NO_LOOKUP=1 keeps the
             // one-hot operand table feeding the MFMAs (BSRC = 1)

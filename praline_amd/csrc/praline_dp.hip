@@ -777,6 +777,11 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     if (pl->ref) { opt.split_layout = false; opt.tp = 1; }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
     if (const char *env = getenv("PRALINE_NO_W2")) opt.shared_waves = env[0] != '1';
+    {   // score plans on one-hot arenas run the lookup instances: three waves per SIMD (168 VGPRs, 4.75 KB of LDS per wave)
+        const char *nl = getenv("PRALINE_NO_LOOKUP");
+        if (!want_paths && a.onehot && a.nterm16 == 1 && a.nr16 > 0 && match_mode() == PRALINE_MATCH_FAST && !(nl && nl[0] == '1'))
+            opt.wave_slots = 3072;
+    }
     if (const char *env = getenv("PRALINE_W_SLOTS")) opt.wave_slots = atoll(env);
     if (const char *env = getenv("PRALINE_W_SNAKE")) opt.snake = atoi(env) != 0;
     if (const char *env = getenv("PRALINE_WG_XCD")) opt.wg_xcd = atoi(env) != 0;
@@ -1057,12 +1062,14 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         else if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // refined below (nterm, chain)
         else if (la.a16 == nullptr) snprintf(kn, sizeof(kn), "k_dp_split<%d, %s>", a.nstep, lb);
         else {
-            const bool table = a.nterm16 == 1 && a16.sym8 != nullptr && !(!pl.wg.empty() && a16.stage);
-            const bool four = a16.stage && !table && (!pl.wg.empty() || (!pl.wg_singles.empty() &&
-                              !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')));
             const char *nl = getenv("PRALINE_NO_LOOKUP");
+            const bool lookup = !(nl && nl[0] == '1');
+            const bool shared = !pl.wg.empty() && a16.stage;
+            const bool table = a.nterm16 == 1 && a16.sym8 != nullptr && (!shared || lookup);   // one-hot path (lookup or operand table)
+            const bool four = (shared && (!table || lookup)) || (a16.stage && !table && !pl.wg_singles.empty() &&
+                              !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1'));
             snprintf(kn, sizeof(kn), "k_dp_split16<%d, %d, %s, %d, %d, false>", a.nr16, a.nterm16, lb,
-                     table ? ((nl && nl[0] == '1') ? 1 : 3) : (a16.stage ? 2 : 0), four ? 4 : 1);
+                     table ? (lookup ? 3 : 1) : (a16.stage ? 2 : 0), four ? 4 : 1);
         }
         pl.last_kernel = kn;
     }
@@ -1084,7 +1091,10 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             if (!pl.d_wg.p) { RC(pl.d_wg.upload(pl.wg, st)); }
             la.wg = pl.d_wg.p;
             la.n_wg = (unsigned)pl.wg.size();
-            a16.sym8 = nullptr;
+            // one-hot arenas keep their symbol stream: the shared waves look their match scores up (BSRC = 3);
+            // PRALINE_NO_LOOKUP=1: the staged operand stream as for float profiles
+            const char *nl = getenv("PRALINE_NO_LOOKUP");
+            if (a.nterm16 != 1 || (nl && nl[0] == '1')) a16.sym8 = nullptr;
         }
         // large batches: four independent tasks per workgroup (wg_singles) for arenas without the one-hot table
         // (measured, float profiles: +0..6 %); one-hot arenas are faster on the table path in every mode (C4 rank
