@@ -466,6 +466,14 @@ def main():
         c4_all = int((w4["lens"][p4[:, 0]].astype(np.int64) * w4["lens"][p4[:, 1]]).sum())
         variants["c4_all_pairs_one_gpu_gcups"] = c4_all / timed(lambda: (a4.premultiply(), pl4.run("global", GAP_OPEN, GAP_EXTEND)), reps=2) / 1e9
         pl4.close(); a4.close()
+        # ... the same shard with ONE-HOT sequences (integer scoring, bit-exact): the match-score lookup kernel
+        rng4 = np.random.default_rng(4)
+        a4 = native.Arena([one_hot(rng4.integers(0, 20, int(L)), 27) for L in w4["lens"]], w4["S"])
+        pl4 = native.Plan(a4, s4)
+        for m4 in ("global", "local"):
+            variants["c4_rank_share_onehot_%s_gcups" % m4] = c4 / timed(lambda: pl4.run(m4, GAP_OPEN, GAP_EXTEND), reps=3) / 1e9
+        variants["c4_rank_share_onehot_kernel"] = pl4.kernel_name()
+        pl4.close(); a4.close()
         del w4
         # C5: one column shard of 14 (9 249 pairs, 2.3e11 cells), 5 kb nucleotide sequences
         w5 = make_workload("c5")
