@@ -435,9 +435,12 @@ def test_operand_stream_variants_agree_bitwise(nat, bba, kind, monkeypatch):
             profs = [synth_profile(rng, int(L))[0] for L in lens]
     pairs = all_pairs(N)
     results = {}
-    for variant, env in (("default", {}), ("staged", {"PRALINE_NO_ONEHOT": "1"}),
+    # default: one-hot arenas look their match scores up (no MFMA; shared waves here, four singles with PRALINE_NO_W2);
+    # "table": the one-hot operand table feeding MFMAs; "staged" / "lanes": the operand streams of float profiles
+    for variant, env in (("default", {}), ("lookup_singles", {"PRALINE_NO_W2": "1"}), ("table", {"PRALINE_NO_LOOKUP": "1"}),
+                         ("table_singles", {"PRALINE_NO_LOOKUP": "1", "PRALINE_NO_W2": "1"}), ("staged", {"PRALINE_NO_ONEHOT": "1"}),
                          ("lanes", {"PRALINE_NO_ONEHOT": "1", "PRALINE_NO_STAGE": "1"})):
-        for k in ("PRALINE_NO_ONEHOT", "PRALINE_NO_STAGE"):
+        for k in ("PRALINE_NO_ONEHOT", "PRALINE_NO_STAGE", "PRALINE_NO_LOOKUP", "PRALINE_NO_W2"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -446,12 +449,14 @@ def test_operand_stream_variants_agree_bitwise(nat, bba, kind, monkeypatch):
         for mode in MODES:
             plan.run(mode, *GAPS)
             results[(variant, mode)] = plan.scores().copy()
+        if kind != "profile" and variant in ("default", "lookup_singles") and not any(os.environ.get(k) for k in ("PRALINE_KERNEL", "PRALINE_MM")):
+            assert ", 3, " in plan.kernel_name(), plan.kernel_name()       # the lookup instances ran
         plan.close()
         arena.close()
     for mode in MODES:
         ref = results[("lanes", mode)]
         assert np.isfinite(ref).all()
-        for variant in ("default", "staged"):
+        for variant in ("default", "lookup_singles", "table", "table_singles", "staged"):
             assert np.array_equal(bits(results[(variant, mode)]), bits(ref)), (kind, variant, mode)
 
 
