@@ -97,6 +97,21 @@ template <int NR, int NTERM> static void launch16_tb(const LaunchArgs &la, const
     hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, LOC, MSK>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,      \
                        la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells, la.rp,      \
                        (int)la.n_tasks)
+    if constexpr (NTERM == 1) {
+        // integer scoring on a one-hot arena: the match scores are looked up (no MFMA, two waves per SIMD);
+        // PRALINE_NO_LOOKUP=1 keeps the MFMA instances
+        const char *nl = getenv("PRALINE_NO_LOOKUP");
+        if (a16.sym8 != nullptr && !(nl && nl[0] == '1')) {
+#define PRALINE_TB_LAUNCH_LK(LOC, MSK)                                                                                   \
+    hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, LOC, MSK, false, false, 3>), grid, block, 0, la.stream, a16, la.tasks,  \
+                       la.lane_one, la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells,  \
+                       la.rp, (int)la.n_tasks)
+            if (local) { if (mask) PRALINE_TB_LAUNCH_LK(true, true); else PRALINE_TB_LAUNCH_LK(true, false); }
+            else { if (mask) PRALINE_TB_LAUNCH_LK(false, true); else PRALINE_TB_LAUNCH_LK(false, false); }
+#undef PRALINE_TB_LAUNCH_LK
+            return;
+        }
+    }
     if (local) { if (mask) PRALINE_TB_LAUNCH(true, true); else PRALINE_TB_LAUNCH(true, false); }
     else { if (mask) PRALINE_TB_LAUNCH(false, true); else PRALINE_TB_LAUNCH(false, false); }
 #undef PRALINE_TB_LAUNCH
@@ -111,6 +126,19 @@ template <int NR, int NTERM> static void launch16_tb_chain(const LaunchArgs &la,
     hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, LOC, MSK, true>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one, \
                        la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells, la.rp,       \
                        (int)la.n_tasks, flags, max_strips + 1, (float4 *)cand, every)
+    if constexpr (NTERM == 1) {
+        const char *nl = getenv("PRALINE_NO_LOOKUP");
+        if (a16.sym8 != nullptr && !(nl && nl[0] == '1')) {
+#define PRALINE_CHAIN_LAUNCH_LK(LOC, MSK)                                                                                \
+    hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, LOC, MSK, true, false, 3>), grid, block, 0, la.stream, a16, la.tasks,   \
+                       la.lane_one, la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells,  \
+                       la.rp, (int)la.n_tasks, flags, max_strips + 1, (float4 *)cand, every)
+            if (local) { if (mask) PRALINE_CHAIN_LAUNCH_LK(true, true); else PRALINE_CHAIN_LAUNCH_LK(true, false); }
+            else { if (mask) PRALINE_CHAIN_LAUNCH_LK(false, true); else PRALINE_CHAIN_LAUNCH_LK(false, false); }
+#undef PRALINE_CHAIN_LAUNCH_LK
+            return;
+        }
+    }
     if (local) { if (mask) PRALINE_CHAIN_LAUNCH(true, true); else PRALINE_CHAIN_LAUNCH(true, false); }
     else { if (mask) PRALINE_CHAIN_LAUNCH(false, true); else PRALINE_CHAIN_LAUNCH(false, false); }
 #undef PRALINE_CHAIN_LAUNCH

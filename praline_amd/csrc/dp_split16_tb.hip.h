@@ -106,11 +106,21 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
                                                 unsigned symw = 0)
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
-    constexpr int NM = NTERM * NR;
+    // BSRC = 3 (one-hot arenas, integer scoring): the match scores are looked up in the strip's LDS table
+    // (dp_split16.hip.h, lookup_stride): CUR holds this lane's 16 scores of its row, PREV receives the next row's (symbol
+    // symw) - no MFMA, no operand registers, no accumulator tiles.
+    constexpr bool LOOKUP = BSRC == 3;
+    constexpr int NM = LOOKUP ? 1 : NTERM * NR;
     constexpr bool INTS = NTERM == 1;
     float m[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) m[c] = DM ? CUR[c] : (h ? PREV[c] : CUR[c]);
+    for (int c = 0; c < 16; ++c) m[c] = (DM || LOOKUP) ? CUR[c] : (h ? PREV[c] : CUR[c]);
+    if constexpr (LOOKUP) {
+        const float4 *q = reinterpret_cast<const float4 *>(onehot_lane + symw * lookup_stride());
+        const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+        PREV[0] = a0.x; PREV[1] = a0.y; PREV[2] = a0.z; PREV[3] = a0.w; PREV[4] = a1.x; PREV[5] = a1.y; PREV[6] = a1.z; PREV[7] = a1.w;
+        PREV[8] = a2.x; PREV[9] = a2.y; PREV[10] = a2.z; PREV[11] = a2.w; PREV[12] = a3.x; PREV[13] = a3.y; PREV[14] = a3.z; PREV[15] = a3.w;
+    }
 
     const float4 bv = bnd_pref;  // states (M, U, L) of the boundary cell (yy, x0)
     if constexpr (CHAIN) {
@@ -145,7 +155,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         const int r = k % NR;
         const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);
         const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+        if constexpr (!LOOKUP) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
         if constexpr (DM) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aopH[ia]), as_half8(BOLD[ib]), acc, 0, 0, 0);
         // pin the MFMA at the START of its chunk: left alone the scheduler sinks it to the end of the step and
         // then pads ~35 s_nop for the MFMA -> VALU result hazard in front of the next step's select
@@ -207,8 +217,10 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     } else {
         row_cells(std::false_type{});
     }
-    PREV = acc;
-    if constexpr (BSRC == 1) {
+    if constexpr (!LOOKUP) PREV = acc;
+    if constexpr (LOOKUP) {
+        // (the table serves every row of the strip)
+    } else if constexpr (BSRC == 1) {
         const unsigned sym = (symw >> (8 * SB)) & 0xffu;
         const float4 *bsrc = reinterpret_cast<const float4 *>(onehot_lane + sym * onehot_stride(NR));
 #pragma unroll
@@ -327,8 +339,11 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #ifndef PRALINE_TB2_WAVES_PER_SIMD
 #define PRALINE_TB2_WAVES_PER_SIMD 2
 #endif
+#ifndef PRALINE_TB_LOOKUP_WAVES
+#define PRALINE_TB_LOOKUP_WAVES 2   // waves per SIMD of the lookup instances (no operand / accumulator registers)
+#endif
 template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool TWOPASS = false, int BSRC = 0>
-__global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE_TB_WAVES_PER_SIMD) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC == 3 ? PRALINE_TB_LOOKUP_WAVES : PRALINE_TB_WAVES_PER_SIMD)) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one,
                                                        const int32_t *__restrict__ lane_pair, float4 *bnd,
                                                        uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,
@@ -339,10 +354,13 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
-    constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0);   // see split16_tb_step
+    constexpr bool LOOKUP = BSRC == 3;
+    constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0) && !LOOKUP;   // see split16_tb_step
     constexpr int SINK = TWOPASS ? 1 : 0;
     static_assert(!(CHAIN && TWOPASS), "the two-pass fill is a task-mode kernel");
-    static_assert(BSRC == 0 || (BSRC == 1 && TWOPASS && DM), "the one-hot table feeds the single-term forward fill");
+    static_assert(BSRC == 0 || (BSRC == 1 && TWOPASS && DM) || (LOOKUP && NTERM == 1 && !TWOPASS),
+                  "the one-hot table feeds the single-term forward fill; the lookup serves the single-pass integer-scoring fill");
+    __shared__ __attribute__((aligned(16))) char lookup_all[LOOKUP ? 4 * lookup_bytes(NR) : 16];   // one table per wave of the block
     __shared__ __attribute__((aligned(16))) char onehot_tab[BSRC == 1 ? onehot_bytes(NR) : 16];
     if constexpr (BSRC == 1) {
         _Float16 *tab = reinterpret_cast<_Float16 *>(onehot_tab);
@@ -386,7 +404,11 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
     const int acol = 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
     const char *qA = ar.Q16 + ((int64_t)ar.row_off[two] + acol) * ar.row_bytes + h * ar.half_bytes;
     const unsigned *pSym = (BSRC == 1) ? reinterpret_cast<const unsigned *>(ar.sym8 + (have_pair ? ar.row_off[my_one] : 0)) : nullptr;
-    const char *onehot_lane = onehot_tab + h * (16 * NR);
+    char *lookup_tab = lookup_all + (LOOKUP ? (int)((threadIdx.x >> 6) & 3) * lookup_bytes(NR) : 0);
+    const char *onehot_lane = LOOKUP ? lookup_tab + h * 64 : onehot_tab + h * (16 * NR);
+    // LOOKUP: at step T the lower half fetches the scores of row T + 1 (symbol byte T of the sequence), the upper half
+    // those of row T (byte T - 1)
+    const unsigned char *psym = LOOKUP ? ar.sym8 + (have_pair ? ar.row_off[my_one] : 0) - h : nullptr;
 
     if (CHAIN && chain_strip >= nstrips) return;
     // boundary columns: float4 [y][32]; chain mode keeps one per strip boundary, [strip][y][32]
@@ -460,7 +482,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
             srect[r][3] = 0;
         }
         float4 aop[NOP];
-        {
+        if constexpr (!LOOKUP) {
             const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.row_bytes);
 #pragma unroll
             for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
@@ -500,7 +522,30 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
         unsigned sw0 = 0;   // BSRC == 1: the symbols of rows 1 .. 4
-        {
+        unsigned symA = 0, symB = 0, symC = 0;   // LOOKUP: the symbols three steps ahead (rotate like the boundary prefetch)
+        if constexpr (LOOKUP) {
+            // this strip's table: lane (column j, half h) transposes the hi pieces of half h of the pre-multiplied row
+            // x0 + j (exact mode: Q2 = hi exactly), k = 16 r + 8 h + jj  ->  lookup_tab[k][j]
+            const char *src = ar.Q16 + ((int64_t)ar.row_off[two] + x0 + j) * ar.row_bytes + h * ar.half_bytes;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const half8 hv = as_half8(reinterpret_cast<const float4 *>(src)[r]);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    *reinterpret_cast<float *>(lookup_tab + (16 * r + 8 * h + jj) * lookup_stride() + j * 4) = (float)hv[jj];
+            }
+            if (h == 0) *reinterpret_cast<float *>(lookup_tab + (16 * NR) * lookup_stride() + j * 4) = 0.0f;   // padding rows: symbol 16 NR
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            // scores of row 1 (lower half; the upper half's first step is undone below), symbols for the steps 1, 2, 3
+            const unsigned first = h ? 0u : (unsigned)psym[0];
+            const float4 *q = reinterpret_cast<const float4 *>(onehot_lane + first * lookup_stride());
+            const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+            accA[0] = a0.x; accA[1] = a0.y; accA[2] = a0.z; accA[3] = a0.w; accA[4] = a1.x; accA[5] = a1.y; accA[6] = a1.z; accA[7] = a1.w;
+            accA[8] = a2.x; accA[9] = a2.y; accA[10] = a2.z; accA[11] = a2.w; accA[12] = a3.x; accA[13] = a3.y; accA[14] = a3.z; accA[15] = a3.w;
+            symA = psym[1]; symB = psym[2]; symC = psym[3];
+        } else {
             float4 b1[NOP];
             const float4 *s1 = reinterpret_cast<const float4 *>(pB);
             const float4 *s2 = reinterpret_cast<const float4 *>(pB + b_stride);
@@ -551,6 +596,14 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
                                                 aopH, b_next, b_stride, bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu,  \
                                                 cxl, cpxm, cpxu, cpxl, cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, \
                                                 ge, xb, srect, nullptr, nullptr, 0, ckpt_strip, nullptr, 0, onehot_lane, SYMW)
+        // match-score lookup: the step fetches the next row's scores with SYM, which is then refilled three steps ahead
+#define PRALINE_TB_STEP_LK(T, CUR, PREV, PREF, SYM)                                                                   \
+        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, false, SINK, 3>((T) - h, L1, have_pair, h, CUR, PREV, bX, bX, aop, aopH, \
+                                                b_next, b_stride, bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl,   \
+                                                cpxm, cpxu, cpxl, cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge,  \
+                                                xb, srect, chain_in, &chain_seen, (T) + 3, ckpt_strip, nullptr, 0,          \
+                                                onehot_lane, SYM);                                                          \
+        SYM = psym[(T) + 3];
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
             const int yy_ = (T) - h;                                                                                 \
@@ -573,7 +626,8 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
         {
             const float best_s = best_run;
             const int by = best_y, bx = best_x, bk = best_k;
-            if constexpr (BSRC == 1) PRALINE_TB_STEP_OH(1, accA, accB, bX, bZ, bnd_prefA, sw0, 3);
+            if constexpr (LOOKUP) { PRALINE_TB_STEP_LK(1, accA, accB, bnd_prefA, symA) }
+            else if constexpr (BSRC == 1) PRALINE_TB_STEP_OH(1, accA, accB, bX, bZ, bnd_prefA, sw0, 3);
             else if constexpr (DM) PRALINE_TB_STEP(1, accA, accB, bX, bZ, bnd_prefA);
             else PRALINE_TB_STEP(1, accA, accB, bX, bX, bnd_prefA);
             if (h) {
@@ -632,7 +686,20 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
                 // their consumers are dispatched a round later anyway (chain_every, set by the host)
                 if (t - 2 >= chain_next) { chain_publish(chain_out, t - 2, lane); chain_next = t - 2 + chain_every; }
             }
-            if constexpr (DM) {
+            if constexpr (LOOKUP) {
+                PRALINE_TB_STEP_LK(t, accB, accA, bnd_prefB, symB)
+                PRALINE_TB_TAILS(t)
+                PRALINE_TB_STEP_LK(t + 1, accA, accB, bnd_prefC, symC)
+                PRALINE_TB_TAILS(t + 1)
+                PRALINE_TB_STEP_LK(t + 2, accB, accA, bnd_prefA, symA)
+                PRALINE_TB_TAILS(t + 2)
+                PRALINE_TB_STEP_LK(t + 3, accA, accB, bnd_prefB, symB)
+                PRALINE_TB_TAILS(t + 3)
+                PRALINE_TB_STEP_LK(t + 4, accB, accA, bnd_prefC, symC)
+                PRALINE_TB_TAILS(t + 4)
+                PRALINE_TB_STEP_LK(t + 5, accA, accB, bnd_prefA, symA)
+                PRALINE_TB_TAILS(t + 5)
+            } else if constexpr (DM) {
                 PRALINE_TB_STEP(t, accB, accA, bY, bX, bnd_prefB);
                 PRALINE_TB_TAILS(t)
                 PRALINE_TB_STEP(t + 1, accA, accB, bZ, bY, bnd_prefC);
@@ -661,6 +728,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : PRALINE
             }
         }
 #undef PRALINE_TB_STEP
+#undef PRALINE_TB_STEP_LK
 #undef PRALINE_TB_STEP_OH
 #undef PRALINE_TB_TAILS
         if constexpr (CHAIN) chain_publish(chain_out, PRALINE_CHAIN_DONE, lane);
