@@ -104,7 +104,8 @@ def barriers(nstrips, it, W):
 
 def test_shared_wave_descriptors(sched):
     rng = np.random.default_rng(2)
-    for n, slots in ((40, 2048), (256, 2048), (300, 2048), (128, 512)):
+    # (3 072 slots: the plans of one-hot arenas, whose lookup kernels run three waves per SIMD)
+    for n, slots in ((40, 2048), (256, 2048), (300, 2048), (128, 512), (256, 3072), (330, 3072)):
         lens = synth_lengths(rng, n, 400)
         pairs = all_pairs(n)
         tf, lp, wf, ns = sched(lens, pairs, wave_slots=slots)
