@@ -10,7 +10,11 @@ N = 4096
 lens = synth_lengths(rng, N, 400)
 pairs = allpairs.enumerate_pairs(N)
 mine = pairs[allpairs.shard_columns(lens, pairs, 8)[3]]
-profs = [synth_profile(rng, int(L)) for L in lens]
+if os.environ.get("ONEHOT") == "1":   # plain sequences: integer scoring, the match-score lookup kernel
+    from bench import one_hot
+    profs = [one_hot(rng.integers(0, 20, int(L)), 27) for L in lens]
+else:
+    profs = [synth_profile(rng, int(L)) for L in lens]
 ar = nat.Arena(profs, blosum62_matrix())
 cells = int((lens[mine[:, 0]].astype(np.int64) * lens[mine[:, 1]]).sum())
 for G in os.environ.get("GS", "0,16,64,256,1024,4096").split(","):
@@ -20,5 +24,5 @@ for G in os.environ.get("GS", "0,16,64,256,1024,4096").split(","):
     ms = []
     for _ in range(3):
         pl.run("global", -11, -1); ms.append(pl.kernel_ms())
-    print("G=%s tasks=%d %.1f ms %.0f GCUPS" % (G, pl.tasks, np.median(ms), cells / np.median(ms) / 1e6), flush=True)
+    print("G=%s tasks=%d %.1f ms %.0f GCUPS %s" % (G, pl.tasks, np.median(ms), cells / np.median(ms) / 1e6, pl.kernel_name()), flush=True)
     pl.close()
