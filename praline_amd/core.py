@@ -249,20 +249,33 @@ class TypeIndex(object):
         """Register every component published under the `praline.type` entry-point group - what the reference does
         (manager.py:72-85): this package's own components (setup.py) and any third-party aligner installed beside it.
         Without packaging metadata (a bare source tree) the in-package list is registered."""
-        found = False
+        # This package's components come first and are never displaced: the group is shared with the reference
+        # distribution (`praline-aln` publishes the same tids), and with both installed "last one wins" would hand the
+        # managers of this package foreign Component classes in unspecified order.
+        from . import component
+        own = {}
+        for cls in component.COMPONENTS:
+            self.register(cls)
+            own[cls.tid] = cls
         try:
             from importlib import metadata
             eps = metadata.entry_points()
             group = eps.select(group=ENTRY_POINT_GROUP) if hasattr(eps, "select") else eps.get(ENTRY_POINT_GROUP, [])
-            for entry_point in group:
-                self.register(entry_point.load())
-                found = True
-        except ImportError:
-            pass
-        if not found:
-            from . import component
-            for cls in component.COMPONENTS:
-                self.register(cls)
+        except Exception:
+            return
+        for entry_point in group:
+            try:
+                cls = entry_point.load()
+            except Exception:
+                continue   # a distribution whose import fails here (the reference without its dependencies) is skipped
+            # third-party components must be written against THIS runtime (a subclass of its Component) and may
+            # add tids, not replace the package's own
+            if not (isinstance(cls, type) and issubclass(cls, Component)):
+                continue
+            tid = getattr(cls, "tid", None)
+            if tid is None or (tid in own and own[tid] is not cls):
+                continue
+            self.register(cls)
 
     def resolve(self, tid):
         try:

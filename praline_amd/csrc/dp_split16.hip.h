@@ -25,7 +25,9 @@
 #include "dp_arena16.h"
 
 #ifndef PRALINE_S16_ABLATE
-#define PRALINE_S16_ABLATE 0   // experiments only: 1 no operand refills, 2 no boundary column traffic, 4 no MFMAs
+#define PRALINE_S16_ABLATE 0   // experiments only (results invalid): 1 no operand refills, 2 no boundary column traffic, 4 no MFMAs;
+                               // staged stream: 8 no in-loop DMA, 16 no LDS operand / boundary reads, 32 no half select,
+                               // 64 L chain cut (every column's L from its U), 256 no vmcnt wait
 #endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -234,7 +236,7 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     f2 m2[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        if constexpr (DM || LOOKUP) { m2[c].x = CUR[2 * c]; m2[c].y = CUR[2 * c + 1]; }
+        if constexpr (DM || LOOKUP || (PRALINE_S16_ABLATE & 32) != 0) { m2[c].x = CUR[2 * c]; m2[c].y = CUR[2 * c + 1]; }
         else { m2[c].x = h ? PREV[2 * c] : CUR[2 * c]; m2[c].y = h ? PREV[2 * c + 1] : CUR[2 * c + 1]; }
     }
 
@@ -243,11 +245,15 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
         constexpr int NOPB = ((NTERM == 1) ? 1 : 2) * NR;
         // the DMA of operand row t+2 and boundary row t+1 was issued three steps ago: everything but the
         // last two steps' pieces has landed
+#if !(PRALINE_S16_ABLATE & 256)
         PRALINE_VMCNT(2 * (NOPB + 1));
+#endif
+#if !(PRALINE_S16_ABLATE & 16)
         bnd_pref = *reinterpret_cast<const float2 *>(stage_lds + ((SB + 1) & 3) * 256 + stage_rd_bnd);
 #pragma unroll
         for (int q = 0; q < NOPB; ++q)
             BFILL[q] = *reinterpret_cast<const float4 *>(stage_lds + 1024 + ((SB + 2) & 3) * stage_slot_bytes(NOPB) + stage_rd[q]);
+#endif
     } else {
 #if !(PRALINE_S16_ABLATE & 2)
         bnd_pref = *reinterpret_cast<const float2 *>(bnd_ld);
@@ -309,7 +315,11 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
             // column 2cp
             const float H0 = max3f(M.x, U.x, lrun);
             const float lin0 = lrun;
+#if PRALINE_S16_ABLATE & 64
+            lrun = __builtin_fmaxf(Mo.x, Ug.x + ge);
+#else
             lrun = __builtin_fmaxf(Mo.x, lrun + ge);      // L[y][x+1]   (cext.c:169-183,276-283)
+#endif
             // column 2cp + 1
             const float H1 = max3f(M.y, U.y, lrun);
             if constexpr (KEEP != 0) {
@@ -330,7 +340,11 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
                     }
                 }
             }
+#if PRALINE_S16_ABLATE & 64
+            lrun = __builtin_fmaxf(Mo.y, Ug.y + ge);
+#else
             lrun = __builtin_fmaxf(Mo.y, lrun + ge);
+#endif
             if (LOCAL) best_run = max3f(best_run, H0, H1);
             Uc[2 * cp] = __builtin_fmaxf(Mo.x, Ug.x);        // U[y+1][x]   (cext.c:152-166,247-254)
             Uc[2 * cp + 1] = __builtin_fmaxf(Mo.y, Ug.y);
@@ -346,8 +360,10 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     } else if constexpr (BSRC == 2) {
         // rows t+5 / t+4 go where rows t+1 / t lived (both consumed: their reads were waited for)
         constexpr int NOPB = ((NTERM == 1) ? 1 : 2) * NR;
+#if !(PRALINE_S16_ABLATE & 8)
         stage_issue<NOPB>(stage_cur[0], *stage_gofs, stage_lds_addr + 1024 + ((SB + 1) & 3) * stage_slot_bytes(NOPB),
                           stage_cur[1], stage_gofs_n, stage_lds_addr + (SB & 3) * 256);
+#endif
         stage_cur[0] += 64 * NR;  // one arena row
         stage_cur[1] += 256;
     } else if constexpr (ONEHOT) {

@@ -1,0 +1,18 @@
+#!/bin/sh
+# Build a variant of libpraline_dp.so whose dp_split16 / dp_tb2 translation units are compiled with extra flags
+# (A/B and ablation experiments: PRALINE_LIB=<path> selects the build at run time).
+#   scripts/build_variant.sh <name> [flags for dp_split16_instance.hip / dp_tb2_instance.hip ...]
+# -> variants/libpraline_dp_<name>.so   (git-ignored; travels to the GPU box with the snapshot)
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; shift
+C=$ROOT/praline_amd/csrc
+OUT=$ROOT/variants; mkdir -p $OUT/obj_$NAME
+make -s -C $C all
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wall -Wno-unused-but-set-variable -fno-fast-math -ffp-contract=off -fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form"
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $C/dp_split16_instance.hip -o $OUT/obj_$NAME/dp_split16.o &
+if [ -n "$VARIANT_TB" ]; then /opt/rocm/bin/hipcc $FLAGS "$@" -c $C/dp_tb2_instance.hip -o $OUT/obj_$NAME/dp_tb2.o & else cp $C/build/dp_tb2.o $OUT/obj_$NAME/dp_tb2.o; fi
+wait
+OBJS=$(ls $C/build/*.o | grep -v "dp_split16.o\|dp_tb2.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $OUT/obj_$NAME/dp_split16.o $OUT/obj_$NAME/dp_tb2.o -o $OUT/libpraline_dp_$NAME.so
+echo built $OUT/libpraline_dp_$NAME.so

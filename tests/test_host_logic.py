@@ -396,10 +396,49 @@ def test_entry_point_metadata_registers_the_components(tmp_path):
             "assert names == sorted(c.__name__ for c in component.COMPONENTS), names\n"
             "assert all(e.load() is getattr(component, e.name) for e in eps)\n"
             "idx = core.TypeIndex(); idx._types = {}\n"
-            "component.COMPONENTS = []          # the fallback list is not what registers them\n"
             "idx.autoregister()\n"
             "assert idx.resolve('praline.component.PairwiseAligner') is component.PairwiseAligner\n"
             "assert len(idx._types) == 9\n" % (str(tmp_path), root))
+    subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_autoregister_is_not_displaced_by_a_second_distribution(tmp_path):
+    """The `praline.type` group is shared with the reference distribution, which publishes the SAME tids
+    (/root/reference/setup.py:8-20).  With both installed, this package's managers must still resolve its own classes:
+    a foreign class under a colliding tid, a class that is not a subclass of this runtime's Component and an entry point
+    whose import fails are all skipped; a third-party aligner written against this runtime (new tid) is added."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, "setup.py", "-q", "egg_info", "--egg-base", str(tmp_path)], cwd=root)
+    other = tmp_path / "other"
+    (other / "fakepraline").mkdir(parents=True)
+    (other / "fakepraline" / "__init__.py").write_text(
+        "from praline_amd import core\n"
+        "class Foreign(object):\n"
+        "    tid = 'praline.component.PairwiseAligner'\n"
+        "class Collides(core.Component):\n"
+        "    tid = 'praline.component.GuideTreeBuilder'\n"
+        "class MyAligner(core.Component):\n"
+        "    tid = 'third.party.MyAligner'\n")
+    info = other / "fakepraline-1.0.dist-info"
+    info.mkdir()
+    (info / "METADATA").write_text("Metadata-Version: 2.1\nName: fakepraline\nVersion: 1.0\n")
+    (info / "entry_points.txt").write_text(
+        "[praline.type]\n"
+        "PairwiseAligner = fakepraline:Foreign\n"
+        "GuideTreeBuilder = fakepraline:Collides\n"
+        "MyAligner = fakepraline:MyAligner\n"
+        "Broken = fakepraline_does_not_exist:Nothing\n")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from praline_amd import core, component\n"
+            "import fakepraline\n"
+            "idx = core.TypeIndex()\n"
+            "idx.autoregister()\n"
+            "for cls in component.COMPONENTS:\n"
+            "    assert idx.resolve(cls.tid) is cls, cls.tid\n"
+            "assert idx.resolve('third.party.MyAligner') is fakepraline.MyAligner\n"
+            "assert len(idx._types) == len(component.COMPONENTS) + 1\n" % (str(other), str(tmp_path), root))
     subprocess.check_call([sys.executable, "-c", code])
 
 
