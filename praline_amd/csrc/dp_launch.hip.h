@@ -44,6 +44,19 @@ void praline_launch_split_f16(const float *src, int KP, int KS, int n_active, in
                               hipStream_t stream);
 int praline_launch_scores_tile16(const Arena16Dev &a16, int nr, int nterm, int one, int two, int L1, int L2, float *m,
                                  hipStream_t stream);
+// k_dp_pipe (dp_pipe_instance.hip): pipeline workgroups over PipeItem lists (scores only)
+struct PipeLaunch {
+    const PipeItem *items;
+    unsigned n_items;
+    const WaveTask *tasks;
+    const int32_t *set_one, *lane_pair;
+    void *bnd;
+    float *scores;
+    RunParams rp;
+    hipStream_t stream;
+};
+bool praline_pipe_supported(int nr, int nterm);
+int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm, bool local);
 // two-pass alignments with paths (dp_tb2_instance.hip): flag-free forward fill, then block recompute + traceback
 struct Trace2Args {
     const int64_t *slot_off;

@@ -24,6 +24,24 @@ struct WgDesc {
     int32_t pad[2];
 };
 
+// Pipeline workgroups (k_dp_pipe, dp_pipe.hip.h): the four waves of a workgroup sweep the strips of a LIST of tasks that
+// share one set of 32 sequences one - wave r takes the strips r, r + 4, ... of the concatenated strip list and runs
+// PRALINE_PIPE_LAG steps behind wave r - 1 - so the set's operand rows are streamed into LDS once per workgroup and
+// step, and a strip's boundary column reaches the next strip through LDS (every fourth hand-off through `bnd`).
+struct PipeItem {
+    int32_t set;        // index into set_one [n_sets][32]
+    int32_t task0;      // first task of the list (tasks task0 .. task0 + ntasks - 1 share the set; PipeTask order)
+    int32_t ntasks;
+    int32_t nstrips;    // strips of the whole list
+    int32_t rsteps;     // steps per round (a multiple of 12, >= max_l1 + 1, >= PRALINE_PIPE_MIN_STEPS)
+    int32_t nrounds;    // ceil(nstrips / 4)
+    int64_t bnd_off;    // float2 element offset of the workgroup's wrap-around boundary column [rsteps + 16][32]
+};
+#define PRALINE_PIPE_LAG 2          // steps between consecutive waves of a pipeline workgroup
+#define PRALINE_PIPE_RING 12        // operand rows held by the workgroup's LDS ring
+#define PRALINE_PIPE_MIN_STEPS 36   // shortest round: the wrap-around hand-off (wave 3 -> wave 0) goes through memory
+#define PRALINE_PIPE_MAX_TASKS 32   // tasks per item (the per-task result table lives in LDS)
+
 // two-pass alignments with paths: rows per kept boundary column beyond max_l1, and checkpoint blocks per strip (one
 // per 32 rows; the unrolled loops compute rows up to max_l1 + 12; block 0 is never written)
 #define PRALINE_TB2_PAD 72

@@ -674,6 +674,12 @@ struct praline_plan {
     // instances need 256 VGPRs + ~130 AGPRs, the four-wave ones 185-219: two waves per SIMD)
     std::vector<WgDesc> wg_singles;
     DevBuf<WgDesc> d_wg_singles;
+    // pipeline workgroups (k_dp_pipe, dp_pipe.hip.h): scores-only plans on float-profile arenas
+    PipeSchedule pipe;
+    DevBuf<PipeItem> d_pipe_items;
+    DevBuf<WaveTask> d_pipe_tasks;
+    DevBuf<int32_t> d_pipe_set_one, d_pipe_lane_pair;
+    DevBuf<float2> d_pipe_bnd;
     DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
@@ -788,6 +794,21 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     if (const char *env = getenv("PRALINE_WG_BALANCE")) opt.balance = atoi(env) != 0;
     Schedule sch;
     build_schedule(a.len.data(), n_pairs, pairs, opt, sch);
+    // scores-only plans on float-profile arenas (128-byte operand rows): pipeline workgroups (PRALINE_NO_PIPE=1: the task
+    // schedule above, as for every other kind of plan)
+    {
+        const char *np = getenv("PRALINE_NO_PIPE");
+        const Arena16Dev v16 = a.view16();
+        if (!want_paths && !pl->ref && opt.split_layout && a.nr16 > 0 && v16.stage && v16.sym8 == nullptr &&
+            praline_pipe_supported(a.nr16, a.nterm16) && match_mode() == PRALINE_MATCH_FAST && !(np && np[0] == '1') && n_pairs > 0) {
+            int min_len = a.max_len;
+            for (int64_t p = 0; p < n_pairs; ++p) min_len = std::min(min_len, std::min(a.len[pairs[2 * p]], a.len[pairs[2 * p + 1]]));
+            PipeOptions po;
+            if (const char *env = getenv("PRALINE_PIPE_BLOCK")) po.block_twos = atoi(env);
+            if (const char *env = getenv("PRALINE_PIPE_SLOTS")) po.wg_slots = atoll(env);
+            if (min_len >= 1) build_pipe_schedule(a.len.data(), a.n_seqs, n_pairs, pairs, po, pl->pipe);
+        }
+    }
     pl->tp = sch.tp;
     pl->split = sch.split;
     pl->tasks.swap(sch.tasks);
@@ -817,6 +838,19 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     }
     if (pl->ref && !want_paths) {
         if ((rc = pl->d_pairs.upload(pl->h_pairs, st))) { delete pl; return rc; }
+    }
+    if (pl->pipe.ok) {
+        if ((rc = pl->d_pipe_items.upload(pl->pipe.items, st)) || (rc = pl->d_pipe_tasks.upload(pl->pipe.tasks, st)) ||
+            (rc = pl->d_pipe_set_one.upload(pl->pipe.set_one, st)) || (rc = pl->d_pipe_lane_pair.upload(pl->pipe.lane_pair, st)) ||
+            (rc = pl->d_pipe_bnd.alloc((size_t)pl->pipe.bnd_elems))) {
+            delete pl;
+            return rc;
+        }
+        // (rows the kernels never write only feed padding rows; keep them free of NaN bit patterns)
+        if (hipMemsetAsync(pl->d_pipe_bnd.p, 0, (size_t)pl->pipe.bnd_elems * sizeof(float2), st) != hipSuccess) {
+            delete pl;
+            return fail(PRALINE_ERR_DEVICE, "plan upload: memset failed");
+        }
     }
     if (want_paths) {
         std::vector<int32_t> pv(pairs, pairs + 2 * n_pairs);
@@ -863,6 +897,7 @@ extern "C" int64_t praline_plan_cells(const praline_plan *plan) { return plan ? 
 extern "C" int64_t praline_plan_steps(const praline_plan *plan)
 {
     if (!plan) return 0;
+    if (plan->pipe.ok) return plan->pipe.steps;   // wave steps of the pipeline launch (idle waves of the last rounds included)
     int64_t steps = 0;
     for (const WaveTask &wt : plan->tasks)
         if (wt.max_l1 > 0) steps += (int64_t)wt.nstrips * (wt.max_l1 + 1);
@@ -871,6 +906,7 @@ extern "C" int64_t praline_plan_steps(const praline_plan *plan)
 extern "C" int64_t praline_plan_tasks(const praline_plan *plan)
 {
     if (!plan) return 0;
+    if (plan->pipe.ok) return (int64_t)plan->pipe.tasks.size();
     int64_t n = 0;
     for (const WaveTask &wt : plan->tasks) n += wt.max_l1 > 0;
     return n;
@@ -1077,6 +1113,26 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         HIPCHK(hipEventRecord(pl.ev0, st));
         RC(plan_run_ref(pl, la, mode, local));
         HIPCHK(hipEventRecord(pl.ev1, st));
+        return PRALINE_OK;
+    }
+    if (!pl.want_paths && pl.pipe.ok && la.a16 != nullptr) {
+        char kn[160];
+        snprintf(kn, sizeof(kn), "k_dp_pipe<%d, %d, %s>", a.nr16, a.nterm16, local ? "true" : "false");
+        pl.last_kernel = kn;
+        PipeLaunch pp;
+        pp.items = pl.d_pipe_items.p;
+        pp.n_items = (unsigned)pl.pipe.items.size();
+        pp.tasks = pl.d_pipe_tasks.p;
+        pp.set_one = pl.d_pipe_set_one.p;
+        pp.lane_pair = pl.d_pipe_lane_pair.p;
+        pp.bnd = pl.d_pipe_bnd.p;
+        pp.scores = la.scores;
+        pp.rp = la.rp;
+        pp.stream = st;
+        HIPCHK(hipEventRecord(pl.ev0, st));
+        RC(praline_launch_pipe(pp, a16, a.nr16, a.nterm16, local));
+        HIPCHK(hipEventRecord(pl.ev1, st));
+        HIPCHK(hipGetLastError());
         return PRALINE_OK;
     }
     if (!pl.want_paths) {

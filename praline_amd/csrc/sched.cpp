@@ -511,6 +511,223 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
     out.cells = cells;
 }
 
+// ---- pipeline workgroups (k_dp_pipe) ---------------------------------------------------------------------------
+// 1. The distinct sequences two are taken in index order, `block_twos` at a time; the sequences one of a block's pairs
+//    are pooled, sorted by length (descending) and cut into sets of 32 - neighbouring sequences two of an all-pairs or
+//    one-against-all list have (nearly) the same partners, so almost every lane of a (set, two) task holds a pair.
+// 2. A (set, block) list of tasks is cut into workgroup items.  The four waves of an item take the strips of its task
+//    list round-robin, so an item costs ceil(strips / 4) rounds of `rsteps` steps; the cut is the smallest cost bound
+//    c* for which the items fit the resident workgroup slots (small batches), or an eighth of a slot's share (large
+//    batches: the dispatcher evens out the rest).
+namespace {
+
+inline int pipe_rsteps(int max_l1)
+{
+    return std::max(PRALINE_PIPE_MIN_STEPS, (max_l1 + 1 + 11) / 12 * 12);
+}
+
+struct PipeList { int32_t set; int32_t rsteps; std::vector<int32_t> task; };   // tasks (indices into a scratch array) of one set
+
+}  // namespace
+
+void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, const PipeOptions &opt,
+                         PipeSchedule &out)
+{
+    out = PipeSchedule();
+    if (n_pairs <= 0 || n_seqs <= 0) return;
+    // pairs by sequence two (counting sort, stable: list order inside a column)
+    std::vector<int64_t> start((size_t)n_seqs + 1, 0);
+    for (int64_t i = 0; i < n_pairs; ++i) ++start[(size_t)pairs[2 * i + 1] + 1];
+    for (size_t t = 1; t < start.size(); ++t) start[t] += start[t - 1];
+    std::vector<int64_t> by_two((size_t)n_pairs);
+    {
+        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        for (int64_t i = 0; i < n_pairs; ++i) by_two[(size_t)fill[(size_t)pairs[2 * i + 1]]++] = i;
+    }
+    std::vector<int32_t> twos;
+    for (int64_t t = 0; t < n_seqs; ++t)
+        if (start[(size_t)t + 1] > start[(size_t)t]) twos.push_back((int32_t)t);
+
+    struct ScratchTask { int32_t two, set, nstrips; int32_t pair[32]; };
+    std::vector<ScratchTask> st;
+    std::vector<PipeList> lists;
+    std::vector<int32_t> set_one;
+    std::vector<int32_t> pos_of((size_t)n_seqs, -1), stamp((size_t)n_seqs, -1);
+    const int B = std::max(1, opt.block_twos);
+    int64_t old_tasks = 0;   // what the per-column schedule would need
+    for (size_t b0 = 0; b0 < twos.size(); b0 += (size_t)B) {
+        const size_t b1 = std::min(twos.size(), b0 + (size_t)B);
+        std::vector<int32_t> uni;
+        for (size_t q = b0; q < b1; ++q) {
+            const int32_t two = twos[q];
+            old_tasks += (start[(size_t)two + 1] - start[(size_t)two] + 31) / 32;
+            for (int64_t k = start[(size_t)two]; k < start[(size_t)two + 1]; ++k) {
+                const int32_t one = pairs[2 * by_two[(size_t)k]];
+                if (stamp[(size_t)one] != (int32_t)b0) { stamp[(size_t)one] = (int32_t)b0; uni.push_back(one); }
+            }
+        }
+        std::sort(uni.begin(), uni.end(), [&](int32_t x, int32_t y) { return lens[x] != lens[y] ? lens[x] > lens[y] : x < y; });
+        for (size_t k = 0; k < uni.size(); ++k) pos_of[(size_t)uni[k]] = (int32_t)k;
+        const size_t nsets = (uni.size() + 31) / 32, set0 = set_one.size() / 32;
+        set_one.resize((set0 + nsets) * 32, -1);
+        for (size_t k = 0; k < uni.size(); ++k) set_one[set0 * 32 + k] = uni[k];
+        const size_t list0 = lists.size();
+        lists.resize(list0 + nsets);
+        for (size_t g = 0; g < nsets; ++g) {
+            lists[list0 + g].set = (int32_t)(set0 + g);
+            lists[list0 + g].rsteps = pipe_rsteps(lens[uni[g * 32]]);
+        }
+        std::vector<int32_t> task_of(nsets);
+        for (size_t q = b0; q < b1; ++q) {
+            const int32_t two = twos[q];
+            std::fill(task_of.begin(), task_of.end(), -1);
+            for (int64_t k = start[(size_t)two]; k < start[(size_t)two + 1]; ++k) {
+                const int64_t pi = by_two[(size_t)k];
+                const int32_t pos = pos_of[(size_t)pairs[2 * pi]];
+                const size_t g = (size_t)pos / 32;
+                if (task_of[g] < 0) {
+                    ScratchTask t;
+                    t.two = two; t.set = (int32_t)(set0 + g); t.nstrips = (lens[two] + 31) / 32;
+                    for (int l = 0; l < 32; ++l) t.pair[l] = -1;
+                    task_of[g] = (int32_t)st.size();
+                    st.push_back(t);
+                    lists[list0 + g].task.push_back(task_of[g]);
+                }
+                int32_t &slot = st[(size_t)task_of[g]].pair[pos % 32];
+                if (slot >= 0) return;   // the same pair twice in the list: not for this layout
+                slot = (int32_t)pi;
+            }
+        }
+    }
+    if (st.empty() || lens == nullptr) return;
+    for (const ScratchTask &t : st)
+        if (t.nstrips <= 0) return;   // empty sequence two
+    if ((double)n_pairs < opt.min_fill * 32.0 * (double)st.size() || (int64_t)st.size() > old_tasks + old_tasks / 4 + 8) return;
+
+    // ---- items: cut every list under the cost bound c* ----
+    auto list_cost = [&](const PipeList &l, size_t a, size_t b) {   // tasks a .. b - 1 of the list
+        int64_t q = 0;
+        for (size_t k = a; k < b; ++k) q += st[(size_t)l.task[k]].nstrips;
+        return (q + 3) / 4 * (int64_t)l.rsteps;
+    };
+    auto cut_count = [&](int64_t cstar, std::vector<std::pair<int32_t, std::pair<int32_t, int32_t>>> *cuts) {
+        int64_t n = 0;
+        for (size_t li = 0; li < lists.size(); ++li) {
+            const PipeList &l = lists[li];
+            size_t a = 0;
+            while (a < l.task.size()) {
+                size_t b = a + 1;
+                int64_t q = st[(size_t)l.task[a]].nstrips;
+                while (b < l.task.size() && b - a < PRALINE_PIPE_MAX_TASKS) {
+                    const int64_t q2 = q + st[(size_t)l.task[b]].nstrips;
+                    if ((q2 + 3) / 4 * (int64_t)l.rsteps > cstar) break;
+                    q = q2; ++b;
+                }
+                if (cuts) cuts->push_back({(int32_t)li, {(int32_t)a, (int32_t)b}});
+                ++n;
+                a = b;
+            }
+        }
+        return n;
+    };
+    int64_t total = 0, one_max = 0;
+    for (const PipeList &l : lists) {
+        total += list_cost(l, 0, l.task.size());
+        for (size_t k = 0; k < l.task.size(); ++k) one_max = std::max(one_max, list_cost(l, k, k + 1));
+    }
+    int64_t cstar;
+    {
+        int64_t lo = one_max, hi = std::max(one_max, total);
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if (cut_count(mid, nullptr) <= opt.wg_slots) hi = mid; else lo = mid + 1;
+        }
+        cstar = lo;
+        // large batches: the slot bound only holds with the task cap lifted - cut into eighths of a slot's share instead
+        if (cut_count(cstar, nullptr) > opt.wg_slots) cstar = std::max(one_max, total / (8 * std::max<int64_t>(opt.wg_slots, 1)));
+    }
+    std::vector<std::pair<int32_t, std::pair<int32_t, int32_t>>> cuts;
+    cut_count(cstar, &cuts);
+
+    // launch order: longest first; when everything is resident at once (two workgroups per CU: launch positions b and
+    // b + 256 share a CU), the longest share their CUs with the shortest
+    std::vector<int64_t> cost(cuts.size());
+    for (size_t c = 0; c < cuts.size(); ++c) cost[c] = list_cost(lists[(size_t)cuts[c].first], (size_t)cuts[c].second.first, (size_t)cuts[c].second.second);
+    std::vector<int32_t> order(cuts.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
+    if ((int64_t)order.size() > 256 && (int64_t)order.size() <= opt.wg_slots) {
+        std::vector<int32_t> snake(order.begin(), order.begin() + 256);
+        for (size_t k = order.size(); k > 256; --k) snake.push_back(order[k - 1]);
+        order.swap(snake);
+    }
+
+    out.set_one.swap(set_one);
+    out.tasks.reserve(st.size());
+    out.lane_pair.reserve(st.size() * 32);
+    int64_t bnd = 0;
+    for (int32_t c : order) {
+        const PipeList &l = lists[(size_t)cuts[(size_t)c].first];
+        const int32_t a = cuts[(size_t)c].second.first, b = cuts[(size_t)c].second.second;
+        PipeItem it;
+        it.set = l.set;
+        it.task0 = (int32_t)out.tasks.size();
+        it.ntasks = b - a;
+        it.nstrips = 0;
+        it.rsteps = l.rsteps;
+        for (int32_t k = a; k < b; ++k) {
+            const ScratchTask &t = st[(size_t)l.task[(size_t)k]];
+            WaveTask wt;
+            wt.two[0] = t.two; wt.two[1] = -1;
+            wt.max_l1 = lens[out.set_one[(size_t)l.set * 32]];
+            wt.nstrips = t.nstrips;
+            wt.bnd_off = 0; wt.tb_off = 0; wt.aux_off = 0;
+            out.tasks.push_back(wt);
+            for (int q = 0; q < 32; ++q) {
+                out.lane_pair.push_back(t.pair[q]);
+                out.lanes_used += t.pair[q] >= 0;
+            }
+            it.nstrips += t.nstrips;
+        }
+        it.nrounds = (it.nstrips + 3) / 4;
+        it.bnd_off = bnd;
+        bnd += (int64_t)(it.rsteps + 16) * 32;
+        out.steps += 4 * (int64_t)it.nrounds * it.rsteps;
+        out.items.push_back(it);
+    }
+    out.bnd_elems = bnd;
+    out.ok = true;
+}
+
+extern "C" int praline_sched_pipe_test(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int block_twos,
+                                       int64_t wg_slots, int64_t cap_items, int64_t cap_tasks, int64_t cap_sets, int64_t *n_items_out,
+                                       int64_t *n_tasks_out, int64_t *n_sets_out, int32_t *item_fields /* [cap_items][6]: set, task0, ntasks, nstrips, rsteps, nrounds */,
+                                       int32_t *task_fields /* [cap_tasks][3]: two, max_l1, nstrips */, int32_t *lane_pair /* [cap_tasks][32] */,
+                                       int32_t *set_one /* [cap_sets][32] */)
+{
+    PipeOptions opt;
+    if (block_twos > 0) opt.block_twos = block_twos;
+    if (wg_slots > 0) opt.wg_slots = wg_slots;
+    PipeSchedule s;
+    build_pipe_schedule(lens, n_seqs, n_pairs, pairs, opt, s);
+    *n_items_out = (int64_t)s.items.size();
+    *n_tasks_out = (int64_t)s.tasks.size();
+    *n_sets_out = (int64_t)s.set_one.size() / 32;
+    if (!s.ok) return 1;
+    if (*n_items_out > cap_items || *n_tasks_out > cap_tasks || *n_sets_out > cap_sets) return -1;
+    for (size_t i = 0; i < s.items.size(); ++i) {
+        const PipeItem &it = s.items[i];
+        int32_t *f = item_fields + 6 * i;
+        f[0] = it.set; f[1] = it.task0; f[2] = it.ntasks; f[3] = it.nstrips; f[4] = it.rsteps; f[5] = it.nrounds;
+    }
+    for (size_t t = 0; t < s.tasks.size(); ++t) {
+        task_fields[3 * t] = s.tasks[t].two[0]; task_fields[3 * t + 1] = s.tasks[t].max_l1; task_fields[3 * t + 2] = s.tasks[t].nstrips;
+    }
+    std::copy(s.lane_pair.begin(), s.lane_pair.end(), lane_pair);
+    std::copy(s.set_one.begin(), s.set_one.end(), set_one);
+    return 0;
+}
+
 // ---- C entry point for the CPU unit tests (tests/test_scheduler_cpu.py; not part of libpraline_dp's ABI) ----
 extern "C" int praline_sched_test(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, int want_paths, int xcd_group,
                                   int64_t wave_slots, int64_t cap_tasks, int64_t cap_wg, int64_t *n_tasks_out,

@@ -32,6 +32,25 @@ struct Schedule {
     int64_t path_cap = 0, cells = 0;
 };
 
+// Pipeline-workgroup schedule of a scores-only plan (k_dp_pipe): sets of 32 sequences one shared by the tasks of a block
+// of sequences two, tasks cut into workgroup items.
+struct PipeSchedule {
+    bool ok = false;                      // false: the pair list does not suit the layout (the caller keeps the task schedule)
+    std::vector<PipeItem> items;          // launch order
+    std::vector<WaveTask> tasks;          // two[0], max_l1 (of the set), nstrips; the tasks of an item are consecutive
+    std::vector<int32_t> set_one;         // [n_sets][32] arena index of each lane's sequence one (-1: no sequence)
+    std::vector<int32_t> lane_pair;       // [n_tasks][32] pair index, -1 = no pair in this lane
+    int64_t bnd_elems = 0;                // float2 elements of the wrap-around boundary columns
+    int64_t lanes_used = 0, steps = 0;    // pairs placed; wave steps of the launch (4 x nrounds x rsteps summed over the items)
+};
+struct PipeOptions {
+    int block_twos = 16;                  // sequences two per block (their sequences one are pooled into the sets)
+    int64_t wg_slots = 512;               // resident workgroups (256 CUs x 2)
+    double min_fill = 0.55;               // give up below this share of occupied lanes
+};
+void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, const PipeOptions &opt,
+                         PipeSchedule &out);
+
 // Launch order for an ordered list of n work items: groups of G consecutive items on one XCD (block b runs on
 // XCD b % 8), groups dealt round-robin over the XCDs.  Returns, per block, the item it runs (-1: padding).
 std::vector<int64_t> xcd_group_order(int64_t n, int G);
