@@ -51,12 +51,14 @@ struct PipeLaunch {
     const WaveTask *tasks;
     const int32_t *set_one, *lane_pair;
     void *bnd;
+    void *analytic;         // float2 [analytic_rows][32]: the analytic column 0, rewritten by every launch
+    int analytic_rows;
     float *scores;
     RunParams rp;
     hipStream_t stream;
 };
 bool praline_pipe_supported(int nr, int nterm);
-int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm, bool local);
+int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm);
 // two-pass alignments with paths (dp_tb2_instance.hip): flag-free forward fill, then block recompute + traceback
 struct Trace2Args {
     const int64_t *slot_off;

@@ -1,41 +1,62 @@
 // dp_pipe.hip.h -- k_dp_pipe: the scores-only fill as a PIPELINE of the four waves of a workgroup.
 //
 // What round 3's measurements said about k_dp_split16 on float profiles (scripts/exp_ablate16.py, scripts/micro/
-// step_cost.hip): a saturated launch is bound by its memory instructions, not by the vector ALU -
-// every wave streams its own 32 operand rows (4 KiB per step, 11.5 TB/s of L2 -> LDS traffic at 2.9 TCUPS, the
-// measured ceiling of that gather pattern) and round-trips the strip-boundary column through memory (one 256-byte
-// store and one 256-byte DMA per step: 16 % of the launch); without both the same recurrence runs twice as fast.
+// step_cost.hip, issue_cost.hip):
+//   * a saturated launch is bound by its memory instructions, not by the vector ALU - every wave streams its own 32
+//     operand rows (4 KiB per step: 11.5 TB/s of L2 -> LDS traffic at 2.9 TCUPS, the measured ceiling of that gather
+//     pattern) and round-trips the strip-boundary column through memory (16 % of the launch);
+//   * a wave issues ONE instruction of any kind per ~5.5 cycles, and a scalar branch costs it ~25: what a step costs
+//     is its instruction count, whatever the pipes do.
 //
 // Here the four waves of a workgroup work on tasks that share ONE set of 32 sequences one (PipeItem, sched.cpp):
 //   * wave r sweeps the strips r, r + 4, r + 8, ... of the item's concatenated strip list (the strips of task 0, then
 //     of task 1, ...), PRALINE_PIPE_LAG = 2 steps behind wave r - 1: all four are within 6 rows of each other;
 //   * the set's operand rows are therefore streamed ONCE per workgroup and step: wave r fetches a quarter of the row
-//     (pairs 8 r .. 8 r + 7, one 1 KiB LDS-DMA) five steps ahead into a 12-row ring that all four waves read
-//     (a quarter of the bytes and a quarter of the DMA instructions per wave);
+//     (pairs 8 r .. 8 r + 7, one 1 KiB LDS-DMA) six steps ahead into a 12-row ring that all four waves read
+//     (a quarter of the bytes and of the DMA instructions per wave);
 //   * a strip's boundary column (H, L of its last column, row by row) is handed to the wave of the next strip through
-//     a four-row LDS ring; only the hand-off from wave 3 to wave 0's next strip goes through memory (`bnd`, one round
-//     = rsteps - 6 steps later);
+//     a 12-row LDS ring; only the hand-off from wave 3 to wave 0's next strip goes through memory (`bnd`, one round
+//     = rsteps - 6 steps later), four rows (1 KiB) per store / DMA; a task's first strip reads the analytic column 0
+//     from `analytic` (written once per launch by k_pipe_analytic) the same way;
 //   * the waves meet at one s_barrier per step: it orders ring writes (every wave waits for its own DMA piece of the
-//     row three steps after issuing it), ring reuse and the boundary hand-off.
+//     row four steps after issuing it), ring reuse and the boundary hand-off;
+//   * the step itself is branch-free apart from one wave-uniform test every fourth step (boundary blocks) and the
+//     snapshot test, which only exists in the iterations that can contain a sequence's last row (SNAP).
 // The arithmetic of a cell is split16_step's (dp_split16.hip.h) instruction for instruction - scores are bit-identical
 // to k_dp_split16 (tests/test_gpu_parity.py::test_pipeline_workgroups_agree_bitwise).
 //
 // Step u (0-based) of a round: lower half DP row u + 1, upper half row u.  A round has rsteps = 12 k >= max_l1 + 1
 // steps; stream position p = round * rsteps + u holds the operand row u + 1 of every sequence of the set and lives in
-// ring slot p % 12 = u % 12: static per unrolled step, the same for every wave.
+// ring slot p % 12 = u % 12: static per unrolled step, the same for every wave.  Boundary rows live in slot row % 12 of
+// the consumer's ring.
 //
-// LDS per workgroup: [12 x 4 KiB ring][4 x 4 KiB A tiles of the next strips][4 x 1 KiB boundary rings][results].
+// LDS per workgroup (80 KiB: two workgroups per CU): [12 x 4 KiB operand ring][4 x 4 KiB A tiles of the next strips]
+// [4 x 3 KiB boundary rings][3 KiB wave 3's outgoing rows][1 KiB results].
 #pragma once
 #include "dp_split16.hip.h"
 
 __host__ __device__ constexpr int pipe_ring_bytes() { return PRALINE_PIPE_RING * 4096; }
+__host__ __device__ constexpr int pipe_bring_bytes() { return 12 * 256; }
+__host__ __device__ constexpr int pipe_res_bytes() { return PRALINE_PIPE_MAX_TASKS * 2 * 32 * 4; }
 __host__ __device__ constexpr int pipe_lds_bytes()
 {
-    return pipe_ring_bytes() + 4 * 4096 + 4 * 1024 + PRALINE_PIPE_MAX_TASKS * 2 * 32 * 4;
+    return pipe_ring_bytes() + 4 * 4096 + 5 * pipe_bring_bytes() + pipe_res_bytes();
 }
+static_assert(pipe_lds_bytes() <= 80 * 1024, "two pipeline workgroups per CU");
 
 // barrier of the pipeline: every LDS access of this wave (the hand-off write above all) has completed before it
 #define PRALINE_PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PRALINE_PIPE_AHEAD 6   // the operand stream runs this many positions ahead of wave 0's step
+
+// the analytic column 0 of a task - (o[y,0,1], -inf) for every pair - as float2 [rows][32]: what a task's FIRST strip
+// reads as its boundary column (praline/component/align.py:371-376)
+__global__ void k_pipe_analytic(float2 *col, int rows, RunParams rp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = i >> 5;
+    if (y >= rows) return;
+    col[i] = make_float2(y >= 1 ? boundary_value(y, rp.go1, rp.ge1, mode_free_one(rp.mode)) : 0.0f, PRALINE_NEG_INF);
+}
 
 struct PipeDma {
     unsigned long long src;    // wave-uniform: P16 + (row of the next position to fetch) * row bytes
@@ -44,10 +65,6 @@ struct PipeDma {
     unsigned rsteps;
     unsigned ring_lo, ring_hi; // ring bounds for this wave's piece (dst wraps from ring_hi to ring_lo)
     unsigned gofs;             // per-lane byte offset of the piece (VGPR)
-    // wave 0 only: boundary rows from `bnd`
-    unsigned long long bsrc;   // address of the next boundary row to fetch
-    unsigned bdst_base, brow;  // LDS ring base; next row index (ring slot = brow & 3)
-    unsigned bgofs;
 };
 
 // one operand piece (1 KiB) of the next stream position
@@ -68,62 +85,47 @@ __device__ __forceinline__ void pipe_issue(PipeDma &d)
         d.src -= (unsigned long long)d.rsteps * 128ull;
     }
 }
-// wave 0: the boundary row `brow` of the wrap-around column (256 bytes: float2 per pair)
-__device__ __forceinline__ void pipe_issue_bnd(PipeDma &d)
+// four boundary rows (1 KiB: float2 [4][32]) from memory into a boundary ring
+__device__ __forceinline__ void pipe_issue_block(unsigned long long src, unsigned dst, unsigned lane16)
 {
     unsigned keep;
-    const unsigned dst = d.bdst_base + (d.brow & 3u) * 256u;
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dword %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
                  : "=&s"(keep)
-                 : "v"(d.bgofs), "s"(d.bsrc), "s"(dst)
+                 : "v"(lane16), "s"(src), "s"(dst)
                  : "memory");
-    d.bsrc += 256;
-    d.brow += 1;
-    // the column is rewritten every round (rows 1 .. rsteps; row rsteps is never written: it only feeds padding rows)
-    if (d.brow > d.rsteps) {
-        asm volatile("");
-        d.brow = 1;
-        d.bsrc -= (unsigned long long)d.rsteps * 256ull;
-    }
 }
 
-// The per-step wait: every memory operation of this wave older than the last two steps' has completed - ranks 0 and 3
-// issue two per step (piece + boundary DMA / boundary store), ranks 1 and 2 one; `extra`: the four A-tile DMAs of the
-// next strip were issued within those two steps.
-__device__ __forceinline__ void pipe_wait(bool wait4, bool extra)
-{
-    if (extra) { if (wait4) PRALINE_VMCNT(8); else PRALINE_VMCNT(6); }
-    else { if (wait4) PRALINE_VMCNT(4); else PRALINE_VMCNT(2); }
-}
-
-struct PipeStrip {             // wave-uniform facts of the strip being swept
-    bool first;                // strip 0 of its task: the boundary column is the analytic column 0
-    bool last_owner;           // (per lane) last strip && this half holds column L2
-    int xb, L2;
+// Boundary traffic of a wave, per strip (wave-uniform).
+struct PipeBnd {
+    unsigned long long in_src;   // next block of the incoming column to fetch (analytic column or the wrap-around column)
+    bool in_dma;                 // this strip's boundary column comes from memory (wave 0, or the task's first strip)
+    unsigned long long out_dst;  // wave 3: next block of the wrap-around column to store
+    bool out_mem;                // wave 3: rows go to memory (four at a time)
+    unsigned ring_addr;          // LDS address of this wave's incoming ring
+    const char *out_stage;       // wave 3: its outgoing rows in LDS (+ lane * 16)
 };
 
-// One step of an active wave.  K = u % 12.  Register roles as in split16_step (BSRC = 2 without DM):
+// One step.  K = u % 12.  Register roles as in split16_step (BSRC = 2 without DM):
 //   CUR row u + 1's scores, PREV row u's (receives row u + 2's); BOPS operands of row u + 2, BFILL receives row u + 3.
-template <int NR, int NTERM, bool LOCAL, int K>
+template <int NR, int NTERM, bool LOCAL, bool SEMI, int K, bool SNAP>
 __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                           const float4 (&BOPS)[4], float4 (&BFILL)[4], const float4 (&aop)[4],
                                           const char *ring, const unsigned (&stage_rd)[4], const char *bnd_in, char *bnd_out,
-                                          char *&bnd_st, bool to_memory, bool wait4, PipeDma &dma, bool has_bnd_dma,
+                                          bool wr_lane, PipeDma &dma, PipeBnd &pb, unsigned lane16,
                                           float (&Hs)[17], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
                                           float &best_run, float &col_run, float &out_best, float &out_rowmax, float &out_colmax,
-                                          float &out_corner, float go, float ge, bool free_one, bool semiglobal, int cidx,
-                                          const PipeStrip &sp, bool may_snap, bool extra_ops = false)
+                                          float &out_corner, float go, float ge, int cidx, bool last_owner, int xb, int L2)
 {
     static_assert(NR == 2 && (NTERM == 2 || NTERM == 3), "k_dp_pipe is built for the 128-byte operand rows of float-profile arenas");
     constexpr int NM = NTERM * NR;
-    const int yy = u + 1 - h;   // this lane's DP row
-    // every DMA piece older than two steps has landed (this wave's share of the rows read below), then the barrier: the
-    // other waves' shares too, and the previous step's boundary hand-off
-    pipe_wait(wait4, (K == 1 || K == 2) && extra_ops);
+    // every memory operation of this wave but the three youngest has completed: its pieces of the rows read below (issued
+    // >= 4 steps ago; a block DMA / store or the A-tile fetch among the youngest only makes the wait stricter), then
+    // the barrier: the other waves' pieces too, and the previous step's boundary hand-off
+    PRALINE_VMCNT(3);
     PRALINE_PIPE_BARRIER();
-    // boundary column of row u + 1: (H[y][x0], L[y][x0 + 1]); u = K (mod 12), so the ring slots are static
-    float2 bv = *reinterpret_cast<const float2 *>(bnd_in + ((K + 1) & 3) * 256);
+    // boundary column of row u + 1: (H[y][x0], L[y][x0 + 1]); u = K (mod 12), so every ring slot is static
+    const float2 bv = *reinterpret_cast<const float2 *>(bnd_in + ((K + 1) % 12) * 256);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         BFILL[q] = *reinterpret_cast<const float4 *>(ring + ((K + 2) % PRALINE_PIPE_RING) * 4096 + stage_rd[q]);
@@ -135,10 +137,6 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
         m2[c].y = h ? PREV[2 * c + 1] : CUR[2 * c + 1];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (sp.first) {   // column 0 of the task: o[y,0,1], no L (a real branch: one strip in ~13 pays for the float64 form)
-        asm volatile("");
-        bv = make_float2(boundary_value(u + 1, go, ge, free_one), PRALINE_NEG_INF);
-    }
     Hs[0] = h ? hd_x : dH;
     float lrun = h ? l_x : bv.y;
     const float hd_out = Hs[16];
@@ -175,68 +173,78 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
         __builtin_amdgcn_sched_barrier(0);
     }
     PREV = acc;
-    // hand the last column to the next strip: through LDS (the next wave reads it after the next barrier), wave 3
-    // through memory (wave 0 fetches it a round later)
-    if (to_memory) {
-        if (h) {
-            const unsigned long long v = (unsigned long long)__float_as_uint(Hs[16]) | ((unsigned long long)__float_as_uint(lrun) << 32);
-            __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long *>(bnd_st));
-        }
-    } else {
-        if (h) *reinterpret_cast<float2 *>(bnd_out + (K & 3) * 256) = make_float2(Hs[16], lrun);   // row yy = u: slot u & 3
-    }
-    bnd_st += 256;
+    // hand row yy = u of the last column to the next strip (ring slot u % 12 of the next wave; wave 3: its own staging
+    // ring; lanes of the lower half and strips that end a task write nothing)
+    if (wr_lane) *reinterpret_cast<float2 *>(bnd_out + (K % 12) * 256) = make_float2(Hs[16], lrun);
     pipe_issue(dma);
-    if (has_bnd_dma) pipe_issue_bnd(dma);
+    if constexpr ((K & 3) == 3) {
+        // every fourth step: the next four rows of a boundary column that lives in memory -
+        //   incoming (wave 0, or a task's first strip): rows u + 5 .. u + 8 -> ring slots (K + 5) % 12 ..
+        //   outgoing (wave 3): rows u - 3 .. u, just completed in the staging ring
+        if (pb.in_dma) {
+            pipe_issue_block(pb.in_src, pb.ring_addr + ((K + 5) % 12) * 256, lane16);
+            pb.in_src += 1024;
+        }
+        if (pb.out_mem) {
+            const f4n v = *reinterpret_cast<const f4n *>(pb.out_stage + (K - 3) * 256);
+            __builtin_nontemporal_store(v, reinterpret_cast<f4n *>(pb.out_dst + lane16));
+            pb.out_dst += 1024;
+        }
+    }
     dH = bv.x;
     hd_x = from_lower_half(hd_out);
     l_x = from_lower_half(lrun);
-    if (semiglobal && sp.last_owner) col_run = __builtin_fmaxf(col_run, select16s(Hs, cidx));
-    if (may_snap && have_pair && yy == L1) {
-        if constexpr (LOCAL) asm volatile("");   // keep this a branch (see split16_step, SNAPBR)
-        if (LOCAL) out_best = best_run;
-        if (semiglobal) {
+    if constexpr (SEMI) {
+        // (a branch over 16 instructions: the strips that own a last column are one in ~13)
+        if (last_owner) col_run = __builtin_fmaxf(col_run, select16s(Hs, cidx));
+    }
+    if constexpr (SNAP) {
+        if (have_pair && u + 1 - h == L1) {
+            if constexpr (LOCAL) asm volatile("");   // keep this a branch (see split16_step, SNAPBR)
+            if (LOCAL) out_best = best_run;
+            if (SEMI) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-                out_rowmax = __builtin_fmaxf(out_rowmax, (sp.xb + c + 1 <= sp.L2) ? Hs[c + 1] : PRALINE_NEG_INF);
-            out_colmax = col_run;
+                for (int c = 0; c < 16; ++c)
+                    out_rowmax = __builtin_fmaxf(out_rowmax, (xb + c + 1 <= L2) ? Hs[c + 1] : PRALINE_NEG_INF);
+                out_colmax = col_run;
+            }
+            if (last_owner) out_corner = select16s(Hs, cidx);
         }
-        if (sp.last_owner) out_corner = select16s(Hs, cidx);
     }
 }
 
 // a step of a wave that has no strip (lead-in, the last round's spare waves): its share of the operand stream only
-__device__ __forceinline__ void pipe_idle_step(bool wait4, PipeDma &dma, bool has_bnd_dma)
+__device__ __forceinline__ void pipe_idle_step(PipeDma &dma)
 {
-    pipe_wait(wait4, false);
+    PRALINE_VMCNT(3);
     PRALINE_PIPE_BARRIER();
     pipe_issue(dma);
-    if (has_bnd_dma) pipe_issue_bnd(dma);
 }
 
-template <int NR, int NTERM, bool LOCAL>
+template <int NR, int NTERM, bool LOCAL, bool SEMI>
 __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeItem *__restrict__ items, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ set_one, const int32_t *__restrict__ lane_pair,
-                                                    float2 *bnd, float *__restrict__ scores, RunParams rp)
+                                                    float2 *bnd, const float2 *__restrict__ analytic, float *__restrict__ scores,
+                                                    RunParams rp)
 {
+    static_assert(!(LOCAL && SEMI), "one mode at a time");
     __shared__ __attribute__((aligned(16))) char lds[pipe_lds_bytes()];
     char *ring = lds;
     const int rank = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform (SGPR)
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     char *atile = lds + pipe_ring_bytes() + rank * 4096;
-    char *bin_all = lds + pipe_ring_bytes() + 4 * 4096;          // boundary rings: [wave][4 rows][32 pairs] float2
-    float *res = reinterpret_cast<float *>(lds + pipe_ring_bytes() + 4 * 4096 + 4 * 1024);   // [task][2][32]
+    char *bring_all = lds + pipe_ring_bytes() + 4 * 4096;          // boundary rings [wave 0..3][12 rows][32] float2, then wave 3's outgoing rows
+    float *res = reinterpret_cast<float *>(bring_all + 5 * pipe_bring_bytes());   // [task][2][32]
     const PipeItem it = items[blockIdx.x];
     const int rsteps = it.rsteps, nrounds = it.nrounds, nstrips_all = it.nstrips;
     const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
-    const bool semiglobal = rp.mode >= 2;
     const float go = rp.go1, ge = rp.ge1;
     const float o001 = free_one ? 0.0f : (go - ge);
     const float o002 = free_two ? 0.0f : (go - ge);
     const float h00 = max3f(0.0f, o001, o002);
 
     // defined LDS contents before the first DMA / hand-off; results start at -inf
-    for (int i = threadIdx.x * 16; i < pipe_ring_bytes() + 4 * 4096 + 4 * 1024; i += 256 * 16)
+    for (int i = threadIdx.x * 16; i < pipe_ring_bytes() + 4 * 4096 + 5 * pipe_bring_bytes(); i += 256 * 16)
         *reinterpret_cast<float4 *>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = threadIdx.x; i < PRALINE_PIPE_MAX_TASKS * 2 * 32; i += 256) res[i] = PRALINE_NEG_INF;
     __syncthreads();
@@ -249,6 +257,10 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
     for (int off = 32; off >= 1; off >>= 1) min_l1 = min(min_l1, __shfl_xor(min_l1, off));
     min_l1 = __builtin_amdgcn_readfirstlane(min_l1);
 
+    auto uniform64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    };
     // ---- this wave's share of the operand stream: piece `rank` = pairs 8 rank .. 8 rank + 7 of every row ----
     PipeDma dma;
     unsigned stage_rd[4];
@@ -262,43 +274,48 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             stage_rd[q] = (unsigned)j * 128u + (((unsigned)(h * 4 + q)) ^ stage_swz<C>((unsigned)j)) * 16u;
-        const unsigned long long pb = reinterpret_cast<unsigned long long>(ar.P16);
-        dma.src = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32)) << 32) |
-                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pb);
+        dma.src = uniform64(reinterpret_cast<unsigned long long>(ar.P16));
         const unsigned ring_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)ring);
         dma.ring_lo = ring_addr + (unsigned)rank * 1024u;
         dma.ring_hi = dma.ring_lo + (unsigned)pipe_ring_bytes();
         dma.dst = dma.ring_lo;
         dma.left = (unsigned)rsteps;
         dma.rsteps = (unsigned)rsteps;
-        const unsigned long long bb = reinterpret_cast<unsigned long long>(bnd + it.bnd_off);
-        dma.bsrc = (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bb >> 32)) << 32) |
-                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb)) + 256ull;   // row 1
-        dma.bdst_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)bin_all);            // wave 0's ring
-        dma.brow = 1;
-        dma.bgofs = (unsigned)lane * 4u;
     }
-    const bool wait4 = rank == 0 || rank == 3;     // two memory operations per step (piece + boundary DMA / store)
-    const bool has_bnd_dma = rank == 0;
-    const bool to_memory = rank == 3;
-    const char *bnd_in = bin_all + rank * 1024 + j * 8;                   // rows handed to this wave
-    char *bnd_out = bin_all + ((rank + 1) & 3) * 1024 + j * 8;            // rows this wave hands on (waves 0..2)
-    char *bnd_col = reinterpret_cast<char *>(bnd + it.bnd_off + j);       // wave 3: the wrap-around column, float2 [row][32]
-
-    // positions 0..4 of the stream (and wave 0's boundary rows 1..4: garbage for the first round - its first strip is
-    // a task's first strip - but the ring's accounting starts here); everything lands before the first barrier
-#pragma unroll
-    for (int i = 0; i < 5; ++i) pipe_issue(dma);
-    if (has_bnd_dma) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pipe_issue_bnd(dma);
-    }
-    PRALINE_VMCNT(0);
-    PRALINE_PIPE_BARRIER();
-    for (int i = 0; i < PRALINE_PIPE_LAG * rank; ++i) pipe_idle_step(wait4, dma, has_bnd_dma);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned long long wrap_col = uniform64(reinterpret_cast<unsigned long long>(bnd + it.bnd_off));      // float2 [rsteps + 16][32]
+    const unsigned long long analytic_col = uniform64(reinterpret_cast<unsigned long long>(analytic));
+    PipeBnd pb;
+    pb.ring_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(bring_all + rank * pipe_bring_bytes()));
+    pb.out_mem = rank == 3;
+    pb.out_stage = bring_all + 4 * pipe_bring_bytes() + lane * 16;
+    pb.out_dst = wrap_col;
+    pb.in_dma = false;
+    pb.in_src = 0;
+    const char *bnd_in = bring_all + rank * pipe_bring_bytes() + j * 8;           // rows handed to this wave
+    char *bnd_out = bring_all + (rank + 1) * pipe_bring_bytes() + j * 8;          // rows this wave hands on (wave 3: its staging ring)
 
     // ---- this wave's strips ----
     int ti = 0, s = rank;          // task (inside the item) and strip of this wave's current strip
+    const bool any = rank < nstrips_all;
+    if (any) {
+        while (s >= tasks[it.task0 + ti].nstrips) { s -= tasks[it.task0 + ti].nstrips; ++ti; }
+    }
+    // positions 0 .. AHEAD - 1 of the stream, and the first two boundary blocks (rows 0 .. 7) of the wave's first strip
+    // when they come from memory: the analytic column - a wave's first strip can only be fed from memory if it is a
+    // task's first strip (wave 0's predecessor, the wrap-around column, does not exist yet)
+#pragma unroll
+    for (int i = 0; i < PRALINE_PIPE_AHEAD; ++i) pipe_issue(dma);
+    if (any && s == 0) {
+        pipe_issue_block(analytic_col, pb.ring_addr, lane16);
+        pipe_issue_block(analytic_col + 1024, pb.ring_addr + 1024, lane16);
+        pb.in_dma = true;
+        pb.in_src = analytic_col + 2048;
+    }
+    PRALINE_VMCNT(0);
+    PRALINE_PIPE_BARRIER();
+    for (int i = 0; i < PRALINE_PIPE_LAG * rank; ++i) pipe_idle_step(dma);
+
     int cidx = 0;
     float4 aop[4], b0[4], b1[4];
     f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -311,10 +328,9 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
     for (int round = 0; round < nrounds; ++round) {
         const int q = 4 * round + rank;
         if (q >= nstrips_all) {   // no strip left for this wave (last round only)
-            for (int u = 0; u < rsteps; ++u) pipe_idle_step(wait4, dma, has_bnd_dma);
+            for (int u = 0; u < rsteps; ++u) pipe_idle_step(dma);
             continue;
         }
-        while (s >= tasks[it.task0 + ti].nstrips) { s -= tasks[it.task0 + ti].nstrips; ++ti; }
         const WaveTask tk = tasks[it.task0 + ti];
         const int two = tk.two[0];
         const int L2 = ar.len[two];
@@ -322,14 +338,15 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
         const int clast = (L2 - 1) & 31;
         const bool own_last = (clast >> 4) == h;
         const int x0 = s * 32;
-        PipeStrip sp;
-        sp.first = s == 0;
-        sp.last_owner = (s == nstrips - 1) && own_last;
-        sp.xb = x0 + 16 * h;
-        sp.L2 = L2;
+        const bool last_owner = (s == nstrips - 1) && own_last;
+        const int xb = x0 + 16 * h;
         cidx = clast & 15;
         asm volatile("" : "+v"(cidx));
         const bool have_pair = have_one && lane_pair[(it.task0 + ti) * 32 + j] >= 0;
+        // the upper half hands its rows on - unless this strip ends its task: the next strip then starts from the
+        // analytic column, which its wave fetches into the same ring
+        const bool wr_lane = h == 1 && (s < nstrips - 1 || rank == 3);
+        pb.out_dst = wrap_col;
 
         if (!started) {
             // pipeline prologue of the wave's first strip: A tile straight from memory, operand rows 1 and 2 from the
@@ -355,14 +372,14 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
             }
         }
         // (later strips: the previous round's last step already used this strip's A tile - accA holds row 1's scores,
-        // b0 row 2's operands)
+        // b0 row 2's operands - and its first two boundary blocks were requested at steps rsteps - 5 and rsteps - 1)
 
         float Hs[17], Uc[16];
         Hs[0] = PRALINE_NEG_INF;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            Hs[c + 1] = boundary_value(sp.xb + c + 1, go, ge, free_two);   // H[0][x] = o[0,x,2]
-            Uc[c] = PRALINE_NEG_INF;                                        // U[1][x]
+            Hs[c + 1] = boundary_value(xb + c + 1, go, ge, free_two);   // H[0][x] = o[0,x,2]
+            Uc[c] = PRALINE_NEG_INF;                                     // U[1][x]
         }
         float dH = (s == 0) ? h00 : boundary_value(x0, go, ge, free_two);
         float hd_x = PRALINE_NEG_INF, l_x = PRALINE_NEG_INF;
@@ -371,76 +388,87 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
         float out_best = PRALINE_NEG_INF, out_rowmax = PRALINE_NEG_INF, out_colmax = PRALINE_NEG_INF, out_corner = PRALINE_NEG_INF;
         float best_run = LOCAL ? h00 : PRALINE_NEG_INF;
         float col_run = PRALINE_NEG_INF;
-        char *bnd_st = bnd_col;   // upper half stores row yy = u (row 0: dummy)
 
-        // the next strip of this wave (strip q + 4): its A tile is fetched into LDS during the last iteration
+        // the next strip of this wave (strip q + 4): its A tile is fetched into LDS during the last iteration, its
+        // boundary blocks (if they come from memory) from step rsteps - 5 on
         int ti_n = ti, s_n = s + 4;
         const bool more = q + 4 < nstrips_all;
         if (more) {
             while (s_n >= tasks[it.task0 + ti_n].nstrips) { s_n -= tasks[it.task0 + ti_n].nstrips; ++ti_n; }
         }
+        const bool in_dma_next = more && (rank == 0 || s_n == 0);
+        const unsigned long long in_src_next = s_n == 0 ? analytic_col : wrap_col;
 
-#define PRALINE_PIPE_STEP(KK, CURA, PREVA, BUSE, BFIL)                                                                 \
-        pipe_step<NR, NTERM, LOCAL, KK>(u0 + KK, L1, have_pair, h, CURA, PREVA, BUSE, BFIL, aop, ring, stage_rd, bnd_in, bnd_out, \
-                                        bnd_st, to_memory, wait4, dma, has_bnd_dma, Hs, Uc, dH, hd_x, l_x, best_run, col_run, \
-                                        out_best, out_rowmax, out_colmax, out_corner, go, ge, free_one, semiglobal, cidx, sp, \
-                                        (u0 + KK + 1) >= min_l1, a_fetch)
-        for (int u0 = 0; u0 < rsteps; u0 += 12) {
-            const bool last_it = u0 + 12 >= rsteps;
-            const bool a_fetch = last_it && more;
-            if (u0 == 0) {
-                // step 0: only the lower half has a row (row 1); the upper half's garbage is undone right after
-                float Hsave[17];
-#pragma unroll
-                for (int c = 0; c < 17; ++c) Hsave[c] = Hs[c];
-                const float best_s = best_run, col_s = col_run;
-                PRALINE_PIPE_STEP(0, accA, accB, b0, b1);
-                if (h) {
-#pragma unroll
-                    for (int c = 0; c < 17; ++c) Hs[c] = Hsave[c];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) Uc[c] = PRALINE_NEG_INF;
-                    best_run = best_s;
-                    col_run = col_s;
-                }
-            } else {
-                PRALINE_PIPE_STEP(0, accA, accB, b0, b1);
-            }
-            if (a_fetch) {
-                // A tile of strip q + 4 (rows x0' .. x0' + 31 of its sequence two, this lane's 64 bytes) -> LDS
-                const unsigned long long qa = reinterpret_cast<unsigned long long>(ar.Q16) +
-                                              ((unsigned long long)ar.row_off[tasks[it.task0 + ti_n].two[0]] + (unsigned long long)(s_n * 32)) * 128ull;
-                const unsigned long long qs = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(qa >> 32)) << 32) |
-                                              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)qa);
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    unsigned keep;
-                    const unsigned go_ = a_gofs + 16u * qq, dst = a_lds + 1024u * qq;
-                    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                                 "global_load_lds_dwordx4 %1, %2\n\t"
-                                 : "=&s"(keep)
-                                 : "v"(go_), "s"(qs), "s"(dst)
-                                 : "memory");
-                }
-            }
-            PRALINE_PIPE_STEP(1, accB, accA, b1, b0);
-            PRALINE_PIPE_STEP(2, accA, accB, b0, b1);
-            PRALINE_PIPE_STEP(3, accB, accA, b1, b0);
-            PRALINE_PIPE_STEP(4, accA, accB, b0, b1);
-            PRALINE_PIPE_STEP(5, accB, accA, b1, b0);
-            PRALINE_PIPE_STEP(6, accA, accB, b0, b1);
-            PRALINE_PIPE_STEP(7, accB, accA, b1, b0);
-            PRALINE_PIPE_STEP(8, accA, accB, b0, b1);
-            PRALINE_PIPE_STEP(9, accB, accA, b1, b0);
-            PRALINE_PIPE_STEP(10, accA, accB, b0, b1);
-            if (a_fetch) {
-                // the last step's MFMAs compute row 1 of the NEXT strip: switch to its A tile (fetched >= 10 steps ago:
-                // every per-step wait since has covered it)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) aop[qq] = *reinterpret_cast<const float4 *>(atile + 1024 * qq + lane * 16);
-            }
-            PRALINE_PIPE_STEP(11, accB, accA, b1, b0);
+#define PRALINE_PIPE_STEP(KK, SN, CURA, PREVA, BUSE, BFIL)                                                             \
+        pipe_step<NR, NTERM, LOCAL, SEMI, KK, SN>(u0 + KK, L1, have_pair, h, CURA, PREVA, BUSE, BFIL, aop, ring, stage_rd, bnd_in, \
+                                                  bnd_out, wr_lane, dma, pb, lane16, Hs, Uc, dH, hd_x, l_x, best_run, col_run, \
+                                                  out_best, out_rowmax, out_colmax, out_corner, go, ge, cidx, last_owner, xb, L2)
+#define PRALINE_PIPE_TAIL(SN)                                                                                          \
+            PRALINE_PIPE_STEP(1, SN, accB, accA, b1, b0);                                                              \
+            PRALINE_PIPE_STEP(2, SN, accA, accB, b0, b1);                                                              \
+            PRALINE_PIPE_STEP(3, SN, accB, accA, b1, b0);                                                              \
+            PRALINE_PIPE_STEP(4, SN, accA, accB, b0, b1);                                                              \
+            PRALINE_PIPE_STEP(5, SN, accB, accA, b1, b0);                                                              \
+            PRALINE_PIPE_STEP(6, SN, accA, accB, b0, b1);                                                              \
+            if (last_it) {   /* the block requested at step 7 (rows rsteps .. rsteps + 3) is the next strip's rows 0 .. 3 */ \
+                pb.in_dma = in_dma_next;                                                                               \
+                pb.in_src = in_src_next;                                                                               \
+            }                                                                                                          \
+            PRALINE_PIPE_STEP(7, SN, accB, accA, b1, b0);                                                              \
+            PRALINE_PIPE_STEP(8, SN, accA, accB, b0, b1);                                                              \
+            PRALINE_PIPE_STEP(9, SN, accB, accA, b1, b0);                                                              \
+            PRALINE_PIPE_STEP(10, SN, accA, accB, b0, b1);                                                             \
+            if (a_fetch) {                                                                                             \
+                /* the last step's MFMAs compute row 1 of the NEXT strip: switch to its A tile (fetched 10 steps ago) */ \
+                _Pragma("unroll") for (int qq = 0; qq < 4; ++qq)                                                       \
+                    aop[qq] = *reinterpret_cast<const float4 *>(atile + 1024 * qq + lane * 16);                        \
+            }                                                                                                          \
+            PRALINE_PIPE_STEP(11, SN, accB, accA, b1, b0)
+        // one 12-step iteration; SN: with the snapshot test (the iterations that can contain a sequence's last row)
+#define PRALINE_PIPE_ITER(SN)                                                                                          \
+        {                                                                                                              \
+            const bool last_it = u0 + 12 >= rsteps;                                                                    \
+            const bool a_fetch = last_it && more;                                                                      \
+            if (u0 == 0) {                                                                                             \
+                /* step 0: only the lower half has a row (row 1); the upper half's garbage is undone right after */    \
+                float Hsave[17];                                                                                       \
+                _Pragma("unroll") for (int c = 0; c < 17; ++c) Hsave[c] = Hs[c];                                       \
+                const float best_s = best_run, col_s = col_run;                                                        \
+                PRALINE_PIPE_STEP(0, SN, accA, accB, b0, b1);                                                          \
+                if (h) {                                                                                               \
+                    _Pragma("unroll") for (int c = 0; c < 17; ++c) Hs[c] = Hsave[c];                                   \
+                    _Pragma("unroll") for (int c = 0; c < 16; ++c) Uc[c] = PRALINE_NEG_INF;                            \
+                    best_run = best_s;                                                                                 \
+                    col_run = col_s;                                                                                   \
+                }                                                                                                      \
+            } else {                                                                                                   \
+                PRALINE_PIPE_STEP(0, SN, accA, accB, b0, b1);                                                          \
+            }                                                                                                          \
+            if (a_fetch) {                                                                                             \
+                /* A tile of strip q + 4 (rows x0' .. x0' + 31 of its sequence two, this lane's 64 bytes) -> LDS */    \
+                const unsigned long long qs = uniform64(reinterpret_cast<unsigned long long>(ar.Q16) +                 \
+                                              ((unsigned long long)ar.row_off[tasks[it.task0 + ti_n].two[0]] + (unsigned long long)(s_n * 32)) * 128ull); \
+                _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                                                     \
+                    unsigned keep;                                                                                     \
+                    const unsigned go_ = a_gofs + 16u * qq, dst = a_lds + 1024u * qq;                                  \
+                    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"                                                    \
+                                 "global_load_lds_dwordx4 %1, %2\n\t"                                                  \
+                                 : "=&s"(keep)                                                                         \
+                                 : "v"(go_), "s"(qs), "s"(dst)                                                         \
+                                 : "memory");                                                                          \
+                }                                                                                                      \
+            }                                                                                                          \
+            PRALINE_PIPE_TAIL(SN);                                                                                     \
         }
+        // two loops rather than a test per iteration: the compiler spills when both bodies hang off one branch
+        int u0 = 0;
+        // first iteration whose rows u0 .. u0 + 12 reach min_l1.  (LOCAL: every iteration keeps the test - without any branch
+        // the twelve steps fuse into one basic block and the compiler spills ~110 registers: see split16_step, SNAPBR.)
+        const int u_snap = LOCAL ? 0 : min(rsteps, max(0, (min_l1 - 1) / 12 * 12));
+        for (; u0 < u_snap; u0 += 12) PRALINE_PIPE_ITER(false)
+        for (; u0 < rsteps; u0 += 12) PRALINE_PIPE_ITER(true)
+#undef PRALINE_PIPE_ITER
+#undef PRALINE_PIPE_TAIL
 #undef PRALINE_PIPE_STEP
 
         // ---- fold this strip's share into the task's results ----
@@ -451,12 +479,13 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
             const float best_all = __builtin_fmaxf(out_best, partner_value(out_best, h));
             if (h == 0) {
                 float *r0 = res + ti * 64 + j;
-                const float v0 = LOCAL ? best_all : (semiglobal ? rowmax_all : corner_all);
+                const float v0 = LOCAL ? best_all : (SEMI ? rowmax_all : corner_all);
                 if (v0 != PRALINE_NEG_INF) atomicMax(r0, v0);
-                if (semiglobal && colmax_all != PRALINE_NEG_INF) atomicMax(r0 + 32, colmax_all);
+                if (SEMI && colmax_all != PRALINE_NEG_INF) atomicMax(r0 + 32, colmax_all);
             }
         }
-        s += 4;
+        ti = ti_n;
+        s = s_n;
     }
     // the other waves are up to 6 steps behind
     for (int i = 0; i < PRALINE_PIPE_LAG * (3 - rank); ++i) {
@@ -474,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
         const float v0 = res[t * 64 + j], v1 = res[t * 64 + 32 + j];
         float score;
         if (LOCAL) score = __builtin_fmaxf(v0, h00);
-        else if (semiglobal) {
+        else if (SEMI) {
             // o[L1,0,1] and o[0,L2,2] are the column-0 / row-0 members of the last row / last column (align.py:406-424)
             const float rowmax = __builtin_fmaxf(v0, boundary_value(L1, go, ge, free_one));
             const float colmax = __builtin_fmaxf(v1, boundary_value(L2, go, ge, free_two));

@@ -2,23 +2,27 @@
 #include "dp_launch.hip.h"
 #include "dp_pipe.hip.h"
 
-template <int NR, int NTERM> static void launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, bool local)
+template <int NR, int NTERM> static void launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16)
 {
     const dim3 grid(pl.n_items), block(256);
-    if (local)
-        hipLaunchKernelGGL((k_dp_pipe<NR, NTERM, true>), grid, block, 0, pl.stream, a16, pl.items, pl.tasks, pl.set_one, pl.lane_pair,
-                           (float2 *)pl.bnd, pl.scores, pl.rp);
-    else
-        hipLaunchKernelGGL((k_dp_pipe<NR, NTERM, false>), grid, block, 0, pl.stream, a16, pl.items, pl.tasks, pl.set_one, pl.lane_pair,
-                           (float2 *)pl.bnd, pl.scores, pl.rp);
+    // the analytic column 0 (gap scores and mode of this run) that every task's first strip reads
+    hipLaunchKernelGGL(k_pipe_analytic, dim3((unsigned)((pl.analytic_rows * 32 + 255) / 256)), dim3(256), 0, pl.stream,
+                       (float2 *)pl.analytic, pl.analytic_rows, pl.rp);
+#define PRALINE_PIPE_LAUNCH(LOC, SEMI)                                                                                  \
+    hipLaunchKernelGGL((k_dp_pipe<NR, NTERM, LOC, SEMI>), grid, block, 0, pl.stream, a16, pl.items, pl.tasks, pl.set_one, \
+                       pl.lane_pair, (float2 *)pl.bnd, (const float2 *)pl.analytic, pl.scores, pl.rp)
+    if (pl.rp.mode == PRALINE_MODE_LOCAL) PRALINE_PIPE_LAUNCH(true, false);
+    else if (pl.rp.mode >= 2) PRALINE_PIPE_LAUNCH(false, true);
+    else PRALINE_PIPE_LAUNCH(false, false);
+#undef PRALINE_PIPE_LAUNCH
 }
 
 bool praline_pipe_supported(int nr, int nterm) { return nr == 2 && (nterm == 2 || nterm == 3); }
 
-int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm, bool local)
+int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm)
 {
-    if (nr == 2 && nterm == 2) launch_pipe<2, 2>(pl, a16, local);
-    else if (nr == 2 && nterm == 3) launch_pipe<2, 3>(pl, a16, local);
+    if (nr == 2 && nterm == 2) launch_pipe<2, 2>(pl, a16);
+    else if (nr == 2 && nterm == 3) launch_pipe<2, 3>(pl, a16);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }

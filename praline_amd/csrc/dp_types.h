@@ -40,7 +40,7 @@ struct PipeItem {
 #define PRALINE_PIPE_LAG 2          // steps between consecutive waves of a pipeline workgroup
 #define PRALINE_PIPE_RING 12        // operand rows held by the workgroup's LDS ring
 #define PRALINE_PIPE_MIN_STEPS 36   // shortest round: the wrap-around hand-off (wave 3 -> wave 0) goes through memory
-#define PRALINE_PIPE_MAX_TASKS 32   // tasks per item (the per-task result table lives in LDS)
+#define PRALINE_PIPE_MAX_TASKS 4    // tasks per item (the per-task result table lives in LDS: 256 bytes per task)
 
 // two-pass alignments with paths: rows per kept boundary column beyond max_l1, and checkpoint blocks per strip (one
 // per 32 rows; the unrolled loops compute rows up to max_l1 + 12; block 0 is never written)

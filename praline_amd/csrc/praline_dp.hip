@@ -679,7 +679,8 @@ struct praline_plan {
     DevBuf<PipeItem> d_pipe_items;
     DevBuf<WaveTask> d_pipe_tasks;
     DevBuf<int32_t> d_pipe_set_one, d_pipe_lane_pair;
-    DevBuf<float2> d_pipe_bnd;
+    DevBuf<float2> d_pipe_bnd, d_pipe_analytic;
+    int pipe_analytic_rows = 0;
     DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
@@ -846,6 +847,8 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             delete pl;
             return rc;
         }
+        for (const PipeItem &pi : pl->pipe.items) pl->pipe_analytic_rows = std::max(pl->pipe_analytic_rows, pi.rsteps + 16);
+        if ((rc = pl->d_pipe_analytic.alloc((size_t)pl->pipe_analytic_rows * 32))) { delete pl; return rc; }
         // (rows the kernels never write only feed padding rows; keep them free of NaN bit patterns)
         if (hipMemsetAsync(pl->d_pipe_bnd.p, 0, (size_t)pl->pipe.bnd_elems * sizeof(float2), st) != hipSuccess) {
             delete pl;
@@ -1117,7 +1120,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     }
     if (!pl.want_paths && pl.pipe.ok && la.a16 != nullptr) {
         char kn[160];
-        snprintf(kn, sizeof(kn), "k_dp_pipe<%d, %d, %s>", a.nr16, a.nterm16, local ? "true" : "false");
+        snprintf(kn, sizeof(kn), "k_dp_pipe<%d, %d, %s, %s>", a.nr16, a.nterm16, local ? "true" : "false", mode >= 2 ? "true" : "false");
         pl.last_kernel = kn;
         PipeLaunch pp;
         pp.items = pl.d_pipe_items.p;
@@ -1126,11 +1129,13 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         pp.set_one = pl.d_pipe_set_one.p;
         pp.lane_pair = pl.d_pipe_lane_pair.p;
         pp.bnd = pl.d_pipe_bnd.p;
+        pp.analytic = pl.d_pipe_analytic.p;
+        pp.analytic_rows = pl.pipe_analytic_rows;
         pp.scores = la.scores;
         pp.rp = la.rp;
         pp.stream = st;
         HIPCHK(hipEventRecord(pl.ev0, st));
-        RC(praline_launch_pipe(pp, a16, a.nr16, a.nterm16, local));
+        RC(praline_launch_pipe(pp, a16, a.nr16, a.nterm16));
         HIPCHK(hipEventRecord(pl.ev1, st));
         HIPCHK(hipGetLastError());
         return PRALINE_OK;

@@ -610,49 +610,79 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
         for (size_t k = a; k < b; ++k) q += st[(size_t)l.task[k]].nstrips;
         return (q + 3) / 4 * (int64_t)l.rsteps;
     };
-    auto cut_count = [&](int64_t cstar, std::vector<std::pair<int32_t, std::pair<int32_t, int32_t>>> *cuts) {
+    // items of one list under the bound c*: bin packing of its tasks (<= PRALINE_PIPE_MAX_TASKS per item) into bins of
+    // floor(c* / rsteps) rounds = 4 x that many strips, first fit decreasing - long and short sequences two end up
+    // together, so the strip totals come out near the multiples of four that the rounds are made of
+    struct Cut { int32_t list; std::vector<int32_t> task; };
+    // max_tasks: tasks per item; n_single: per list, this share (in 1/1024) of its tasks - the shortest - become items
+    // of their own (large batches: the short items the dispatcher fills the tail of the launch with)
+    auto cut_count = [&](int64_t cstar, int max_tasks, int single_share, std::vector<Cut> *cuts) {
         int64_t n = 0;
+        std::vector<int32_t> order;
+        std::vector<int64_t> load;
+        std::vector<int32_t> count;
+        std::vector<std::vector<int32_t>> member;
         for (size_t li = 0; li < lists.size(); ++li) {
             const PipeList &l = lists[li];
-            size_t a = 0;
-            while (a < l.task.size()) {
-                size_t b = a + 1;
-                int64_t q = st[(size_t)l.task[a]].nstrips;
-                while (b < l.task.size() && b - a < PRALINE_PIPE_MAX_TASKS) {
-                    const int64_t q2 = q + st[(size_t)l.task[b]].nstrips;
-                    if ((q2 + 3) / 4 * (int64_t)l.rsteps > cstar) break;
-                    q = q2; ++b;
-                }
-                if (cuts) cuts->push_back({(int32_t)li, {(int32_t)a, (int32_t)b}});
-                ++n;
-                a = b;
+            const int64_t cap = std::max<int64_t>(1, cstar / l.rsteps) * 4;   // strips per item
+            order.assign(l.task.begin(), l.task.end());
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return st[(size_t)x].nstrips > st[(size_t)y].nstrips; });
+            const size_t n_single = (order.size() * (size_t)single_share + 1023) / 1024;
+            const size_t n_packed = order.size() - std::min(order.size(), n_single);
+            load.clear(); count.clear();
+            if (cuts) member.clear();
+            for (size_t k = 0; k < order.size(); ++k) {
+                const int32_t t = order[k];
+                const int64_t q = st[(size_t)t].nstrips;
+                size_t b = 0;
+                if (k >= n_packed) b = load.size();
+                else
+                    while (b < load.size() && (count[b] >= max_tasks || load[b] + q > cap)) ++b;
+                if (b == load.size()) { load.push_back(0); count.push_back(0); if (cuts) member.emplace_back(); }
+                load[b] += q; ++count[b];
+                if (k >= n_packed) count[b] = max_tasks;   // closed
+                if (cuts) member[b].push_back(t);
             }
+            n += (int64_t)load.size();
+            if (cuts)
+                for (auto &m : member) cuts->push_back(Cut{(int32_t)li, m});
         }
         return n;
+    };
+    auto item_cost = [&](const Cut &c) {
+        int64_t q = 0;
+        for (int32_t t : c.task) q += st[(size_t)t].nstrips;
+        return (q + 3) / 4 * (int64_t)lists[(size_t)c.list].rsteps;
     };
     int64_t total = 0, one_max = 0;
     for (const PipeList &l : lists) {
         total += list_cost(l, 0, l.task.size());
         for (size_t k = 0; k < l.task.size(); ++k) one_max = std::max(one_max, list_cost(l, k, k + 1));
     }
-    int64_t cstar;
+    // Small batches (up to 2.5 tasks per workgroup slot): everything resident at once - the smallest bound c* whose
+    // items fit the slots.  Larger batches: items of up to k tasks, k a third of a slot's share (at most
+    // PRALINE_PIPE_MAX_TASKS: the strip total of a long list wastes less of its last round), and two slots' worth of
+    // single-task items from the short end of every list to even out the tail of the launch.
+    std::vector<Cut> cuts;
     {
-        int64_t lo = one_max, hi = std::max(one_max, total);
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) / 2;
-            if (cut_count(mid, nullptr) <= opt.wg_slots) hi = mid; else lo = mid + 1;
+        const int64_t n_tasks = (int64_t)st.size(), slots = std::max<int64_t>(opt.wg_slots, 1);
+        if (2 * n_tasks <= 5 * slots) {
+            int64_t lo = one_max, hi = std::max(one_max, total);
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) / 2;
+                if (cut_count(mid, PRALINE_PIPE_MAX_TASKS, 0, nullptr) <= slots) hi = mid; else lo = mid + 1;
+            }
+            cut_count(lo, PRALINE_PIPE_MAX_TASKS, 0, &cuts);
+        } else {
+            const int k = (int)std::min<int64_t>(PRALINE_PIPE_MAX_TASKS, std::max<int64_t>(1, n_tasks / (3 * slots)));
+            const int share = k == 1 ? 0 : (int)std::min<int64_t>(1024, 2 * slots * 1024 / n_tasks);
+            cut_count(INT64_MAX / 8, k, share, &cuts);
         }
-        cstar = lo;
-        // large batches: the slot bound only holds with the task cap lifted - cut into eighths of a slot's share instead
-        if (cut_count(cstar, nullptr) > opt.wg_slots) cstar = std::max(one_max, total / (8 * std::max<int64_t>(opt.wg_slots, 1)));
     }
-    std::vector<std::pair<int32_t, std::pair<int32_t, int32_t>>> cuts;
-    cut_count(cstar, &cuts);
-
     // launch order: longest first; when everything is resident at once (two workgroups per CU: launch positions b and
     // b + 256 share a CU), the longest share their CUs with the shortest
     std::vector<int64_t> cost(cuts.size());
-    for (size_t c = 0; c < cuts.size(); ++c) cost[c] = list_cost(lists[(size_t)cuts[c].first], (size_t)cuts[c].second.first, (size_t)cuts[c].second.second);
+    for (size_t c = 0; c < cuts.size(); ++c) cost[c] = item_cost(cuts[c]);
     std::vector<int32_t> order(cuts.size());
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
@@ -667,16 +697,15 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
     out.lane_pair.reserve(st.size() * 32);
     int64_t bnd = 0;
     for (int32_t c : order) {
-        const PipeList &l = lists[(size_t)cuts[(size_t)c].first];
-        const int32_t a = cuts[(size_t)c].second.first, b = cuts[(size_t)c].second.second;
+        const PipeList &l = lists[(size_t)cuts[(size_t)c].list];
         PipeItem it;
         it.set = l.set;
         it.task0 = (int32_t)out.tasks.size();
-        it.ntasks = b - a;
+        it.ntasks = (int32_t)cuts[(size_t)c].task.size();
         it.nstrips = 0;
         it.rsteps = l.rsteps;
-        for (int32_t k = a; k < b; ++k) {
-            const ScratchTask &t = st[(size_t)l.task[(size_t)k]];
+        for (int32_t tsk : cuts[(size_t)c].task) {
+            const ScratchTask &t = st[(size_t)tsk];
             WaveTask wt;
             wt.two[0] = t.two; wt.two[1] = -1;
             wt.max_l1 = lens[out.set_one[(size_t)l.set * 32]];
