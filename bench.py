@@ -29,7 +29,12 @@ GAP_OPEN, GAP_EXTEND = -11.0, -1.0
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (the kernel's match-score MFMAs are f16)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (the fp32-chain variant)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-PEAK_VALU_GINSTR = 256 * 4 * 2.4 / 4.0     # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+# MI355X_MICROARCH.md (Wave scheduling; cycle constants, v_fma_f32): a SIMD-32 issues a wave64 VALU instruction over 2
+# cycles - 256 CUs x 4 SIMDs x 2.4 GHz / 2.  ONE wave alone only gets an instruction out every ~5.5 cycles (any kind:
+# scripts/micro/step_cost.hip, issue_cost.hip), so W resident waves per SIMD can reach min(1, W x 2 / 5.5) of that peak.
+NOMINAL_GHZ = 2.4
+PEAK_VALU_GINSTR = 256 * 4 * NOMINAL_GHZ / 2.0
+WAVE_ISSUE_CYCLES = 5.5
 
 
 def synth_lengths(rng, n, mu):
@@ -314,6 +319,8 @@ def main():
     ctr = stamped_counters(kernel_name, workload_tag)
     info = arena.info()
     valu_per_step = ctr.get("valu_per_step") if ctr else None
+    res = plan.kernel_resources()
+    clock_ghz = ctr.get("clock_ghz") if ctr else None   # GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the stamped profile
     roofline = {
         # north_star asks for the HBM roofline; the kernel is NOT HBM-bound:
         # its limiter is VALU issue of the recurrence, see "valu" below.
@@ -332,19 +339,27 @@ def main():
                            3: "f16 hi/lo split (3 terms, 6 MFMAs per step)"}.get(info["f16_terms"], "f16"),
                  "frac_of_fp32_mfma_peak": alg_flops / ksec / 1e12 / PEAK_F32_MFMA_TFLOPS,
                  "f16_terms": info["f16_terms"], "f16_ranges": info["f16_ranges"]},
-        # what actually bounds the recurrence: VALU issue.  valu_per_step is the PMC-measured dynamic count
-        # (SQ_INSTS_VALU / steps) of the stamped profile; peak = 1024 SIMDs x one wave64 instruction per 4 cycles.
+        # the vector ALU: valu_per_step is the PMC-measured dynamic count (SQ_INSTS_VALU / wave steps) of the stamped
+        # profile; peak = 1024 SIMDs x one wave64 instruction per 2 cycles at the nominal clock (frac_at_measured_clock:
+        # at the clock the profiled launch ran at).  What bounds the launch is the issue rate of its resident waves:
+        # issue_roof_frac = the share of that peak W waves per SIMD can reach at one instruction per ~5.5 cycles each.
         "valu": ({"achieved": plan.steps * valu_per_step / ksec / 1e9, "peak": PEAK_VALU_GINSTR,
                   "unit": "G wave-instr/s", "frac": plan.steps * valu_per_step / ksec / 1e9 / PEAK_VALU_GINSTR,
+                  "frac_at_measured_clock": (plan.steps * valu_per_step / ksec / 1e9 / (PEAK_VALU_GINSTR * clock_ghz / NOMINAL_GHZ)
+                                             if clock_ghz else None),
+                  "clock_ghz": clock_ghz, "instructions_per_step": ctr.get("insts_per_step"),
                   "valu_per_step": valu_per_step, "steps": plan.steps, "tasks": plan.tasks}
                  if valu_per_step else {"valu_per_step": None, "steps": plan.steps, "tasks": plan.tasks}),
+        "vgprs": res["vgprs"] or None, "lds_bytes_per_workgroup": res["lds_bytes"] or None,
+        "waves_per_simd": res["waves_per_simd"] or None,
+        "issue_roof_frac": (min(1.0, res["waves_per_simd"] * 2.0 / WAVE_ISSUE_CYCLES) if res["waves_per_simd"] else None),
     }
     out = {
         "metric": "GCUPS (DP cell updates/s) all-pairs profile-profile affine align",
         "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         # one GPU runs the metric's configuration (C2); more GPUs split a FIXED list (C4 / C5) -> strong scaling
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "scaling": "strong" if world > 1 else "weak", "workload": wl_name, "vs_baseline": None,
         # arithmetic type of the DP; float-profile match scores come from f16 hi/lo MFMAs with fp32 accumulation
         # (roofline.mfma.dtype), the fp32-chain figure is variants.f32_chain_gcups
         "dtype": "f32", "data": "synthetic",

@@ -272,6 +272,9 @@ int praline_plan_match_kind(const praline_plan *plan);
 /* Timing of the last praline_plan_run on THIS plan, measured with the plan's own HIP events on the launch
  * stream: kernel_ms = the DP kernel alone (scores-only plans) / fill + end cells + traceback (path plans). */
 int praline_plan_last_timing(praline_plan *plan, float *kernel_ms);
+/* Registers per lane, LDS bytes per workgroup and the resulting resident waves per SIMD of the kernel instance the
+ * last run launched (hipFuncGetAttributes); zeros for instances that are not reported (measurement aid, bench.py). */
+int praline_plan_kernel_resources(const praline_plan *plan, int32_t *vgprs, int32_t *lds_bytes, int32_t *waves_per_simd);
 /* The DP kernel instance the last praline_plan_run launched, spelled as rocprofv3 prints it without the leading
  * "void " (e.g. "k_dp_split16<2, 3, false, 2, 4>"); bench.py matches profile files against it. */
 int praline_plan_kernel_name(const praline_plan *plan, char *buf, int64_t size);

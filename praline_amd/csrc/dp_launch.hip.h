@@ -58,6 +58,7 @@ struct PipeLaunch {
     hipStream_t stream;
 };
 bool praline_pipe_supported(int nr, int nterm);
+int praline_pipe_attrs(int nr, int nterm, int mode, int *vgprs, int *lds_bytes);
 int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm);
 // two-pass alignments with paths (dp_tb2_instance.hip): flag-free forward fill, then block recompute + traceback
 struct Trace2Args {

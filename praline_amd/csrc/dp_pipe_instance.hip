@@ -17,6 +17,27 @@ template <int NR, int NTERM> static void launch_pipe(const PipeLaunch &pl, const
 #undef PRALINE_PIPE_LAUNCH
 }
 
+// registers / LDS of the instance a run launches (hipFuncGetAttributes): bench.py reports them beside the roofline
+template <int NR, int NTERM> static int pipe_attrs(int mode, int *vgprs, int *lds_bytes)
+{
+    hipFuncAttributes fa;
+    hipError_t e;
+    if (mode == PRALINE_MODE_LOCAL) e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_dp_pipe<NR, NTERM, true, false>));
+    else if (mode >= 2) e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_dp_pipe<NR, NTERM, false, true>));
+    else e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_dp_pipe<NR, NTERM, false, false>));
+    if (e != hipSuccess) return PRALINE_ERR_DEVICE;
+    *vgprs = fa.numRegs;
+    *lds_bytes = (int)fa.sharedSizeBytes;
+    return PRALINE_OK;
+}
+
+int praline_pipe_attrs(int nr, int nterm, int mode, int *vgprs, int *lds_bytes)
+{
+    if (nr == 2 && nterm == 2) return pipe_attrs<2, 2>(mode, vgprs, lds_bytes);
+    if (nr == 2 && nterm == 3) return pipe_attrs<2, 3>(mode, vgprs, lds_bytes);
+    return PRALINE_ERR_UNSUPPORTED;
+}
+
 bool praline_pipe_supported(int nr, int nterm) { return nr == 2 && (nterm == 2 || nterm == 3); }
 
 int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm)

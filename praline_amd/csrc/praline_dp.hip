@@ -808,6 +808,11 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             if (const char *env = getenv("PRALINE_PIPE_BLOCK")) po.block_twos = atoi(env);
             if (const char *env = getenv("PRALINE_PIPE_SLOTS")) po.wg_slots = atoll(env);
             if (min_len >= 1) build_pipe_schedule(a.len.data(), a.n_seqs, n_pairs, pairs, po, pl->pipe);
+            // below ~200 tasks (all pairs of ~110 sequences) the shared-wave task schedule is as fast or faster
+            // (scripts/exp_pipe_sweep.py): a pipeline item cannot be smaller than one task
+            int64_t min_tasks = 200;
+            if (const char *env = getenv("PRALINE_PIPE_MIN_TASKS")) min_tasks = atoll(env);
+            if (pl->pipe.ok && (int64_t)pl->pipe.tasks.size() < min_tasks) pl->pipe = PipeSchedule();
         }
     }
     pl->tp = sch.tp;
@@ -1525,6 +1530,23 @@ extern "C" int praline_plan_kernel_name(const praline_plan *plan, char *buf, int
 {
     if (!plan || !buf || size <= 0) return fail(PRALINE_ERR_ARG, "NULL argument");
     snprintf(buf, (size_t)size, "%s", plan->last_kernel.c_str());
+    return PRALINE_OK;
+}
+
+extern "C" int praline_plan_kernel_resources(const praline_plan *plan, int32_t *vgprs, int32_t *lds_bytes, int32_t *waves_per_simd)
+{
+    if (!plan || !vgprs || !lds_bytes || !waves_per_simd) return fail(PRALINE_ERR_ARG, "NULL argument");
+    *vgprs = *lds_bytes = *waves_per_simd = 0;
+    if (!plan->pipe.ok || plan->last_mode < 0) return PRALINE_OK;   // (reported for the pipeline workgroups only)
+    int v = 0, l = 0;
+    RC(praline_pipe_attrs(plan->arena->nr16, plan->arena->nterm16, plan->last_mode, &v, &l));
+    *vgprs = v;
+    *lds_bytes = l;
+    // MI355X_MICROARCH.md, register files: allocation granule 8, 512 registers per lane and SIMD; 160 KiB of LDS per CU;
+    // a workgroup of four waves puts one wave on every SIMD
+    const int by_regs = std::min(8, 512 / std::max(8, (v + 7) / 8 * 8));
+    const int by_lds = l > 0 ? (160 * 1024) / l : 8;
+    *waves_per_simd = std::min(by_regs, by_lds);
     return PRALINE_OK;
 }
 

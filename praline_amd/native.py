@@ -94,6 +94,7 @@ def lib():
     L.praline_plan_paths.argtypes = [vp, vp, vp, vp]
     L.praline_batch_scores.argtypes = [vp, i32, f32, f32, i64, vp, vp]
     L.praline_plan_last_timing.argtypes = [vp, ctypes.POINTER(f32)]
+    L.praline_plan_kernel_resources.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.praline_arena_match_scores.argtypes = [vp, i32, i32, i32, vp]
     L.praline_arena_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                      ctypes.POINTER(i32)]
@@ -409,6 +410,12 @@ class Plan(object):
         ms = ctypes.c_float(0.0)
         _check(lib().praline_plan_last_timing(self._h, ctypes.byref(ms)))
         return float(ms.value)
+
+    def kernel_resources(self):
+        """{vgprs, lds_bytes, waves_per_simd} of the kernel instance the last run launched (zeros when not reported)."""
+        v, l, w = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(lib().praline_plan_kernel_resources(self._h, ctypes.byref(v), ctypes.byref(l), ctypes.byref(w)))
+        return {"vgprs": int(v.value), "lds_bytes": int(l.value), "waves_per_simd": int(w.value)}
 
     def add_counts(self, threshold=None, local=False):
         """Fold this plan's (master, slave) paths into the arena's preprofile counts on the device

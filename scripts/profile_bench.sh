@@ -55,6 +55,10 @@ res = {"kernel": kernel, "workload": "%s/%d" % (b["config"]["workload"].split(":
        "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"]}
 if 'SQ_INSTS_VALU' in rows:
     res["valu_per_step"] = rows['SQ_INSTS_VALU'] / steps
+    # every instruction a wave issues per step (VALU incl. MFMA, SALU, LDS, VMEM): what the per-wave issue rate prices
+    res["insts_per_step"] = sum(rows.get(k, 0.0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR')) / steps
+if 'GRBM_GUI_ACTIVE' in rows and trace_avg_ns:
+    res["clock_ghz"] = rows['GRBM_GUI_ACTIVE'] / 8.0 / trace_avg_ns
 if 'FETCH_SIZE' in rows and 'WRITE_SIZE' in rows:
     # MI355X_MICROARCH.md HBM section: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half
     # of the bytes of wide (16 B / lane) coalesced reads -> doubled; WRITE_SIZE is exact for wide stores.

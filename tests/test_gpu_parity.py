@@ -718,3 +718,63 @@ def test_two_pass_forward_on_the_scores_kernel(nat, bba, monkeypatch):
             s_or, p_or = oracle_dp_on_m("global", arena.match_scores(i, j, mk))
             assert res["1"][0][k] == np.float32(s_or) and np.array_equal(res["1"][1][k], p_or), (i, j)
         arena.close()
+
+
+@pytest.mark.parametrize("lists", ["triangle", "ordered", "subset"])
+def test_pipeline_workgroups_agree_bitwise(nat, bba, lists, monkeypatch):
+    """k_dp_pipe (dp_pipe.hip.h: four waves pipeline the strips of tasks that share a set of 32 sequences one; shared
+    operand ring, boundary hand-off through LDS) computes every cell with k_dp_split16's instructions: scores of float
+    profiles must equal the task schedule's bit for bit in all five modes - ragged lengths (1 .. 2 strips up to several
+    rounds, sets with empty lanes, tasks that start in the middle of a round, PRALINE_PIPE_BLOCK / SLOTS cutting the
+    items differently) - and the oracle DP on the device's own match scores for a sample of pairs."""
+    rng = np.random.default_rng({"triangle": 21, "ordered": 22, "subset": 23}[lists])
+    N = 90
+    lens = synth_lengths(rng, N, 140)
+    lens[:8] = (1, 5, 31, 32, 33, 64, 65, 300)
+    profs = [synth_profile(rng, int(L))[0] for L in lens]
+    if lists == "triangle":
+        pairs = all_pairs(N)
+    else:
+        pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j], dtype=np.int32)
+        if lists == "subset":
+            pairs = pairs[rng.random(len(pairs)) < 0.6]
+    for k in ("PRALINE_NO_PIPE", "PRALINE_PIPE_MIN_TASKS", "PRALINE_PIPE_BLOCK", "PRALINE_PIPE_SLOTS"):
+        monkeypatch.delenv(k, raising=False)
+    arena = nat.Arena(profs, bba["S"])
+    if arena.info()["f16_terms"] not in (2, 3) or any(os.environ.get(k) for k in ("PRALINE_KERNEL", "PRALINE_MM", "PRALINE_NO_STAGE")):
+        arena.close()
+        pytest.skip("the pipeline workgroups run the float-profile instances of the staged stream")
+    monkeypatch.setenv("PRALINE_NO_PIPE", "1")
+    plan = nat.Plan(arena, pairs)
+    want = {}
+    for mode in MODES:
+        plan.run(mode, *GAPS)
+        want[mode] = plan.scores().copy()
+    assert "k_dp_pipe" not in plan.kernel_name()
+    kind = plan.match_kind()
+    plan.close()
+    monkeypatch.delenv("PRALINE_NO_PIPE")
+    monkeypatch.setenv("PRALINE_PIPE_MIN_TASKS", "1")
+    for env in ({}, {"PRALINE_PIPE_BLOCK": "3", "PRALINE_PIPE_SLOTS": "16"}, {"PRALINE_PIPE_BLOCK": "64", "PRALINE_PIPE_SLOTS": "100000"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = nat.Plan(arena, pairs)
+        for mode in MODES:
+            plan.run(mode, *GAPS)
+            got = plan.scores()
+            assert "k_dp_pipe" in plan.kernel_name(), plan.kernel_name()
+            assert np.array_equal(bits(got), bits(want[mode])), (lists, env, mode, int((bits(got) != bits(want[mode])).sum()))
+        # other gap scores on the same plan (the analytic column is rewritten by every launch)
+        plan.run("global", -3.5, -0.25)
+        got = plan.scores().copy()
+        plan.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for p in rng.choice(len(pairs), 12, replace=False):
+        i, j = pairs[p]
+        for mode in MODES:
+            s_or, _ = oracle_dp_on_m(mode, arena.match_scores(int(i), int(j), kind))
+            assert want[mode][p] == np.float32(s_or), (mode, i, j)
+        s_or, _ = oracle_dp_on_m("global", arena.match_scores(int(i), int(j), kind), gaps=(-3.5, -0.25))
+        assert got[p] == np.float32(s_or), (i, j)
+    arena.close()

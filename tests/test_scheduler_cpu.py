@@ -147,3 +147,109 @@ def test_four_singles_keep_the_xcd_queues(sched):
     lens = synth_lengths(rng, n, 200)
     tf, lp, wf, ns = sched(lens, all_pairs(n))
     assert len(wf) == 0 and ns == (len(tf) + 31) // 32 * 8
+
+
+# ---- pipeline workgroups (k_dp_pipe): sets of 32 sequences one, tasks, workgroup items ------------------------------
+PIPE_MAX_TASKS, PIPE_MIN_STEPS = 4, 36   # PRALINE_PIPE_MAX_TASKS, PRALINE_PIPE_MIN_STEPS (dp_types.h)
+
+
+@pytest.fixture(scope="module")
+def pipe_sched(sched):
+    lib = ctypes.CDLL(LIB)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.praline_sched_pipe_test.argtypes = [vp, i64, i64, vp, ctypes.c_int, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.praline_sched_pipe_test.restype = ctypes.c_int
+
+    def run(lens, pairs, block_twos=0, wg_slots=0):
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        cap = len(pairs) + 4096
+        n_i, n_t, n_s = i64(0), i64(0), i64(0)
+        items = np.zeros((cap, 6), np.int32)
+        tasks = np.zeros((cap, 3), np.int32)
+        lp = np.zeros((cap, 32), np.int32)
+        so = np.zeros((cap, 32), np.int32)
+        rc = lib.praline_sched_pipe_test(lens.ctypes.data, len(lens), len(pairs), pairs.ctypes.data, block_twos, wg_slots, cap, cap,
+                                         cap, ctypes.byref(n_i), ctypes.byref(n_t), ctypes.byref(n_s), items.ctypes.data,
+                                         tasks.ctypes.data, lp.ctypes.data, so.ctypes.data)
+        assert rc in (0, 1)
+        return rc == 0, items[:n_i.value], tasks[:n_t.value], lp[:n_t.value], so[:n_s.value]
+    return run
+
+
+def check_pipe(lens, pairs, items, tasks, lp, so):
+    seen = lp[lp >= 0]
+    assert np.array_equal(np.sort(seen), np.arange(len(pairs)))            # every pair in exactly one lane of one task
+    covered = np.zeros(len(tasks), bool)
+    for set_id, task0, ntasks, nstrips, rsteps, nrounds in items:
+        assert 1 <= ntasks <= PIPE_MAX_TASKS
+        assert not covered[task0:task0 + ntasks].any()
+        covered[task0:task0 + ntasks] = True
+        ones = so[set_id]
+        max_l1 = lens[ones[ones >= 0]].max()
+        assert ones[0] >= 0 and lens[ones[0]] == max_l1                     # lane 0 holds the longest sequence of the set
+        assert np.all(np.diff(lens[ones[ones >= 0]]) <= 0)                  # ... and the set is sorted by length
+        assert rsteps % 12 == 0 and rsteps >= max(PIPE_MIN_STEPS, max_l1 + 1) and rsteps < max(PIPE_MIN_STEPS, max_l1 + 1) + 12
+        assert nstrips == tasks[task0:task0 + ntasks, 2].sum() and nrounds == (nstrips + 3) // 4
+        for t in range(task0, task0 + ntasks):
+            two, t_max_l1, t_strips = tasks[t]
+            assert t_max_l1 == max_l1 and t_strips == (lens[two] + 31) // 32
+            lanes = np.nonzero(lp[t] >= 0)[0]
+            assert len(lanes) >= 1
+            assert np.all(pairs[lp[t][lanes], 1] == two)                    # one shared sequence two per task
+            assert np.array_equal(pairs[lp[t][lanes], 0], ones[lanes])      # lane l of every task of the set = sequence ones[l]
+    assert covered.all()
+
+
+def test_pipe_schedule_covers_the_pair_list(pipe_sched):
+    rng = np.random.default_rng(5)
+    for n, mu in ((40, 60), (130, 200), (256, 400), (70, 20)):
+        lens = synth_lengths(rng, n, mu)
+        for kind in ("triangle", "ordered", "one-vs-all"):
+            if kind == "triangle":
+                pairs = all_pairs(n)
+            elif kind == "ordered":
+                pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32)
+            else:
+                pairs = np.array([(i, 3) for i in range(n) if i != 3], dtype=np.int32)
+            ok, items, tasks, lp, so = pipe_sched(lens, pairs)
+            # (tiny triangles leave most lanes of their few sets empty: the schedule may decline them)
+            assert ok or (kind == "triangle" and n < 100), (n, kind)
+            if ok:
+                check_pipe(lens, pairs, items, tasks, lp, so)
+            ok, items, tasks, lp, so = pipe_sched(lens, pairs, block_twos=5, wg_slots=64)
+            if ok:
+                check_pipe(lens, pairs, items, tasks, lp, so)
+
+
+def test_pipe_schedule_fits_the_slots_for_small_batches(pipe_sched):
+    """Up to 2.5 tasks per workgroup slot every item is resident at once: at most wg_slots items, and the longest item is
+    within a round of the best possible split of the tasks (the bound is found by bisection)."""
+    rng = np.random.default_rng(2)
+    lens = synth_lengths(rng, 256, 400)
+    pairs = all_pairs(256)
+    ok, items, tasks, lp, so = pipe_sched(lens, pairs)
+    assert ok and len(items) <= 512
+    cost = items[:, 5].astype(np.int64) * items[:, 4]
+    assert cost.max() <= 1.3 * cost.sum() / 512                             # C2: longest item within 30 % of the mean load
+    # large batch: short single-task items exist for the tail of the launch, the bulk sits in PIPE_MAX_TASKS-task items
+    lens = synth_lengths(rng, 1024, 300)
+    ok, items, tasks, lp, so = pipe_sched(lens, all_pairs(1024))
+    assert ok
+    counts = np.bincount(items[:, 2], minlength=PIPE_MAX_TASKS + 1)
+    assert counts[PIPE_MAX_TASKS] > counts[1] >= 512
+
+
+def test_pipe_schedule_declines_what_does_not_fit(pipe_sched):
+    """Lists whose lanes would stay mostly empty (sparse random pairs over many sequences) and lists with a repeated pair
+    keep the task schedule."""
+    rng = np.random.default_rng(7)
+    n = 600
+    lens = synth_lengths(rng, n, 100)
+    sparse = np.stack([rng.integers(0, n, 700), rng.integers(0, n, 700)], axis=1).astype(np.int32)
+    sparse = np.unique(sparse[sparse[:, 0] != sparse[:, 1]], axis=0)
+    ok, *_ = pipe_sched(lens, sparse)
+    assert not ok
+    twice = np.concatenate([all_pairs(40), all_pairs(40)[:3]])
+    ok, *_ = pipe_sched(lens[:40], twice)
+    assert not ok
