@@ -47,6 +47,9 @@ static_assert(pipe_lds_bytes() <= 80 * 1024, "two pipeline workgroups per CU");
 // barrier of the pipeline: every LDS access of this wave (the hand-off write above all) has completed before it
 #define PRALINE_PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PRALINE_PIPE_AHEAD 6   // the operand stream runs this many positions ahead of wave 0's step
+#ifndef PRALINE_PIPE_ABLATE
+#define PRALINE_PIPE_ABLATE 0   // timing experiments only (results invalid): 1 no half select, 2 four more MFMAs per step
+#endif
 
 // the analytic column 0 of a task - (o[y,0,1], -inf) for every pair - as float2 [rows][32]: what a task's FIRST strip
 // reads as its boundary column (praline/component/align.py:371-376)
@@ -133,8 +136,13 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
     f2 m2[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
+#if PRALINE_PIPE_ABLATE & 1
+        m2[c].x = CUR[2 * c];
+        m2[c].y = CUR[2 * c + 1];
+#else
         m2[c].x = h ? PREV[2 * c] : CUR[2 * c];
         m2[c].y = h ? PREV[2 * c + 1] : CUR[2 * c + 1];
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     Hs[0] = h ? hd_x : dH;
@@ -152,6 +160,9 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
         const int ia = (NTERM == 2) ? k : ((term == 0) ? NR + r : r);
         const int ib = (NTERM == 2) ? k : ((term == 1) ? NR + r : r);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ia]), as_half8(BOPS[ib]), acc, 0, 0, 0);
+#if PRALINE_PIPE_ABLATE & 2
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(aop[ib]), as_half8(BOPS[ia]), acc, 0, 0, 0);
+#endif
 #pragma unroll
         for (int cp = (8 * k) / NM; cp < (8 * (k + 1)) / NM; ++cp) {
             f2 M = pk_add(hs, m2[cp]);                            // max_k o[y-1,x-1,k] + m      (cext.c:192-222)

@@ -794,7 +794,6 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     if (const char *env = getenv("PRALINE_WG_XCD")) opt.wg_xcd = atoi(env) != 0;
     if (const char *env = getenv("PRALINE_WG_BALANCE")) opt.balance = atoi(env) != 0;
     Schedule sch;
-    build_schedule(a.len.data(), n_pairs, pairs, opt, sch);
     // scores-only plans on float-profile arenas (128-byte operand rows): pipeline workgroups (PRALINE_NO_PIPE=1: the task
     // schedule above, as for every other kind of plan)
     {
@@ -814,6 +813,13 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             if (const char *env = getenv("PRALINE_PIPE_MIN_TASKS")) min_tasks = atoll(env);
             if (pl->pipe.ok && (int64_t)pl->pipe.tasks.size() < min_tasks) pl->pipe = PipeSchedule();
         }
+    }
+    if (pl->pipe.ok) {
+        // the pipeline schedule is all a scores-only run needs: no task schedule, no per-task boundary scratch
+        sch.split = opt.split_layout;
+        for (int64_t p = 0; p < n_pairs; ++p) sch.cells += (int64_t)a.len[pairs[2 * p]] * a.len[pairs[2 * p + 1]];
+    } else {
+        build_schedule(a.len.data(), n_pairs, pairs, opt, sch);
     }
     pl->tp = sch.tp;
     pl->split = sch.split;
@@ -1123,7 +1129,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         HIPCHK(hipEventRecord(pl.ev1, st));
         return PRALINE_OK;
     }
-    if (!pl.want_paths && pl.pipe.ok && la.a16 != nullptr) {
+    if (!pl.want_paths && pl.pipe.ok) {   // (the match-score mode was read when the plan was created)
         char kn[160];
         snprintf(kn, sizeof(kn), "k_dp_pipe<%d, %d, %s, %s>", a.nr16, a.nterm16, local ? "true" : "false", mode >= 2 ? "true" : "false");
         pl.last_kernel = kn;

@@ -10,9 +10,10 @@ C=$ROOT/praline_amd/csrc
 OUT=$ROOT/variants; mkdir -p $OUT/obj_$NAME
 make -s -C $C all
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wall -Wno-unused-but-set-variable -fno-fast-math -ffp-contract=off -fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form"
-/opt/rocm/bin/hipcc $FLAGS "$@" -c $C/dp_split16_instance.hip -o $OUT/obj_$NAME/dp_split16.o &
+if [ -n "$VARIANT_PIPE_ONLY" ]; then cp $C/build/dp_split16.o $OUT/obj_$NAME/dp_split16.o; else /opt/rocm/bin/hipcc $FLAGS "$@" -c $C/dp_split16_instance.hip -o $OUT/obj_$NAME/dp_split16.o & fi
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $C/dp_pipe_instance.hip -o $OUT/obj_$NAME/dp_pipe.o &
 if [ -n "$VARIANT_TB" ]; then /opt/rocm/bin/hipcc $FLAGS "$@" -c $C/dp_tb2_instance.hip -o $OUT/obj_$NAME/dp_tb2.o & else cp $C/build/dp_tb2.o $OUT/obj_$NAME/dp_tb2.o; fi
 wait
-OBJS=$(ls $C/build/*.o | grep -v "dp_split16.o\|dp_tb2.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $OUT/obj_$NAME/dp_split16.o $OUT/obj_$NAME/dp_tb2.o -o $OUT/libpraline_dp_$NAME.so
+OBJS=$(ls $C/build/*.o | grep -v "dp_split16.o\|dp_tb2.o\|dp_pipe.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $OUT/obj_$NAME/dp_split16.o $OUT/obj_$NAME/dp_pipe.o $OUT/obj_$NAME/dp_tb2.o -o $OUT/libpraline_dp_$NAME.so
 echo built $OUT/libpraline_dp_$NAME.so
