@@ -1,12 +1,59 @@
-"""FASTA in, aligned FASTA out - the two I/O functions the MSA pipeline needs at its ends
-(praline/__init__.py:67-136 load_sequence_fasta, 252-304 write_alignment_fasta).  Host-side text
-handling; nothing here touches the device."""
+"""Score-matrix loader, FASTA in, aligned FASTA out - the I/O functions the MSA pipeline needs at its ends
+(praline/__init__.py:57-102 open_builtin / load_score_matrix, 105-136 load_sequence_fasta, 252-304
+write_alignment_fasta).  Host-side text handling; nothing here touches the device."""
 import io as _io
+import uuid as _uuid
 
 import numpy as np
 
-from .container import PlainTrack, Sequence, TRACK_ID_INPUT
+from .container import Alphabet, PlainTrack, ScoreMatrix, Sequence, TRACK_ID_INPUT
 from .core import DataError
+
+
+def open_builtin(name):
+    """A packaged resource as a text file object - 'matrices/<table>' for the score tables the reference ships
+    (praline/__init__.py:57-65, praline/matrices/*): blosum30 ... blosum100, nucleotide."""
+    from .matrices import builtin_text
+    prefix = "matrices/"
+    if not name.startswith(prefix):
+        raise DataError("unknown builtin resource '{0}'".format(name))
+    try:
+        return _io.StringIO(builtin_text(name[len(prefix):]))
+    except KeyError as e:
+        raise DataError(str(e))
+
+
+def load_score_matrix(f, alphabet=None, encoding="utf-8"):
+    """ScoreMatrix from the reference's text format (praline/__init__.py:67-102): '#' starts a comment, the first
+    non-empty line lists the column symbols, every further line is a row symbol followed by its scores (values beyond the
+    listed columns are ignored).  Without `alphabet` one is made from the column symbols in file order, as the
+    reference does (its id carries a fresh uuid).  `f`: path or file object (text or bytes)."""
+    handle = open(f, "rb") if isinstance(f, str) else f
+    try:
+        raw = handle.read()
+    finally:
+        if isinstance(f, str):
+            handle.close()
+    text = raw.decode(encoding) if isinstance(raw, bytes) else raw
+    rows = []
+    for line in text.splitlines():
+        cut = line.find("#")
+        if cut >= 0:
+            line = line[:cut]
+        line = line.strip()
+        if line:
+            rows.append(line.split())
+    if not rows:
+        raise DataError("empty score matrix")
+    columns = rows[0]
+    scores = {}
+    for row in rows[1:]:
+        for i, value in enumerate(row[1:]):
+            if i < len(columns):
+                scores[row[0], columns[i]] = float(value)
+    if not alphabet:
+        alphabet = Alphabet("__anonymous_from_matrix_{0}__".format(_uuid.uuid4().hex), [(s, i) for i, s in enumerate(columns)])
+    return ScoreMatrix(scores, [alphabet, alphabet])
 
 
 def load_sequence_fasta(source, alphabet, track_id=TRACK_ID_INPUT):

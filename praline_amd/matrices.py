@@ -80,3 +80,27 @@ def nucleotide_matrix():
         for j, v in enumerate(row):
             m[i, j] = m[j, i] = float(v)
     return m
+
+
+def builtin_names():
+    """Names of the packaged score tables (the reference's praline/matrices directory: blosum30 ... blosum100, nucleotide)."""
+    from .matrix_tables import TABLES
+    return sorted(TABLES)
+
+
+def builtin_text(name):
+    """A packaged table in the reference's text format (header row of column symbols, then one row per symbol:
+    the symbol followed by its scores), as praline.load_score_matrix reads it (praline/__init__.py:67-102)."""
+    from .matrix_tables import TABLES
+    if name not in TABLES:
+        raise KeyError("no packaged score matrix named %r (have: %s)" % (name, ", ".join(sorted(TABLES))))
+    symbols, tri = TABLES[name]
+    rows = [r.split() for r in tri.strip().splitlines()]
+    n = len(symbols)
+    full = [[rows[max(i, j)][min(i, j)] for j in range(n)] for i in range(n)]
+    width = max(len(v) for r in full for v in r) + 1
+    lines = ["# %s (values as packaged with PRALINE: public NCBI table)" % name,
+             " " + "".join(s.rjust(width) for s in symbols)]
+    for i, s in enumerate(symbols):
+        lines.append(s + "".join(v.rjust(width) for v in full[i]))
+    return "\n".join(lines) + "\n"

@@ -1,14 +1,18 @@
 #!/bin/bash
 # usage: scripts/profile_paths.sh <tag>   (run on the GPU box via gpurun)
-# PMC counters of the with-paths pipeline (scripts/exp_paths_prof.py, N=256): per-launch averages per kernel.
+# Kernel trace + PMC counters of the with-paths pipeline (scripts/exp_paths_prof2.py: C2 float in chain mode, a C3 slice
+# in task mode / two passes): per-launch averages per kernel -> gpurun_out/prof_<tag>/{kernel_stats.csv,summary.txt}.
 set -e
 TAG=${1:-paths}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-export TMPDIR=/tmp N=256
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE"; do
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 scripts/exp_paths_prof2.py > $OUT/trace.log 2>&1 || (tail -20 $OUT/trace.log; exit 1)
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+cat $OUT/trace.log | grep GCUPS
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$name -- python3 scripts/exp_paths_prof.py > $OUT/pmc_$name.log 2>&1 || { echo "pmc $set failed"; tail -3 $OUT/pmc_$name.log; continue; }
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$name -- python3 scripts/exp_paths_prof2.py > $OUT/pmc_$name.log 2>&1 || { echo "pmc $set failed"; tail -3 $OUT/pmc_$name.log; continue; }
 done
 python3 - "$OUT" <<'PY'
 import csv, sys, glob, collections

@@ -27,6 +27,12 @@ Fixtures (all arrays little-endian numpy):
   multitrack.npz           num_sets = 2 and 3 match-score matrices + alignments
   synthetic_c1.npz         BASELINE config 0: seed 1, N=8, mu=100, one-hot, BLOSUM62, global
   synthetic_dna.npz        small DNA (A=15, packaged nucleotide matrix) cases, all modes
+  matrices.npz             every packaged score table (praline/matrices/*) as the reference's load_score_matrix
+                           parses it: float32 [27, 27] over ALPHABET_AA (the BLOSUM tables) / [15, 15] over ALPHABET_DNA
+  BBA0184.{cli,multitrack}.aln, BBA0184.{motif,ss}.tfa, motif_score_matrix
+                           the reference's shipped known-answer alignments and their annotation inputs (extra/data),
+                           byte copies - data the end-to-end tests reproduce   (`make_golden.py matrices` writes only
+                           matrices.npz and these copies)
 """
 import hashlib
 import os
@@ -456,5 +462,22 @@ def main():
     save("synthetic_dna.npz", **dn)
 
 
+def make_matrices():
+    import shutil
+    out = {}
+    mdir = os.path.join(REF_ROOT, "praline", "matrices")
+    for name in sorted(os.listdir(mdir)):
+        alphabet = ct.ALPHABET_DNA if name == "nucleotide" else ct.ALPHABET_AA
+        out[name] = load_score_matrix(open_builtin("matrices/" + name), alphabet=alphabet).matrix.astype(np.float32)
+    save("matrices.npz", **out)
+    for fn in ("BBA0184.cli.aln", "BBA0184.multitrack.aln", "BBA0184.motif.tfa", "BBA0184.ss.tfa", "motif_score_matrix"):
+        shutil.copyfile(os.path.join(DATA, fn), os.path.join(HERE, fn))
+        print("copied %s" % fn)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "matrices":
+        make_matrices()
+    else:
+        main()
+        make_matrices()
