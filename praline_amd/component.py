@@ -1097,9 +1097,14 @@ COMPONENTS = [PairwiseAligner, RawPairwiseAligner, ProfileBuilder, DummyMasterSl
 
 # ---- the batching seam -----------------------------------------------------------------------------
 class BatchManager(Manager):
-    """Manager whose execute_many recognises a homogeneous list of PairwiseAligner requests (what
-    Execution.run hands over for the reference's all-pairs fan-outs, praline/core/execution.py:158-188)
-    and runs it as one device submission per mode; anything else falls back to the serial loop.
+    """Manager whose execute_many recognises the homogeneous request lists that Execution.run hands over for the
+    reference's fan-outs (praline/core/execution.py:158-188) and runs each as a few device submissions:
+      * PairwiseAligner lists (guide tree, ad-hoc rescoring): one submission per mode;
+      * Global / LocalMasterSlaveAligner lists - the workflow's preprofile stage, ONE Execution with a task per master
+        (praline/component/workflow.py:139-161): one plan over every (master, slave) pair, one run per Waterman-Eggert
+        iteration with the path bounding boxes turned into the next iteration's masks on the device;
+      * ProfileBuilder lists (workflow.py:211-224): counted on the host, one scatter-add per alignment.
+    Anything else falls back to the serial loop.
 
     rank / world / group: this process's place in a torch.distributed process group, one process per GPU - the
     counterpart of the reference's ParallelExecutionManager worker pool (praline/core/manager.py:401-463).  The
@@ -1112,9 +1117,84 @@ class BatchManager(Manager):
             raise ValueError("rank {0} outside a world of {1}".format(rank, world))
         self.rank, self.world, self.group = rank, world, group
 
+    def _emit(self, requests, results, parent_tag):
+        """Begin / Complete messages of the requests that were answered in bulk, the serial path for the others."""
+        for message in self._emit(requests, results, parent_tag):
+            yield message
+
+    def _master_slave_batch(self, requests):
+        """Outputs of a list of Global / LocalMasterSlaveAligner requests (None where a request has to take the serial
+        path): requests that agree on track sets, score matrices, gap series and iteration count share ONE arena and ONE
+        path plan; per Waterman-Eggert iteration one run, scores and paths back, then the bounds -> masks step on the
+        device (praline/component/preprofile.py:114-156, 213-269)."""
+        results = [None] * len(requests)
+        groups = {}
+        for k, (tid, inputs, tag, env) in enumerate(requests):
+            cls = GlobalMasterSlaveAligner if tid == GlobalMasterSlaveAligner.tid else LocalMasterSlaveAligner
+            component = cls(self, env, tag)
+            self._check_request(component, inputs, env)
+            aligner, aligner_env = _resolve_aligner(component)
+            local = cls is LocalMasterSlaveAligner
+            iterations = component.environment['waterman_eggert_iterations'] if local else 1
+            if not _is_device_aligner(aligner) or not inputs['slave_sequences'] or iterations < 1 or iterations > native.MAX_RECTS + 1:
+                continue   # another aligner component / nothing to align / more masks than the device slots hold
+            for s in inputs['slave_sequences']:
+                _validate_track_sets(inputs['master_sequence'], s, inputs['track_id_sets'], inputs['track_id_sets'],
+                                     inputs['score_matrices'])
+            key = (local, tuple(map(tuple, inputs['track_id_sets'])), tuple(id(sm) for sm in inputs['score_matrices']),
+                   tuple(aligner_env['gap_series']), iterations)
+            groups.setdefault(key, []).append((k, component.environment['score_threshold']))
+        for (local, _, _, gap_series, iterations), members in groups.items():
+            first = requests[members[0][0]][1]
+            batch = PairwiseBatch(first['track_id_sets'], first['track_id_sets'], first['score_matrices'], list(gap_series))
+            pairs, owner = [], []
+            for k, _ in members:
+                inputs = requests[k][1]
+                m = batch._arena_index(inputs['master_sequence'], 0)
+                for s in inputs['slave_sequences']:
+                    pairs.append((m, batch._arena_index(s, 0)))
+                owner.append(len(pairs))
+            per_pair = [[] for _ in pairs]      # (score, path) per iteration
+            arena = native.Arena(batch._profiles, batch.S, set_sizes=batch.sizes)
+            try:
+                plan = native.Plan(arena, np.array(pairs, dtype=np.int32), want_paths=True)
+                try:
+                    for it in range(iterations):
+                        plan.run("local" if local else "global", batch.gap_open, batch.gap_extend)
+                        sc, pt = plan.scores(), plan.paths()
+                        for q in range(len(pairs)):
+                            per_pair[q].append((float(sc[q]), np.array(pt[q], dtype=int)))
+                        if it + 1 < iterations:
+                            plan.mask_path_bounds()
+                finally:
+                    plan.close()
+            finally:
+                arena.close()
+            lo = 0
+            for (k, threshold), hi in zip(members, owner):
+                inputs = requests[k][1]
+                results[k] = {'alignment': merge_master_slave(inputs['master_sequence'], inputs['slave_sequences'],
+                                                              per_pair[lo:hi], threshold, local=local)}
+                lo = hi
+        return results
+
     def execute_many(self, requests, parent_tag):
         self._require_open()
         requests = list(requests)
+        tids = set(tid for tid, _, _, _ in requests)
+        if len(requests) >= 2 and tids <= {GlobalMasterSlaveAligner.tid, LocalMasterSlaveAligner.tid}:
+            for message in self._emit(requests, self._master_slave_batch(requests), parent_tag):
+                yield message
+            return
+        if len(requests) >= 2 and tids == {ProfileBuilder.tid}:
+            results = []
+            for tid, inputs, tag, env in requests:
+                self._check_request(ProfileBuilder(self, env, tag), inputs, env)
+                track = inputs['alignment'].items[0].get_track(inputs['track_id'])
+                results.append({'profile_track': ProfileTrack(get_frequencies(inputs['alignment'], inputs['track_id']), track.alphabet)})
+            for message in self._emit(requests, results, parent_tag):
+                yield message
+            return
         if len(requests) < 2 or any(tid != PairwiseAligner.tid for tid, _, _, _ in requests):
             for message in Manager.execute_many(self, requests, parent_tag):
                 yield message
@@ -1150,14 +1230,5 @@ class BatchManager(Manager):
                 results[k] = {'alignment': Alignment([inputs['sequence_one'], inputs['sequence_two']],
                                                      _path_for_output(inputs['mode'], pt)),
                               'score': sc}
-        for k, (tid, inputs, tag, env) in enumerate(requests):
-            if results[k] is None:
-                for message in self._invoke(tid, inputs, tag, env, parent_tag=parent_tag):
-                    yield message
-                continue
-            begin = BeginMessage(parent_tag)
-            begin.tag = tag
-            yield begin
-            done = CompleteMessage(outputs=results[k])
-            done.tag = tag
-            yield done
+        for message in self._emit(requests, results, parent_tag):
+            yield message

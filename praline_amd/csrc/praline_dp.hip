@@ -119,6 +119,7 @@ extern "C" int praline_synchronize(void)
 {
     if (!g_rt.ready) return PRALINE_OK;
     HIPCHK(hipStreamSynchronize(g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream2));
     return PRALINE_OK;
 }
 
@@ -147,6 +148,7 @@ extern "C" int praline_pool_trim(void)
 {
     if (!g_rt.ready) return PRALINE_OK;
     HIPCHK(hipStreamSynchronize(g_rt.stream));
+    HIPCHK(hipStreamSynchronize(g_rt.stream2));
     pool_clear();
     return PRALINE_OK;
 }
@@ -157,8 +159,13 @@ extern "C" void *praline_stream(void) { return g_rt.ready ? (void *)g_rt.stream 
 // Device buffers come from a small pool: plans allocate multi-GB scratch (strip boundaries, packed
 // traceback, paths) and hipMalloc / hipFree of such blocks costs 100s of ms.  Released blocks are kept
 // and handed out again when a request fits (block <= 2x request); praline_shutdown frees them.
-struct PoolBlock { void *p; size_t bytes; };
+// The pool is STREAM-ORDERED over the library's two streams: a released block carries two events, recorded on both
+// streams at release time, and is only handed out again once both have completed - a buffer that is replaced while
+// kernels of an earlier launch (on either stream) may still be using it can therefore never reach another user early.
+// (Round 2's chunk-scratch race was this: a block released inside the chunk loop went to the other stream's set.)
+struct PoolBlock { void *p; size_t bytes; hipEvent_t ev[2]; };
 static std::vector<PoolBlock> g_pool;
+static std::vector<hipEvent_t> g_pool_events;   // spare events
 static size_t g_pool_bytes = 0;
 // Cap of the cached (released, not yet freed) bytes: PRALINE_POOL_KEEP_MB, default 64 GiB of the 288 - two launch
 // chunks' worth of path-plan scratch (24 GiB each, PRALINE_TB_BUDGET_MB): with a smaller cap every C3-size plan paid
@@ -174,19 +181,49 @@ static size_t pool_keep_bytes()
     return keep;
 }
 
+static hipEvent_t pool_event()
+{
+    if (!g_pool_events.empty()) { hipEvent_t e = g_pool_events.back(); g_pool_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+
+static bool pool_block_ready(const PoolBlock &b)
+{
+    for (int k = 0; k < 2; ++k)
+        if (b.ev[k] && hipEventQuery(b.ev[k]) != hipSuccess) return false;
+    return true;
+}
+
+static void pool_block_retire(PoolBlock &b, bool wait)
+{
+    for (int k = 0; k < 2; ++k)
+        if (b.ev[k]) {
+            if (wait) (void)hipEventSynchronize(b.ev[k]);
+            g_pool_events.push_back(b.ev[k]);
+            b.ev[k] = nullptr;
+        }
+}
+
 static void *pool_alloc(size_t bytes, size_t *got)
 {
-    size_t best = (size_t)-1;
-    for (size_t i = 0; i < g_pool.size(); ++i)
-        // smallest cached block that fits; a request of a GiB or more takes ANY block that fits (a first hipMalloc of a
-        // 24 GiB scratch block costs the better part of a second - more than the C3 stage it serves), smaller ones
-        // only blocks of up to twice their size
-        if (g_pool[i].bytes >= bytes && (bytes >= ((size_t)1 << 30) || g_pool[i].bytes <= 2 * bytes + (1 << 20)) &&
-            (best == (size_t)-1 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+    // smallest cached block that fits and whose release point both streams have passed; a request of a GiB or more
+    // takes ANY block that fits (a first hipMalloc of a 24 GiB scratch block costs the better part of a second - more
+    // than the C3 stage it serves) and would rather wait for a block in flight than go to the driver; smaller ones
+    // only take blocks of up to twice their size
+    size_t best = (size_t)-1, best_busy = (size_t)-1;
+    for (size_t i = 0; i < g_pool.size(); ++i) {
+        if (!(g_pool[i].bytes >= bytes && (bytes >= ((size_t)1 << 30) || g_pool[i].bytes <= 2 * bytes + (1 << 20)))) continue;
+        size_t &slot = pool_block_ready(g_pool[i]) ? best : best_busy;
+        if (slot == (size_t)-1 || g_pool[i].bytes < g_pool[slot].bytes) slot = i;
+    }
+    if (best == (size_t)-1 && best_busy != (size_t)-1 && bytes >= ((size_t)1 << 30)) best = best_busy;
     if (best != (size_t)-1) {
         PoolBlock b = g_pool[best];
         g_pool.erase(g_pool.begin() + best);
         g_pool_bytes -= b.bytes;
+        pool_block_retire(b, true);
         *got = b.bytes;
         return b.p;
     }
@@ -194,9 +231,7 @@ static void *pool_alloc(size_t bytes, size_t *got)
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         // give cached blocks back to the driver and retry once
-        for (auto &b : g_pool) (void)hipFree(b.p);
-        g_pool.clear();
-        g_pool_bytes = 0;
+        pool_clear();
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return nullptr;
     }
@@ -207,16 +242,28 @@ static void *pool_alloc(size_t bytes, size_t *got)
 static void pool_release(void *p, size_t bytes)
 {
     if (!p) return;
-    if (bytes < ((size_t)1 << 20) || g_pool_bytes + bytes > pool_keep_bytes()) { (void)hipFree(p); return; }
-    g_pool.push_back({p, bytes});
+    // (hipFree waits for the device: a small block that is freed outright cannot be in use afterwards either)
+    if (bytes < ((size_t)1 << 20) || g_pool_bytes + bytes > pool_keep_bytes() || !g_rt.ready) { (void)hipFree(p); return; }
+    PoolBlock b{p, bytes, {pool_event(), pool_event()}};
+    const hipStream_t streams[2] = {g_rt.stream, g_rt.stream2};
+    for (int k = 0; k < 2; ++k)
+        if (!b.ev[k] || hipEventRecord(b.ev[k], streams[k]) != hipSuccess) {
+            // no event to order the reuse by: fall back to the driver (synchronising free)
+            pool_block_retire(b, false);
+            (void)hipFree(p);
+            return;
+        }
+    g_pool.push_back(b);
     g_pool_bytes += bytes;
 }
 
 static void pool_clear()
 {
-    for (auto &b : g_pool) (void)hipFree(b.p);
+    for (auto &b : g_pool) { pool_block_retire(b, true); (void)hipFree(b.p); }
     g_pool.clear();
     g_pool_bytes = 0;
+    for (hipEvent_t e : g_pool_events) (void)hipEventDestroy(e);
+    g_pool_events.clear();
 }
 
 extern "C" int64_t praline_pool_cached_bytes(void) { return (int64_t)g_pool_bytes; }
@@ -902,7 +949,9 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
 extern "C" int praline_plan_destroy(praline_plan *plan)
 {
     if (!plan) return PRALINE_OK;
-    if (g_rt.ready) (void)hipStreamSynchronize(g_rt.stream);
+    // (blocks of a MiB and more go back to the stream-ordered pool; smaller ones are freed, which waits for the device -
+    // the explicit waits keep the plan's host-side state from outliving work that still reads it)
+    if (g_rt.ready) { (void)hipStreamSynchronize(g_rt.stream); (void)hipStreamSynchronize(g_rt.stream2); }
     delete plan;
     return PRALINE_OK;
 }
@@ -1296,6 +1345,12 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                      pl.has_rects ? "true" : "false");
             pl.last_kernel = kn;
             if (pl.bnd_off0.size() != nt) { pl.bnd_off0.resize(nt); for (size_t t = 0; t < nt; ++t) pl.bnd_off0[t] = pl.tasks[t].bnd_off; }
+            // the chunk cutting below rewrites the tasks' boundary offsets; the single pass and chain mode address the
+            // plan's shared boundary buffer through the scheduler's offsets: put them back on EVERY way out
+            struct RestoreBnd {
+                praline_plan &pl;
+                ~RestoreBnd() { for (size_t t = 0; t < pl.tasks.size() && t < pl.bnd_off0.size(); ++t) pl.tasks[t].bnd_off = pl.bnd_off0[t]; }
+            } restore_bnd{pl};
             if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
             int rc2 = PRALINE_OK;
             // plans that need several chunks: half the budget per chunk, two scratch sets, alternating streams
@@ -1339,12 +1394,8 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                     need_bk[c & 1] = std::max(need_bk[c & 1], chunks[c].bnd_e);
                     need_ax[c & 1] = std::max(need_ax[c & 1], chunks[c].aux_e);
                 }
-                const bool grow = pl.d_tb.n < (size_t)need_ck[0] || pl.d_tb_b.n < (size_t)need_ck[1] || pl.d_bnd2.n < (size_t)need_bk[0] ||
-                                  pl.d_bnd2_b.n < (size_t)need_bk[1] || pl.d_aux.n < (size_t)need_ax[0] || pl.d_aux_b.n < (size_t)need_ax[1];
-                if (grow) {   // (an earlier run's kernels may still be reading the blocks that are about to be replaced)
-                    HIPCHK(hipStreamSynchronize(st));
-                    HIPCHK(hipStreamSynchronize(g_rt.stream2));
-                }
+                // (an earlier run's kernels may still be reading a block that is replaced here: the pool is stream-ordered -
+                // the old block is not handed out again before both streams have passed this point - so no host wait)
                 if (pl.d_tb.n < (size_t)need_ck[0]) RC(pl.d_tb.alloc((size_t)need_ck[0]));
                 if (pl.d_bnd2.n < (size_t)need_bk[0]) RC(pl.d_bnd2.alloc((size_t)need_bk[0]));
                 if (pl.d_aux.n < (size_t)need_ax[0]) RC(pl.d_aux.alloc((size_t)need_ax[0]));
@@ -1398,8 +1449,6 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             la.stream = st;
             if (forked && (hipEventRecord(g_rt.ev_join, g_rt.stream2) != hipSuccess || hipStreamWaitEvent(st, g_rt.ev_join, 0) != hipSuccess))
                 rc2 = fail(PRALINE_ERR_DEVICE, "stream join failed");
-            // the single pass and chain mode address the plan's shared boundary buffer through the scheduler's offsets
-            for (size_t t = 0; t < nt; ++t) pl.tasks[t].bnd_off = pl.bnd_off0[t];
             if (rc2 != PRALINE_OK) return rc2;
             // (d_tasks holds two-pass offsets now: the next single-pass run uploads its own)
             HIPCHK(hipEventRecord(pl.ev1, st));
@@ -1438,12 +1487,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             need_tb[c & 1] = std::max(need_tb[c & 1], (size_t)chunks[c].tb_e * tb_elem_bytes);
             need_ax[c & 1] = std::max(need_ax[c & 1], (size_t)chunks[c].aux_e);
         }
-        const bool grow = pl.d_tb.n < need_tb[0] || pl.d_aux.n < need_ax[0] ||
-                          (chunks.size() > 1 && (pl.d_tb_b.n < need_tb[1] || pl.d_aux_b.n < need_ax[1]));
-        if (grow) {   // (an earlier run's kernels may still be reading the blocks that are about to be replaced)
-            HIPCHK(hipStreamSynchronize(st));
-            HIPCHK(hipStreamSynchronize(g_rt.stream2));
-        }
+        // (blocks replaced here may still be read by an earlier run's kernels: stream-ordered pool, no host wait)
         if (pl.d_tb.n < need_tb[0]) RC(pl.d_tb.alloc(need_tb[0]));
         if (pl.d_aux.n < need_ax[0]) RC(pl.d_aux.alloc(need_ax[0]));
         if (chunks.size() > 1) {
@@ -1454,6 +1498,16 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
     HIPCHK(hipMemcpyAsync(pl.d_tasks.p, pl.tasks.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));   // (before the fork)
     bool forked = false;
+    // every way out of the loop below joins the second stream again (an error return would otherwise leave stream2's
+    // kernels unordered against whatever the main stream does next with the plan's buffers)
+    struct JoinGuard {
+        bool &forked; hipStream_t st;
+        ~JoinGuard()
+        {
+            if (forked && hipEventRecord(g_rt.ev_join, g_rt.stream2) == hipSuccess) (void)hipStreamWaitEvent(st, g_rt.ev_join, 0);
+            forked = false;
+        }
+    } join_guard{forked, st};
     for (size_t c = 0; c < chunks.size(); ++c) {
         const int set = (int)(c & 1);
         hipStream_t cs = set ? g_rt.stream2 : st;
@@ -1527,6 +1581,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     if (forked) {
         HIPCHK(hipEventRecord(g_rt.ev_join, g_rt.stream2));
         HIPCHK(hipStreamWaitEvent(st, g_rt.ev_join, 0));
+        forked = false;
     }
     HIPCHK(hipEventRecord(pl.ev1, st));
     return PRALINE_OK;

@@ -27,15 +27,16 @@ def _advances(path):
 
 def get_frequencies(alignment, trid):
     """Per alignment column, the symbol counts of the sequences that advance in that column
-    (util/align.py:187-213); rows of -1 (local padding) never advance."""
+    (util/align.py:187-213); rows of -1 (local padding) never advance.  One scatter-add over all (column, sequence)
+    advances (the reference loops over columns and sequences in Python)."""
     path = np.asarray(alignment.path)
     tracks = [seq.get_track(trid) for seq in alignment.items]
     freqs = np.zeros((path.shape[0] - 1, tracks[0].alphabet.size), dtype=int)
-    adv = _advances(path)
-    for j, track in enumerate(tracks):
-        rows = np.nonzero(adv[:, j])[0]
-        syms = track.values[path[rows + 1, j] - 1]
-        np.add.at(freqs, (rows, syms), 1)
+    rows, cols = np.nonzero(_advances(path))
+    if len(rows):
+        offsets = np.concatenate([[0], np.cumsum([len(t.values) for t in tracks])[:-1]])
+        values = np.concatenate([np.asarray(t.values) for t in tracks])
+        np.add.at(freqs, (rows, values[offsets[cols] + path[rows + 1, cols] - 1]), 1)
     return freqs
 
 

@@ -323,3 +323,57 @@ def test_chunked_path_plans_on_two_streams(nat, monkeypatch):
         assert ref[0][k] == np.float32(s_or)
         assert np.array_equal(ref[1][ref[2][k]:ref[2][k] + ref[3][k]], p_or)
     arena.close()
+
+
+def test_scratch_growth_between_back_to_back_path_runs(nat, monkeypatch):
+    """The device-buffer pool is stream-ordered (csrc/praline_dp.hip, pool_release / pool_alloc): a scratch block that a
+    run replaces while an earlier run's kernels - on either of the library's two streams - may still be using it is not
+    handed to anyone before both streams have passed the release point.  Two plans, runs queued back to back WITHOUT any
+    host synchronisation under budgets that make every run re-cut its chunks and GROW its scratch sets (small budget: many
+    chunks on two streams; larger budget: fewer, larger blocks; a second plan picking blocks up in between): scores and
+    every path of every run must equal the one-chunk reference."""
+    from praline_amd.matrices import nucleotide_matrix
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chunked_paths_dna.npz"))
+    lens, pairs, sym = d["lens"], d["pairs"], d["sym"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    profs = [np.eye(15, dtype=np.float32)[sym[off[i]:off[i + 1]]] for i in range(len(lens))]
+    arena = nat.Arena(profs, nucleotide_matrix())
+    half = len(pairs) // 2
+    subsets = (pairs[:half], pairs[half // 2:half // 2 + half])
+
+    def results(plan):
+        sc = plan.scores().copy()
+        buf, o, r = plan.paths_packed()
+        return sc, buf.copy(), o.copy(), r.copy()
+
+    monkeypatch.setenv("PRALINE_TB_BUDGET_MB", "160000")
+    ref = []
+    for sub in subsets:
+        for two in ("0", "2"):
+            monkeypatch.setenv("PRALINE_TB_TWOPASS", two)
+            plan = nat.Plan(arena, sub, want_paths=True)
+            plan.run("global", *GAPS)
+            if two == "0":
+                ref.append(results(plan))
+            else:
+                got = results(plan)
+                assert all(np.array_equal(a, b) for a, b in zip(got, ref[-1]))
+            plan.close()
+    nat.pool_trim()
+    for two in ("0", "2"):
+        monkeypatch.setenv("PRALINE_TB_TWOPASS", two)
+        plans = [nat.Plan(arena, sub, want_paths=True) for sub in subsets]
+        outs = []
+        # every run below is queued behind the previous one with no host wait in between; the budgets rise, so every
+        # run replaces its scratch blocks with larger ones while the previous run is still executing
+        for budget, which in (("1500", 0), ("2500", 1), ("4000", 0), ("9000", 1), ("20000", 0), ("160000", 1)):
+            monkeypatch.setenv("PRALINE_TB_BUDGET_MB", budget)
+            plans[which].run("global", *GAPS)
+            if budget in ("9000", "20000", "160000"):
+                outs.append((which, budget, results(plans[which])))   # (reading the results waits for that run only)
+        for which, budget, got in outs:
+            assert np.array_equal(bits(got[0]), bits(ref[which][0])), (two, which, budget)
+            assert all(np.array_equal(a, b) for a, b in zip(got[1:], ref[which][1:])), (two, which, budget)
+        for p in plans:
+            p.close()
+    arena.close()

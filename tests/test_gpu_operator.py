@@ -498,3 +498,141 @@ def test_preprofile_counts_through_rccl_in_place(env, seqs):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _multitrack_inputs():
+    """BBA0184 with its annotation tracks, read from the reference's own input files (tests/golden: byte copies of
+    extra/data) through this package's loaders."""
+    import os
+    from conftest import GOLDEN as GOLDEN_DIR
+    from praline_amd import io as pio
+    g = lambda fn: os.path.join(GOLDEN_DIR, fn)
+    seqs = pio.load_sequence_fasta(g("BBA0184.tfa"), ct.ALPHABET_AA)
+    blosum = pio.load_score_matrix(pio.open_builtin("matrices/blosum62"), alphabet=ct.ALPHABET_AA)
+    return g, seqs, blosum
+
+
+def _tree_msa(manager, seqs, track_id_sets, score_matrices):
+    keys = {"gap_series": [-11.0, -1.0], "linkage_method": "average", "dist_mode": "global", "merge_mode": "global"}
+    tree = run_one(manager, comp.GuideTreeBuilder, keys, sequences=seqs, track_id_sets=track_id_sets,
+                   score_matrices=score_matrices)['guide_tree']
+    return run_one(manager, comp.TreeMultipleSequenceAligner, keys, sequences=seqs, guide_tree=tree,
+                   track_id_sets=track_id_sets, score_matrices=score_matrices)['alignment']
+
+
+def test_end_to_end_multitrack_cli_alignment(env):
+    """extra/data/BBA0184.cli.aln, the reference's second shipped known-answer file, byte for byte on the device path:
+    `multitrack_cli.py BBA0184.tfa out -a BBA0184.motif.tfa:motif_score_matrix` (extra/multitrack_cli.py:40-193) = the
+    annotation score matrix loaded WITHOUT an alphabet (one is made from its header), the annotation FASTA read with
+    that alphabet, dummy master-slave alignments -> ProfileBuilder, then guide tree + TreeMSA over the two track sets
+    [preprofile] and [motif] (merge / dist global, average linkage), FASTA out."""
+    import io
+    from praline_amd import io as pio
+    g, seqs, blosum = _multitrack_inputs()
+    want = open(g("BBA0184.cli.aln")).read()
+    motif_sm = pio.load_score_matrix(g("motif_score_matrix"))
+    trid = "praline.example.CustomTrackFile_motif_score_matrix"
+    for s, a in zip(seqs, pio.load_sequence_fasta(g("BBA0184.motif.tfa"), motif_sm.alphabets[0])):
+        s.add_track(trid, a.get_track(ct.TRACK_ID_INPUT))
+    for manager in (env["serial"], env["batch"]):
+        for m, master in enumerate(seqs):
+            slaves = [s for k, s in enumerate(seqs) if k != m]
+            aln = run_one(manager, comp.DummyMasterSlaveAligner, master_sequence=master, slave_sequences=slaves,
+                          track_id_sets=[[ct.TRACK_ID_INPUT], [trid]], score_matrices=[blosum, motif_sm])['alignment']
+            track = run_one(manager, comp.ProfileBuilder, alignment=aln, track_id=ct.TRACK_ID_INPUT)['profile_track']
+            if ct.TRACK_ID_PREPROFILE in dict(master.tracks):
+                master.replace_track(ct.TRACK_ID_PREPROFILE, track)
+            else:
+                master.add_track(ct.TRACK_ID_PREPROFILE, track)
+        msa = _tree_msa(manager, seqs, [[ct.TRACK_ID_PREPROFILE], [trid]], [blosum, motif_sm])
+        assert pio.write_alignment_fasta(io.StringIO(), msa, ct.TRACK_ID_INPUT) == want, type(manager).__name__
+
+
+def test_end_to_end_multitrack_notebook_alignment(env):
+    """extra/data/BBA0184.multitrack.aln (extra/MSAMultiTrack.ipynb), byte for byte: three track sets - residues (global
+    master-slave preprofiles), motif matches (15 / 0) and three-state secondary structure (3 / 0) - through
+    GlobalMasterSlaveAligner -> ProfileBuilder -> GuideTreeBuilder -> TreeMultipleSequenceAligner: num_sets = 3 in the
+    match-score build of every alignment (cext.c:389-420 sums the sets)."""
+    import io
+    from praline_amd import io as pio
+    g, seqs, blosum = _multitrack_inputs()
+    want = open(g("BBA0184.multitrack.aln")).read()
+    a_motif = ct.Alphabet("praline.example.SimpleMotifMatch", [("*", 0), ("M", 1)])
+    a_ss = ct.Alphabet("praline.example.ThreeStateSecondaryStructure", [("C", 0), ("H", 1), ("E", 2)])
+    sm_motif = ct.ScoreMatrix({("M", "M"): 15, ("M", "*"): 0, ("*", "M"): 0, ("*", "*"): 0}, [a_motif, a_motif])
+    sm_ss = ct.ScoreMatrix({(a, b): (3 if a == b else 0) for a in "CHE" for b in "CHE"}, [a_ss, a_ss])
+    t_motif, t_ss = "praline.example.MotifTrack", "praline.example.SecondaryStructureTrack"
+    for s, m, q in zip(seqs, pio.load_sequence_fasta(g("BBA0184.motif.tfa"), a_motif), pio.load_sequence_fasta(g("BBA0184.ss.tfa"), a_ss)):
+        s.add_track(t_motif, m.get_track(ct.TRACK_ID_INPUT))
+        s.add_track(t_ss, q.get_track(ct.TRACK_ID_INPUT))
+    sms = [blosum, sm_motif, sm_ss]
+    for manager in (env["serial"], env["batch"]):
+        tracks = []
+        for m, master in enumerate(seqs):
+            slaves = [s for k, s in enumerate(seqs) if k != m]
+            aln = run_one(manager, comp.GlobalMasterSlaveAligner, {"gap_series": [-11.0, -1.0]}, master_sequence=master,
+                          slave_sequences=slaves, track_id_sets=[[ct.TRACK_ID_INPUT], [t_motif], [t_ss]],
+                          score_matrices=sms)['alignment']
+            tracks.append(run_one(manager, comp.ProfileBuilder, alignment=aln, track_id=ct.TRACK_ID_INPUT)['profile_track'])
+        for s, t in zip(seqs, tracks):
+            if ct.TRACK_ID_PREPROFILE in dict(s.tracks):
+                s.replace_track(ct.TRACK_ID_PREPROFILE, t)
+            else:
+                s.add_track(ct.TRACK_ID_PREPROFILE, t)
+        msa = _tree_msa(manager, seqs, [[ct.TRACK_ID_PREPROFILE], [t_motif], [t_ss]], sms)
+        assert pio.write_alignment_fasta(io.StringIO(), msa, ct.TRACK_ID_INPUT) == want, type(manager).__name__
+
+
+def test_preprofile_stage_behind_execute_many(env, seqs, monkeypatch):
+    """The reference's workflow hands Manager.execute_many ONE list with a Global / LocalMasterSlaveAligner task per master
+    and then one with a ProfileBuilder task per master (praline/component/workflow.py:139-161, 211-224).  Under
+    BatchManager the first list is one arena, one path plan over every (master, slave) pair and one run per
+    Waterman-Eggert iteration (the masks are built on the device), the second is counted in bulk - with the outputs of the
+    reference's own run (tests/golden/preprofile.npz) and of the serial manager."""
+    from praline_amd import native
+    d = load_golden("preprofile.npz")
+    runs, plans = [], []
+    orig_run, orig_init = native.Plan.run, native.Plan.__init__
+    monkeypatch.setattr(native.Plan, "run", lambda self, *a, **k: (runs.append(1), orig_run(self, *a, **k))[1])
+    monkeypatch.setattr(native.Plan, "__init__", lambda self, *a, **k: (plans.append(1), orig_init(self, *a, **k))[1])
+    for component, keys, golden, iterations in ((comp.GlobalMasterSlaveAligner, {}, {0: "global_m0_", 2: "global_m2_"}, 1),
+                                                (comp.LocalMasterSlaveAligner, {}, {0: "local_m0_", 4: "local_m4_"}, 2),
+                                                (comp.LocalMasterSlaveAligner, {"score_threshold": 100.0}, {0: "local_thr_m0_"}, 2),
+                                                (comp.LocalMasterSlaveAligner, {"waterman_eggert_iterations": 3}, {0: "local_we3_m0_"}, 3)):
+        outs = {}
+        for name in ("batch", "serial"):
+            ex = core.Execution(env[name], "root")
+            for m, master in enumerate(seqs):
+                ex.add_task(component).environment(core.Environment({}), core.Environment(dict(keys))).inputs(
+                    master_sequence=master, slave_sequences=[s for k, s in enumerate(seqs) if k != m],
+                    track_id_sets=T_IN, score_matrices=[env["blosum"]])
+            del runs[:], plans[:]
+            alignments = [o['alignment'] for o in core.run(ex)]
+            if name == "batch":
+                assert len(plans) == 1 and len(runs) == iterations, (component.__name__, keys, len(plans), len(runs))
+            else:
+                assert len(runs) >= len(seqs)       # (the serial manager: at least one submission per master)
+            ex = core.Execution(env[name], "root")
+            for aln in alignments:
+                ex.add_task(comp.ProfileBuilder).environment(core.Environment({}), core.Environment({})).inputs(
+                    alignment=aln, track_id=ct.TRACK_ID_INPUT)
+            del runs[:]
+            tracks = [o['profile_track'] for o in core.run(ex)]
+            assert not runs                         # counting needs no device work
+            outs[name] = (alignments, tracks)
+        for m in range(len(seqs)):
+            assert np.array_equal(np.asarray(outs["batch"][0][m].path), np.asarray(outs["serial"][0][m].path)), (keys, m)
+            assert np.array_equal(outs["batch"][1][m].counts, outs["serial"][1][m].counts), (keys, m)
+        for m, key in golden.items():
+            assert np.array_equal(np.asarray(outs["batch"][0][m].path), d[key + "msa_path"]), key
+            assert np.array_equal(outs["batch"][1][m].counts, d[key + "profile_counts"]), key
+            assert np.array_equal(outs["batch"][1][m].profile, d[key + "profile_f32"]), key
+    # a mixed list (two component kinds) and a user's own aligner stay on the reference's per-task path
+    ex = core.Execution(env["batch"], "root")
+    ex.add_task(comp.GlobalMasterSlaveAligner).environment(core.Environment({}), core.Environment({})).inputs(
+        master_sequence=seqs[0], slave_sequences=seqs[1:], track_id_sets=T_IN, score_matrices=[env["blosum"]])
+    ex.add_task(comp.ProfileBuilder).environment(core.Environment({}), core.Environment({})).inputs(
+        alignment=outs["serial"][0][0], track_id=ct.TRACK_ID_INPUT)
+    mixed = core.run(ex)
+    assert np.array_equal(np.asarray(mixed[0]['alignment'].path), d["global_m0_msa_path"])
+    assert np.array_equal(mixed[1]['profile_track'].counts, outs["serial"][1][0].counts)

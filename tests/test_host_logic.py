@@ -496,3 +496,35 @@ def test_merge_levels_groups_independent_steps():
         for lv in levels:
             used = [c for k in lv for c in steps[k]]
             assert len(used) == len(set(used))
+
+
+def test_load_score_matrix_reads_the_reference_text_format(tmp_path):
+    """io.load_score_matrix / io.open_builtin (praline/__init__.py:57-102): every table the reference packages
+    (praline/matrices/*: 15 BLOSUM tables + nucleotide) parses to the array the reference's own loader produces
+    (tests/golden/matrices.npz, written by make_golden.py from the real reference); comments, ragged rows, extra columns
+    and the anonymous alphabet follow the reference."""
+    from praline_amd import io as pio
+    from praline_amd import matrices
+    want = load_golden("matrices.npz")
+    assert sorted(want.files) == matrices.builtin_names()
+    for name in want.files:
+        alphabet = ct.ALPHABET_DNA if name == "nucleotide" else ct.ALPHABET_AA
+        m = pio.load_score_matrix(pio.open_builtin("matrices/" + name), alphabet=alphabet)
+        assert m.matrix.dtype == np.float32 and np.array_equal(m.matrix, want[name]), name
+        assert m.alphabets == [alphabet, alphabet]
+    assert np.array_equal(pio.load_score_matrix(pio.open_builtin("matrices/blosum62"), ct.ALPHABET_AA).matrix, ct.blosum62().matrix)
+    with pytest.raises(core.DataError):
+        pio.open_builtin("matrices/blosum63")
+    # a file on disk: comment lines, a trailing comment, a value beyond the header (ignored), no alphabet given
+    path = tmp_path / "m.txt"
+    path.write_text("# toy\n   *  M   # columns\n*  0  0  99\nM  0  15\n")
+    m = pio.load_score_matrix(str(path))
+    assert m.alphabets[0] is m.alphabets[1] and m.alphabets[0].aid.startswith("__anonymous_from_matrix_")
+    assert m.alphabets[0].symbol_to_index("*") == 0 and m.alphabets[0].symbol_to_index("M") == 1 and m.alphabets[0].size == 2
+    assert np.array_equal(m.matrix, np.array([[0, 0], [0, 15]], dtype=np.float32))
+    # the shipped annotation matrix (extra/data/motif_score_matrix), from bytes
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "motif_score_matrix"), "rb") as f:
+        m2 = pio.load_score_matrix(f)
+    assert np.array_equal(m2.matrix, m.matrix)
+    with pytest.raises(core.AlphabetError):
+        pio.load_score_matrix(pio.open_builtin("matrices/blosum62"), alphabet=ct.ALPHABET_DNA)   # symbols the alphabet lacks
