@@ -1119,8 +1119,17 @@ class BatchManager(Manager):
 
     def _emit(self, requests, results, parent_tag):
         """Begin / Complete messages of the requests that were answered in bulk, the serial path for the others."""
-        for message in self._emit(requests, results, parent_tag):
-            yield message
+        for k, (tid, inputs, tag, env) in enumerate(requests):
+            if results[k] is None:
+                for message in self._invoke(tid, inputs, tag, env, parent_tag=parent_tag):
+                    yield message
+                continue
+            begin = BeginMessage(parent_tag)
+            begin.tag = tag
+            yield begin
+            done = CompleteMessage(outputs=results[k])
+            done.tag = tag
+            yield done
 
     def _master_slave_batch(self, requests):
         """Outputs of a list of Global / LocalMasterSlaveAligner requests (None where a request has to take the serial

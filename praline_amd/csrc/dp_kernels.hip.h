@@ -317,6 +317,9 @@ __device__ __forceinline__ float select32(const float (&v)[32], int idx)
 // summation order; TP must be 1.  Everything after the match scores is the same code.
 // MASK: 0 no zero rectangles, 1 up to PRALINE_MAX_RECTS per pair held in registers, 2 any number per pair, walked in
 // memory for every row (plans in which some pair has more than PRALINE_MAX_RECTS: many Waterman-Eggert iterations).
+#ifdef PRALINE_EXP_BATCH_MASK2
+__device__ unsigned praline_dbg[128];
+#endif
 template <int NSTEP, int TP, bool LOCAL, int OUT, int MASK, int MSRC = 0>
 __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__restrict__ tasks,
                                                  const int32_t *__restrict__ lane_one,
@@ -470,6 +473,21 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
             unsigned zrow = 0;
             if constexpr (MASK == 2) {
                 if (my_zm != nullptr && y <= L1 && s < my_strips) zrow = my_zm[(int64_t)s * (L1 + 1) + y];
+#ifdef PRALINE_EXP_BATCH_MASK2_DBG
+                // experiment builds (scripts/exp_mask2.py): what does the kernel see where the host put zeros?
+                if constexpr (MSRC == 0 && LOCAL && OUT == 1) {
+                    if (zrow != 0) {
+                        const unsigned again = my_zm ? *reinterpret_cast<const volatile unsigned *>(my_zm + (int64_t)s * (L1 + 1) + y) : 0xdeadbeefu;
+                        const unsigned n = atomicAdd(&praline_dbg[0], 1u);
+                        if (again == 0) atomicAdd(&praline_dbg[1], 1u);
+                        if (n < 12) {
+                            praline_dbg[8 + 6 * n] = (unsigned)my_pair; praline_dbg[9 + 6 * n] = ((unsigned)s << 16) | (unsigned)y;
+                            praline_dbg[10 + 6 * n] = zrow; praline_dbg[11 + 6 * n] = again; praline_dbg[12 + 6 * n] = (unsigned)lane;
+                            praline_dbg[13 + 6 * n] = (unsigned)L1;
+                        }
+                    }
+                }
+#endif
             }
             float m[32];
             if constexpr (MSRC == 1) {

@@ -101,6 +101,13 @@ template <int NSTEP> static int launch_nstep(const LaunchArgs &la, int tp, bool 
         else return PRALINE_ERR_UNSUPPORTED;
     } else {
         if (tp != 1) return PRALINE_ERR_UNSUPPORTED;
+#ifdef PRALINE_EXP_BATCH_MASK2
+        // experiment builds only (scripts/exp_mask2.py): the MFMA-fed column-mask instance, see DESIGN section 3.5
+        if (mask == 2) {
+            if (local) launch_one<NSTEP, 1, true, 1, 2>(la); else launch_one<NSTEP, 1, false, 1, 2>(la);
+            return PRALINE_OK;
+        }
+#endif
         if (mask == 2) return PRALINE_ERR_UNSUPPORTED;   // column-mask plans run on the dense-match-score instances (dp_ref_instance.hip)
         if (local) { if (mask) launch_one<NSTEP, 1, true, 1, 1>(la); else launch_one<NSTEP, 1, true, 1, 0>(la); }
         else { if (mask) launch_one<NSTEP, 1, false, 1, 1>(la); else launch_one<NSTEP, 1, false, 1, 0>(la); }

@@ -828,6 +828,12 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     // (The MFMA-fed k_dp_batch instance with those masks gave wrong LOCAL scores under ROCm 7.2 - codegen-sensitive,
     // not understood - so it is not used.)
     pl->ref = match_mode() == PRALINE_MATCH_REFERENCE || a.wide || many_rects;
+    if (many_rects && !a.wide && match_mode() != PRALINE_MATCH_REFERENCE && getenv("PRALINE_EXP_BATCH_MASK2") && want_paths) {
+        // experiment (needs a library built with -DPRALINE_EXP_BATCH_MASK2): column masks on the MFMA-fed k_dp_batch
+        pl->ref = false;
+        opt.split_layout = false;
+        opt.tp = 1;
+    }
     if (pl->ref) { opt.split_layout = false; opt.tp = 1; }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
     if (const char *env = getenv("PRALINE_NO_W2")) opt.shared_waves = env[0] != '1';
