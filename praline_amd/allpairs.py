@@ -103,21 +103,31 @@ def _group_device(group):
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def group_is_nccl(group=None):
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+
 def all_gather_scores(local, shards, rank, world, group=None):
     """The exchange step of the all-pairs stage for host-side callers (GuideTreeBuilder): `local` = this rank's
-    scores in the order of shards[rank]; returns the complete float32 list in pair order, identical on every rank.
-    One all_gather_into_tensor (RCCL over xGMI under the nccl backend)."""
+    scores in the order of shards[rank] - a numpy array, or a torch tensor that is already on the group's device (the
+    kernels wrote into it: nothing moves through host memory before the exchange); returns the complete float32 list in
+    pair order as a numpy array, identical on every rank.  One all_gather_into_tensor (RCCL over xGMI under the nccl
+    backend), the reorder into pair order on the same device, one copy to the host."""
     import torch
     import torch.distributed as dist
     src, dst, shard_len = gather_maps(shards)
     dev = _group_device(group)
     padded = torch.zeros(shard_len, dtype=torch.float32, device=dev)
-    padded[:len(shards[rank])] = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float32), device=dev)
+    if isinstance(local, torch.Tensor):
+        padded[:len(shards[rank])] = local.to(dev)
+    else:
+        padded[:len(shards[rank])] = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float32), device=dev)
     gathered = torch.zeros(shard_len * world, dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(gathered, padded, group=group)
-    out = np.zeros(sum(len(ix) for ix in shards), dtype=np.float32)
-    out[dst] = gathered.cpu().numpy()[src]
-    return out
+    ordered = torch.zeros(sum(len(ix) for ix in shards), dtype=torch.float32, device=dev)
+    ordered[torch.as_tensor(dst, device=dev)] = gathered[torch.as_tensor(src, device=dev)]
+    return ordered.cpu().numpy()
 
 
 def all_reduce_counts(counts, group=None):

@@ -115,14 +115,21 @@ class PairwiseBatch(object):
         self.requests.append((mode, self._arena_index(sequence_one, 0), self._arena_index(sequence_two, 1), rects))
         return len(self.requests) - 1
 
-    def scores_for_pairs(self, sequences, ii, jj, modes):
+    def scores_for_pairs(self, sequences, ii, jj, modes, on_device=False):
         """Scores only, for the pairs (sequences[ii[k]], sequences[jj[k]]) in mode modes[k] (array of mode names):
         the whole list as one device submission per mode, without a Python-level request per pair (an all-pairs
-        stage of 400 sequences is 79 800 requests).  Both roles must use the same track sets."""
+        stage of 400 sequences is 79 800 requests).  Both roles must use the same track sets.
+        on_device: return a float32 torch tensor on the library's device instead of a numpy array - the kernels write
+        straight into it (the exchange step of a multi-GPU stage then never moves its shard through host memory)."""
         if self.ids_one != self.ids_two:
             raise ComponentError("scores_for_pairs needs identical track id sets for both sequences")
         ii, jj, modes = np.asarray(ii), np.asarray(jj), np.asarray(modes)
-        out = np.zeros(len(ii), dtype=np.float32)
+        if on_device:
+            import torch
+            out = torch.zeros(max(len(ii), 1), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))[:len(ii)]
+            torch.cuda.current_stream().synchronize()      # the library's stream must see the zero fill
+        else:
+            out = np.zeros(len(ii), dtype=np.float32)
         if len(ii) == 0:
             return out
         idx = np.array([self._arena_index(seq, 0) for seq in sequences], dtype=np.int32)
@@ -135,8 +142,19 @@ class PairwiseBatch(object):
                 pairs = np.stack([idx[ii[sel]], idx[jj[sel]]], axis=1).astype(np.int32)
                 plan = native.Plan(arena, pairs, want_paths=False)
                 try:
-                    plan.run(mode, self.gap_open, self.gap_extend)
-                    out[sel] = plan.scores()
+                    if on_device and len(sel) == len(ii):
+                        plan.run(mode, self.gap_open, self.gap_extend, d_scores=out.data_ptr())
+                        native.synchronize()
+                    elif on_device:
+                        import torch
+                        part = torch.zeros(len(sel), dtype=torch.float32, device=out.device)
+                        torch.cuda.current_stream().synchronize()
+                        plan.run(mode, self.gap_open, self.gap_extend, d_scores=part.data_ptr())
+                        native.synchronize()
+                        out[torch.as_tensor(sel, device=out.device)] = part
+                    else:
+                        plan.run(mode, self.gap_open, self.gap_extend)
+                        out[sel] = plan.scores()
                 finally:
                     plan.close()
         finally:
@@ -714,7 +732,9 @@ class GuideTreeBuilder(Component):
         pairs = np.stack([ii, jj], axis=1)
         shards = allpairs.shard_columns(lens, pairs, world)
         mine = shards[self.manager.rank]
-        local = batch.scores_for_pairs(sequences, ii[mine], jj[mine], np.asarray(modes)[mine])
+        # under RCCL the shard stays on the device: kernels -> all-gather -> reorder -> ONE copy of the complete list
+        on_device = allpairs.group_is_nccl(self.manager.group)
+        local = batch.scores_for_pairs(sequences, ii[mine], jj[mine], np.asarray(modes)[mine], on_device=on_device)
         return allpairs.all_gather_scores(local, shards, self.manager.rank, world, self.manager.group)
 
 

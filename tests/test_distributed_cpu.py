@@ -112,7 +112,8 @@ def _operator_worker(rank, world, port, out_dir):
     scores_for_pairs, slave_counts = _cpu_seams(comp, ct, util, orc, np)
     calls = {"pairs": 0, "prepairs": 0}
 
-    def counted_scores(self, sequences, ii, jj, modes):
+    def counted_scores(self, sequences, ii, jj, modes, on_device=False):
+        assert not on_device            # (gloo: the shard is a numpy array; under RCCL it stays on the device)
         calls["pairs"] += len(ii)
         return scores_for_pairs(self, sequences, ii, jj, modes)
 

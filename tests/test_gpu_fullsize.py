@@ -183,7 +183,7 @@ def test_c3_build_preprofiles_full_size_two_pass_local(nat, bba):
         assert np.array_equal(np.asarray(tracks[i].counts), np.asarray(want.counts)), i
 
 
-def test_c4_rank_share_full_size(nat, bba):
+def test_c4_rank_share_full_size(nat, bba, monkeypatch):
     """BASELINE config 3: 4096 seqs ~400 aa over 8 ranks - one rank's column shard (1.05 M pairs, 1.7e11
     cells), float profiles and one-hot: finite scores, exact symmetry and self-alignment under integer
     scoring, oracle spot checks."""
@@ -228,19 +228,32 @@ def test_c4_rank_share_full_size(nat, bba):
             i, j = mine[k]
             assert scm[k] == np.float32(orc.pairwise_score_fast(mode, one_hot(vals[i], 27), one_hot(vals[j], 27), S, GO, GE)), mode
     arena.close()
-    # float profiles on a 150 k-pair part of the same shard
+    # float profiles on the WHOLE shard (1.05 M pairs: the pipeline workgroups, k_dp_pipe): 24 pairs against the oracle in
+    # the reference's summation order (1e-5 relative, north_star) and bit for bit against the oracle DP on the device's own
+    # match scores; a 40 000-pair sample bit for bit against the task schedule's kernel (k_dp_split16)
     profs = [synth_profile(rng, int(L))[0] for L in lens]
     arena = nat.Arena(profs, S)
-    part = mine[::7]
-    plan = nat.Plan(arena, part)
+    plan = nat.Plan(arena, mine)
     plan.run("global", GO, GE)
-    scf = plan.scores()
+    scf = plan.scores().copy()
+    kind, kernel = plan.match_kind(), plan.kernel_name()
     plan.close()
     assert np.isfinite(scf).all()
-    for k in rng.integers(0, len(part), 4):
-        i, j = part[k]
+    for k in rng.choice(len(mine), 24, replace=False):
+        i, j = mine[k]
         ref = orc.pairwise_score_fast("global", profs[i], profs[j], S, GO, GE)
-        assert abs(scf[k] - ref) <= 1e-5 * abs(ref)
+        assert abs(scf[k] - ref) <= 1e-5 * abs(ref), (i, j)
+        s_or, _ = oracle_dp_on_m("global", arena.match_scores(int(i), int(j), kind))
+        assert scf[k] == np.float32(s_or), (i, j)
+    if "k_dp_pipe" in kernel:
+        monkeypatch.setenv("PRALINE_NO_PIPE", "1")
+        sample = np.sort(rng.choice(len(mine), 40000, replace=False))
+        plan = nat.Plan(arena, mine[sample])
+        plan.run("global", GO, GE)
+        assert "k_dp_pipe" not in plan.kernel_name()
+        assert np.array_equal(bits(plan.scores()), bits(scf[sample]))
+        plan.close()
+        monkeypatch.delenv("PRALINE_NO_PIPE")
     arena.close()
 
 

@@ -636,3 +636,42 @@ def test_preprofile_stage_behind_execute_many(env, seqs, monkeypatch):
     mixed = core.run(ex)
     assert np.array_equal(np.asarray(mixed[0]['alignment'].path), d["global_m0_msa_path"])
     assert np.array_equal(mixed[1]['profile_track'].counts, outs["serial"][1][0].counts)
+
+
+def test_score_shard_stays_on_the_device_through_the_exchange(env, seqs):
+    """Under RCCL the all-pairs stage keeps its score shard on the device: PairwiseBatch.scores_for_pairs(on_device=True)
+    lets the kernels write into a torch tensor, allpairs.all_gather_scores gathers and reorders it there and copies the
+    complete list once (the benchmarked path, bench.py).  One rank here (a one-rank nccl group exercises the RCCL call):
+    the result equals the host path's bit for bit, for one mode and for a mixed-mode list."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from praline_amd import allpairs
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    torch.cuda.set_device(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert allpairs.group_is_nccl(None)
+        n = len(seqs)
+        ii, jj = np.triu_indices(n, k=1)
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        shards = allpairs.shard_columns(lens, np.stack([ii, jj], axis=1), 1)
+        for modes in (np.array(["global"] * len(ii)), np.array(["global", "semiglobal_both", "local"])[np.arange(len(ii)) % 3]):
+            batch = comp.PairwiseBatch(T_IN, T_IN, [env["blosum"]], [-11.0, -1.0])
+            mine = shards[0]
+            host = batch.scores_for_pairs(seqs, ii[mine], jj[mine], modes[mine])
+            dev = batch.scores_for_pairs(seqs, ii[mine], jj[mine], modes[mine], on_device=True)
+            assert isinstance(dev, torch.Tensor) and dev.is_cuda
+            assert np.array_equal(dev.cpu().numpy(), host)
+            full = allpairs.all_gather_scores(dev, shards, 0, 1, None)
+            want = np.zeros(len(ii), dtype=np.float32)
+            want[mine] = host
+            assert np.array_equal(full, want)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -210,8 +210,9 @@ def test_c2_float_profile_alignments_vs_reference_order(nat, bba):
     except OSError:
         pass
     print("C2 float-profile path parity:", json.dumps(stats))
-    # the fast mode is allowed to differ only on rounding-level ties, and rarely
-    assert stats["paths_differing_total"] <= 0.02 * stats["alignments"], stats
+    # the fast mode is allowed to differ only on rounding-level ties, and rarely: 1 of 10 240 alignments was measured
+    # (profiles/r02_parity_c2_float_paths.json); ten times that is the bound
+    assert stats["paths_differing_total"] <= 0.001 * stats["alignments"], stats
 
 
 def test_wide_alphabets_take_the_reference_order_path(nat):
