@@ -499,12 +499,32 @@ def main():
         pl5 = native.Plan(a5, s5)
         variants["c5_shard_gcups"] = c5 / timed(lambda: (a5.premultiply(), pl5.run("global", GAP_OPEN, GAP_EXTEND)), reps=2) / 1e9
         variants["c5_shard_kernel"] = pl5.kernel_name()
+        pl5.close()
+        # ... and ALL 130 816 pairs of C5 (3.3e12 cells) on this one GPU
+        pl5 = native.Plan(a5, p5)
+        c5_all = int((w5["lens"][p5[:, 0]].astype(np.int64) * w5["lens"][p5[:, 1]]).sum())
+        variants["c5_all_pairs_one_gpu_gcups"] = c5_all / timed(lambda: (a5.premultiply(), pl5.run("global", GAP_OPEN, GAP_EXTEND)), reps=2) / 1e9
         pl5.close(); a5.close()
+        del w5
+        # the preprofile stage of C3 from Sequences to ProfileTracks (component.build_preprofiles: N (N - 1) alignments with
+        # paths per pass, counting on the device paths; host-inclusive wall time)
+        from praline_amd import component as comp_, container as ct_
+        rng3 = np.random.default_rng(3)
+        l3 = synth_lengths(rng3, 1024, 250)
+        seqs3 = [ct_.Sequence("s%d" % k, [(ct_.TRACK_ID_INPUT, ct_.PlainTrack(None, ct_.ALPHABET_AA, raw_indices=rng3.integers(0, 20, int(L))))])
+                 for k, L in enumerate(l3)]
+        for m3, it3 in (("global", 1), ("local", 2)):
+            comp_.build_preprofiles(seqs3, ct_.TRACK_ID_INPUT, ct_.blosum62(), mode=m3, waterman_eggert_iterations=it3)
+            t_a = time.perf_counter()
+            comp_.build_preprofiles(seqs3, ct_.TRACK_ID_INPUT, ct_.blosum62(), mode=m3, waterman_eggert_iterations=it3)
+            variants["c3_build_preprofiles_%s_ms" % m3] = (time.perf_counter() - t_a) * 1e3
+        del seqs3
         native.pool_trim()
         variants["note"] = ("driver-timed like `value` (inputs / results in HBM).  with_paths = fill with packed traceback + "
                             "end cells + device traceback; onehot = integer scoring (bit-exact mode); f32_chain = fp32 MFMA "
                             "match scores; reference_order = PRALINE_MATCH_REFERENCE (bit-identical alignments for float "
-                            "profiles); c3 = all 1 047 552 ordered pairs with paths; c4 = shard 3 of 8; c5 = shard 5 of 14")
+                            "profiles); c3 = all 1 047 552 ordered pairs with paths (build_preprofiles: sequences in, profile tracks "
+                            "out, local = two Waterman-Eggert passes); c4 = shard 3 of 8; c5 = shard 5 of 14")
         out["variants"] = variants
 
     # ---- CPU baseline: the oracle (C restatement of the reference path) on the host cores ----

@@ -436,6 +436,10 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     std::vector<char> has_mass(A, 0), has_score(A, 0);
     std::vector<unsigned char> sym_raw((size_t)rr, 255);
     bool all_onehot_rows = true;
+    // ... and whether some value is NOT a normal float16 (13 low mantissa bits set, or an exponent outside -14 .. 15): such
+    // an arena needs the hi/lo split whatever S is, so the device-side exactness check (and the second packing launch
+    // that follows its read-back) can be skipped - float profiles, i.e. every preprofile / profile-profile stage
+    unsigned inexact_bits = 0;
     {
         std::vector<int> col_nz(A, 0);
         for (int64_t r = 0; r < rr; ++r) {
@@ -447,6 +451,10 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
                 nz += is_nz;
                 hot += is_nz * i;
                 ones += row[i] == 1.0f;
+                unsigned u;
+                memcpy(&u, &row[i], 4);
+                const unsigned e = (u >> 23) & 0xffu;
+                inexact_bits |= is_nz ? ((u & 0x1fffu) | (unsigned)(e < 113u) | (unsigned)(e > 142u)) : 0u;
             }
             if (nz == 1 && ones == 1) sym_raw[(size_t)r] = (unsigned char)hot;
             else all_onehot_rows = false;
@@ -515,14 +523,24 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         (rc = a->d_P.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) ||
         (rc = a->d_flag16.alloc(1)) || (a->onehot && (rc = a->d_sym8.upload(sym8, st))) || (rc = a->d_sym_raw.upload(sym_raw, st)) ||
         (a->nr16 > 0 && ((rc = a->d_P16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)) ||
-                         (rc = a->d_Q16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)))) ||
-        (rc = arena_launch_premultiply(a, true))) {
+                         (rc = a->d_Q16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16))))) {
         delete a;
         return rc;
     }
+    const bool host_knows_split = a->nr16 > 0 && inexact_bits != 0;
+    if (host_knows_split) {
+        // profiles that float16 cannot hold: three terms (K-packed into four MFMAs for at most 21 active symbols), one
+        // fused pack / pre-multiply / split launch, no read-back
+        const char *pk = getenv("PRALINE_PACKED3");
+        a->nterm16 = (a->nr16 == 2 && 3 * a->n_active <= 63 && !(pk && pk[0] == '0')) ? 2 : 3;
+        rc = arena_launch_premultiply(a);
+    } else {
+        rc = arena_launch_premultiply(a, true);
+    }
+    if (rc != PRALINE_OK) { delete a; return rc; }
     hipError_t e = hipStreamSynchronize(st);  // host vectors above go out of scope
     if (e != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena upload: %s", hipGetErrorString(e)); }
-    if (a->nr16 > 0) {
+    if (a->nr16 > 0 && !host_knows_split) {
         int flag = 1;
         e = hipMemcpy(&flag, a->d_flag16.p, sizeof(int), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena flag: %s", hipGetErrorString(e)); }
