@@ -439,7 +439,15 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     // ... and whether some value is NOT a normal float16 (13 low mantissa bits set, or an exponent outside -14 .. 15): such
     // an arena needs the hi/lo split whatever S is, so the device-side exactness check (and the second packing launch
     // that follows its read-back) can be skipped - float profiles, i.e. every preprofile / profile-profile stage
+    // (looked for in the first 64 K values only: float profiles show one in their first rows, and arenas that show none
+    // there keep the device-side check)
     unsigned inexact_bits = 0;
+    for (int64_t k = 0, n = std::min<int64_t>(rr * A, 65536); k < n && !inexact_bits; ++k) {
+        unsigned u;
+        memcpy(&u, &profiles[k], 4);
+        const unsigned e = (u >> 23) & 0xffu;
+        if (u & 0x7fffffffu) inexact_bits = (u & 0x1fffu) | (unsigned)(e < 113u) | (unsigned)(e > 142u);
+    }
     {
         std::vector<int> col_nz(A, 0);
         for (int64_t r = 0; r < rr; ++r) {
@@ -451,10 +459,6 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
                 nz += is_nz;
                 hot += is_nz * i;
                 ones += row[i] == 1.0f;
-                unsigned u;
-                memcpy(&u, &row[i], 4);
-                const unsigned e = (u >> 23) & 0xffu;
-                inexact_bits |= is_nz ? ((u & 0x1fffu) | (unsigned)(e < 113u) | (unsigned)(e > 142u)) : 0u;
             }
             if (nz == 1 && ones == 1) sym_raw[(size_t)r] = (unsigned char)hot;
             else all_onehot_rows = false;
