@@ -12,5 +12,11 @@ struct Arena16Dev {
     int stage;              // 1: use the LDS-staged operand stream (k_dp_split16 BSRC = 2)
     int row_bytes;          // 2 * half_bytes
     int half_bytes;         // 2 (pieces) * NR * 16
+    // dense-tile instances (BSRC = 4, reference-order match scores, dp_reftile.hip.h): task t's tile at dense + dense_off[t]
+    const float *dense = nullptr;
+    const int64_t *dense_off = nullptr;
 };
+#ifndef PRALINE_DENSE_PAD
+#define PRALINE_DENSE_PAD 24   // rows per strip of a dense tile beyond max_l1 (row 0 + the DP kernels' look-ahead)
+#endif
 

@@ -4,6 +4,7 @@
 #pragma once
 #include "dp_kernels.hip.h"
 #include "dp_arena16.h"
+#include "dp_reftile.h"
 #include "praline_dp.h"
 
 struct LaunchArgs {
@@ -73,6 +74,15 @@ int praline_launch_tb2_backward(const LaunchArgs &la, const Arena16Dev &a16, con
 // the same forward fill on the staged scores kernel (k_dp_split16<..., KEEP>, la.wg workgroups): la.bnd its (H, L) hand-off
 // columns, keep_bnd / ckpt the kept columns (at tk.aux_off) and row checkpoints (at tk.tb_off)
 int praline_launch_keep_forward(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, void *keep_bnd, float *ckpt);
+// reference-order match scores in the split-strip layout (dp_dense_instance.hip): the interleaved table, the tile kernel,
+// and the dense-tile instances of the scores / path kernels (a16.dense, a16.dense_off set)
+int praline_launch_build_reft2(const float *raw, const float *S, int A, const int32_t *row_off_raw, const int32_t *len,
+                               const int64_t *pr_off, int64_t PR, const unsigned char *nzidx, const unsigned char *nzcnt,
+                               const int32_t *set_lo, int n_sets, int TB, float *T2, int n_seqs, hipStream_t stream);
+bool praline_match_tile_supported(int A, int TB);
+int praline_launch_match_tile(const RefTileArgs &g, int TB, unsigned n_blocks, hipStream_t stream);
+int praline_launch_dense(const LaunchArgs &la, const Arena16Dev &a16, bool local);
+int praline_launch_dense_tb(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask);
 // k_dp_batch on dense reference-order match scores (dp_ref_instance.hip)
 int praline_launch_dp_ref(const LaunchArgs &la, bool local, int out, int mask);
 // k_dp_batch instances (dp_instance.hip)

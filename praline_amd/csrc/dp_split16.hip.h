@@ -226,7 +226,8 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     static_assert(!DM || BSRC == 2 || BSRC == 1, "the double-MFMA tile is wired for the staged stream and the one-hot table");
     static_assert(KEEP == 0 || !DM, "the kept states are taken from the non-DM tile");
     constexpr bool ONEHOT = BSRC == 1;
-    constexpr bool LOOKUP = BSRC == 3;   // CUR: this lane's 16 match scores of its row; PREV receives the next row's (symbol symw)
+    constexpr bool DENSE = BSRC == 4;    // the next row's scores are read from a dense tile (dp_reftile.hip.h) at onehot_lane
+    constexpr bool LOOKUP = BSRC == 3 || DENSE;   // CUR: this lane's 16 match scores of its row; PREV receives the next row's (symbol symw)
     // bnd_pref: this step's boundary value on entry; refilled with the value 3 rows ahead.
     // BOPS: B operands of row t+1 on entry; refilled with row t+4 (3-deep rings, the caller rotates
     // the register names through a 6x unrolled loop).
@@ -282,7 +283,14 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    if constexpr (LOOKUP) {
+    if constexpr (DENSE) {
+        // the next row's match scores: one 64-byte line of the task's dense tile, read once (streaming loads)
+        const f4n *q = reinterpret_cast<const f4n *>(onehot_lane);
+        const f4n a0 = __builtin_nontemporal_load(q), a1 = __builtin_nontemporal_load(q + 1), a2 = __builtin_nontemporal_load(q + 2),
+                  a3 = __builtin_nontemporal_load(q + 3);
+        PREV[0] = a0.x; PREV[1] = a0.y; PREV[2] = a0.z; PREV[3] = a0.w; PREV[4] = a1.x; PREV[5] = a1.y; PREV[6] = a1.z; PREV[7] = a1.w;
+        PREV[8] = a2.x; PREV[9] = a2.y; PREV[10] = a2.z; PREV[11] = a2.w; PREV[12] = a3.x; PREV[13] = a3.y; PREV[14] = a3.z; PREV[15] = a3.w;
+    } else if constexpr (LOOKUP) {
         // the next row's match scores: this lane's 16 strip columns of the table row of that row's symbol
         const float4 *q = reinterpret_cast<const float4 *>(onehot_lane + symw * lookup_stride());
         const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
@@ -461,7 +469,7 @@ __device__ unsigned long long *praline_trace_buf = nullptr;
 #define PRALINE_LOOKUP_WAVES 3   // waves per SIMD the lookup instances are compiled for (168 VGPRs)
 #endif
 template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int WPG = 1, bool KEEP = false>
-__global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES : 1)) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(256, KEEP ? 2 : ((BSRC == 3 || BSRC == 4) ? PRALINE_LOOKUP_WAVES : 1)) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ lane_one,
                                                     const int32_t *__restrict__ lane_pair, float2 *bnd,
                                                     float *__restrict__ scores, RunParams rp, int n_tasks,
@@ -473,7 +481,9 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
     static_assert(WPG == 1 || (WPG == 4 && (BSRC == 2 || BSRC == 3)), "four-wave workgroups use the staged stream or the match-score lookup");
     constexpr bool LOOKUP = BSRC == 3;
+    constexpr bool DENSE = BSRC == 4;   // match scores from the task's dense tile (ar.dense, dp_reftile.hip.h): no operands at all
     static_assert(!LOOKUP || (NTERM == 1 && !KEEP), "the match-score lookup is an exact-mode path");
+    static_assert(!DENSE || (NTERM == 1 && !KEEP && WPG == 1), "the dense-tile instances are plain one-task waves");
     constexpr bool MW = WPG > 1;
     constexpr bool SNAPBR = LOCAL && !MW;   // see split16_step
 #ifdef PRALINE_TRACE
@@ -546,6 +556,12 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
     const unsigned *pSym = reinterpret_cast<const unsigned *>(ar.sym8 + (have_pair ? ar.row_off[my_one] : 0));
     char *lookup_tab = lookup_all + (LOOKUP ? wv * lookup_bytes(NR) : 0);
     const char *onehot_lane = LOOKUP ? lookup_tab + h * 64 : onehot_tab + h * (16 * NR);
+    // DENSE: this lane's 64-byte line of row y of strip s is at dense_task + s * dense_strip + y * 4096 (the upper half's
+    // pointer is one row back: at step T both halves fetch "row T + 1")
+    const int64_t dense_strip = (int64_t)(max_l1 + PRALINE_DENSE_PAD) * 4096;
+    const char *dense_task = DENSE ? reinterpret_cast<const char *>(ar.dense + ar.dense_off[task]) + (int64_t)lane * 64 - (int64_t)h * 4096
+                                   : nullptr;
+    const char *dense_lane = dense_task;
     // STAGED: per-lane source offsets of the DMA pieces and LDS read addresses (see the comment above)
     unsigned stage_gofs[4] = {0, 0, 0, 0}, stage_rd[4] = {0, 0, 0, 0};
     const unsigned stage_rd_bnd = (unsigned)j * 8u;
@@ -634,7 +650,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
         const bool last_owner = (s == nstrips - 1) && own_last;
 
         float4 aop[NOP];
-        if constexpr (!LOOKUP) {
+        if constexpr (!LOOKUP && !DENSE) {
             const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.row_bytes);
 #pragma unroll
             for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
@@ -719,6 +735,17 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
             cb += 64 * NR;
             stage_cur[0] = cb;  // next: operand row 6 (step 1)
             stage_cur[1] = cn;  // next: boundary row 5 (step 1)
+        } else if constexpr (DENSE) {
+            // row 1 of the strip (the upper half takes row 0: its first step is undone below)
+            dense_lane = dense_task + (int64_t)s * dense_strip;
+            const f4n *q = reinterpret_cast<const f4n *>(dense_lane + 4096);
+            const f4n a0 = __builtin_nontemporal_load(q), a1 = __builtin_nontemporal_load(q + 1), a2 = __builtin_nontemporal_load(q + 2),
+                      a3 = __builtin_nontemporal_load(q + 3);
+            accA[0] = a0.x; accA[1] = a0.y; accA[2] = a0.z; accA[3] = a0.w; accA[4] = a1.x; accA[5] = a1.y; accA[6] = a1.z; accA[7] = a1.w;
+            accA[8] = a2.x; accA[9] = a2.y; accA[10] = a2.z; accA[11] = a2.w; accA[12] = a3.x; accA[13] = a3.y; accA[14] = a3.z; accA[15] = a3.w;
+            p0 = *reinterpret_cast<const float2 *>(my_bnd + BROW);      // row 1
+            p1 = *reinterpret_cast<const float2 *>(my_bnd + 2 * BROW);  // row 2
+            p2 = *reinterpret_cast<const float2 *>(my_bnd + 3 * BROW);  // row 3
         } else if constexpr (LOOKUP) {
             // this strip's table: lane (c = lane & 31, half hh) transposes the hi pieces of half hh of the pre-multiplied
             // row x0 + c (exact mode: Q2 = hi exactly), k = 16 r + 8 hh + jj  ->  lookup_tab[k][c]
@@ -793,6 +820,13 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
                                        bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYM, \
                                        nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
+        // dense tile: CUR holds this row's scores, PREV receives the next row's (lower half: row T + 1, upper half: row T)
+#define PRALINE_STEP16M(T, CUR, PREV, PSLOT)                                                                          \
+        split16_step<NR, NTERM, LOCAL, 4, 0, false, SNAPBR>((T) - h, L1, have_pair, h, CUR, PREV, b0, aop, aop, b0, b0, b_next, b_stride, bnd_ld, \
+                                       bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
+                                       out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2,           \
+                                       dense_lane + (int64_t)((T) + 1) * 4096, 0u,                                     \
+                                       nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
         // one-hot table with DM: BUSE holds row T+1, BOLD row T (refilled with row T+4 once its MFMAs are issued)
 #define PRALINE_STEP16XD(T, CUR, PREV, BUSE, BOLD, PSLOT, SYMW, SB)                                                   \
         split16_step<NR, NTERM, LOCAL, BSRC, SB, true, SNAPBR>((T) - h, L1, have_pair, h, CUR, PREV, BUSE, aop, aopH, BOLD, BOLD, b_next, b_stride, bnd_ld, \
@@ -828,7 +862,8 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
 #pragma unroll
             for (int c = 0; c < 17; ++c) Hsave[c] = Hs[c];
             const float best_s = best_run, col_s = col_run;
-            if constexpr (LOOKUP) PRALINE_STEP16L(1, accA, accB, p0, ((h ? (lw0 << 8) : lw0) >> 8) & 0xffu);
+            if constexpr (DENSE) PRALINE_STEP16M(1, accA, accB, p0);
+            else if constexpr (LOOKUP) PRALINE_STEP16L(1, accA, accB, p0, ((h ? (lw0 << 8) : lw0) >> 8) & 0xffu);
             else if constexpr (DM && ONEHOT) PRALINE_STEP16XD(1, accA, accB, b0, b3, p0, d1, 0);
             else if constexpr (DM) PRALINE_STEP16D(1, accA, accB, b0, b1, 1, b2);
             else if constexpr (STAGED) PRALINE_STEP16S(1, accA, accB, b0, b1, 1);
@@ -878,6 +913,21 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
                 PRALINE_STEP16S(t + 10, accB, accA, b1, b0, 0);
                 PRALINE_STEP16S(t + 11, accA, accB, b0, b1, 1);
                 }
+            }
+        } else if constexpr (DENSE) {
+            for (int t = 2; t <= max_l1 + 1; t += 12) {
+                PRALINE_STEP16M(t, accB, accA, p1);
+                PRALINE_STEP16M(t + 1, accA, accB, p2);
+                PRALINE_STEP16M(t + 2, accB, accA, p0);
+                PRALINE_STEP16M(t + 3, accA, accB, p1);
+                PRALINE_STEP16M(t + 4, accB, accA, p2);
+                PRALINE_STEP16M(t + 5, accA, accB, p0);
+                PRALINE_STEP16M(t + 6, accB, accA, p1);
+                PRALINE_STEP16M(t + 7, accA, accB, p2);
+                PRALINE_STEP16M(t + 8, accB, accA, p0);
+                PRALINE_STEP16M(t + 9, accA, accB, p1);
+                PRALINE_STEP16M(t + 10, accB, accA, p2);
+                PRALINE_STEP16M(t + 11, accA, accB, p0);
             }
         } else if constexpr (LOOKUP) {
             const unsigned *pn = pSym + 4;
@@ -957,6 +1007,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
         }
 #undef PRALINE_STEP16
 #undef PRALINE_STEP16L
+#undef PRALINE_STEP16M
 #undef PRALINE_STEP16S
 #undef PRALINE_STEP16K
 #undef PRALINE_STEP16D

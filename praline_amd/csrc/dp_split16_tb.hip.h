@@ -109,13 +109,22 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     // BSRC = 3 (one-hot arenas, integer scoring): the match scores are looked up in the strip's LDS table
     // (dp_split16.hip.h, lookup_stride): CUR holds this lane's 16 scores of its row, PREV receives the next row's (symbol
     // symw) - no MFMA, no operand registers, no accumulator tiles.
-    constexpr bool LOOKUP = BSRC == 3;
+    // BSRC = 4 (reference-order match scores): the same, the next row's scores read from the task's dense tile
+    // (dp_reftile.hip.h) at onehot_lane; any profiles - the NTERM = 3 instances, which compare the candidate sums
+    constexpr bool DENSE = BSRC == 4;
+    constexpr bool LOOKUP = BSRC == 3 || DENSE;
     constexpr int NM = LOOKUP ? 1 : NTERM * NR;
     constexpr bool INTS = NTERM == 1;
     float m[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) m[c] = (DM || LOOKUP) ? CUR[c] : (h ? PREV[c] : CUR[c]);
-    if constexpr (LOOKUP) {
+    if constexpr (DENSE) {
+        const f4n *q = reinterpret_cast<const f4n *>(onehot_lane);
+        const f4n a0 = __builtin_nontemporal_load(q), a1 = __builtin_nontemporal_load(q + 1), a2 = __builtin_nontemporal_load(q + 2),
+                  a3 = __builtin_nontemporal_load(q + 3);
+        PREV[0] = a0.x; PREV[1] = a0.y; PREV[2] = a0.z; PREV[3] = a0.w; PREV[4] = a1.x; PREV[5] = a1.y; PREV[6] = a1.z; PREV[7] = a1.w;
+        PREV[8] = a2.x; PREV[9] = a2.y; PREV[10] = a2.z; PREV[11] = a2.w; PREV[12] = a3.x; PREV[13] = a3.y; PREV[14] = a3.z; PREV[15] = a3.w;
+    } else if constexpr (LOOKUP) {
         const float4 *q = reinterpret_cast<const float4 *>(onehot_lane + symw * lookup_stride());
         const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
         PREV[0] = a0.x; PREV[1] = a0.y; PREV[2] = a0.z; PREV[3] = a0.w; PREV[4] = a1.x; PREV[5] = a1.y; PREV[6] = a1.z; PREV[7] = a1.w;
@@ -343,7 +352,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #define PRALINE_TB_LOOKUP_WAVES 2   // waves per SIMD of the lookup instances (no operand / accumulator registers)
 #endif
 template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool TWOPASS = false, int BSRC = 0>
-__global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC == 3 ? PRALINE_TB_LOOKUP_WAVES : PRALINE_TB_WAVES_PER_SIMD)) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : ((BSRC == 3 || BSRC == 4) ? PRALINE_TB_LOOKUP_WAVES : PRALINE_TB_WAVES_PER_SIMD)) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one,
                                                        const int32_t *__restrict__ lane_pair, float4 *bnd,
                                                        uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,
@@ -355,11 +364,13 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
     constexpr bool LOOKUP = BSRC == 3;
-    constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0) && !LOOKUP;   // see split16_tb_step
+    constexpr bool DENSE = BSRC == 4;   // match scores from the task's dense tile (ar.dense): no operands, no MFMA
+    constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0) && !LOOKUP && !DENSE;   // see split16_tb_step
     constexpr int SINK = TWOPASS ? 1 : 0;
     static_assert(!(CHAIN && TWOPASS), "the two-pass fill is a task-mode kernel");
-    static_assert(BSRC == 0 || (BSRC == 1 && TWOPASS && DM) || (LOOKUP && NTERM == 1 && !TWOPASS),
-                  "the one-hot table feeds the single-term forward fill; the lookup serves the single-pass integer-scoring fill");
+    static_assert(BSRC == 0 || (BSRC == 1 && TWOPASS && DM) || (LOOKUP && NTERM == 1 && !TWOPASS) || (DENSE && NTERM == 3 && !TWOPASS),
+                  "the one-hot table feeds the single-term forward fill; the lookup serves the single-pass integer-scoring fill; "
+                  "dense tiles feed the single-pass fill with candidate sums");
     __shared__ __attribute__((aligned(16))) char lookup_all[LOOKUP ? 4 * lookup_bytes(NR) : 16];   // one table per wave of the block
     __shared__ __attribute__((aligned(16))) char onehot_tab[BSRC == 1 ? onehot_bytes(NR) : 16];
     if constexpr (BSRC == 1) {
@@ -409,6 +420,12 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
     // LOOKUP: at step T the lower half fetches the scores of row T + 1 (symbol byte T of the sequence), the upper half
     // those of row T (byte T - 1)
     const unsigned char *psym = LOOKUP ? ar.sym8 + (have_pair ? ar.row_off[my_one] : 0) - h : nullptr;
+    // DENSE: this lane's 64-byte line of row y of strip s is at dense_task + s * dense_strip + y * 4096 (the upper half's
+    // pointer is one row back: at step T both halves fetch "row T + 1")
+    const int64_t dense_strip = (int64_t)(max_l1 + PRALINE_DENSE_PAD) * 4096;
+    const char *dense_task = DENSE ? reinterpret_cast<const char *>(ar.dense + ar.dense_off[task]) + (int64_t)lane * 64 - (int64_t)h * 4096
+                                   : nullptr;
+    const char *dense_lane = dense_task;
 
     if (CHAIN && chain_strip >= nstrips) return;
     // boundary columns: float4 [y][32]; chain mode keeps one per strip boundary, [strip][y][32]
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
             srect[r][3] = 0;
         }
         float4 aop[NOP];
-        if constexpr (!LOOKUP) {
+        if constexpr (!LOOKUP && !DENSE) {
             const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.row_bytes);
 #pragma unroll
             for (int q = 0; q < NOP; ++q) aop[q] = sa[q];
@@ -523,7 +540,15 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
         f32x16 accB = accA;
         unsigned sw0 = 0;   // BSRC == 1: the symbols of rows 1 .. 4
         unsigned symA = 0, symB = 0, symC = 0;   // LOOKUP: the symbols three steps ahead (rotate like the boundary prefetch)
-        if constexpr (LOOKUP) {
+        if constexpr (DENSE) {
+            // row 1 of the strip (the upper half takes row 0: its first step is undone below)
+            dense_lane = dense_task + (int64_t)s * dense_strip;
+            const f4n *q = reinterpret_cast<const f4n *>(dense_lane + 4096);
+            const f4n a0 = __builtin_nontemporal_load(q), a1 = __builtin_nontemporal_load(q + 1), a2 = __builtin_nontemporal_load(q + 2),
+                      a3 = __builtin_nontemporal_load(q + 3);
+            accA[0] = a0.x; accA[1] = a0.y; accA[2] = a0.z; accA[3] = a0.w; accA[4] = a1.x; accA[5] = a1.y; accA[6] = a1.z; accA[7] = a1.w;
+            accA[8] = a2.x; accA[9] = a2.y; accA[10] = a2.z; accA[11] = a2.w; accA[12] = a3.x; accA[13] = a3.y; accA[14] = a3.z; accA[15] = a3.w;
+        } else if constexpr (LOOKUP) {
             // this strip's table: lane (column j, half h) transposes the hi pieces of half h of the pre-multiplied row
             // x0 + j (exact mode: Q2 = hi exactly), k = 16 r + 8 h + jj  ->  lookup_tab[k][j]
             const char *src = ar.Q16 + ((int64_t)ar.row_off[two] + x0 + j) * ar.row_bytes + h * ar.half_bytes;
@@ -604,6 +629,13 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
                                                 xb, srect, chain_in, &chain_seen, (T) + 3, ckpt_strip, nullptr, 0,          \
                                                 onehot_lane, SYM);                                                          \
         SYM = psym[(T) + 3];
+        // dense tile: the step fetches the next row's scores (lower half: row T + 1, upper half: row T)
+#define PRALINE_TB_STEP_DN(T, CUR, PREV, PREF)                                                                        \
+        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, false, SINK, 4>((T) - h, L1, have_pair, h, CUR, PREV, bX, bX, aop, aopH, \
+                                                b_next, b_stride, bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl,   \
+                                                cpxm, cpxu, cpxl, cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge,  \
+                                                xb, srect, chain_in, &chain_seen, (T) + 3, ckpt_strip, nullptr, 0,          \
+                                                dense_lane + (int64_t)((T) + 1) * 4096, 0u);
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
             const int yy_ = (T) - h;                                                                                 \
@@ -626,7 +658,8 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
         {
             const float best_s = best_run;
             const int by = best_y, bx = best_x, bk = best_k;
-            if constexpr (LOOKUP) { PRALINE_TB_STEP_LK(1, accA, accB, bnd_prefA, symA) }
+            if constexpr (DENSE) { PRALINE_TB_STEP_DN(1, accA, accB, bnd_prefA) }
+            else if constexpr (LOOKUP) { PRALINE_TB_STEP_LK(1, accA, accB, bnd_prefA, symA) }
             else if constexpr (BSRC == 1) PRALINE_TB_STEP_OH(1, accA, accB, bX, bZ, bnd_prefA, sw0, 3);
             else if constexpr (DM) PRALINE_TB_STEP(1, accA, accB, bX, bZ, bnd_prefA);
             else PRALINE_TB_STEP(1, accA, accB, bX, bX, bnd_prefA);
@@ -686,7 +719,20 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
                 // their consumers are dispatched a round later anyway (chain_every, set by the host)
                 if (t - 2 >= chain_next) { chain_publish(chain_out, t - 2, lane); chain_next = t - 2 + chain_every; }
             }
-            if constexpr (LOOKUP) {
+            if constexpr (DENSE) {
+                PRALINE_TB_STEP_DN(t, accB, accA, bnd_prefB)
+                PRALINE_TB_TAILS(t)
+                PRALINE_TB_STEP_DN(t + 1, accA, accB, bnd_prefC)
+                PRALINE_TB_TAILS(t + 1)
+                PRALINE_TB_STEP_DN(t + 2, accB, accA, bnd_prefA)
+                PRALINE_TB_TAILS(t + 2)
+                PRALINE_TB_STEP_DN(t + 3, accA, accB, bnd_prefB)
+                PRALINE_TB_TAILS(t + 3)
+                PRALINE_TB_STEP_DN(t + 4, accB, accA, bnd_prefC)
+                PRALINE_TB_TAILS(t + 4)
+                PRALINE_TB_STEP_DN(t + 5, accA, accB, bnd_prefA)
+                PRALINE_TB_TAILS(t + 5)
+            } else if constexpr (LOOKUP) {
                 PRALINE_TB_STEP_LK(t, accB, accA, bnd_prefB, symB)
                 PRALINE_TB_TAILS(t)
                 PRALINE_TB_STEP_LK(t + 1, accA, accB, bnd_prefC, symC)
@@ -729,6 +775,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
         }
 #undef PRALINE_TB_STEP
 #undef PRALINE_TB_STEP_LK
+#undef PRALINE_TB_STEP_DN
 #undef PRALINE_TB_STEP_OH
 #undef PRALINE_TB_TAILS
         if constexpr (CHAIN) chain_publish(chain_out, PRALINE_CHAIN_DONE, lane);

@@ -342,6 +342,11 @@ struct praline_arena {
     DevBuf<float> d_reft;    // T[row][i][b] (k_build_reft), ref_tb floats per (row, symbol); ref_tb = 0: not built
     int ref_tb = 0;
     bool ref_ready = false;
+    // the same half-terms with two adjacent columns interleaved, for k_match_tile (dp_reftile.hip.h): T2[i][pair row][b][2]
+    DevBuf<float> d_reft2;
+    DevBuf<int64_t> d_pr_off;   // first pair row of every sequence
+    int64_t pair_rows = 0;
+    int reft2_state = 0;        // 0: not tried, 1: built, -1: not available for this arena (alphabet / row density)
     // resident progressive alignment (praline_arena_append_merged): integer counts of every row, capacities
     DevBuf<int32_t> d_cnt;
     bool have_cnt = false;
@@ -581,6 +586,7 @@ extern "C" int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets
     if (lo.back() != arena->A) return fail(PRALINE_ERR_ARG, "track-set sizes sum to %d, the arena alphabet is %d", lo.back(), arena->A);
     arena->set_lo.swap(lo);
     arena->ref_ready = false;
+    arena->reft2_state = 0;
     return PRALINE_OK;
 }
 
@@ -644,6 +650,28 @@ static int arena_ensure_ref(praline_arena *a)
         a->d_reft.release();
     }
     a->ref_ready = true;
+    return PRALINE_OK;
+}
+
+// the interleaved table of k_match_tile; state -1 when the arena does not qualify (more than 32 symbols, rows with more
+// than 8 nonzeros, table over the limit): such plans keep the k_match_reft / k_dp_batch path
+static int arena_ensure_reft2(praline_arena *a)
+{
+    if (a->reft2_state != 0) return PRALINE_OK;
+    RC(arena_ensure_ref(a));
+    a->reft2_state = -1;
+    if (a->wide || a->nr16 <= 0 || a->ref_tb <= 0 || !praline_match_tile_supported(a->A, a->ref_tb)) return PRALINE_OK;
+    hipStream_t st = g_rt.stream;
+    std::vector<int64_t> pr_off((size_t)a->n_seqs);
+    int64_t pr = 0;
+    for (int64_t q = 0; q < a->n_seqs; ++q) { pr_off[(size_t)q] = pr; pr += (a->len[(size_t)q] + 1) / 2; }
+    a->pair_rows = std::max<int64_t>(pr, 1);
+    RC(a->d_pr_off.upload(pr_off, st));
+    RC(a->d_reft2.alloc((size_t)a->A * (size_t)a->pair_rows * (size_t)a->ref_tb * 2));
+    RC(praline_launch_build_reft2(a->d_raw.p, a->d_S.p, a->A, a->d_row_off_raw.p, a->d_len.p, a->d_pr_off.p, a->pair_rows, a->d_nzidx.p,
+                                  a->d_nzcnt.p, a->d_set_lo.p, (int)a->set_lo.size() - 1, a->ref_tb, a->d_reft2.p, (int)a->n_seqs, st));
+    HIPCHK(hipStreamSynchronize(st));   // (pr_off goes out of scope)
+    a->reft2_state = 1;
     return PRALINE_OK;
 }
 
@@ -775,6 +803,11 @@ struct praline_plan {
     DevBuf<int64_t> d_m_off;
     DevBuf<int32_t> d_chunk_pairs;
     DevBuf<float> d_mref;
+    // reference-order match scores on the split-strip kernels (k_match_tile + the dense-tile instances, dp_reftile.hip.h)
+    bool ref_tile = false;
+    DevBuf<float> d_dense, d_dense_b;       // two tile sets: chunks alternate between the two streams
+    DevBuf<int64_t> d_dense_off;
+    DevBuf<RefTileBlock> d_tile_blocks;
     // mask_kind 2: column masks per (pair, strip, row) for k_dp_batch MASK = 2 (k_build_zmask)
     DevBuf<unsigned> d_zmask;
     DevBuf<int64_t> d_zm_off;
@@ -855,6 +888,14 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         pl->ref = false;
         opt.split_layout = false;
         opt.tp = 1;
+    }
+    // reference order on the split-strip kernels: arenas of up to 32 symbols whose rows hold at most 8 nonzeros
+    // (PRALINE_NO_REFTILE=1: the one-cell-per-thread kernels and k_dp_batch, as for wide arenas and many-rectangle plans)
+    if (pl->ref && match_mode() == PRALINE_MATCH_REFERENCE && !a.wide && !many_rects && opt.split_layout && a.nr16 > 0 &&
+        !(getenv("PRALINE_NO_REFTILE") && getenv("PRALINE_NO_REFTILE")[0] == '1')) {
+        int rc = arena_ensure_reft2(arena);
+        if (rc != PRALINE_OK) { delete pl; return rc; }
+        if (a.reft2_state == 1) { pl->ref = false; pl->ref_tile = true; }
     }
     if (pl->ref) { opt.split_layout = false; opt.tp = 1; }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
@@ -1142,6 +1183,158 @@ static int plan_run_ref(praline_plan &pl, LaunchArgs la, int mode, bool local)
     return PRALINE_OK;
 }
 
+// dense match-score tiles per launch chunk and tile set (bytes)
+static size_t reftile_budget_bytes()
+{
+    if (const char *env = getenv("PRALINE_REFTILE_BUDGET_MB")) return (size_t)atoll(env) << 20;
+    return (size_t)16 << 30;
+}
+
+// PRALINE_MATCH_REFERENCE on the split-strip kernels: per chunk of tasks k_match_tile writes the reference-order match
+// scores as dense tiles (4 bytes per cell and padding), the dense-tile instance of k_dp_split16 (scores) or
+// k_dp_split16_tb (+ k_traceback) consumes them.  Chunks alternate between two tile sets / scratch sets on the two
+// streams, so the (VALU-bound) match scores of one chunk overlap the (HBM-bound) fill of the previous one.
+static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int mode, bool local)
+{
+    praline_arena &a = *pl.arena;
+    if (a.reft2_state == 0) RC(arena_ensure_reft2(&a));   // (the arena changed since the plan was made)
+    if (a.reft2_state != 1) return fail(PRALINE_ERR_UNSUPPORTED, "the arena no longer qualifies for the reference-order tiles");
+    hipStream_t st = g_rt.stream;
+    const size_t nt = pl.tasks.size();
+    const bool semiglobal = mode >= 2;
+    size_t m_budget = reftile_budget_bytes(), tb_budget = tb_budget_bytes();
+    auto tile_floats = [&](const WaveTask &wt) { return (int64_t)wt.nstrips * (wt.max_l1 + PRALINE_DENSE_PAD) * 1024; };
+    {
+        int64_t all_m = 0, all_tb = 0;
+        for (size_t t = 0; t < nt; ++t) { all_m += tile_floats(pl.tasks[t]) * 4; all_tb += pl.want_paths ? pl.tb_elems[t] * 8 : 0; }
+        // several chunks: two sets are alive at once
+        if ((size_t)all_m > m_budget) m_budget /= 2;
+        if ((size_t)all_tb > tb_budget) tb_budget /= 2;
+        if (const char *env = getenv("PRALINE_REFTILE_CHUNKS")) {   // experiments: at least this many chunks
+            const int n = atoi(env);
+            if (n > 1) m_budget = std::min(m_budget, (size_t)(all_m / n + (64 << 20)));
+        }
+    }
+    struct Chunk { size_t t0, t1, b0, b1; int64_t m_e, tb_e, aux_e; };
+    std::vector<Chunk> chunks;
+    std::vector<int64_t> dense_off(nt);
+    std::vector<RefTileBlock> blocks;
+    for (size_t t0 = 0; t0 < nt;) {
+        size_t t1 = t0;
+        const size_t b0 = blocks.size();
+        int64_t m_e = 0, tb_e = 0, aux_e = 0;
+        while (t1 < nt) {
+            const WaveTask &wt = pl.tasks[t1];
+            const int64_t m_add = tile_floats(wt), tb_add = pl.want_paths ? pl.tb_elems[t1] : 0;
+            if (t1 > t0 && ((size_t)(m_e + m_add) * 4 > m_budget || (size_t)(tb_e + tb_add) * 8 > tb_budget)) break;
+            dense_off[t1] = m_e;
+            pl.tasks[t1].tb_off = tb_e;
+            pl.tasks[t1].aux_off = aux_e;
+            m_e += m_add;
+            tb_e += tb_add;
+            aux_e += (pl.want_paths && semiglobal) ? pl.aux_elems[t1] : 0;
+            if (wt.max_l1 > 0 && wt.two[0] >= 0) {
+                const int l2 = a.len[(size_t)wt.two[0]];
+                for (int c = 0; c * PRALINE_REFTILE_COLS < l2; ++c) blocks.push_back({(int32_t)(t1 - t0), c});
+            }
+            ++t1;
+        }
+        chunks.push_back({t0, t1, b0, blocks.size(), m_e, tb_e, aux_e});
+        t0 = t1;
+    }
+    {
+        size_t need_m[2] = {1, 1}, need_tb[2] = {0, 0}, need_ax[2] = {1, 1};
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            need_m[c & 1] = std::max(need_m[c & 1], (size_t)chunks[c].m_e);
+            need_tb[c & 1] = std::max(need_tb[c & 1], (size_t)chunks[c].tb_e * 8);
+            need_ax[c & 1] = std::max(need_ax[c & 1], (size_t)chunks[c].aux_e);
+        }
+        // (every buffer is sized once, before the loop: see the chunk loops of praline_plan_run)
+        if (pl.d_dense.n < need_m[0]) RC(pl.d_dense.alloc(need_m[0]));
+        if (chunks.size() > 1 && pl.d_dense_b.n < need_m[1]) RC(pl.d_dense_b.alloc(need_m[1]));
+        if (pl.want_paths) {
+            if (pl.d_tb.n < need_tb[0]) RC(pl.d_tb.alloc(need_tb[0]));
+            if (pl.d_aux.n < need_ax[0]) RC(pl.d_aux.alloc(need_ax[0]));
+            if (chunks.size() > 1) {
+                if (pl.d_tb_b.n < need_tb[1]) RC(pl.d_tb_b.alloc(need_tb[1]));
+                if (pl.d_aux_b.n < need_ax[1]) RC(pl.d_aux_b.alloc(need_ax[1]));
+            }
+        }
+    }
+    if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
+    if (pl.d_dense_off.n < nt) RC(pl.d_dense_off.alloc(nt));
+    if (pl.d_tile_blocks.n < blocks.size()) RC(pl.d_tile_blocks.alloc(std::max<size_t>(blocks.size(), 1)));
+    HIPCHK(hipMemcpyAsync(pl.d_tasks.p, pl.tasks.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));   // (before the fork)
+    HIPCHK(hipMemcpyAsync(pl.d_dense_off.p, dense_off.data(), nt * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (!blocks.empty())
+        HIPCHK(hipMemcpyAsync(pl.d_tile_blocks.p, blocks.data(), blocks.size() * sizeof(RefTileBlock), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // (the host lists go out of scope)
+    bool forked = false;
+    struct JoinGuard {
+        bool &forked; hipStream_t st;
+        ~JoinGuard()
+        {
+            if (forked && hipEventRecord(g_rt.ev_join, g_rt.stream2) == hipSuccess) (void)hipStreamWaitEvent(st, g_rt.ev_join, 0);
+            forked = false;
+        }
+    } join_guard{forked, st};
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        const int set = (int)(c & 1);
+        hipStream_t cs = set ? g_rt.stream2 : st;
+        if (set && !forked) {
+            HIPCHK(hipEventRecord(g_rt.ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0));
+            forked = true;
+        }
+        const Chunk &ch = chunks[c];
+        float *tiles = set ? pl.d_dense_b.p : pl.d_dense.p;
+        RefTileArgs g;
+        g.raw = a.d_raw.p;
+        g.A = a.A;
+        g.T2 = a.d_reft2.p;
+        g.PR = a.pair_rows;
+        g.row_off_raw = a.d_row_off_raw.p;
+        g.len = a.d_len.p;
+        g.pr_off = a.d_pr_off.p;
+        g.set_lo = a.d_set_lo.p;
+        g.n_sets = (int)a.set_lo.size() - 1;
+        g.tasks = pl.d_tasks.p + ch.t0;
+        g.lane_one = pl.d_lane_one.p + ch.t0 * 32;
+        g.dense_off = pl.d_dense_off.p + ch.t0;
+        g.m = tiles;
+        g.blocks = pl.d_tile_blocks.p + ch.b0;
+        g.waves = 0;
+        int rc = praline_launch_match_tile(g, a.ref_tb, (unsigned)(ch.b1 - ch.b0), cs);
+        if (rc != PRALINE_OK) return fail(rc, "k_match_tile launch failed (A=%d, tb=%d)", a.A, a.ref_tb);
+        a16.dense = tiles;
+        a16.dense_off = pl.d_dense_off.p + ch.t0;
+        la.stream = cs;
+        la.tasks = pl.d_tasks.p + ch.t0;
+        la.lane_one = pl.d_lane_one.p + ch.t0 * 32;
+        la.lane_pair = pl.d_lane_pair.p + ch.t0 * 32;
+        la.n_tasks = (unsigned)(ch.t1 - ch.t0);
+        la.bnd = pl.d_bnd.p;
+        if (!pl.want_paths) {
+            la.tb = nullptr;
+            la.aux = nullptr;
+            rc = praline_launch_dense(la, a16, local);
+            if (rc != PRALINE_OK) return fail(rc, "dense-tile scores launch failed");
+        } else {
+            la.tb = (uint4 *)(set ? pl.d_tb_b.p : pl.d_tb.p);
+            la.aux = set ? pl.d_aux_b.p : pl.d_aux.p;
+            rc = praline_launch_dense_tb(la, a16, local, pl.has_rects);
+            if (rc != PRALINE_OK) return fail(rc, "dense-tile path launch failed");
+            RC(launch_traceback(pl, la, ch.t0, ch.t1, mode));
+        }
+    }
+    if (forked) {
+        HIPCHK(hipEventRecord(g_rt.ev_join, g_rt.stream2));
+        HIPCHK(hipStreamWaitEvent(st, g_rt.ev_join, 0));
+        forked = false;
+    }
+    return PRALINE_OK;
+}
+
 extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, float gap_extend, void *d_scores)
 {
     if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
@@ -1203,6 +1396,16 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     if (pl.ref) {
         HIPCHK(hipEventRecord(pl.ev0, st));
         RC(plan_run_ref(pl, la, mode, local));
+        HIPCHK(hipEventRecord(pl.ev1, st));
+        return PRALINE_OK;
+    }
+    if (pl.ref_tile) {
+        char kn[160];
+        if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<1, 3, %s, %s, false, false, 4>", local ? "true" : "false", pl.has_rects ? "true" : "false");
+        else snprintf(kn, sizeof(kn), "k_dp_split16<1, 1, %s, 4, 1, false>", local ? "true" : "false");
+        pl.last_kernel = kn;
+        HIPCHK(hipEventRecord(pl.ev0, st));
+        RC(plan_run_reftile(pl, la, a16, mode, local));
         HIPCHK(hipEventRecord(pl.ev1, st));
         return PRALINE_OK;
     }
@@ -1805,6 +2008,7 @@ extern "C" int praline_arena_append_merged_many(praline_arena *arena, praline_pl
     a->all_onehot = false;
     if (a->nr16 > 0 && a->nterm16 == 1) a->nterm16 = 3;   // (an exact arena keeps the standard layout; its new rows need the lo pieces)
     a->ref_ready = false;
+    a->reft2_state = 0;
     a->d_counts.release();
     a->counts_ext = nullptr;
     if (!a->wide) {   // packed operands of the new rows only (they are contiguous in the padded row space)
@@ -2178,7 +2382,7 @@ extern "C" int praline_arena_info(const praline_arena *arena, int32_t *n_active,
 extern "C" int praline_plan_match_kind(const praline_plan *plan)
 {
     if (!plan) return -1;
-    if (plan->ref) return 2;
+    if (plan->ref || plan->ref_tile) return 2;
     if (plan->split && plan->arena->nr16 > 0) {
         if (plan->want_paths) return 1;  // k_dp_split16_tb
         if (match_mode() != PRALINE_MATCH_F32) return 1;
