@@ -7,6 +7,7 @@
 #include "dp_reftile.hip.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 int praline_launch_build_reft2(const float *raw, const float *S, int A, const int32_t *row_off_raw, const int32_t *len,
                                const int64_t *pr_off, int64_t PR, const unsigned char *nzidx, const unsigned char *nzcnt,
@@ -18,29 +19,47 @@ int praline_launch_build_reft2(const float *raw, const float *S, int A, const in
     return hipGetLastError() == hipSuccess ? PRALINE_OK : PRALINE_ERR_DEVICE;
 }
 
-// LDS of one k_match_tile workgroup of `waves` waves
-static size_t match_tile_lds(int A, int TB, int waves) { return (size_t)A * (TB / 2) * 1024 + (size_t)waves * ((size_t)A * 64 + 128) + 256; }
+// LDS of one k_match_tile workgroup of `waves` waves with G rows per work item
+static size_t match_tile_lds(int A, int TB, int waves, int G) { return (size_t)A * (TB / 2) * 1024 + (size_t)waves * ((size_t)A * G * 4 + 128) + 256 + 512; }
+static const size_t kLdsPerCu = (size_t)160 * 1024;
 
 bool praline_match_tile_supported(int A, int TB)
 {
-    return (TB == 4 || TB == 8) && A >= 1 && A <= 32 && match_tile_lds(A, TB, 8) <= (size_t)160 * 1024;
+    return (TB == 4 || TB == 8) && A >= 1 && A <= 32 && match_tile_lds(A, TB, 8, 16) <= kLdsPerCu;
 }
 
-template <int TB, bool MULTI> static int launch_tile(RefTileArgs g, unsigned n_blocks, hipStream_t stream)
+template <int TB, bool MULTI, int G> static int launch_tile(RefTileArgs g, unsigned n_blocks, int waves, hipStream_t stream)
 {
-    // as many waves per workgroup as the LDS beside the table rows allows (one workgroup per CU: 16 = four per SIMD)
-    int waves = MULTI ? 12 : 16;   // (the instances with per-set sums hold 32 more registers: launch bounds 768)
-    while (waves > 4 && match_tile_lds(g.A, TB, waves) > (size_t)160 * 1024) --waves;
-    const size_t lds = match_tile_lds(g.A, TB, waves);
+    const size_t lds = match_tile_lds(g.A, TB, waves, G);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_tile<TB, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_tile<TB, MULTI, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PRALINE_ERR_DEVICE;
         lds_set = lds;
     }
     g.waves = waves;
-    hipLaunchKernelGGL((k_match_tile<TB, MULTI>), dim3(n_blocks), dim3(64 * waves), lds, stream, g);
+    hipLaunchKernelGGL((k_match_tile<TB, MULTI, G>), dim3(n_blocks), dim3(64 * waves), lds, stream, g);
     return hipGetLastError() == hipSuccess ? PRALINE_OK : PRALINE_ERR_DEVICE;
+}
+
+template <int TB, bool MULTI> static int launch_tile_g(const RefTileArgs &g, unsigned n_blocks, hipStream_t stream)
+{
+    // 16 rows per work item and as many waves as the LDS beside the table rows allows (one workgroup per CU: 16 waves =
+    // four per SIMD).  Measured on C2 (k_match_tile alone): 16 rows x 16 waves 12.8 ms, 16 x 12 13.8, 32 rows x 12 waves
+    // 13.7, 32 x 8 16.4 - the kernel wants waves, not fewer table-row reads.  PRALINE_REFTILE_G=32 selects the 32-row
+    // instances (12 waves, no per-set sums).
+    int G = 16, waves = 12;
+    if (const char *env = getenv("PRALINE_REFTILE_G")) { if (atoi(env) == 32 && !MULTI) G = 32; }
+    if (G == 32 && match_tile_lds(g.A, TB, waves, 32) > kLdsPerCu) G = 16;
+    if (G == 16) {
+        waves = MULTI ? 12 : 16;
+        while (waves > 4 && match_tile_lds(g.A, TB, waves, 16) > kLdsPerCu) --waves;
+    }
+    if (const char *env = getenv("PRALINE_REFTILE_WAVES")) { const int w = atoi(env); if (w >= 1 && w <= waves) waves = w; }
+    if constexpr (!MULTI) {
+        if (G == 32) return launch_tile<TB, MULTI, 32>(g, n_blocks, waves, stream);
+    }
+    return launch_tile<TB, MULTI, 16>(g, n_blocks, waves, stream);
 }
 
 int praline_launch_match_tile(const RefTileArgs &g, int TB, unsigned n_blocks, hipStream_t stream)
@@ -48,8 +67,8 @@ int praline_launch_match_tile(const RefTileArgs &g, int TB, unsigned n_blocks, h
     if (n_blocks == 0) return PRALINE_OK;
     if (!praline_match_tile_supported(g.A, TB)) return PRALINE_ERR_UNSUPPORTED;
     const bool multi = g.n_sets > 1;
-    if (TB == 4) return multi ? launch_tile<4, true>(g, n_blocks, stream) : launch_tile<4, false>(g, n_blocks, stream);
-    return multi ? launch_tile<8, true>(g, n_blocks, stream) : launch_tile<8, false>(g, n_blocks, stream);
+    if (TB == 4) return multi ? launch_tile_g<4, true>(g, n_blocks, stream) : launch_tile_g<4, false>(g, n_blocks, stream);
+    return multi ? launch_tile_g<8, true>(g, n_blocks, stream) : launch_tile_g<8, false>(g, n_blocks, stream);
 }
 
 // scores only: one wave (= one task) per workgroup

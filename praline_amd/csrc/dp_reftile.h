@@ -7,7 +7,11 @@
 #define PRALINE_REFTILE_ROWS 16     // rows y per work item of k_match_tile
 #define PRALINE_REFTILE_COLS 128    // columns x per workgroup
 
-struct RefTileBlock { int32_t task, chunk; };   // workgroup -> (task of the launch, 128-column chunk of its sequence two)
+// Workgroup -> (group of tasks that share their 32 sequences one, 128-column chunk of the group's sequences two laid end
+// to end, each padded to whole 32-column strips).  The group's record in RefTileArgs::grp at `base`: count + 1 cumulative
+// pair-row counts (16 per strip), then the count task
+// indices (relative to RefTileArgs::tasks).
+struct RefTileBlock { int32_t base, count, chunk, pad; };
 
 struct RefTileArgs {
     const float *raw;               // raw profiles [rows_raw][A]
@@ -23,6 +27,7 @@ struct RefTileArgs {
     const int64_t *dense_off;       // float offset of each task's tile in m
     float *m;
     const RefTileBlock *blocks;
+    const int32_t *grp;             // group records (see RefTileBlock)
     int waves;                      // waves per workgroup (blockDim.x / 64)
 };
 

@@ -59,12 +59,11 @@ __global__ void k_build_reft2(const float *__restrict__ raw, const float *__rest
     }
 }
 
-// acc += t * v for both halves; the second factor is the low (HI = false) or the high half of vv
-template <bool HI> __device__ __forceinline__ rt_f2 rt_term(rt_f2 acc, rt_f2 t, rt_f2 vv)
+// acc += t * v for both halves, v a wave-uniform value in the low word of an SGPR pair
+__device__ __forceinline__ rt_f2 rt_term(rt_f2 acc, rt_f2 t, unsigned long long v_sgpr)
 {
     rt_f2 p;
-    if constexpr (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(p) : "v"(t), "v"(vv));
-    else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(t), "v"(vv));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(t), "s"(v_sgpr));
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(acc) : "v"(acc), "v"(p));
     return acc;
 }
@@ -76,14 +75,19 @@ __device__ __forceinline__ rt_f2 rt_add(rt_f2 a, rt_f2 b)
     return d;
 }
 
-// One workgroup: the table rows of 128 columns (64 pair rows) of a task's sequence two in LDS; its waves take the work
-// items (pair j of the task, 16 rows y of that pair's sequence one) from a shared counter.
-// LDS: tile [A][TB / 2][64] float4 | per wave: sv [A][16] floats (+ 128 bytes) | counter, prefix [33].
-template <int TB, bool MULTI>
-__global__ __launch_bounds__(MULTI ? 768 : 1024) void k_match_tile(RefTileArgs g)
+// One workgroup: the table rows of 128 columns (64 pair rows) in LDS - a chunk of the sequences two of a GROUP of tasks
+// with the same 32 sequences one, laid end to end (so only a group's last chunk has idle lanes) -; its waves take the
+// work items (pair j, G rows y of that pair's sequence one) from a shared counter.  A wave holds the item's G x 2
+// accumulators in registers, keeps the item's rows transposed in LDS (sv[symbol][row]: lane r reads row r's value of the
+// symbol at hand, v_readlane hands it to the packed multiplies as an SGPR) and fetches the NEXT item's rows from memory
+// while it works on this one.
+// LDS: tile [A][TB / 2][64] float4 | per wave: sv [A][G] floats (+ 128 bytes) | counter, prefix [33] | colrow [64].
+template <int TB, bool MULTI, int G>
+__global__ __launch_bounds__((MULTI || G == 32) ? 768 : 1024) void k_match_tile(RefTileArgs g)
 {
+    static_assert(G == 16 || G == 32, "16 or 32 rows per work item");
     constexpr int NQ = TB / 2;                  // 16-byte pieces per (symbol, pair row)
-    constexpr int G = PRALINE_REFTILE_ROWS;
+    constexpr int NX = (G * 32 + 63) / 64;      // registers of a lane's share of an item's rows (alphabets of up to 32 symbols)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int A = g.A;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -92,27 +96,44 @@ __global__ __launch_bounds__(MULTI ? 768 : 1024) void k_match_tile(RefTileArgs g
     char *wbase = lds + (size_t)A * NQ * 1024 + (size_t)wave * wave_bytes;
     float *sv = reinterpret_cast<float *>(wbase);
     int *ctl = reinterpret_cast<int *>(lds + (size_t)A * NQ * 1024 + (size_t)g.waves * wave_bytes);   // [0]: counter, [1 .. 34): prefix
+    long long *colrow = reinterpret_cast<long long *>(ctl + 64);                                     // [64]: arena pair row of column pair l, -1: none
 
     const RefTileBlock blk = g.blocks[blockIdx.x];
-    const WaveTask tk = g.tasks[blk.task];
+    const int32_t *cum = g.grp + blk.base, *tix = cum + blk.count + 1;
+    // this lane's column pair: pair row P of the group's sequences two laid end to end -> (task, pair row inside its two)
+    const int P = blk.chunk * 64 + lane;
+    int lo = 0;
+    {
+        int hi = blk.count;                     // cum[lo] <= P < cum[hi]  (P past the end: the last task, masked below)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cum[mid] <= P) lo = mid; else hi = mid;
+        }
+    }
+    const int my_task = tix[lo];
+    const WaveTask tk = g.tasks[my_task];
     const int two = tk.two[0];
     const int L2 = g.len[two];
-    const int npr = (L2 + 1) >> 1;
-    const int k0 = blk.chunk * 64;              // first pair row of the chunk (inside the sequence)
-    const int64_t pr0 = g.pr_off[two] + k0;
+    const int kk = P - cum[lo];                 // pair row inside the sequence
+    const bool col_ok = P < cum[blk.count];
     const int nstrips = (L2 + 31) >> 5;
     const int rows_t = tk.max_l1 + PRALINE_DENSE_PAD;
+    // (the group's record counts whole strips per sequence: pair rows past the sequence's end produce zeros)
+    if (wave == 0) colrow[lane] = (col_ok && 2 * kk < L2) ? g.pr_off[two] + kk : -1ll;
+    __syncthreads();
 
     // ---- the chunk's table rows ----
     for (int e = threadIdx.x; e < A * NQ * 64; e += blockDim.x) {
         const int l = e & 63, iq = e >> 6;      // iq = i * NQ + q
         const int i = iq / NQ, q = iq - i * NQ;
+        const long long pr = colrow[l];
         rt_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (k0 + l < npr) v = *reinterpret_cast<const rt_f4 *>(g.T2 + (((int64_t)i * g.PR + pr0 + l) * TB) * 2 + q * 4);
+        if (pr >= 0) v = *reinterpret_cast<const rt_f4 *>(g.T2 + (((int64_t)i * g.PR + pr) * TB) * 2 + q * 4);
         tile[e] = v;
     }
+    const int task0 = tix[0];                   // (every task of the group has the same 32 sequences one)
     if (threadIdx.x < 32) {
-        const int one = g.lane_one[blk.task * 32 + threadIdx.x];
+        const int one = g.lane_one[task0 * 32 + threadIdx.x];
         const int ng = one >= 0 ? (g.len[one] + G - 1) / G : 0;
         // exclusive prefix over the 32 pairs
         int incl = ng;
@@ -128,33 +149,52 @@ __global__ __launch_bounds__(MULTI ? 768 : 1024) void k_match_tile(RefTileArgs g
     const int n_items = ctl[1 + 32];
 
     // this lane's two columns and where they go
-    const int x0 = blk.chunk * PRALINE_REFTILE_COLS + 2 * lane;
-    const bool store_ok = x0 < nstrips * 32;
-    float *out_lane = g.m + g.dense_off[blk.task] + ((int64_t)(x0 >> 5) * rows_t * 2 + ((x0 >> 4) & 1)) * 512 + (x0 & 15);
+    const int x0 = 2 * kk;
+    const bool store_ok = col_ok && x0 < nstrips * 32;
+    float *out_lane = g.m + g.dense_off[my_task] + ((int64_t)(x0 >> 5) * rows_t * 2 + ((x0 >> 4) & 1)) * 512 + (x0 & 15);
 
-    for (;;) {
+    // work items: (pair j, row group).  `grab` takes the next one and starts the loads of its rows (nx: element e = lane
+    // + 64 k of the G x A block of raw profile rows, zero past the sequence's end)
+    struct Item { int j, y0, ny; };
+    float nx[NX];
+    auto grab = [&](Item &it) __attribute__((always_inline)) {
         int item = 0;
         if (lane == 0) item = atomicAdd(&ctl[0], 1);
         item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
+        if (item >= n_items) { it.j = -1; it.y0 = 0; it.ny = 0; return; }
         // the pair whose groups include this item: the number of pairs whose inclusive prefix is <= item
         const int incl_l = ctl[2 + (lane & 31)];
-        const int j = __builtin_popcountll(__ballot(lane < 32 && incl_l <= item));
-        const int rg = item - __builtin_amdgcn_readfirstlane(ctl[1 + j]);
-        const int one = g.lane_one[blk.task * 32 + j];
+        it.j = __builtin_popcountll(__ballot(lane < 32 && incl_l <= item));
+        const int rg = item - __builtin_amdgcn_readfirstlane(ctl[1 + it.j]);
+        const int one = g.lane_one[task0 * 32 + it.j];
         const int L1 = g.len[one];
-        const int y0 = rg * G;
-        const int ny = min(G, L1 - y0);
-        const float *rows1 = g.raw + ((int64_t)g.row_off_raw[one] + y0) * A;
-
-        // ---- the 16 rows of sequence one, transposed: sv[i][yy] ----
-        for (int e = lane; e < G * A; e += 64) {
-            const int yy = e / A, i = e - yy * A;
-            sv[i * G + yy] = yy < ny ? rows1[e] : 0.0f;
+        it.y0 = rg * G;
+        it.ny = min(G, L1 - it.y0);
+        const float *rows1 = g.raw + ((int64_t)g.row_off_raw[one] + it.y0) * A;
+        const int n_valid = it.ny * A;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int e = lane + 64 * k;
+            nx[k] = e < n_valid ? rows1[e] : 0.0f;
+        }
+    };
+    Item cur, nxt;
+    grab(nxt);
+    while (nxt.j >= 0) {
+        cur = nxt;
+        // ---- the item's rows, transposed: sv[i][yy] ----
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int e = lane + 64 * k;
+            if (e < G * A) {
+                const int yy = e / A, i = e - yy * A;
+                sv[i * G + yy] = nx[k];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        grab(nxt);   // (its loads arrive while this item is computed)
         // symbol i (lane i): which of the rows hold a nonzero; the work list = the symbols with any, ascending
         unsigned mask = 0;
         int my_set = 0;
@@ -166,15 +206,15 @@ __global__ __launch_bounds__(MULTI ? 768 : 1024) void k_match_tile(RefTileArgs g
                 while (my_set + 1 < g.n_sets && lane >= g.set_lo[my_set + 1]) ++my_set;
             }
         }
-        // the work list = the symbols with a nonzero in any of the rows, ascending: the set bits of `hits`; lane i's word =
-        // its rows | (MULTI: the per-set sum is folded into the score before this symbol, the first of a later set) << 16
+        // the work list = the set bits of `hits`; MULTI: `folds` marks the symbols that are the first of a later track set
+        // (the per-set sum is folded into the score before them)
         const unsigned long long hits = __ballot(mask != 0u);
-        unsigned word = mask;
+        unsigned long long folds = 0ull;
         if constexpr (MULTI) {
             const unsigned long long below = hits & ((1ull << lane) - 1ull);
             const int prev = below ? 63 - __builtin_clzll(below) : lane;
             const int prev_set = __shfl(my_set, prev);
-            if (below != 0ull && prev_set != my_set) word |= 1u << 16;
+            folds = __ballot(mask != 0u && below != 0ull && prev_set != my_set);
         }
         unsigned long long rest = hits;
 
@@ -184,40 +224,42 @@ __global__ __launch_bounds__(MULTI ? 768 : 1024) void k_match_tile(RefTileArgs g
 #pragma unroll
         for (int yy = 0; yy < (MULTI ? G : 1); ++yy) score[yy] = rt_f2{0.0f, 0.0f};
 
-        // one (symbol, 16 rows) entry: the symbol's table row of this lane's column pair and its 16 row values
-        struct Entry { unsigned w; rt_f4 t[NQ]; rt_f4 v[G / 4]; };
+        // one (symbol, G rows) entry: the symbol's table row of this lane's column pair, the rows that hold the symbol
+        // and their values (lane r: row r)
+        struct Entry { unsigned rows; bool live, fold; rt_f4 t[NQ]; float v; };
         auto fetch = [&](Entry &en) __attribute__((always_inline)) {
             int i = 0;
-            en.w = 0u;                                      // past the list: symbol 0, no rows
-            if (rest != 0ull) {
+            en.rows = 0u;                                   // past the list: symbol 0, no rows
+            en.live = rest != 0ull;
+            en.fold = false;
+            if (en.live) {
                 i = __builtin_ctzll(rest);
                 rest &= rest - 1ull;
-                en.w = (unsigned)__builtin_amdgcn_readlane((int)word, i);
+                en.rows = (unsigned)__builtin_amdgcn_readlane((int)mask, i);
+                if constexpr (MULTI) en.fold = ((folds >> i) & 1ull) != 0ull;
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) en.t[q] = tile[(i * NQ + q) * 64 + lane];
-#pragma unroll
-            for (int q = 0; q < G / 4; ++q) en.v[q] = *reinterpret_cast<const rt_f4 *>(sv + i * G + 4 * q);
+            en.v = sv[i * G + (lane & (G - 1))];
         };
         auto work = [&](const Entry &en) __attribute__((always_inline)) {
             if constexpr (MULTI) {
-                if (en.w & (1u << 16)) {
+                if (en.fold) {
 #pragma unroll
                     for (int yy = 0; yy < G; ++yy) { score[yy] = rt_add(score[yy], acc[yy]); acc[yy] = rt_f2{0.0f, 0.0f}; }
                 }
             }
-            const unsigned rows = en.w & 0xffffu;
+            const unsigned rows = en.rows;
 #pragma unroll
             for (int yy = 0; yy < G; ++yy) {
                 if (rows & (1u << yy)) {
-                    const rt_f4 vq = en.v[yy >> 2];
-                    const rt_f2 vv = (yy & 2) ? rt_f2{vq.z, vq.w} : rt_f2{vq.x, vq.y};
+                    const unsigned long long vs = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(en.v), yy);
                     rt_f2 a = acc[yy];
 #pragma unroll
                     for (int b = 0; b < TB; ++b) {
                         const rt_f4 tq = en.t[b >> 1];
                         const rt_f2 t = (b & 1) ? rt_f2{tq.z, tq.w} : rt_f2{tq.x, tq.y};
-                        a = (yy & 1) ? rt_term<true>(a, t, vv) : rt_term<false>(a, t, vv);
+                        a = rt_term(a, t, vs);
                     }
                     acc[yy] = a;
                 }
@@ -225,7 +267,7 @@ __global__ __launch_bounds__(MULTI ? 768 : 1024) void k_match_tile(RefTileArgs g
         };
         Entry ea, eb;
         fetch(ea);
-        while (ea.w != 0u) {
+        while (ea.live) {
             fetch(eb);
             work(ea);
             fetch(ea);
@@ -233,10 +275,10 @@ __global__ __launch_bounds__(MULTI ? 768 : 1024) void k_match_tile(RefTileArgs g
         }
         // ---- the scores of the item's rows ----
         if (store_ok) {
-            float *o = out_lane + (int64_t)j * 16 + (int64_t)(y0 + 1) * 1024;
+            float *o = out_lane + (int64_t)cur.j * 16 + (int64_t)(cur.y0 + 1) * 1024;
 #pragma unroll
             for (int yy = 0; yy < G; ++yy) {
-                if (yy < ny) {
+                if (yy < cur.ny) {
                     rt_f2 r = acc[yy];
                     if constexpr (MULTI) r = rt_add(score[yy], acc[yy]);
                     __builtin_nontemporal_store(r, reinterpret_cast<rt_f2 *>(o + (int64_t)yy * 1024));

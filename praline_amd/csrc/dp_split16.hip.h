@@ -37,6 +37,18 @@ __device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bi
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4n __attribute__((ext_vector_type(4)));
 
+// A lane's 64-byte line of a dense tile (BSRC = 4) arrives as four 16-byte loads.  Plain loads: the first one brings the
+// line into the CU's L1 and the other three hit there; streaming (nt) loads fetched every line four times from L2
+// (measured on C2: 25 GB of tiles in 8.7 ms = 11.5 TB/s of L2 reads, the L2's ceiling).
+#ifndef PRALINE_DENSE_NT
+#define PRALINE_DENSE_NT 0
+#endif
+#if PRALINE_DENSE_NT
+#define PRALINE_DENSE_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define PRALINE_DENSE_LOAD(p) (*(p))
+#endif
+
 // One-hot operand table (LDS): row `sym` holds the B operand slots of a profile row with all its mass
 // on active symbol sym, [hh][r][8 halves]; row 16 NR is the all-zero row (padding rows, symbols that
 // cannot score).  The odd 16-byte row stride spreads the rows over the LDS banks.
@@ -286,8 +298,7 @@ __device__ __forceinline__ void split16_step(int yy, int L1, bool have_pair, int
     if constexpr (DENSE) {
         // the next row's match scores: one 64-byte line of the task's dense tile, read once (streaming loads)
         const f4n *q = reinterpret_cast<const f4n *>(onehot_lane);
-        const f4n a0 = __builtin_nontemporal_load(q), a1 = __builtin_nontemporal_load(q + 1), a2 = __builtin_nontemporal_load(q + 2),
-                  a3 = __builtin_nontemporal_load(q + 3);
+        const f4n a0 = PRALINE_DENSE_LOAD(q), a1 = PRALINE_DENSE_LOAD(q + 1), a2 = PRALINE_DENSE_LOAD(q + 2), a3 = PRALINE_DENSE_LOAD(q + 3);
         PREV[0] = a0.x; PREV[1] = a0.y; PREV[2] = a0.z; PREV[3] = a0.w; PREV[4] = a1.x; PREV[5] = a1.y; PREV[6] = a1.z; PREV[7] = a1.w;
         PREV[8] = a2.x; PREV[9] = a2.y; PREV[10] = a2.z; PREV[11] = a2.w; PREV[12] = a3.x; PREV[13] = a3.y; PREV[14] = a3.z; PREV[15] = a3.w;
     } else if constexpr (LOOKUP) {
@@ -468,8 +479,11 @@ __device__ unsigned long long *praline_trace_buf = nullptr;
 #ifndef PRALINE_LOOKUP_WAVES
 #define PRALINE_LOOKUP_WAVES 3   // waves per SIMD the lookup instances are compiled for (168 VGPRs)
 #endif
+#ifndef PRALINE_DENSE_WAVES
+#define PRALINE_DENSE_WAVES 2    // waves per SIMD of the dense-tile instances (four 16-register sets of match scores in flight)
+#endif
 template <int NR, int NTERM, bool LOCAL, int BSRC = 0, int WPG = 1, bool KEEP = false>
-__global__ __launch_bounds__(256, KEEP ? 2 : ((BSRC == 3 || BSRC == 4) ? PRALINE_LOOKUP_WAVES : 1)) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES : (BSRC == 4 ? PRALINE_DENSE_WAVES : 1))) void k_dp_split16(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ lane_one,
                                                     const int32_t *__restrict__ lane_pair, float2 *bnd,
                                                     float *__restrict__ scores, RunParams rp, int n_tasks,
@@ -690,6 +704,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : ((BSRC == 3 || BSRC == 4) ? PRALINE
         float4 b0[NOP], b1[NOP], b2[NOP], b3[NOP];   // b3: one-hot table with DM (four sets: rows t .. t+3)
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
+        f32x16 accC = accA, accD = accA;   // DENSE: four sets
         unsigned d1 = 0, d2 = 0, d3 = 0, d4 = 0;  // ONEHOT: symbols of the rows the next 12 steps refill
         unsigned lw0 = 0, lw1 = 0, lw2 = 0, lw3 = 0;   // LOOKUP: the 16-byte symbol window
         float2 p0, p1, p2;
@@ -736,13 +751,17 @@ __global__ __launch_bounds__(256, KEEP ? 2 : ((BSRC == 3 || BSRC == 4) ? PRALINE
             stage_cur[0] = cb;  // next: operand row 6 (step 1)
             stage_cur[1] = cn;  // next: boundary row 5 (step 1)
         } else if constexpr (DENSE) {
-            // row 1 of the strip (the upper half takes row 0: its first step is undone below)
+            // rows 1, 2, 3 of the strip (the upper half takes rows 0, 1, 2: its first step is undone below); four register
+            // sets rotate, the step at T fetches row T + 3: a row's loads have three steps (~1 us) to arrive
             dense_lane = dense_task + (int64_t)s * dense_strip;
-            const f4n *q = reinterpret_cast<const f4n *>(dense_lane + 4096);
-            const f4n a0 = __builtin_nontemporal_load(q), a1 = __builtin_nontemporal_load(q + 1), a2 = __builtin_nontemporal_load(q + 2),
-                      a3 = __builtin_nontemporal_load(q + 3);
-            accA[0] = a0.x; accA[1] = a0.y; accA[2] = a0.z; accA[3] = a0.w; accA[4] = a1.x; accA[5] = a1.y; accA[6] = a1.z; accA[7] = a1.w;
-            accA[8] = a2.x; accA[9] = a2.y; accA[10] = a2.z; accA[11] = a2.w; accA[12] = a3.x; accA[13] = a3.y; accA[14] = a3.z; accA[15] = a3.w;
+#pragma unroll
+            for (int r = 1; r <= 3; ++r) {
+                const f4n *q = reinterpret_cast<const f4n *>(dense_lane + (int64_t)r * 4096);
+                const f4n a0 = PRALINE_DENSE_LOAD(q), a1 = PRALINE_DENSE_LOAD(q + 1), a2 = PRALINE_DENSE_LOAD(q + 2), a3 = PRALINE_DENSE_LOAD(q + 3);
+                f32x16 &d = r == 1 ? accA : (r == 2 ? accB : accC);
+                d[0] = a0.x; d[1] = a0.y; d[2] = a0.z; d[3] = a0.w; d[4] = a1.x; d[5] = a1.y; d[6] = a1.z; d[7] = a1.w;
+                d[8] = a2.x; d[9] = a2.y; d[10] = a2.z; d[11] = a2.w; d[12] = a3.x; d[13] = a3.y; d[14] = a3.z; d[15] = a3.w;
+            }
             p0 = *reinterpret_cast<const float2 *>(my_bnd + BROW);      // row 1
             p1 = *reinterpret_cast<const float2 *>(my_bnd + 2 * BROW);  // row 2
             p2 = *reinterpret_cast<const float2 *>(my_bnd + 3 * BROW);  // row 3
@@ -820,12 +839,12 @@ __global__ __launch_bounds__(256, KEEP ? 2 : ((BSRC == 3 || BSRC == 4) ? PRALINE
                                        bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2, onehot_lane, SYM, \
                                        nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
-        // dense tile: CUR holds this row's scores, PREV receives the next row's (lower half: row T + 1, upper half: row T)
+        // dense tile: CUR holds this row's scores, PREV receives those of the row three steps on (lower half: row T + 3)
 #define PRALINE_STEP16M(T, CUR, PREV, PSLOT)                                                                          \
         split16_step<NR, NTERM, LOCAL, 4, 0, false, SNAPBR>((T) - h, L1, have_pair, h, CUR, PREV, b0, aop, aop, b0, b0, b_next, b_stride, bnd_ld, \
                                        bnd_st, PSLOT, Hs, Uc, dH, hd_x, l_x, best_run, col_run, out_best, out_rowmax,  \
                                        out_colmax, out_corner, go, ge, semiglobal, last_owner, cidx, xb, L2,           \
-                                       dense_lane + (int64_t)((T) + 1) * 4096, 0u,                                     \
+                                       dense_lane + (int64_t)((T) + 3) * 4096, 0u,                                     \
                                        nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, (T) >= min_l1)
         // one-hot table with DM: BUSE holds row T+1, BOLD row T (refilled with row T+4 once its MFMAs are issued)
 #define PRALINE_STEP16XD(T, CUR, PREV, BUSE, BOLD, PSLOT, SYMW, SB)                                                   \
@@ -862,7 +881,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : ((BSRC == 3 || BSRC == 4) ? PRALINE
 #pragma unroll
             for (int c = 0; c < 17; ++c) Hsave[c] = Hs[c];
             const float best_s = best_run, col_s = col_run;
-            if constexpr (DENSE) PRALINE_STEP16M(1, accA, accB, p0);
+            if constexpr (DENSE) PRALINE_STEP16M(1, accA, accD, p0);
             else if constexpr (LOOKUP) PRALINE_STEP16L(1, accA, accB, p0, ((h ? (lw0 << 8) : lw0) >> 8) & 0xffu);
             else if constexpr (DM && ONEHOT) PRALINE_STEP16XD(1, accA, accB, b0, b3, p0, d1, 0);
             else if constexpr (DM) PRALINE_STEP16D(1, accA, accB, b0, b1, 1, b2);
@@ -917,17 +936,17 @@ __global__ __launch_bounds__(256, KEEP ? 2 : ((BSRC == 3 || BSRC == 4) ? PRALINE
         } else if constexpr (DENSE) {
             for (int t = 2; t <= max_l1 + 1; t += 12) {
                 PRALINE_STEP16M(t, accB, accA, p1);
-                PRALINE_STEP16M(t + 1, accA, accB, p2);
-                PRALINE_STEP16M(t + 2, accB, accA, p0);
-                PRALINE_STEP16M(t + 3, accA, accB, p1);
+                PRALINE_STEP16M(t + 1, accC, accB, p2);
+                PRALINE_STEP16M(t + 2, accD, accC, p0);
+                PRALINE_STEP16M(t + 3, accA, accD, p1);
                 PRALINE_STEP16M(t + 4, accB, accA, p2);
-                PRALINE_STEP16M(t + 5, accA, accB, p0);
-                PRALINE_STEP16M(t + 6, accB, accA, p1);
-                PRALINE_STEP16M(t + 7, accA, accB, p2);
+                PRALINE_STEP16M(t + 5, accC, accB, p0);
+                PRALINE_STEP16M(t + 6, accD, accC, p1);
+                PRALINE_STEP16M(t + 7, accA, accD, p2);
                 PRALINE_STEP16M(t + 8, accB, accA, p0);
-                PRALINE_STEP16M(t + 9, accA, accB, p1);
-                PRALINE_STEP16M(t + 10, accB, accA, p2);
-                PRALINE_STEP16M(t + 11, accA, accB, p0);
+                PRALINE_STEP16M(t + 9, accC, accB, p1);
+                PRALINE_STEP16M(t + 10, accD, accC, p2);
+                PRALINE_STEP16M(t + 11, accA, accD, p0);
             }
         } else if constexpr (LOOKUP) {
             const unsigned *pn = pSym + 4;

@@ -120,8 +120,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     for (int c = 0; c < 16; ++c) m[c] = (DM || LOOKUP) ? CUR[c] : (h ? PREV[c] : CUR[c]);
     if constexpr (DENSE) {
         const f4n *q = reinterpret_cast<const f4n *>(onehot_lane);
-        const f4n a0 = __builtin_nontemporal_load(q), a1 = __builtin_nontemporal_load(q + 1), a2 = __builtin_nontemporal_load(q + 2),
-                  a3 = __builtin_nontemporal_load(q + 3);
+        const f4n a0 = PRALINE_DENSE_LOAD(q), a1 = PRALINE_DENSE_LOAD(q + 1), a2 = PRALINE_DENSE_LOAD(q + 2), a3 = PRALINE_DENSE_LOAD(q + 3);
         PREV[0] = a0.x; PREV[1] = a0.y; PREV[2] = a0.z; PREV[3] = a0.w; PREV[4] = a1.x; PREV[5] = a1.y; PREV[6] = a1.z; PREV[7] = a1.w;
         PREV[8] = a2.x; PREV[9] = a2.y; PREV[10] = a2.z; PREV[11] = a2.w; PREV[12] = a3.x; PREV[13] = a3.y; PREV[14] = a3.z; PREV[15] = a3.w;
     } else if constexpr (LOOKUP) {
@@ -351,8 +350,11 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #ifndef PRALINE_TB_LOOKUP_WAVES
 #define PRALINE_TB_LOOKUP_WAVES 2   // waves per SIMD of the lookup instances (no operand / accumulator registers)
 #endif
+#ifndef PRALINE_TB_DENSE_WAVES
+#define PRALINE_TB_DENSE_WAVES 1   // waves per SIMD of the dense-tile instances
+#endif
 template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool TWOPASS = false, int BSRC = 0>
-__global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : ((BSRC == 3 || BSRC == 4) ? PRALINE_TB_LOOKUP_WAVES : PRALINE_TB_WAVES_PER_SIMD)) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC == 3 ? PRALINE_TB_LOOKUP_WAVES : (BSRC == 4 ? PRALINE_TB_DENSE_WAVES : PRALINE_TB_WAVES_PER_SIMD))) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one,
                                                        const int32_t *__restrict__ lane_pair, float4 *bnd,
                                                        uint2 *__restrict__ tb, float *__restrict__ aux, RectList rl,
@@ -538,16 +540,21 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : ((BSRC 
         float4 bX[NOP], bY[NOP], bZ[NOP];   // bZ: DM only (rows t, t+1, t+2 rotate through three sets)
         f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         f32x16 accB = accA;
+        f32x16 accC = accA;   // DENSE: three sets
         unsigned sw0 = 0;   // BSRC == 1: the symbols of rows 1 .. 4
         unsigned symA = 0, symB = 0, symC = 0;   // LOOKUP: the symbols three steps ahead (rotate like the boundary prefetch)
         if constexpr (DENSE) {
-            // row 1 of the strip (the upper half takes row 0: its first step is undone below)
+            // rows 1 and 2 of the strip (the upper half takes rows 0 and 1: its first step is undone below); three register
+            // sets rotate, the step at T fetches row T + 2
             dense_lane = dense_task + (int64_t)s * dense_strip;
-            const f4n *q = reinterpret_cast<const f4n *>(dense_lane + 4096);
-            const f4n a0 = __builtin_nontemporal_load(q), a1 = __builtin_nontemporal_load(q + 1), a2 = __builtin_nontemporal_load(q + 2),
-                      a3 = __builtin_nontemporal_load(q + 3);
-            accA[0] = a0.x; accA[1] = a0.y; accA[2] = a0.z; accA[3] = a0.w; accA[4] = a1.x; accA[5] = a1.y; accA[6] = a1.z; accA[7] = a1.w;
-            accA[8] = a2.x; accA[9] = a2.y; accA[10] = a2.z; accA[11] = a2.w; accA[12] = a3.x; accA[13] = a3.y; accA[14] = a3.z; accA[15] = a3.w;
+#pragma unroll
+            for (int r = 1; r <= 2; ++r) {
+                const f4n *q = reinterpret_cast<const f4n *>(dense_lane + (int64_t)r * 4096);
+                const f4n a0 = PRALINE_DENSE_LOAD(q), a1 = PRALINE_DENSE_LOAD(q + 1), a2 = PRALINE_DENSE_LOAD(q + 2), a3 = PRALINE_DENSE_LOAD(q + 3);
+                f32x16 &d = r == 1 ? accA : accB;
+                d[0] = a0.x; d[1] = a0.y; d[2] = a0.z; d[3] = a0.w; d[4] = a1.x; d[5] = a1.y; d[6] = a1.z; d[7] = a1.w;
+                d[8] = a2.x; d[9] = a2.y; d[10] = a2.z; d[11] = a2.w; d[12] = a3.x; d[13] = a3.y; d[14] = a3.z; d[15] = a3.w;
+            }
         } else if constexpr (LOOKUP) {
             // this strip's table: lane (column j, half h) transposes the hi pieces of half h of the pre-multiplied row
             // x0 + j (exact mode: Q2 = hi exactly), k = 16 r + 8 h + jj  ->  lookup_tab[k][j]
@@ -629,13 +636,13 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : ((BSRC 
                                                 xb, srect, chain_in, &chain_seen, (T) + 3, ckpt_strip, nullptr, 0,          \
                                                 onehot_lane, SYM);                                                          \
         SYM = psym[(T) + 3];
-        // dense tile: the step fetches the next row's scores (lower half: row T + 1, upper half: row T)
+        // dense tile: the step fetches the scores of the row two steps on (lower half: row T + 2)
 #define PRALINE_TB_STEP_DN(T, CUR, PREV, PREF)                                                                        \
         split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, false, SINK, 4>((T) - h, L1, have_pair, h, CUR, PREV, bX, bX, aop, aopH, \
                                                 b_next, b_stride, bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl,   \
                                                 cpxm, cpxu, cpxl, cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge,  \
                                                 xb, srect, chain_in, &chain_seen, (T) + 3, ckpt_strip, nullptr, 0,          \
-                                                dense_lane + (int64_t)((T) + 1) * 4096, 0u);
+                                                dense_lane + (int64_t)((T) + 2) * 4096, 0u);
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
             const int yy_ = (T) - h;                                                                                 \
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : ((BSRC 
         {
             const float best_s = best_run;
             const int by = best_y, bx = best_x, bk = best_k;
-            if constexpr (DENSE) { PRALINE_TB_STEP_DN(1, accA, accB, bnd_prefA) }
+            if constexpr (DENSE) { PRALINE_TB_STEP_DN(1, accA, accC, bnd_prefA) }
             else if constexpr (LOOKUP) { PRALINE_TB_STEP_LK(1, accA, accB, bnd_prefA, symA) }
             else if constexpr (BSRC == 1) PRALINE_TB_STEP_OH(1, accA, accB, bX, bZ, bnd_prefA, sw0, 3);
             else if constexpr (DM) PRALINE_TB_STEP(1, accA, accB, bX, bZ, bnd_prefA);
@@ -722,15 +729,15 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : ((BSRC 
             if constexpr (DENSE) {
                 PRALINE_TB_STEP_DN(t, accB, accA, bnd_prefB)
                 PRALINE_TB_TAILS(t)
-                PRALINE_TB_STEP_DN(t + 1, accA, accB, bnd_prefC)
+                PRALINE_TB_STEP_DN(t + 1, accC, accB, bnd_prefC)
                 PRALINE_TB_TAILS(t + 1)
-                PRALINE_TB_STEP_DN(t + 2, accB, accA, bnd_prefA)
+                PRALINE_TB_STEP_DN(t + 2, accA, accC, bnd_prefA)
                 PRALINE_TB_TAILS(t + 2)
-                PRALINE_TB_STEP_DN(t + 3, accA, accB, bnd_prefB)
+                PRALINE_TB_STEP_DN(t + 3, accB, accA, bnd_prefB)
                 PRALINE_TB_TAILS(t + 3)
-                PRALINE_TB_STEP_DN(t + 4, accB, accA, bnd_prefC)
+                PRALINE_TB_STEP_DN(t + 4, accC, accB, bnd_prefC)
                 PRALINE_TB_TAILS(t + 4)
-                PRALINE_TB_STEP_DN(t + 5, accA, accB, bnd_prefA)
+                PRALINE_TB_STEP_DN(t + 5, accA, accC, bnd_prefA)
                 PRALINE_TB_TAILS(t + 5)
             } else if constexpr (LOOKUP) {
                 PRALINE_TB_STEP_LK(t, accB, accA, bnd_prefB, symB)

@@ -25,6 +25,7 @@
 #include <numeric>
 #include <string>
 #include <vector>
+#include <unordered_map>
 
 // --------------------------------------------------------------------------------------------
 // errors + runtime
@@ -805,9 +806,11 @@ struct praline_plan {
     DevBuf<float> d_mref;
     // reference-order match scores on the split-strip kernels (k_match_tile + the dense-tile instances, dp_reftile.hip.h)
     bool ref_tile = false;
-    DevBuf<float> d_dense, d_dense_b;       // two tile sets: chunks alternate between the two streams
+    DevBuf<float> d_dense;                  // the tiles of one launch chunk
     DevBuf<int64_t> d_dense_off;
     DevBuf<RefTileBlock> d_tile_blocks;
+    DevBuf<int32_t> d_tile_grp;
+    std::vector<int32_t> h_lane_one;        // [task][32], host copy (groups of tasks with the same sequences one)
     // mask_kind 2: column masks per (pair, strip, row) for k_dp_batch MASK = 2 (k_build_zmask)
     DevBuf<unsigned> d_zmask;
     DevBuf<int64_t> d_zm_off;
@@ -954,6 +957,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         pl->h_lane_pair = sch.lane_pair;
         pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);
     }
+    if (pl->ref_tile) pl->h_lane_one = sch.lane_one;
     const int64_t bnd = pl->bnd_elems, cap = pl->path_cap;
 
     hipStream_t st = g_rt.stream;
@@ -1183,17 +1187,18 @@ static int plan_run_ref(praline_plan &pl, LaunchArgs la, int mode, bool local)
     return PRALINE_OK;
 }
 
-// dense match-score tiles per launch chunk and tile set (bytes)
+// dense match-score tiles per launch chunk (bytes)
 static size_t reftile_budget_bytes()
 {
     if (const char *env = getenv("PRALINE_REFTILE_BUDGET_MB")) return (size_t)atoll(env) << 20;
-    return (size_t)16 << 30;
+    return (size_t)32 << 30;
 }
 
 // PRALINE_MATCH_REFERENCE on the split-strip kernels: per chunk of tasks k_match_tile writes the reference-order match
 // scores as dense tiles (4 bytes per cell and padding), the dense-tile instance of k_dp_split16 (scores) or
-// k_dp_split16_tb (+ k_traceback) consumes them.  Chunks alternate between two tile sets / scratch sets on the two
-// streams, so the (VALU-bound) match scores of one chunk overlap the (HBM-bound) fill of the previous one.
+// k_dp_split16_tb (+ k_traceback) consumes them.  One stream, one tile set: a k_match_tile workgroup fills its CU
+// (registers and LDS), so a second stream only time-slices the chip (measured on C2: four chunks alternating between
+// two streams 31 ms, one chunk 19 ms).
 static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int mode, bool local)
 {
     praline_arena &a = *pl.arena;
@@ -1202,23 +1207,37 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
     hipStream_t st = g_rt.stream;
     const size_t nt = pl.tasks.size();
     const bool semiglobal = mode >= 2;
-    size_t m_budget = reftile_budget_bytes(), tb_budget = tb_budget_bytes();
+    const size_t m_budget = reftile_budget_bytes(), tb_budget = tb_budget_bytes();
     auto tile_floats = [&](const WaveTask &wt) { return (int64_t)wt.nstrips * (wt.max_l1 + PRALINE_DENSE_PAD) * 1024; };
-    {
-        int64_t all_m = 0, all_tb = 0;
-        for (size_t t = 0; t < nt; ++t) { all_m += tile_floats(pl.tasks[t]) * 4; all_tb += pl.want_paths ? pl.tb_elems[t] * 8 : 0; }
-        // several chunks: two sets are alive at once
-        if ((size_t)all_m > m_budget) m_budget /= 2;
-        if ((size_t)all_tb > tb_budget) tb_budget /= 2;
-        if (const char *env = getenv("PRALINE_REFTILE_CHUNKS")) {   // experiments: at least this many chunks
-            const int n = atoi(env);
-            if (n > 1) m_budget = std::min(m_budget, (size_t)(all_m / n + (64 << 20)));
-        }
-    }
     struct Chunk { size_t t0, t1, b0, b1; int64_t m_e, tb_e, aux_e; };
     std::vector<Chunk> chunks;
     std::vector<int64_t> dense_off(nt);
     std::vector<RefTileBlock> blocks;
+    std::vector<int32_t> grp;   // group records (dp_reftile.h)
+    // k_match_tile's workgroups of a chunk: the tasks are grouped by their 32 sequences one (the schedule gives every
+    // sequence two of a set of ones its own task), a group's sequences two are laid end to end and cut into 128 columns
+    auto add_blocks = [&](size_t t0, size_t t1) {
+        std::unordered_map<std::string, size_t> index;
+        std::vector<std::vector<int32_t>> members;
+        for (size_t t = t0; t < t1; ++t) {
+            const WaveTask &wt = pl.tasks[t];
+            if (wt.max_l1 <= 0 || wt.two[0] < 0 || a.len[(size_t)wt.two[0]] <= 0) continue;
+            const std::string key(reinterpret_cast<const char *>(pl.h_lane_one.data() + t * 32), 32 * sizeof(int32_t));
+            auto it = index.find(key);
+            if (it == index.end()) { it = index.emplace(key, members.size()).first; members.emplace_back(); }
+            members[it->second].push_back((int32_t)(t - t0));
+        }
+        for (const std::vector<int32_t> &mem : members) {
+            const int32_t base = (int32_t)grp.size();
+            int32_t cum = 0;
+            // (whole strips: the columns between the end of a sequence and the end of its last strip receive zeros - local
+            // alignments must not see stale positive scores there)
+            for (int32_t tr : mem) { grp.push_back(cum); cum += (a.len[(size_t)pl.tasks[t0 + (size_t)tr].two[0]] + 31) / 32 * 16; }
+            grp.push_back(cum);
+            grp.insert(grp.end(), mem.begin(), mem.end());
+            for (int32_t c = 0; c * 64 < cum; ++c) blocks.push_back({base, (int32_t)mem.size(), c, 0});
+        }
+    };
     for (size_t t0 = 0; t0 < nt;) {
         size_t t1 = t0;
         const size_t b0 = blocks.size();
@@ -1233,61 +1252,37 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
             m_e += m_add;
             tb_e += tb_add;
             aux_e += (pl.want_paths && semiglobal) ? pl.aux_elems[t1] : 0;
-            if (wt.max_l1 > 0 && wt.two[0] >= 0) {
-                const int l2 = a.len[(size_t)wt.two[0]];
-                for (int c = 0; c * PRALINE_REFTILE_COLS < l2; ++c) blocks.push_back({(int32_t)(t1 - t0), c});
-            }
             ++t1;
         }
+        add_blocks(t0, t1);
         chunks.push_back({t0, t1, b0, blocks.size(), m_e, tb_e, aux_e});
         t0 = t1;
     }
     {
-        size_t need_m[2] = {1, 1}, need_tb[2] = {0, 0}, need_ax[2] = {1, 1};
-        for (size_t c = 0; c < chunks.size(); ++c) {
-            need_m[c & 1] = std::max(need_m[c & 1], (size_t)chunks[c].m_e);
-            need_tb[c & 1] = std::max(need_tb[c & 1], (size_t)chunks[c].tb_e * 8);
-            need_ax[c & 1] = std::max(need_ax[c & 1], (size_t)chunks[c].aux_e);
+        size_t need_m = 1, need_tb = 0, need_ax = 1;
+        for (const Chunk &ch : chunks) {
+            need_m = std::max(need_m, (size_t)ch.m_e);
+            need_tb = std::max(need_tb, (size_t)ch.tb_e * 8);
+            need_ax = std::max(need_ax, (size_t)ch.aux_e);
         }
         // (every buffer is sized once, before the loop: see the chunk loops of praline_plan_run)
-        if (pl.d_dense.n < need_m[0]) RC(pl.d_dense.alloc(need_m[0]));
-        if (chunks.size() > 1 && pl.d_dense_b.n < need_m[1]) RC(pl.d_dense_b.alloc(need_m[1]));
+        if (pl.d_dense.n < need_m) RC(pl.d_dense.alloc(need_m));
         if (pl.want_paths) {
-            if (pl.d_tb.n < need_tb[0]) RC(pl.d_tb.alloc(need_tb[0]));
-            if (pl.d_aux.n < need_ax[0]) RC(pl.d_aux.alloc(need_ax[0]));
-            if (chunks.size() > 1) {
-                if (pl.d_tb_b.n < need_tb[1]) RC(pl.d_tb_b.alloc(need_tb[1]));
-                if (pl.d_aux_b.n < need_ax[1]) RC(pl.d_aux_b.alloc(need_ax[1]));
-            }
+            if (pl.d_tb.n < need_tb) RC(pl.d_tb.alloc(need_tb));
+            if (pl.d_aux.n < need_ax) RC(pl.d_aux.alloc(need_ax));
         }
     }
     if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
     if (pl.d_dense_off.n < nt) RC(pl.d_dense_off.alloc(nt));
     if (pl.d_tile_blocks.n < blocks.size()) RC(pl.d_tile_blocks.alloc(std::max<size_t>(blocks.size(), 1)));
-    HIPCHK(hipMemcpyAsync(pl.d_tasks.p, pl.tasks.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));   // (before the fork)
+    if (pl.d_tile_grp.n < grp.size()) RC(pl.d_tile_grp.alloc(std::max<size_t>(grp.size(), 1)));
+    HIPCHK(hipMemcpyAsync(pl.d_tasks.p, pl.tasks.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(pl.d_dense_off.p, dense_off.data(), nt * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (!grp.empty()) HIPCHK(hipMemcpyAsync(pl.d_tile_grp.p, grp.data(), grp.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (!blocks.empty())
         HIPCHK(hipMemcpyAsync(pl.d_tile_blocks.p, blocks.data(), blocks.size() * sizeof(RefTileBlock), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // (the host lists go out of scope)
-    bool forked = false;
-    struct JoinGuard {
-        bool &forked; hipStream_t st;
-        ~JoinGuard()
-        {
-            if (forked && hipEventRecord(g_rt.ev_join, g_rt.stream2) == hipSuccess) (void)hipStreamWaitEvent(st, g_rt.ev_join, 0);
-            forked = false;
-        }
-    } join_guard{forked, st};
-    for (size_t c = 0; c < chunks.size(); ++c) {
-        const int set = (int)(c & 1);
-        hipStream_t cs = set ? g_rt.stream2 : st;
-        if (set && !forked) {
-            HIPCHK(hipEventRecord(g_rt.ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0));
-            forked = true;
-        }
-        const Chunk &ch = chunks[c];
-        float *tiles = set ? pl.d_dense_b.p : pl.d_dense.p;
+    for (const Chunk &ch : chunks) {
         RefTileArgs g;
         g.raw = a.d_raw.p;
         g.A = a.A;
@@ -1301,14 +1296,15 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
         g.tasks = pl.d_tasks.p + ch.t0;
         g.lane_one = pl.d_lane_one.p + ch.t0 * 32;
         g.dense_off = pl.d_dense_off.p + ch.t0;
-        g.m = tiles;
+        g.m = pl.d_dense.p;
         g.blocks = pl.d_tile_blocks.p + ch.b0;
+        g.grp = pl.d_tile_grp.p;
         g.waves = 0;
-        int rc = praline_launch_match_tile(g, a.ref_tb, (unsigned)(ch.b1 - ch.b0), cs);
+        int rc = praline_launch_match_tile(g, a.ref_tb, (unsigned)(ch.b1 - ch.b0), st);
         if (rc != PRALINE_OK) return fail(rc, "k_match_tile launch failed (A=%d, tb=%d)", a.A, a.ref_tb);
-        a16.dense = tiles;
+        a16.dense = pl.d_dense.p;
         a16.dense_off = pl.d_dense_off.p + ch.t0;
-        la.stream = cs;
+        la.stream = st;
         la.tasks = pl.d_tasks.p + ch.t0;
         la.lane_one = pl.d_lane_one.p + ch.t0 * 32;
         la.lane_pair = pl.d_lane_pair.p + ch.t0 * 32;
@@ -1320,17 +1316,12 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
             rc = praline_launch_dense(la, a16, local);
             if (rc != PRALINE_OK) return fail(rc, "dense-tile scores launch failed");
         } else {
-            la.tb = (uint4 *)(set ? pl.d_tb_b.p : pl.d_tb.p);
-            la.aux = set ? pl.d_aux_b.p : pl.d_aux.p;
+            la.tb = (uint4 *)pl.d_tb.p;
+            la.aux = pl.d_aux.p;
             rc = praline_launch_dense_tb(la, a16, local, pl.has_rects);
             if (rc != PRALINE_OK) return fail(rc, "dense-tile path launch failed");
             RC(launch_traceback(pl, la, ch.t0, ch.t1, mode));
         }
-    }
-    if (forked) {
-        HIPCHK(hipEventRecord(g_rt.ev_join, g_rt.stream2));
-        HIPCHK(hipStreamWaitEvent(st, g_rt.ev_join, 0));
-        forked = false;
     }
     return PRALINE_OK;
 }

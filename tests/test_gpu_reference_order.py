@@ -107,6 +107,72 @@ def test_reference_order_multiset_and_masks(nat, bba):
         assert np.array_equal(res_l["local"][1][k], p_or), (i, j)
 
 
+def test_reference_order_tiles(nat, bba, monkeypatch):
+    """Reference-order plans on arenas of up to 32 symbols and 8 nonzeros per row run k_match_tile (packed fp32, table rows
+    in LDS) + the dense-tile instances of the split-strip kernels (dp_reftile.hip.h).  Ragged lengths around the strip /
+    chunk / row-group boundaries, two track sets, Waterman-Eggert rectangles, every mode, scores-only and with paths:
+    bit-identical to the oracle's reference-order evaluation (cext.c:33-97,389-420) AND to the one-cell-per-thread
+    kernels + k_dp_batch (PRALINE_NO_REFTILE=1); a second run of the same plan reuses stale tile memory."""
+    rng = np.random.default_rng(41)
+    lens = [41, 70, 33, 64, 9, 130, 257, 1, 2, 31, 32, 33, 127, 128, 129, 300, 16, 17, 15]
+    p27 = [synth_profile(rng, L)[0] for L in lens]
+    assert max(int((p != 0).sum(axis=1).max()) for p in p27) <= 7
+    p3 = []
+    for L in lens:
+        c = np.zeros((L, 3), dtype=np.float32)          # one nonzero per row: 8 per row with the first set's 7
+        c[np.arange(L), rng.integers(0, 3, L)] = rng.uniform(0.5, 1.5, L).astype(np.float32)
+        p3.append(c)
+    S3 = rng.normal(0, 2, (3, 3)).astype(np.float32)
+    S2 = np.zeros((30, 30), dtype=np.float32)
+    S2[:27, :27] = bba["S"]
+    S2[27:, 27:] = S3
+    cat = [np.concatenate([a, b], axis=1) for a, b in zip(p27, p3)]
+    n = len(lens)
+    pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32)
+    rects = [[(3, 8, 2, 9), (20, 30, 25, 40)] if k % 3 == 0 else [] for k in range(len(pairs))]
+    check = np.random.default_rng(3).choice(len(pairs), 60, replace=False)      # pairs compared with the (slow) oracle
+
+    def run(arena, mode, want_paths, tile, rects=None, twice=False):
+        monkeypatch.setenv("PRALINE_NO_REFTILE", "0" if tile else "1")
+        plan = nat.Plan(arena, pairs, want_paths=want_paths, rects=rects)
+        plan.run(mode, GO, GE)
+        if twice:
+            plan.run("local" if mode != "local" else "global", GO, GE)       # leaves other scores in the tile memory
+            plan.run(mode, GO, GE)
+        out = (plan.scores().copy(), [p.copy() for p in plan.paths()] if want_paths else None, plan.kernel_name(), plan.match_kind())
+        plan.close()
+        return out
+
+    nat.set_match_mode("ref")
+    try:
+        for name, profs, S, sets in (("one set", p27, bba["S"], None), ("two sets", cat, S2, [27, 3])):
+            arena = nat.Arena(profs, S, set_sizes=sets) if sets else nat.Arena(profs, S)
+            for mode in MODES:
+                t_sc, _, t_kn, t_kind = run(arena, mode, False, True, twice=True)
+                o_sc, _, o_kn, _ = run(arena, mode, False, False)
+                assert "k_dp_split16<1, 1" in t_kn and ", 4, 1, false>" in t_kn and "k_dp_batch" in o_kn, (t_kn, o_kn)
+                assert t_kind == 2
+                assert np.array_equal(bits(t_sc), bits(o_sc)), (name, mode)
+                t_sc2, t_paths, t_kn, _ = run(arena, mode, True, True)
+                o_sc2, o_paths, _, _ = run(arena, mode, True, False)
+                assert "k_dp_split16_tb<1, 3" in t_kn and t_kn.endswith(", 4>"), t_kn
+                assert np.array_equal(bits(t_sc2), bits(o_sc2)) and np.array_equal(bits(t_sc2), bits(t_sc)), (name, mode)
+                assert all(np.array_equal(x, y) for x, y in zip(t_paths, o_paths)), (name, mode)
+                for k in check:
+                    i, j = pairs[k]
+                    tracks = ([p27[i], p3[i]], [p27[j], p3[j]], [bba["S"], S3]) if sets else ([p27[i]], [p27[j]], [bba["S"]])
+                    s_or, p_or = orc.pairwise_align(mode, tracks[0], tracks[1], tracks[2], (GO, GE))
+                    assert t_sc2[k] == np.float32(s_or) and np.array_equal(t_paths[k], p_or), (name, mode, i, j)
+            # Waterman-Eggert rectangles (local; the register-resident masks of the split-strip path kernels)
+            t_sc, t_paths, t_kn, _ = run(arena, "local", True, True, rects=rects)
+            o_sc, o_paths, _, _ = run(arena, "local", True, False, rects=rects)
+            assert "true, true, false, false, 4>" in t_kn, t_kn
+            assert np.array_equal(bits(t_sc), bits(o_sc)) and all(np.array_equal(x, y) for x, y in zip(t_paths, o_paths)), name
+            arena.close()
+    finally:
+        nat.set_match_mode(None)
+
+
 def exact_path_score(path, p1, p2, S, mode, L1, L2):
     """Score of an alignment path in EXACT rational arithmetic on the float32 inputs: diagonal steps add
     sum_ij p1[y,i] S[i,j] p2[x,j]; a run of k gap steps costs GO + (k - 1) GE unless it runs along a free edge
