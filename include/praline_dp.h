@@ -212,6 +212,17 @@ int64_t praline_plan_path_capacity(const praline_plan *plan); /* rows: sum (L1+L
  * order, or NULL to use the plan's own buffer. */
 int praline_plan_run(praline_plan *plan, int mode, float gap_open, float gap_extend,
                      void *d_scores);
+/* Per-position gap scores.  The reference's fill honours one (open, extend) per position of each sequence
+ * (GapScoreModel, praline/container/score.py:45-68; cext.c:155-158 reads g1[y-1] for U[y][x], cext.c:172-175 g2[x-1]
+ * for L[y][x]; boundary cells align.py:371-385), PairwiseAligner fills the rows with one constant (align.py:212-217).
+ * praline_arena_set_gap_scores stores g = float32 [sum of the lengths][2] (arena order, all values <= 0; NULL removes
+ * them) on the device; plans created while they are set keep the k_dp_batch task layout, take their match scores from
+ * dense matrices (the fp32 MFMA chain of praline_build_scores kind 0, or the reference order under
+ * PRALINE_MATCH_REFERENCE) and run with them through praline_plan_run_gaps - scores-only or with paths, all five
+ * modes, zero rectangles included.  praline_plan_run on such a plan still takes one constant pair.  Constant-gap
+ * plans are not affected (the tuned split-strip kernels). */
+int praline_arena_set_gap_scores(praline_arena *arena, const float *g);
+int praline_plan_run_gaps(praline_plan *plan, int mode, void *d_scores);
 /* Copies the scores of the last praline_plan_run (pair order) to the host - from the plan's own buffer or from
  * the d_scores that run was given; synchronises. */
 int praline_plan_scores(praline_plan *plan, float *scores);

@@ -93,7 +93,31 @@ class PairwiseBatch(object):
         self.S, self.sizes = _block_diagonal(score_matrices)
         self._index = {}      # (id(sequence), role) -> arena index
         self._profiles = []
+        self._owner = []      # arena index -> id(sequence)
+        self._gaps = {}       # id(sequence) -> float32 [len, 2] per-position (open, extend): set_gap_scores
         self.requests = []    # (mode, arena_one, arena_two, rects or None)
+
+    def set_gap_scores(self, sequence, gap_score_model):
+        """Per-position gap scores for one sequence: a GapScoreModel (praline/container/score.py:45-68) or a float
+        [len, 2] array of (open, extend) rows.  The reference's fill reads them per position (cext.c:155-158,172-175);
+        PairwiseAligner itself only ever builds constant rows (align.py:212-217).  Sequences without a model keep the
+        batch's gap series.  Batches with models run on the per-position instances of the batched kernels
+        (praline_plan_run_gaps)."""
+        g = np.ascontiguousarray(getattr(gap_score_model, 'scores', gap_score_model), dtype=np.float32)
+        if g.ndim != 2 or g.shape[1] != 2:
+            raise ComponentError("gap scores must have shape (len, 2)")
+        self._gaps[id(sequence)] = g
+
+    def _gap_rows(self):
+        rows = []
+        for sid, prof in zip(self._owner, self._profiles):
+            g = self._gaps.get(sid)
+            if g is None:
+                g = np.tile(np.array([[self.gap_open, self.gap_extend]], dtype=np.float32), (prof.shape[0], 1))
+            if g.shape[0] != prof.shape[0]:
+                raise ComponentError("gap score model of length %d for a sequence of length %d" % (g.shape[0], prof.shape[0]))
+            rows.append(g)
+        return rows
 
     def _arena_index(self, sequence, role):
         key = (id(sequence), role if self.ids_one != self.ids_two else 0)
@@ -107,6 +131,7 @@ class PairwiseBatch(object):
                 parts.append(p)
             self._index[key] = len(self._profiles)
             self._profiles.append(np.concatenate(parts, axis=1) if len(parts) > 1 else parts[0])
+            self._owner.append(id(sequence))
         return self._index[key]
 
     def add(self, mode, sequence_one, sequence_two, rects=None):
@@ -170,6 +195,8 @@ class PairwiseBatch(object):
             return scores, paths
         arena = native.Arena(self._profiles, self.S, set_sizes=self.sizes)
         try:
+            if self._gaps:
+                arena.set_gap_scores(self._gap_rows())
             for mode in MODES:
                 sel = [k for k, r in enumerate(self.requests) if r[0] == mode]
                 if not sel:
@@ -180,7 +207,10 @@ class PairwiseBatch(object):
                     rects = [list(self.requests[k][3] or []) for k in sel]
                 plan = native.Plan(arena, pairs, want_paths=want_paths or rects is not None, rects=rects)
                 try:
-                    plan.run(mode, self.gap_open, self.gap_extend)
+                    if self._gaps:
+                        plan.run_gaps(mode)
+                    else:
+                        plan.run(mode, self.gap_open, self.gap_extend)
                     sc = plan.scores()
                     pt = plan.paths() if want_paths else None
                 finally:

@@ -47,6 +47,10 @@ struct RunParams {
     int mode;
     float go1, ge1;  // gap open / extend of gap_score_model_one (state U, cext.c:155-158)
     float go2, ge2;  // gap open / extend of gap_score_model_two (state L, cext.c:172-175)
+    // per-position gap scores (GapScoreModel, praline/container/score.py:45-68; cext.c:155-158,172-175 read g1[y-1],
+    // g2[x-1]): float [rows_pad][2] = (open, extend) of every arena row, indexed like the padded profile rows
+    // (ArenaDev::row_off[seq] + position); nullptr: the constant scores above
+    const float *gaps = nullptr;
 };
 
 struct RectList {
@@ -66,6 +70,15 @@ __device__ __forceinline__ bool mode_free_two(int mode) { return mode == 2 || mo
 __device__ __forceinline__ float boundary_value(int idx, float go, float ge, bool is_free)
 {
     return is_free ? 0.0f : (float)((double)(idx - 1) * (double)ge + (double)go);
+}
+
+// The same with per-position gap scores g = (open, extend) rows of the sequence (align.py:371-385):
+// o[0,0,k] = open[0] - extend[0];  o[idx,0,1] / o[0,idx,2] = (idx - 1) * extend[idx - 1] + open[0]  (float64, one rounding).
+__device__ __forceinline__ float boundary_value_pp(int idx, const float *g, bool is_free)
+{
+    if (is_free) return 0.0f;
+    const int k = idx > 0 ? idx - 1 : 0;
+    return (float)((double)(idx - 1) * (double)g[2 * k + 1] + (double)g[0]);
 }
 
 __device__ __forceinline__ float max3f(float a, float b, float c)
@@ -271,6 +284,33 @@ __global__ __launch_bounds__(64) void k_scores_tile(ArenaDev ar, int one, int tw
     }
 }
 
+// The same for the pairs chunk_pairs[0 .. gridDim.x) of a plan, pair p's matrix at mref + m_off[p] (plans that run with
+// per-position gap scores take their match scores from dense matrices, like the reference-order plans).
+__global__ __launch_bounds__(64) void k_scores_tile_batch(ArenaDev ar, const int32_t *__restrict__ pairs,
+                                                           const int32_t *__restrict__ chunk_pairs,
+                                                           const int64_t *__restrict__ m_off, int nstep, int tiles_x,
+                                                           float *__restrict__ mref)
+{
+    const int p = chunk_pairs[blockIdx.x];
+    const int one = pairs[2 * p], two = pairs[2 * p + 1];
+    const int lane = threadIdx.x;
+    const int j = lane & 31, h = lane >> 5;
+    const int L1 = ar.len[one], L2 = ar.len[two];
+    const int y0 = (int)(blockIdx.y / tiles_x) * 32, x0 = (int)(blockIdx.y % tiles_x) * 32;
+    if (y0 >= L1 || x0 >= L2) return;
+    const float *pa = ar.P + ((int64_t)ar.row_off[one] + y0 + j) * ar.KP + h * ar.KS;
+    const float *qb = ar.Q + ((int64_t)ar.row_off[two] + x0 + j) * ar.KP + h * ar.KS;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < nstep; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], acc, 0, 0, 0);
+    float *m = mref + m_off[p];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int x = x0 + j;
+        if (y < L1 && x < L2) m[(int64_t)y * L2 + x] = acc[r];
+    }
+}
+
 #endif  // PRALINE_AUX_KERNELS
 
 // --------------------------------------------------------------------------------------------
@@ -320,7 +360,10 @@ __device__ __forceinline__ float select32(const float (&v)[32], int idx)
 #ifdef PRALINE_EXP_BATCH_MASK2
 __device__ unsigned praline_dbg[128];
 #endif
-template <int NSTEP, int TP, bool LOCAL, int OUT, int MASK, int MSRC = 0>
+// PPG (with MSRC = 1, TP = 1): per-position gap scores rp.gaps - U[y][x] takes (open, extend) of position y - 1 of the
+// lane's sequence one, L[y][x] those of position x - 1 of the shared sequence two (cext.c:155-158,172-175), the boundary
+// cells follow align.py:371-385.  The shared sequence's scores of a strip are staged in LDS (wave-uniform reads).
+template <int NSTEP, int TP, bool LOCAL, int OUT, int MASK, int MSRC = 0, bool PPG = false>
 __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__restrict__ tasks,
                                                  const int32_t *__restrict__ lane_one,
                                                  const int32_t *__restrict__ lane_pair,
@@ -332,6 +375,8 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
                                                  const int64_t *__restrict__ m_off = nullptr)
 {
     static_assert(MSRC == 0 || TP == 1, "the dense match-score source is wired for TP = 1");
+    static_assert(!PPG || (MSRC == 1 && TP == 1), "per-position gap scores are wired for the dense match-score source");
+    __shared__ float g2s[PPG ? 2 * 36 : 2];   // PPG: (open, extend) of positions x0 - 1 .. x0 + 32 of sequence two
     constexpr int NQ = (NSTEP + 3) / 4;  // float4 loads per operand
     const int lane = threadIdx.x;
     const int half = lane >> 5;
@@ -401,9 +446,14 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
     float *lastcol = aux + tk.aux_off + lane;                                 // [y][3][64]
     float *lastrow = aux + tk.aux_off + (int64_t)(tk.max_l1 + 1) * 3 * 64 + lane;  // [x-1][3][64]
 
+    // PPG: the gap-score rows of this lane's sequence one and of the shared sequence two
+    const float *g1p = PPG ? rp.gaps + (int64_t)(my_one >= 0 ? ar.row_off[my_one] : 0) * 2 : nullptr;
+    const float *g2p = PPG ? rp.gaps + (int64_t)(tk.two[0] >= 0 ? ar.row_off[tk.two[0]] : 0) * 2 : nullptr;
+    const int L2_shared = (PPG && tk.two[0] >= 0) ? ar.len[tk.two[0]] : 0;
+
     // ---- boundary cells (praline/component/align.py:367-385) ----
-    const float o001 = free_one ? 0.0f : (go1 - ge1);
-    const float o002 = free_two ? 0.0f : (go2 - ge2);
+    const float o001 = free_one ? 0.0f : (PPG ? boundary_value_pp(0, g1p, false) : (go1 - ge1));
+    const float o002 = free_two ? 0.0f : (PPG ? boundary_value_pp(0, g2p, false) : (go2 - ge2));
     const float h00 = max3f(0.0f, o001, o002);
 
     // ---- end-cell bookkeeping ----
@@ -415,8 +465,8 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
         if (o001 > best) { best = o001; best_k = 1; }
         if (o002 > best) { best = o002; best_k = 2; }
     }
-    float rowmax = have_pair ? boundary_value(L1, go1, ge1, free_one) : PRALINE_NEG_INF;  // o[L1,0,1]
-    float colmax = have_pair ? boundary_value(L2, go2, ge2, free_two) : PRALINE_NEG_INF;  // o[0,L2,2]
+    float rowmax = have_pair ? (PPG ? boundary_value_pp(L1, g1p, free_one) : boundary_value(L1, go1, ge1, free_one)) : PRALINE_NEG_INF;  // o[L1,0,1]
+    float colmax = have_pair ? (PPG ? boundary_value_pp(L2, g2p, free_two) : boundary_value(L2, go2, ge2, free_two)) : PRALINE_NEG_INF;  // o[0,L2,2]
     float corner_h = PRALINE_NEG_INF;
     float corner_m = PRALINE_NEG_INF, corner_u = PRALINE_NEG_INF, corner_l = PRALINE_NEG_INF;
 
@@ -445,17 +495,43 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
         // per-column state carried down the strip (only the set of this OUT variant is live)
         float Hp[32], Uc[32];          // OUT==0
         float Mp[32], Up[32], Lp[32];  // OUT==1
+        if constexpr (PPG) {
+            // g2s[l] = scores of position x0 - 1 + l (zero outside the sequence: such columns reach no reported cell)
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 36) {
+                const int pos = x0 - 1 + lane;
+                const bool ok = pos >= 0 && pos < L2_shared;
+                g2s[2 * lane] = ok ? g2p[2 * pos] : 0.0f;
+                g2s[2 * lane + 1] = ok ? g2p[2 * pos + 1] : 0.0f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
+        const float g2_open0 = PPG ? g2p[0] : 0.0f;
+        // o[0,x,2] of DP column x = x0 + c + 1 (c = -1: the cell left of the strip)
+        auto row0 = [&](int c) __attribute__((always_inline)) {
+            if constexpr (PPG) {
+                if (free_two) return 0.0f;
+                return (float)((double)(x0 + c) * (double)g2s[2 * (c + 1) + 1] + (double)g2_open0);   // (x - 1) * extend[x - 1] + open[0]
+            } else {
+                return boundary_value(x0 + c + 1, go2, ge2, free_two);
+            }
+        };
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
-            const float bl = boundary_value(x0 + c + 1, go2, ge2, free_two);  // o[0,x,2]
+            const float bl = row0(c);  // o[0,x,2]
             Hp[c] = bl; Uc[c] = PRALINE_NEG_INF;
             Mp[c] = PRALINE_NEG_INF; Up[c] = PRALINE_NEG_INF; Lp[c] = bl;
         }
         // states of the cell (y-1, x0), the diagonal input of column x0+1: row 0 first
         float dM = (s == 0) ? 0.0f : PRALINE_NEG_INF;
         float dU = (s == 0) ? o001 : PRALINE_NEG_INF;
-        float dL = (s == 0) ? o002 : boundary_value(x0, go2, ge2, free_two);
+        float dL = (s == 0) ? o002 : row0(-1);
         float dH = (s == 0) ? h00 : dL;
+        // PPG: (open, extend) of positions y - 1 and y of this lane's sequence one (one row ahead)
+        float2 g1a = make_float2(0.0f, 0.0f), g1b = g1a;
+        if constexpr (PPG) { g1a = make_float2(g1p[0], g1p[1]); g1b = make_float2(g1p[2], g1p[3]); }
 
         // B operands of row 1
         float4 nA[NQ], nB[NQ];
@@ -467,6 +543,9 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
         }
 
         for (int y = 1; y <= tk.max_l1; ++y) {
+            // PPG: gy1 = scores of position y - 1 (U[y][x], the boundary cell o[y,0,1]), gy = those of position y (U[y+1][x])
+            const float2 gy1 = g1a, gy = g1b;
+            if constexpr (PPG) { g1a = g1b; g1b = make_float2(g1p[2 * (y + 1)], g1p[2 * (y + 1) + 1]); }
             // MASK == 2: bit c of zrow = cell (y, x0 + c + 1) lies in one of this pair's rectangles; the words were
             // prepared by k_build_zmask (walking the rectangle list here, in a loop, miscompiled the LOCAL instance with
             // ROCm 7.2: wrong scores even with empty lists)
@@ -543,7 +622,10 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
                 }
                 if constexpr (OUT == 0) {
                     float hl, lin;  // H of cell (y, x0) and the L state of cell (y, x0+1)
-                    if (s == 0) { hl = boundary_value(y, go1, ge1, free_one); lin = PRALINE_NEG_INF; }
+                    if (s == 0) {
+                        hl = PPG ? (free_one ? 0.0f : (float)((double)(y - 1) * (double)gy1.y + (double)g1p[0])) : boundary_value(y, go1, ge1, free_one);
+                        lin = PRALINE_NEG_INF;
+                    }
                     else { const float2 bv = bnd2[(int64_t)y * 64]; hl = bv.x; lin = bv.y; }
                     float hd = dH, lrun = lin;
 #pragma unroll
@@ -564,8 +646,13 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
                         }
                         const float H = max3f(M, U, Lc);
                         if (LOCAL) best = __builtin_fmaxf(best, H);
+                        if constexpr (PPG) {
+                            Uc[c] = __builtin_fmaxf(M + gy.x, U + gy.y);                                   // U[y+1][x]: position y of one
+                            lrun = __builtin_fmaxf(M + g2s[2 * (c + 2)], Lc + g2s[2 * (c + 2) + 1]);       // L[y][x+1]: position x of two
+                        } else {
                         Uc[c] = __builtin_fmaxf(M + go1, U + ge1);   // U[y+1][x]   (cext.c:152-166,247-254)
                         lrun = __builtin_fmaxf(M + go2, Lc + ge2);   // L[y][x+1]   (cext.c:169-183,276-283)
+                        }
                         hd = Hp[c];
                         Hp[c] = H;
                     }
@@ -574,7 +661,11 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
                     if (semiglobal && is_last) colmax = __builtin_fmaxf(colmax, select32(Hp, clast));
                 } else {
                     float bm, bu, bl;  // states of the cell (y, x0)
-                    if (s == 0) { bm = PRALINE_NEG_INF; bu = boundary_value(y, go1, ge1, free_one); bl = PRALINE_NEG_INF; }
+                    if (s == 0) {
+                        bm = PRALINE_NEG_INF;
+                        bu = PPG ? (free_one ? 0.0f : (float)((double)(y - 1) * (double)gy1.y + (double)g1p[0])) : boundary_value(y, go1, ge1, free_one);
+                        bl = PRALINE_NEG_INF;
+                    }
                     else { const float4 bv = bnd4[(int64_t)y * 64]; bm = bv.x; bu = bv.y; bl = bv.z; }
                     float md = dM, ud = dU, ld = dL;   // states of (y-1, x-1)
                     float mleft = bm, lleft = bl;      // states of (y, x-1)
@@ -586,9 +677,10 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
                         const float sMM = md + m[c], sMU = ud + m[c], sML = ld + m[c];
                         float M = max3f(sMM, sMU, sML);
                         if (LOCAL) M = __builtin_fmaxf(M, 0.0f);
-                        const float uo = Mp[c] + go1, ue = Up[c] + ge1;
+                        // (PPG: U[y][x] takes position y - 1 of one, L[y][x] position x - 1 = x0 + c of two)
+                        const float uo = Mp[c] + (PPG ? gy1.x : go1), ue = Up[c] + (PPG ? gy1.y : ge1);
                         float U = __builtin_fmaxf(uo, ue);
-                        const float lo = mleft + go2, le = lleft + ge2;
+                        const float lo = mleft + (PPG ? g2s[2 * (c + 1)] : go2), le = lleft + (PPG ? g2s[2 * (c + 1) + 1] : ge2);
                         float Lc = __builtin_fmaxf(lo, le);
                         bool isMM = sMM == M;
                         bool isMU = !isMM && sMU == M;
@@ -745,10 +837,12 @@ __global__ __launch_bounds__(64) void k_semiglobal_end(ArenaDev ar, const WaveTa
     float rmax = PRALINE_NEG_INF, cmax = PRALINE_NEG_INF;
     int rx = 0, rk = 0, cy = 0, ck = 0;
     {
-        const float b1 = boundary_value(L1, rp.go1, rp.ge1, free_one);   // o[L1, 0, :] = (-inf, b1, -inf)
+        const float *g1p = rp.gaps ? rp.gaps + (int64_t)ar.row_off[pairs[2 * p]] * 2 : nullptr;
+        const float *g2p = rp.gaps ? rp.gaps + (int64_t)ar.row_off[pairs[2 * p + 1]] * 2 : nullptr;
+        const float b1 = g1p ? boundary_value_pp(L1, g1p, free_one) : boundary_value(L1, rp.go1, rp.ge1, free_one);   // o[L1, 0, :] = (-inf, b1, -inf)
         rmax = b1; rx = 0; rk = 1;
         if (!(b1 > PRALINE_NEG_INF)) rk = 0;
-        const float b2 = boundary_value(L2, rp.go2, rp.ge2, free_two);   // o[0, L2, :] = (-inf, -inf, b2)
+        const float b2 = g2p ? boundary_value_pp(L2, g2p, free_two) : boundary_value(L2, rp.go2, rp.ge2, free_two);   // o[0, L2, :] = (-inf, -inf, b2)
         cmax = b2; cy = 0; ck = 2;
         if (!(b2 > PRALINE_NEG_INF)) ck = 0;
     }

@@ -84,7 +84,7 @@ int praline_launch_match_tile(const RefTileArgs &g, int TB, unsigned n_blocks, h
 int praline_launch_dense(const LaunchArgs &la, const Arena16Dev &a16, bool local);
 int praline_launch_dense_tb(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask);
 // k_dp_batch on dense reference-order match scores (dp_ref_instance.hip)
-int praline_launch_dp_ref(const LaunchArgs &la, bool local, int out, int mask);
+int praline_launch_dp_ref(const LaunchArgs &la, bool local, int out, int mask);   // (la.rp.gaps set: the per-position instances)
 // k_dp_batch instances (dp_instance.hip)
 int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, int mask);
 int praline_launch_dp_8(const LaunchArgs &la, int tp, bool local, int out, int mask);

@@ -354,6 +354,10 @@ struct praline_arena {
     int64_t cap_rows_raw = 0, cap_rows_pad = 0, cap_seqs = 0;   // 0: the buffers hold exactly what is in use
     int64_t rp_end = 0;       // padded rows taken by sequences (the zero tail follows)
     bool wide = false;       // more than 32 active symbols: no MFMA operand layouts; every plan runs the reference-order path
+    // per-position gap scores (praline_arena_set_gap_scores): (open, extend) per padded row; plans created while they
+    // are set keep the k_dp_batch task layout and can run with them (praline_plan_run_gaps)
+    DevBuf<float> d_gaps;
+    bool has_gaps = false;
     Arena16Dev view16() const
     {
         Arena16Dev v;
@@ -591,6 +595,31 @@ extern "C" int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets
     return PRALINE_OK;
 }
 
+// Per-position gap scores (GapScoreModel, praline/container/score.py:45-68): g = float32 [sum of the lengths][2] =
+// (open, extend) of every position of every sequence, in arena order; NULL: back to constant gap scores.
+extern "C" int praline_arena_set_gap_scores(praline_arena *arena, const float *g)
+{
+    if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    RC(ensure_runtime(-1));
+    if (!g) { arena->has_gaps = false; arena->d_gaps.release(); return PRALINE_OK; }
+    if (arena->cap_seqs != 0) return fail(PRALINE_ERR_UNSUPPORTED, "gap scores on a growing arena (praline_arena_set_counts) are not supported");
+    const size_t rows = (size_t)arena->rows_pad + 64;
+    std::vector<float> pad(rows * 2, 0.0f);
+    for (int64_t q = 0; q < arena->n_seqs; ++q) {
+        const float *src = g + (size_t)arena->row_off_raw[(size_t)q] * 2;
+        const int L = arena->len[(size_t)q];
+        for (int k = 0; k < 2 * L; ++k) {
+            if (!(src[k] <= 0.0f)) return fail(PRALINE_ERR_UNSUPPORTED, "batched kernels need gap scores <= 0 (sequence %lld, position %d: %g)", (long long)q, k / 2, src[k]);
+        }
+        std::copy(src, src + 2 * (size_t)L, pad.begin() + (size_t)arena->row_off_pad[(size_t)q] * 2);
+    }
+    hipStream_t st = g_rt.stream;
+    RC(arena->d_gaps.upload(pad, st));
+    HIPCHK(hipStreamSynchronize(st));
+    arena->has_gaps = true;
+    return PRALINE_OK;
+}
+
 static int arena_ensure_ref(praline_arena *a);
 
 // reference-order match scores of the pairs chunk_pairs[0 .. n_chunk) into mref + m_off[pair]
@@ -806,6 +835,8 @@ struct praline_plan {
     DevBuf<float> d_mref;
     // reference-order match scores on the split-strip kernels (k_match_tile + the dense-tile instances, dp_reftile.hip.h)
     bool ref_tile = false;
+    bool ppg = false;       // created on an arena with per-position gap scores: k_dp_batch layout, dense match scores
+    bool run_ppg = false;   // the run in progress uses them (praline_plan_run_gaps)
     DevBuf<float> d_dense;                  // the tiles of one launch chunk
     DevBuf<int64_t> d_dense_off;
     DevBuf<RefTileBlock> d_tile_blocks;
@@ -892,15 +923,16 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         opt.split_layout = false;
         opt.tp = 1;
     }
+    pl->ppg = a.has_gaps;
     // reference order on the split-strip kernels: arenas of up to 32 symbols whose rows hold at most 8 nonzeros
     // (PRALINE_NO_REFTILE=1: the one-cell-per-thread kernels and k_dp_batch, as for wide arenas and many-rectangle plans)
-    if (pl->ref && match_mode() == PRALINE_MATCH_REFERENCE && !a.wide && !many_rects && opt.split_layout && a.nr16 > 0 &&
+    if (pl->ref && !pl->ppg && match_mode() == PRALINE_MATCH_REFERENCE && !a.wide && !many_rects && opt.split_layout && a.nr16 > 0 &&
         !(getenv("PRALINE_NO_REFTILE") && getenv("PRALINE_NO_REFTILE")[0] == '1')) {
         int rc = arena_ensure_reft2(arena);
         if (rc != PRALINE_OK) { delete pl; return rc; }
         if (a.reft2_state == 1) { pl->ref = false; pl->ref_tile = true; }
     }
-    if (pl->ref) { opt.split_layout = false; opt.tp = 1; }
+    if (pl->ref || pl->ppg) { opt.split_layout = false; opt.tp = 1; }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
     if (const char *env = getenv("PRALINE_NO_W2")) opt.shared_waves = env[0] != '1';
     {   // score plans on one-hot arenas run the lookup instances: three waves per SIMD (168 VGPRs, 4.75 KB of LDS per wave)
@@ -953,7 +985,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     pl->cells = sch.cells;
     const std::vector<int32_t> &lane_one = sch.lane_one, &lane_pair = sch.lane_pair;
     const std::vector<PairLoc> &loc = sch.loc;
-    if (pl->ref) {
+    if (pl->ref || pl->ppg) {
         pl->h_lane_pair = sch.lane_pair;
         pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);
     }
@@ -968,7 +1000,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         delete pl;
         return rc;
     }
-    if (pl->ref && !want_paths) {
+    if ((pl->ref || pl->ppg) && !want_paths) {
         if ((rc = pl->d_pairs.upload(pl->h_pairs, st))) { delete pl; return rc; }
     }
     if (pl->pipe.ok) {
@@ -1119,7 +1151,7 @@ static size_t ref_budget_bytes()
 static int plan_run_ref(praline_plan &pl, LaunchArgs la, int mode, bool local)
 {
     praline_arena &a = *pl.arena;
-    RC(arena_ensure_ref(&a));
+    if (pl.ref) RC(arena_ensure_ref(&a));
     hipStream_t st = g_rt.stream;
     const size_t nt = pl.tasks.size();
     const size_t m_budget = ref_budget_bytes(), tb_budget = tb_budget_bytes();
@@ -1167,7 +1199,15 @@ static int plan_run_ref(praline_plan &pl, LaunchArgs la, int mode, bool local)
         HIPCHK(hipMemcpyAsync(pl.d_m_off.p, pl.h_m_off.data(), (size_t)pl.n_pairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
         if (!chunk.empty()) {
             HIPCHK(hipMemcpyAsync(pl.d_chunk_pairs.p, chunk.data(), chunk.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            RC(launch_match_ref(&a, pl.d_pairs.p, pl.d_chunk_pairs.p, chunk.size(), max_l1, pl.d_m_off.p, pl.d_mref.p));
+            if (pl.ref) {
+                RC(launch_match_ref(&a, pl.d_pairs.p, pl.d_chunk_pairs.p, chunk.size(), max_l1, pl.d_m_off.p, pl.d_mref.p));
+            } else {
+                // (a plan running with per-position gap scores in the default match mode: the fp32 MFMA chain of k_scores_tile)
+                const int tiles_x = (a.max_len + 31) / 32, tiles_y = (max_l1 + 31) / 32;
+                hipLaunchKernelGGL(k_scores_tile_batch, dim3((unsigned)chunk.size(), (unsigned)(tiles_x * tiles_y)), dim3(64), 0, st,
+                                   a.view(), pl.d_pairs.p, pl.d_chunk_pairs.p, pl.d_m_off.p, a.nstep, tiles_x, pl.d_mref.p);
+                HIPCHK(hipGetLastError());
+            }
         }
         la.tasks = pl.d_tasks.p + t0;
         la.lane_one = pl.d_lane_one.p + t0 * 64;
@@ -1384,7 +1424,13 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         }
         pl.last_kernel = kn;
     }
-    if (pl.ref) {
+    if (pl.run_ppg) {
+        la.rp.gaps = a.d_gaps.p;
+        char kn[160];
+        snprintf(kn, sizeof(kn), "k_dp_batch<2, 1, %s, %d, %d, 1, true>", local ? "true" : "false", pl.want_paths ? 1 : 0, pl.mask_kind);
+        pl.last_kernel = kn;
+    }
+    if (pl.ref || pl.run_ppg) {
         HIPCHK(hipEventRecord(pl.ev0, st));
         RC(plan_run_ref(pl, la, mode, local));
         HIPCHK(hipEventRecord(pl.ev1, st));
@@ -1807,6 +1853,21 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     }
     HIPCHK(hipEventRecord(pl.ev1, st));
     return PRALINE_OK;
+}
+
+// praline_plan_run with the arena's per-position gap scores (praline_arena_set_gap_scores) instead of one (open, extend):
+// U[y][x] takes the scores of position y - 1 of sequence one, L[y][x] those of position x - 1 of sequence two
+// (cext.c:155-158,172-175), the boundary cells follow align.py:371-385.  The plan must have been created while the
+// arena held gap scores (such plans keep the k_dp_batch task layout and take their match scores from dense matrices).
+extern "C" int praline_plan_run_gaps(praline_plan *plan, int mode, void *d_scores)
+{
+    if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
+    if (!plan->ppg) return fail(PRALINE_ERR_UNSUPPORTED, "the plan was created before praline_arena_set_gap_scores");
+    if (!plan->arena->has_gaps || !plan->arena->d_gaps.p) return fail(PRALINE_ERR_ARG, "the arena holds no gap scores");
+    plan->run_ppg = true;
+    const int rc = praline_plan_run(plan, mode, 0.0f, 0.0f, d_scores);
+    plan->run_ppg = false;
+    return rc;
 }
 
 extern "C" int praline_plan_kernel_name(const praline_plan *plan, char *buf, int64_t size)

@@ -88,6 +88,8 @@ def lib():
     L.praline_plan_path_capacity.argtypes = [vp]
     L.praline_plan_path_capacity.restype = i64
     L.praline_plan_run.argtypes = [vp, i32, f32, f32, vp]
+    L.praline_plan_run_gaps.argtypes = [vp, i32, vp]
+    L.praline_arena_set_gap_scores.argtypes = [vp, vp]
     L.praline_plan_scores.argtypes = [vp, vp]
     L.praline_plan_device_scores.argtypes = [vp]
     L.praline_plan_device_scores.restype = vp
@@ -275,6 +277,18 @@ class Arena(object):
             sz = np.ascontiguousarray(set_sizes, dtype=np.int32)
             _check(lib().praline_arena_set_track_sets(h, len(sz), sz.ctypes.data))
 
+    def set_gap_scores(self, gap_scores):
+        """Per-position gap scores (praline_arena_set_gap_scores): a list of float32 [L_s, 2] arrays, one per sequence,
+        or one [sum L, 2] array; None removes them.  Plans created afterwards can `run_gaps`."""
+        if gap_scores is None:
+            _check(lib().praline_arena_set_gap_scores(self._h, None))
+            return
+        g = gap_scores if isinstance(gap_scores, np.ndarray) else np.concatenate([np.asarray(x, dtype=np.float32) for x in gap_scores], axis=0)
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        if g.shape != (int(self.lens.sum()), 2):
+            raise ValueError("gap scores must have shape (%d, 2)" % int(self.lens.sum()))
+        _check(lib().praline_arena_set_gap_scores(self._h, g.ctypes.data))
+
     def set_counts(self, counts, reserve_seqs=0, reserve_rows=0):
         """The integer counts behind the profile rows, int32 [sum L, A] (praline_arena_set_counts): makes the arena
         growable by append_merged."""
@@ -387,6 +401,10 @@ class Plan(object):
         """Asynchronous launch on the library stream.  d_scores: optional DEVICE pointer (int)."""
         _check(lib().praline_plan_run(self._h, MODES[mode], float(gap_open), float(gap_extend),
                                       ctypes.c_void_p(d_scores) if d_scores else None))
+
+    def run_gaps(self, mode, d_scores=None):
+        """run() with the arena's per-position gap scores (Arena.set_gap_scores; praline_plan_run_gaps)."""
+        _check(lib().praline_plan_run_gaps(self._h, MODES[mode], ctypes.c_void_p(d_scores) if d_scores else None))
 
     def scores(self):
         out = np.zeros(self.n, dtype=np.float32)

@@ -1,0 +1,133 @@
+"""Per-position gap scores in the batched kernels (praline_arena_set_gap_scores / praline_plan_run_gaps): the reference's
+fill reads one (open, extend) per position of each sequence (cext.c:155-158,172-175; boundary cells align.py:371-385).
+Checker: the oracle's RawPairwiseAligner restatement on the same match scores."""
+import numpy as np
+import pytest
+
+from conftest import MODES, one_hot, synth_profile
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from praline_amd import native
+    native.init(0)
+    yield native
+    native.set_match_mode(None)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def random_gaps(rng, L, exact):
+    """(open, extend) rows, all negative; exact: multiples of 1/4 (every DP value stays exact in float32)"""
+    if exact:
+        g = np.stack([-rng.integers(8, 60, L) / 4.0, -rng.integers(1, 12, L) / 4.0], axis=1)
+    else:
+        g = np.stack([-rng.uniform(2.0, 15.0, L), -rng.uniform(0.1, 3.0, L)], axis=1)
+    return g.astype(np.float32)
+
+
+def zero_cells(rects, L1, L2):
+    return [(y, x) for (y0, y1, x0, x1) in rects for y in range(y0, y1 + 1) for x in range(x0, x1 + 1) if y <= L1 and x <= L2]
+
+
+@pytest.mark.parametrize("kind", ["onehot", "float", "float-ref"])
+def test_per_position_gap_scores_plans(nat, bba, kind):
+    """Plans created on an arena with gap scores run k_dp_batch<..., PPG>: five modes, scores-only and with paths,
+    Waterman-Eggert rectangles in local mode, ragged lengths across the strip boundary; scores bit-identical and paths
+    identical to the oracle (match scores: exact for sequences, the fp32 MFMA chain / the reference order for float
+    profiles).  A constant-gap run of the same plan still equals the constant-gap oracle."""
+    rng = np.random.default_rng({"onehot": 5, "float": 6, "float-ref": 7}[kind])
+    lens = [37, 64, 1, 33, 90, 32, 65]
+    S = bba["S"]
+    if kind == "onehot":
+        profs = [one_hot(rng.integers(0, 20, L), 27) for L in lens]
+    else:
+        profs = [synth_profile(rng, L)[0] for L in lens]
+    gaps = [random_gaps(rng, L, exact=(kind == "onehot")) for L in lens]
+    n = len(lens)
+    pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32)
+    rects = [[(2, 6, 3, 9), (20, 28, 18, 30)] if k % 2 else [] for k in range(len(pairs))]
+
+    def match(i, j):
+        if kind == "float":
+            return orc.build_scores_fma([profs[i]], [profs[j]], [S])
+        m = np.zeros((lens[i], lens[j]), dtype=np.float32)
+        orc.cext_build_scores([profs[i]], [profs[j]], [orc.build_nonzero_matrix(profs[i])], [orc.build_nonzero_matrix(profs[j])], [S], m)
+        return m
+
+    ms = {(i, j): match(i, j) for i, j in pairs}
+    if kind == "float-ref":
+        nat.set_match_mode("ref")
+    try:
+        arena = nat.Arena(profs, S)
+        arena.set_gap_scores(gaps)
+        for mode in MODES:
+            plan = nat.Plan(arena, pairs, want_paths=True)
+            plan.run_gaps(mode)
+            sc, paths = plan.scores(), plan.paths()
+            assert "true>" in plan.kernel_name() and "k_dp_batch" in plan.kernel_name(), plan.kernel_name()
+            plan.run(mode, -11.0, -1.0)              # the same plan with one constant pair
+            sc_c, paths_c = plan.scores(), plan.paths()
+            plan.close()
+            plan0 = nat.Plan(arena, pairs, want_paths=False)
+            plan0.run_gaps(mode)
+            sc0 = plan0.scores()
+            plan0.close()
+            for k, (i, j) in enumerate(pairs):
+                s_or, p_or = orc.raw_pairwise_align(mode, ms[(i, j)], gaps[i], gaps[j])
+                assert sc[k] == np.float32(s_or), (mode, i, j, sc[k], s_or)
+                assert np.array_equal(paths[k], p_or), (mode, i, j)
+                assert sc0[k] == np.float32(s_or), (mode, i, j, "scores-only")
+                g1, g2 = orc.gap_arrays(lens[i], lens[j], (-11.0, -1.0))
+                s_c, p_c = orc.raw_pairwise_align(mode, ms[(i, j)], g1, g2)
+                assert sc_c[k] == np.float32(s_c) and np.array_equal(paths_c[k], p_c), (mode, i, j, "constant")
+        plan = nat.Plan(arena, pairs, want_paths=True, rects=rects)
+        plan.run_gaps("local")
+        sc, paths = plan.scores(), plan.paths()
+        plan.close()
+        for k, (i, j) in enumerate(pairs):
+            s_or, p_or = orc.raw_pairwise_align("local", ms[(i, j)], gaps[i], gaps[j], zero_idxs=zero_cells(rects[k], lens[i], lens[j]) or None)
+            assert sc[k] == np.float32(s_or) and np.array_equal(paths[k], p_or), ("rects", i, j)
+        # plans made before the gap scores were set, or after they were removed, refuse to run with them
+        arena.set_gap_scores(None)
+        plan = nat.Plan(arena, pairs[:4], want_paths=False)
+        with pytest.raises(Exception):
+            plan.run_gaps("global")
+        plan.close()
+        arena.close()
+    finally:
+        nat.set_match_mode(None)
+
+
+def test_pairwise_batch_with_gap_score_models(nat, bba):
+    """The host mirror: PairwiseBatch.set_gap_scores hands per-sequence GapScoreModels to the device; sequences without
+    one keep the gap series."""
+    from praline_amd import component as comp
+    from praline_amd import container as ct
+    rng = np.random.default_rng(9)
+    lens = [40, 71, 18, 55]
+    idx = [rng.integers(0, 20, L) for L in lens]
+    seqs = [ct.Sequence("s%d" % k, [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=v))]) for k, v in enumerate(idx)]
+    blosum = ct.blosum62()
+    batch = comp.PairwiseBatch([[ct.TRACK_ID_INPUT]], [[ct.TRACK_ID_INPUT]], [blosum], [-11.0, -1.0])
+    gaps = {}
+    for k in (0, 2, 3):
+        gaps[k] = random_gaps(rng, lens[k], exact=True)
+        batch.set_gap_scores(seqs[k], ct.GapScoreModel(seqs[k], gaps[k]))
+    gaps[1] = np.tile(np.array([[-11.0, -1.0]], dtype=np.float32), (lens[1], 1))
+    reqs = [(mode, i, j) for mode in MODES for i in range(4) for j in range(4) if i != j]
+    for mode, i, j in reqs:
+        batch.add(mode, seqs[i], seqs[j])
+    scores, paths = batch.run(want_paths=True)
+    S = np.asarray(blosum.matrix, dtype=np.float32)
+    for (mode, i, j), s_dev, p_dev in zip(reqs, scores, paths):
+        p1, p2 = one_hot(idx[i], S.shape[0]), one_hot(idx[j], S.shape[0])
+        m = np.zeros((lens[i], lens[j]), dtype=np.float32)
+        orc.cext_build_scores([p1], [p2], [orc.build_nonzero_matrix(p1)], [orc.build_nonzero_matrix(p2)], [S], m)
+        s_or, p_or = orc.raw_pairwise_align(mode, m, gaps[i], gaps[j])
+        assert np.float32(s_dev) == np.float32(s_or) and np.array_equal(p_dev, p_or), (mode, i, j)
