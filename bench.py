@@ -427,13 +427,14 @@ def main():
         plan_f.close()
         # the reference's own summation order on the VALU (PRALINE_MATCH_REFERENCE): identical alignments for any profiles
         native.set_match_mode("ref")
-        sub = my_pairs[::8]
+        sub = my_pairs          # (the whole workload: k_match_tile + the dense-tile instances)
         sub_cells = int((lens[sub[:, 0]].astype(np.int64) * lens[sub[:, 1]]).sum())
         plan_r = native.Plan(arena, sub)
-        dt_ref = timed(lambda: plan_r.run(args.mode, GAP_OPEN, GAP_EXTEND), reps=2)
+        dt_ref = timed(lambda: plan_r.run(args.mode, GAP_OPEN, GAP_EXTEND), reps=3)
+        variants["reference_order_kernel"] = plan_r.kernel_name()
         plan_r.close()
         plan_r = native.Plan(arena, sub, want_paths=True)
-        dt_ref_p = timed(lambda: plan_r.run(args.mode, GAP_OPEN, GAP_EXTEND), reps=2)
+        dt_ref_p = timed(lambda: plan_r.run(args.mode, GAP_OPEN, GAP_EXTEND), reps=3)
         plan_r.close()
         native.set_match_mode(None)
         variants["reference_order_gcups"] = sub_cells / dt_ref / 1e9
