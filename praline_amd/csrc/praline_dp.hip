@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -303,6 +304,21 @@ template <typename T> struct DevBuf {
 
 #define RC(expr) do { int rc_ = (expr); if (rc_ != PRALINE_OK) return rc_; } while (0)
 
+// PRALINE_TIMING=1: host-side phase times of arena / plan creation on stderr (scripts/exp_e2e.py)
+struct PhaseTimer {
+    bool on;
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(const char *w) : on(getenv("PRALINE_TIMING") != nullptr), what(w), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *phase)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] %s: %-28s %8.3f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 // --------------------------------------------------------------------------------------------
 // arena
 // --------------------------------------------------------------------------------------------
@@ -417,6 +433,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     // the raw (concatenated) alphabet may be wide; what the kernels bound is the number of ACTIVE symbols (<= 32)
     if (A <= 0 || A > 254) return fail(PRALINE_ERR_ARG, "alphabet size %d not in 1..254 (concatenated track sets)", A);
     RC(ensure_runtime(-1));
+    PhaseTimer pt("arena_create");
     praline_arena *a = new praline_arena();
     a->n_seqs = n_seqs;
     a->A = A;
@@ -459,6 +476,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         if (u & 0x7fffffffu) inexact_bits = (u & 0x1fffu) | (unsigned)(e < 113u) | (unsigned)(e > 142u);
     }
     {
+        // (one core: 0.6 ms for the 11 MB of C2; four threads were slower - 1.0 ms - on the GPU box's host share)
         std::vector<int> col_nz(A, 0);
         for (int64_t r = 0; r < rr; ++r) {
             const float *row = profiles + r * A;
@@ -475,6 +493,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         }
         for (int i = 0; i < A; ++i) has_mass[i] = (char)col_nz[i];
     }
+    pt.mark("host scan of the profiles");
     for (int i = 0; i < A; ++i)
         for (int j = 0; j < A; ++j)
             if (S[i * A + j] != 0.0f) has_score[i] = 1;
@@ -527,6 +546,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     for (int64_t s = 0; s < n_seqs; ++s)
         for (int r = 0; r < (lens[s] + 31) / 32 * 32; ++r) seq_of_rowp[a->row_off_pad[s] + r] = (int32_t)s;
 
+    pt.mark("host tables");
     int rc = PRALINE_OK;
     hipStream_t st = g_rt.stream;
     if ((rc = a->d_raw.alloc((size_t)rr * A)) || (rc = a->d_raw.upload(profiles, (size_t)rr * A, st)) ||
@@ -541,6 +561,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         delete a;
         return rc;
     }
+    pt.mark("allocations + uploads (async)");
     const bool host_knows_split = a->nr16 > 0 && inexact_bits != 0;
     if (host_knows_split) {
         // profiles that float16 cannot hold: three terms (K-packed into four MFMAs for at most 21 active symbols), one
@@ -552,7 +573,9 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         rc = arena_launch_premultiply(a, true);
     }
     if (rc != PRALINE_OK) { delete a; return rc; }
+    pt.mark("premultiply launches");
     hipError_t e = hipStreamSynchronize(st);  // host vectors above go out of scope
+    pt.mark("stream sync");
     if (e != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena upload: %s", hipGetErrorString(e)); }
     if (a->nr16 > 0 && !host_knows_split) {
         int flag = 1;
@@ -888,6 +911,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     if (rect_off && !want_paths && rect_off[n_pairs] > 0)
         return fail(PRALINE_ERR_UNSUPPORTED, "zero rectangles are only supported together with want_paths");
     RC(ensure_runtime(-1));
+    PhaseTimer pt("plan_create");
     const praline_arena &a = *arena;
     bool many_rects = false;   // some pair carries more rectangles than the register-resident mask code holds
     for (int64_t p = 0; p < n_pairs; ++p) {
@@ -972,6 +996,7 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
     } else {
         build_schedule(a.len.data(), n_pairs, pairs, opt, sch);
     }
+    pt.mark("host scheduling");
     pl->tp = sch.tp;
     pl->split = sch.split;
     pl->tasks.swap(sch.tasks);
@@ -1043,7 +1068,9 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
                                pl->d_rects.p, pl->d_zm_off.p, pl->d_zmask.p);
         }
     }
+    pt.mark("allocations + uploads (async)");
     hipError_t e = hipStreamSynchronize(st);
+    pt.mark("stream sync");
     if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
     if (e != hipSuccess) { delete pl; return fail(PRALINE_ERR_DEVICE, "plan upload: %s", hipGetErrorString(e)); }

@@ -616,17 +616,21 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
     struct Cut { int32_t list; std::vector<int32_t> task; };
     // max_tasks: tasks per item; n_single: per list, this share (in 1/1024) of its tasks - the shortest - become items
     // of their own (large batches: the short items the dispatcher fills the tail of the launch with)
+    // (every list's tasks by descending strip count, once: the bisection below packs them a dozen times)
+    std::vector<std::vector<int32_t>> sorted_tasks(lists.size());
+    for (size_t li = 0; li < lists.size(); ++li) {
+        sorted_tasks[li] = lists[li].task;
+        std::stable_sort(sorted_tasks[li].begin(), sorted_tasks[li].end(), [&](int32_t x, int32_t y) { return st[(size_t)x].nstrips > st[(size_t)y].nstrips; });
+    }
     auto cut_count = [&](int64_t cstar, int max_tasks, int single_share, std::vector<Cut> *cuts) {
         int64_t n = 0;
-        std::vector<int32_t> order;
         std::vector<int64_t> load;
         std::vector<int32_t> count;
         std::vector<std::vector<int32_t>> member;
         for (size_t li = 0; li < lists.size(); ++li) {
             const PipeList &l = lists[li];
             const int64_t cap = std::max<int64_t>(1, cstar / l.rsteps) * 4;   // strips per item
-            order.assign(l.task.begin(), l.task.end());
-            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return st[(size_t)x].nstrips > st[(size_t)y].nstrips; });
+            const std::vector<int32_t> &order = sorted_tasks[li];
             const size_t n_single = (order.size() * (size_t)single_share + 1023) / 1024;
             const size_t n_packed = order.size() - std::min(order.size(), n_single);
             load.clear(); count.clear();
@@ -667,12 +671,16 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
     {
         const int64_t n_tasks = (int64_t)st.size(), slots = std::max<int64_t>(opt.wg_slots, 1);
         if (2 * n_tasks <= 5 * slots) {
-            int64_t lo = one_max, hi = std::max(one_max, total);
+            // the bound only acts through floor(c* / rsteps) and every rsteps is a multiple of 12: search the multiples of
+            // 12, from the larger of the longest task and an even share upwards (galloping, then bisection)
+            int64_t lo = (std::max(one_max, (total + slots - 1) / slots) + 11) / 12, hi = lo;
+            const int64_t top = (std::max(one_max, total) + 11) / 12;
+            while (hi < top && cut_count(12 * hi, PRALINE_PIPE_MAX_TASKS, 0, nullptr) > slots) { lo = hi + 1; hi = std::min(top, hi + std::max<int64_t>(1, hi / 8)); }
             while (lo < hi) {
                 const int64_t mid = (lo + hi) / 2;
-                if (cut_count(mid, PRALINE_PIPE_MAX_TASKS, 0, nullptr) <= slots) hi = mid; else lo = mid + 1;
+                if (cut_count(12 * mid, PRALINE_PIPE_MAX_TASKS, 0, nullptr) <= slots) hi = mid; else lo = mid + 1;
             }
-            cut_count(lo, PRALINE_PIPE_MAX_TASKS, 0, &cuts);
+            cut_count(12 * lo, PRALINE_PIPE_MAX_TASKS, 0, &cuts);
         } else {
             const int k = (int)std::min<int64_t>(PRALINE_PIPE_MAX_TASKS, std::max<int64_t>(1, n_tasks / (3 * slots)));
             const int share = k == 1 ? 0 : (int)std::min<int64_t>(1024, 2 * slots * 1024 / n_tasks);

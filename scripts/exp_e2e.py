@@ -13,6 +13,9 @@ profs = [synth_profile(rng, int(L)) for L in lens]
 pairs = np.array([(i, j) for i in range(N) for j in range(i + 1, N)], dtype=np.int32)
 cells = int((lens[pairs[:, 0]].astype(np.int64) * lens[pairs[:, 1]]).sum())
 for rep in range(3):
+    tc = time.perf_counter()
+    cat = np.ascontiguousarray(np.concatenate(profs, axis=0), dtype=np.float32)
+    print("np.concatenate of the profiles: %.2f ms (inside arena below)" % ((time.perf_counter() - tc) * 1e3))
     t0 = time.perf_counter()
     ar = nat.Arena(profs, S)
     t1 = time.perf_counter()
