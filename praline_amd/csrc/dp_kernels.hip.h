@@ -159,6 +159,54 @@ __device__ __forceinline__ void pack_entry(int64_t idx, const float *__restrict_
     P[idx] = v;
 }
 
+// What arena creation needs to know about the raw profiles (praline_arena_create): per row its one-hot symbol (255: the
+// row is not one-hot), and over all rows which symbols carry mass (flags[i], i < A) and how many rows are not one-hot
+// (flags[A]).  One thread per row; the column flags are gathered per workgroup in LDS.
+__global__ __launch_bounds__(256) void k_scan_profiles(const float *__restrict__ raw, int64_t rows, int A, unsigned char *__restrict__ sym_raw,
+                                                       int *__restrict__ flags)
+{
+    __shared__ int col[256];
+    __shared__ int not_hot;
+    col[threadIdx.x] = 0;
+    if (threadIdx.x == 0) not_hot = 0;
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) {
+        const float *row = raw + r * A;
+        int nz = 0, hot = 0, ones = 0;
+        for (int i = 0; i < A; ++i) {
+            const float v = row[i];
+            if (v != 0.0f) { ++nz; hot = i; if (!col[i]) col[i] = 1; }   // (benign race: every writer stores 1)
+            ones += v == 1.0f;
+        }
+        const bool onehot = nz == 1 && ones == 1;
+        sym_raw[r] = onehot ? (unsigned char)hot : (unsigned char)255;
+        if (!onehot) atomicAdd(&not_hot, 1);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < A && col[threadIdx.x]) atomicOr(&flags[threadIdx.x], 1);
+    if (threadIdx.x == 0 && not_hot) atomicAdd(&flags[A], not_hot);
+}
+
+// one-hot arenas: sym8[padded row] = active-symbol slot of the row's symbol (slot_of[255] = "none" for padding rows)
+__global__ void k_build_sym8(const unsigned char *__restrict__ sym_raw, const int32_t *__restrict__ seq_of_rowp,
+                             const int32_t *__restrict__ row_off_pad, const int32_t *__restrict__ row_off_raw,
+                             const int32_t *__restrict__ len, const unsigned char *__restrict__ slot_of, int64_t rows_pad,
+                             int64_t rows_out, unsigned char *__restrict__ sym8)
+{
+    const int64_t rp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rp >= rows_out) return;
+    unsigned char v = slot_of[255];
+    if (rp < rows_pad) {
+        const int s = seq_of_rowp[rp];
+        if (s >= 0) {
+            const int y = (int)(rp - row_off_pad[s]);
+            if (y < len[s]) v = slot_of[sym_raw[row_off_raw[s] + y]];
+        }
+    }
+    sym8[rp] = v;
+}
+
 __global__ void k_pack_profiles(const float *__restrict__ raw, const int32_t *__restrict__ seq_of_rowp,
                                 const int32_t *__restrict__ row_off_pad,
                                 const int32_t *__restrict__ row_off_raw,

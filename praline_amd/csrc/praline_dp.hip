@@ -461,7 +461,6 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     // One pass over the raw profiles gathers everything the host needs from them: which symbols carry mass, and per
     // row whether it is one-hot and on which symbol (counted branch-free so that the loop vectorises).
     std::vector<char> has_mass(A, 0), has_score(A, 0);
-    std::vector<unsigned char> sym_raw((size_t)rr, 255);
     bool all_onehot_rows = true;
     // ... and whether some value is NOT a normal float16 (13 low mantissa bits set, or an exponent outside -14 .. 15): such
     // an arena needs the hi/lo split whatever S is, so the device-side exactness check (and the second packing launch
@@ -475,25 +474,30 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         const unsigned e = (u >> 23) & 0xffu;
         if (u & 0x7fffffffu) inexact_bits = (u & 0x1fffu) | (unsigned)(e < 113u) | (unsigned)(e > 142u);
     }
+    hipStream_t st = g_rt.stream;
     {
-        // (one core: 0.6 ms for the 11 MB of C2; four threads were slower - 1.0 ms - on the GPU box's host share)
-        std::vector<int> col_nz(A, 0);
-        for (int64_t r = 0; r < rr; ++r) {
-            const float *row = profiles + r * A;
-            int nz = 0, hot = 0, ones = 0;
-            for (int i = 0; i < A; ++i) {
-                const int is_nz = row[i] != 0.0f;
-                col_nz[i] |= is_nz;
-                nz += is_nz;
-                hot += is_nz * i;
-                ones += row[i] == 1.0f;
-            }
-            if (nz == 1 && ones == 1) sym_raw[(size_t)r] = (unsigned char)hot;
-            else all_onehot_rows = false;
+        // the raw profiles go up first; the scan of their rows (mass per symbol, one-hot rows) runs on the device - one
+        // small read-back instead of 0.6 ms of host time for the 11 MB of C2
+        DevBuf<int> d_flags;
+        std::vector<int> flags((size_t)A + 1, 0);
+        int rc0 = PRALINE_OK;
+        if ((rc0 = a->d_raw.alloc((size_t)rr * A)) || (rc0 = a->d_raw.upload(profiles, (size_t)rr * A, st)) ||
+            (rc0 = a->d_sym_raw.alloc((size_t)rr)) || (rc0 = d_flags.alloc((size_t)A + 1))) {
+            delete a;
+            return rc0;
         }
-        for (int i = 0; i < A; ++i) has_mass[i] = (char)col_nz[i];
+        hipError_t e0 = hipMemsetAsync(d_flags.p, 0, ((size_t)A + 1) * sizeof(int), st);
+        if (e0 == hipSuccess) {
+            hipLaunchKernelGGL(k_scan_profiles, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, st, a->d_raw.p, rr, A, a->d_sym_raw.p, d_flags.p);
+            e0 = hipGetLastError();
+        }
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(flags.data(), d_flags.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
+        if (e0 != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena scan: %s", hipGetErrorString(e0)); }
+        for (int i = 0; i < A; ++i) has_mass[i] = (char)(flags[(size_t)i] != 0);
+        all_onehot_rows = flags[(size_t)A] == 0;
     }
-    pt.mark("host scan of the profiles");
+    pt.mark("upload + device scan of the profiles");
     for (int i = 0; i < A; ++i)
         for (int j = 0; j < A; ++j)
             if (S[i * A + j] != 0.0f) has_score[i] = 1;
@@ -525,20 +529,17 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     a->KP = 2 * a->KS;
     a->nr16 = a->wide ? 0 : (a->n_active <= 16 ? 1 : 2);
 
-    // one-hot arenas (every row: a single 1, zeros elsewhere): active-symbol bytes for the one-hot operand table
-    std::vector<unsigned char> sym8;
+    // one-hot arenas (every row: a single 1, zeros elsewhere): active-symbol bytes for the one-hot operand table (built
+    // on the device below: k_build_sym8)
+    std::vector<unsigned char> slot_of;
     {
         const bool want_table = a->nr16 > 0 && !(getenv("PRALINE_NO_ONEHOT") && getenv("PRALINE_NO_ONEHOT")[0] == '1');
         a->all_onehot = all_onehot_rows;
         a->onehot = all_onehot_rows && want_table;
         if (a->onehot) {
             const unsigned char none = (unsigned char)(16 * a->nr16);
-            std::vector<unsigned char> slot_of(256, none);
+            slot_of.assign(256, none);
             for (int k = 0; k < a->n_active; ++k) slot_of[a->active[k]] = (unsigned char)k;
-            sym8.assign((size_t)a->rows_pad + 64, none);
-            for (int64_t s = 0; s < n_seqs; ++s)
-                for (int y = 0; y < lens[s]; ++y)
-                    sym8[a->row_off_pad[s] + y] = slot_of[sym_raw[(size_t)(a->row_off_raw[s] + y)]];
         }
     }
 
@@ -548,18 +549,24 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
 
     pt.mark("host tables");
     int rc = PRALINE_OK;
-    hipStream_t st = g_rt.stream;
-    if ((rc = a->d_raw.alloc((size_t)rr * A)) || (rc = a->d_raw.upload(profiles, (size_t)rr * A, st)) ||
-        (rc = a->d_S.alloc((size_t)A * A)) || (rc = a->d_S.upload(S, (size_t)A * A, st)) ||
+    if ((rc = a->d_S.alloc((size_t)A * A)) || (rc = a->d_S.upload(S, (size_t)A * A, st)) ||
         (rc = a->d_len.upload(a->len, st)) || (rc = a->d_row_off_pad.upload(a->row_off_pad, st)) ||
         (rc = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
         (rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
         (rc = a->d_P.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) ||
-        (rc = a->d_flag16.alloc(1)) || (a->onehot && (rc = a->d_sym8.upload(sym8, st))) || (rc = a->d_sym_raw.upload(sym_raw, st)) ||
+        (rc = a->d_flag16.alloc(1)) || (a->onehot && (rc = a->d_sym8.alloc((size_t)a->rows_pad + 64))) ||
         (a->nr16 > 0 && ((rc = a->d_P16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)) ||
                          (rc = a->d_Q16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16))))) {
         delete a;
         return rc;
+    }
+    DevBuf<unsigned char> d_slot_of;
+    if (a->onehot) {
+        if ((rc = d_slot_of.upload(slot_of, st))) { delete a; return rc; }
+        const int64_t rows_out = a->rows_pad + 64;
+        hipLaunchKernelGGL(k_build_sym8, dim3((unsigned)((rows_out + 255) / 256)), dim3(256), 0, st, a->d_sym_raw.p, a->d_seq_of_rowp.p,
+                           a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, d_slot_of.p, a->rows_pad, rows_out, a->d_sym8.p);
+        if (hipGetLastError() != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "k_build_sym8 launch failed"); }
     }
     pt.mark("allocations + uploads (async)");
     const bool host_knows_split = a->nr16 > 0 && inexact_bits != 0;
