@@ -71,6 +71,10 @@ while time.time() < t_end:
     # (of those, the float-profile global plans with their forward fill on the scores kernel, PRALINE_TB_KEEP)
     os.environ["PRALINE_TB_TWOPASS"] = "2" if rng.random() < 0.33 else "0"
     os.environ["PRALINE_TB_KEEP"] = "1" if rng.random() < 0.5 else "0"
+    if os.environ.get("STRESS_VERBOSE") == "1":
+        print("batch %d: kind=%s ref=%s N=%d mu=%d pairs=%d mode=%s paths=%s rects=%s TWOPASS=%s KEEP=%s" % (
+            n_cases, kind, ref_mode, N, mu, len(pairs), mode, want_paths, rects is not None, os.environ["PRALINE_TB_TWOPASS"],
+            os.environ["PRALINE_TB_KEEP"]), flush=True)
     arena = nat.Arena(profs, S)
     plan = nat.Plan(arena, pairs, want_paths=want_paths, rects=rects)
     mk = plan.match_kind()
@@ -85,9 +89,12 @@ while time.time() < t_end:
         # score and path must be identical (races between chunks show up here, not in 24 sampled pairs)
         keep_env = {k: os.environ.get(k) for k in ("PRALINE_TB_TWOPASS", "PRALINE_TB_BUDGET_MB")}
         os.environ["PRALINE_TB_TWOPASS"] = "0" if os.environ.get("PRALINE_TB_TWOPASS") == "2" else "2"
-        bud = rng.choice(["", "40", "500", "3000"])
+        # (a 40 MB budget cuts plans of long sequences into one-task chunks - one wave per launch: minutes per batch)
+        bud = rng.choice(["", "40", "500", "3000"]) if int(lens.max()) * N < 40000 else rng.choice(["", "500", "3000"])
         if bud:
             os.environ["PRALINE_TB_BUDGET_MB"] = str(bud)
+        if os.environ.get("STRESS_VERBOSE") == "1":
+            print("   second configuration: TWOPASS=%s budget=%r" % (os.environ["PRALINE_TB_TWOPASS"], bud), flush=True)
         plan2 = nat.Plan(arena, pairs, want_paths=True, rects=rects)
         plan2.run(mode, -11.0, -1.0)
         sc2 = plan2.scores()

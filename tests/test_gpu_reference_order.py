@@ -163,6 +163,15 @@ def test_reference_order_tiles(nat, bba, monkeypatch):
                     tracks = ([p27[i], p3[i]], [p27[j], p3[j]], [bba["S"], S3]) if sets else ([p27[i]], [p27[j]], [bba["S"]])
                     s_or, p_or = orc.pairwise_align(mode, tracks[0], tracks[1], tracks[2], (GO, GE))
                     assert t_sc2[k] == np.float32(s_or) and np.array_equal(t_paths[k], p_or), (name, mode, i, j)
+            # several launch chunks (tile budget of 2 MiB: a few tasks per chunk), scores-only and with paths
+            monkeypatch.setenv("PRALINE_REFTILE_BUDGET_MB", "2")
+            c_sc, _, _, _ = run(arena, "semiglobal_one", False, True)
+            c_sc2, c_paths, _, _ = run(arena, "local", True, True)
+            monkeypatch.delenv("PRALINE_REFTILE_BUDGET_MB")
+            o_sc, _, _, _ = run(arena, "semiglobal_one", False, False)
+            o_sc2, o_paths, _, _ = run(arena, "local", True, False)
+            assert np.array_equal(bits(c_sc), bits(o_sc)) and np.array_equal(bits(c_sc2), bits(o_sc2)), name
+            assert all(np.array_equal(x, y) for x, y in zip(c_paths, o_paths)), name
             # Waterman-Eggert rectangles (local; the register-resident masks of the split-strip path kernels)
             t_sc, t_paths, t_kn, _ = run(arena, "local", True, True, rects=rects)
             o_sc, o_paths, _, _ = run(arena, "local", True, False, rects=rects)
