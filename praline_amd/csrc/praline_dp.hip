@@ -1554,12 +1554,22 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         }
         tb_nterm = ints ? 1 : 3;
     }
-    const size_t budget = tb_budget_bytes();
+    size_t budget = tb_budget_bytes();
     const bool semiglobal = mode >= 2;
     const size_t tb_elem_bytes = pl.split ? sizeof(uint2) : sizeof(uint4);
     const int lanes_per_task = pl.split ? 32 : 64;
     size_t t0 = 0;
     const size_t nt = pl.tasks.size();
+    if (!getenv("PRALINE_TB_BUDGET_MB") && nt > 0) {
+        // Plans of LONG sequences (more than 8 MiB of packed traceback per task: ~700 x 700 and up) run in chain mode
+        // chunk by chunk; a chunk of a few tasks leaves the chip half empty, so they get up to 48 GiB (of 288) instead
+        // of 8.  Measured, all pairs with paths: 256 x ~1000 aa 38 -> 32 ms, 128 x ~2500 96 -> 70 ms, 96 x ~5000
+        // 371 -> 174 ms.  (Plans of many small tasks keep 8 GiB: within 3 % of 24 GiB on C3, see tb_budget_bytes.)
+        int64_t all = 0;
+        for (size_t t = 0; t < nt; ++t) all += pl.tb_elems[t] * (int64_t)tb_elem_bytes;
+        if ((size_t)all > budget && all / (int64_t)nt > ((int64_t)8 << 20))
+            budget = (size_t)std::min<int64_t>((int64_t)48 << 30, 2 * all);   // (twice: chunked plans cut at half the budget)
+    }
     HIPCHK(hipEventRecord(pl.ev0, st));
     // ---- two passes (dp_trace2.hip.h) for plans too large for chain mode: a flag-free forward fill that keeps the
     // strip boundary columns and (M, U, L) of every 32nd row, then k_trace_recompute rebuilds the flags of only the
@@ -1568,8 +1578,11 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         int64_t single_bytes = 0;
         int all_strips = 0;
         for (size_t t = 0; t < nt; ++t) { single_bytes += pl.tb_elems[t] * (int64_t)tb_elem_bytes; all_strips = std::max(all_strips, (int)pl.tasks[t].nstrips); }
-        const bool would_chain = pl.split && la.a16 != nullptr && all_strips >= 2 && (size_t)single_bytes <= budget &&
-                                 (int64_t)nt <= chain_max_tasks() && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
+        // (plans over the budget are cut into chunks of about half the budget, each of which can run in chain mode)
+        const int64_t chunk_tasks = (size_t)single_bytes <= budget ? (int64_t)nt
+                                                                   : (int64_t)((double)nt * (double)(budget / 2) / (double)single_bytes) + 1;
+        const bool would_chain = pl.split && la.a16 != nullptr && all_strips >= 2 && chunk_tasks <= chain_max_tasks() &&
+                                 !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
         // Default: LOCAL plans only.  Measured on C3 (1 047 552 alignments of ~250 aa, one-hot): local 60.1 -> 47.3 ms,
         // global 54.7 -> 53.7 ms (the forward fill's extra stores and a recompute of ~half the cells eat the saving when
         // every path spans the whole matrix).  PRALINE_TB_TWOPASS=1: every mode, =2: also instead of chain mode, =0: never.
@@ -1810,10 +1823,36 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             forked = false;
         }
     } join_guard{forked, st};
+    // Chain mode (one wave per task AND strip, pipelined across workgroups: dp_split16_tb.hip.h) for chunks of up to
+    // chain_max_tasks() tasks - single alignments, the merge steps of the progressive MSA, C2-sized batches, and the
+    // chunks of plans whose packed traceback exceeds the scratch budget (long sequences: 32 640 alignments of ~1000 x
+    // ~1000 were 96 ms in task mode, three chunks of 380 waves each).  Chain chunks share one set of boundary columns
+    // and flags: they all run on the main stream.
+    bool chain_chunks = pl.split && la.a16 != nullptr && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
+    {
+        int64_t need_bnd = 0;
+        size_t need_flags = 0;
+        for (size_t c = 0; c < chunks.size() && chain_chunks; ++c) {
+            int max_strips = 0;
+            int64_t bnd_e = 0;
+            for (size_t t = chunks[c].t0; t < chunks[c].t1; ++t) {
+                max_strips = std::max(max_strips, (int)pl.tasks[t].nstrips);
+                bnd_e += (int64_t)(pl.tasks[t].nstrips + 1) * (pl.tasks[t].max_l1 + 24) * 32;
+            }
+            if (max_strips < 2 || (int64_t)(chunks[c].t1 - chunks[c].t0) > chain_max_tasks()) chain_chunks = false;
+            need_bnd = std::max(need_bnd, bnd_e);
+            need_flags = std::max(need_flags, (chunks[c].t1 - chunks[c].t0) * (size_t)(max_strips + 1));
+        }
+        if (chain_chunks) {
+            if (pl.d_bnd_chain.n < (size_t)need_bnd * sizeof(float4)) RC(pl.d_bnd_chain.alloc((size_t)need_bnd * sizeof(float4)));
+            if (pl.d_chain_flags.n < need_flags) RC(pl.d_chain_flags.alloc(need_flags));
+            if (local && pl.d_chain_cand.n < need_flags * 32) RC(pl.d_chain_cand.alloc(need_flags * 32));
+        }
+    }
     for (size_t c = 0; c < chunks.size(); ++c) {
         const int set = (int)(c & 1);
-        hipStream_t cs = set ? g_rt.stream2 : st;
-        if (set && !forked) {
+        hipStream_t cs = (set && !chain_chunks) ? g_rt.stream2 : st;
+        if (set && !forked && !chain_chunks) {
             HIPCHK(hipEventRecord(g_rt.ev_fork, st));
             HIPCHK(hipStreamWaitEvent(g_rt.stream2, g_rt.ev_fork, 0));
             forked = true;
@@ -1829,34 +1868,29 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         la.tb = (uint4 *)d_tbs.p;
         la.aux = d_ax.p;
         la.n_tasks = (unsigned)(t1 - t0);
-        // Chain mode for small plans (single alignments, the merge steps of the progressive MSA): one wave per
-        // (task, strip), pipelined across workgroups (dp_split16_tb.hip.h); the plan must be one chunk.
         int max_strips = 0;
         for (size_t t = t0; t < t1; ++t) max_strips = std::max(max_strips, (int)pl.tasks[t].nstrips);
-        const bool chain = pl.split && la.a16 != nullptr && t0 == 0 && t1 == nt && max_strips >= 2 &&
-                           (int64_t)nt <= chain_max_tasks() && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
+        const bool chain = chain_chunks;
         if (chain) {
-            std::vector<WaveTask> ct(pl.tasks.begin(), pl.tasks.end());
+            const size_t nc = t1 - t0;   // tasks of this chunk
+            std::vector<WaveTask> ct(pl.tasks.begin() + (std::ptrdiff_t)t0, pl.tasks.begin() + (std::ptrdiff_t)t1);
             int64_t bnd_e = 0;
             for (WaveTask &wt : ct) {
                 wt.bnd_off = bnd_e;
                 bnd_e += (int64_t)(wt.nstrips + 1) * (wt.max_l1 + 24) * 32;   // float4 elements, [strip boundary][row][32]
             }
-            if (pl.d_bnd_chain.n < (size_t)bnd_e * sizeof(float4)) RC(pl.d_bnd_chain.alloc((size_t)bnd_e * sizeof(float4)));
-            const size_t n_flags = nt * (size_t)(max_strips + 1);
-            if (pl.d_chain_flags.n < n_flags) RC(pl.d_chain_flags.alloc(n_flags));
+            const size_t n_flags = nc * (size_t)(max_strips + 1);
             HIPCHK(hipMemsetAsync(pl.d_chain_flags.p, 0, n_flags * sizeof(int), st));
-            HIPCHK(hipMemcpyAsync(pl.d_tasks.p, ct.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(pl.d_tasks.p + t0, ct.data(), nc * sizeof(WaveTask), hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st));   // ct goes out of scope
             la.bnd = pl.d_bnd_chain.p;
-            if (local && pl.d_chain_cand.n < n_flags * 32) RC(pl.d_chain_cand.alloc(n_flags * 32));
             // rows between two publishes of a strip's progress: few for plans whose strip waves all run at once
             // (a single alignment: the next strip follows a few rows behind), many once a strip level alone
             // fills the chip (the consumers are dispatched a round later; every publish drains the stores)
-            int every = nt >= 512 ? 96 : (nt >= 64 ? 24 : 6);
+            int every = nc >= 512 ? 96 : (nc >= 64 ? 24 : 6);
             {   // short sequences: at least four publishes per strip (co-resident consumers would wait for the end)
                 int rows = 0;
-                for (const WaveTask &wt : pl.tasks) rows = std::max(rows, (int)wt.max_l1);
+                for (const WaveTask &wt : ct) rows = std::max(rows, (int)wt.max_l1);
                 every = std::min(every, std::max(6, rows / 4));
             }
             if (const char *env = getenv("PRALINE_CHAIN_EVERY")) every = std::max(6, atoi(env));
@@ -1864,9 +1898,9 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                                                      pl.d_chain_flags.p, pl.d_chain_cand.p, every);
             if (rc != PRALINE_OK) return fail(rc, "no chain instance of k_dp_split16_tb for nr=%d nterm=%d", a.nr16, tb_nterm);
             if (local) {
-                const int64_t lanes = (int64_t)nt * 32;
-                hipLaunchKernelGGL(k_chain_local_end, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, pl.d_tasks.p,
-                                   pl.d_lane_pair.p, pl.d_chain_cand.p, (int)nt, max_strips + 1, pl.d_end_cells.p, la.scores);
+                const int64_t lanes = (int64_t)nc * 32;
+                hipLaunchKernelGGL(k_chain_local_end, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, la.tasks,
+                                   la.lane_pair, pl.d_chain_cand.p, (int)nc, max_strips + 1, pl.d_end_cells.p, la.scores);
             }
             la.bnd = pl.d_bnd.p;
         } else if (pl.split) {

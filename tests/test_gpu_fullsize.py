@@ -347,6 +347,45 @@ def test_chunked_path_plans_on_two_streams(nat, monkeypatch):
     arena.close()
 
 
+def test_chain_mode_chunk_by_chunk(nat, bba, monkeypatch):
+    """Path plans whose packed traceback exceeds the scratch budget run in chain mode (one wave per task and strip) chunk
+    by chunk - long sequences: a chunk holds few tasks, which task mode would run one wave each.  Float profiles of
+    ~600 aa under a 48 MB budget (three or four tasks per chunk), three modes: scores and every path equal task mode
+    (PRALINE_NO_CHAIN=1) and the one-chunk run; sampled pairs equal the oracle."""
+    from conftest import synth_profile, synth_lengths
+    rng = np.random.default_rng(19)
+    lens = synth_lengths(rng, 40, 600).astype(np.int32)
+    profs = [synth_profile(rng, int(L))[0] for L in lens]
+    pairs = np.array([(i, j) for i in range(40) for j in range(40) if i != j], dtype=np.int32)
+    arena = nat.Arena(profs, bba["S"])
+
+    def run(mode, budget, no_chain):
+        monkeypatch.setenv("PRALINE_TB_TWOPASS", "0")
+        monkeypatch.setenv("PRALINE_TB_BUDGET_MB", budget)
+        monkeypatch.setenv("PRALINE_NO_CHAIN", "1" if no_chain else "0")
+        plan = nat.Plan(arena, pairs, want_paths=True)
+        plan.run(mode, *GAPS)
+        sc = plan.scores().copy()
+        buf, o, r = plan.paths_packed()
+        res = (sc, packed_rows(buf, o, r), o.copy(), r.copy(), plan.match_kind(), buf, plan.kernel_name())
+        plan.close()
+        return res
+
+    for mode in ("global", "local", "semiglobal_one"):
+        one = run(mode, "64000", False)
+        chunks = run(mode, "48", False)
+        tasks = run(mode, "48", True)
+        for other in (chunks, tasks):
+            assert np.array_equal(bits(other[0]), bits(one[0])), mode
+            assert np.array_equal(other[3], one[3]) and np.array_equal(other[1], one[1]), mode
+        for k in np.random.default_rng(3).permutation(len(pairs))[:4]:
+            i, j = pairs[k]
+            s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(int(i), int(j), one[4]))
+            assert chunks[0][k] == np.float32(s_or), (mode, i, j)
+            assert np.array_equal(chunks[5][chunks[2][k]:chunks[2][k] + chunks[3][k]], p_or), (mode, i, j)
+    arena.close()
+
+
 def test_scratch_growth_between_back_to_back_path_runs(nat, monkeypatch):
     """The device-buffer pool is stream-ordered (csrc/praline_dp.hip, pool_release / pool_alloc): a scratch block that a
     run replaces while an earlier run's kernels - on either of the library's two streams - may still be using it is not
