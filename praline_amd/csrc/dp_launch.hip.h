@@ -71,6 +71,9 @@ struct Trace2Args {
 int praline_launch_tb2_forward(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, bool mask);
 int praline_launch_tb2_backward(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, int nr, int nterm, bool local,
                                 bool mask, int keep_in_aux = 0);
+// chain mode without flags: scores only (score plans of a few long sequences)
+int praline_launch_scores_chain(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, int max_strips, int *flags,
+                                void *cand, int every);
 // the same forward fill on the staged scores kernel (k_dp_split16<..., KEEP>, la.wg workgroups): la.bnd its (H, L) hand-off
 // columns, keep_bnd / ckpt the kept columns (at tk.aux_off) and row checkpoints (at tk.tb_off)
 int praline_launch_keep_forward(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, void *keep_bnd, float *ckpt);

@@ -84,7 +84,8 @@ struct TbCarry {
 // SINK: where the per-row flag words go.  0: the traceback planes in global memory (single pass);
 //   1: nowhere - the flag-free FORWARD fill of the two-pass scheme (see k_trace_recompute below): no flag is formed,
 //      instead the three states of every 32nd row are written to ckpt (float4 [block][3][4][64] per strip);
-//   2: an LDS row of the recompute kernel, lds_flags + (row index) * 512 + lane * 8 (no end-cell bookkeeping).
+//   2: an LDS row of the recompute kernel, lds_flags + (row index) * 512 + lane * 8 (no end-cell bookkeeping);
+//   3: nowhere, and no checkpoints either - SCORES ONLY (chain mode for score plans of a few long sequences).
 // BSRC = 1 (one-hot arenas, single-term instances): the operand row of the refill is not loaded from the arena - 64
 // lanes reading 64 different rows per step cost the CU's L1 one tag cycle per lane, which the flag-free forward fill
 // (150 VALU per step instead of 350) no longer hides - but looked up in the one-hot operand table in LDS
@@ -114,7 +115,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     constexpr bool DENSE = BSRC == 4;
     constexpr bool LOOKUP = BSRC == 3 || DENSE;
     constexpr int NM = LOOKUP ? 1 : NTERM * NR;
-    constexpr bool INTS = NTERM == 1;
+    constexpr bool INTS = NTERM == 1 || SINK == 3;   // (scores only: the three sums are needed for the tie flags alone - fl is monotone)
     float m[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) m[c] = (DM || LOOKUP) ? CUR[c] : (h ? PREV[c] : CUR[c]);
@@ -194,12 +195,12 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             // All three are shifted in like the extend bits below: no compare, no VCC write -> v_cndmask wait
             // states, no scalar mask logic.  The maximum is finite in every interior cell (one state of each
             // boundary cell is), so no NaN here.
-            if constexpr (SINK != 1) {
+            if constexpr (SINK != 1 && SINK != 3) {
                 w_nm = shift_in_sign(w_nm, sMM, Mref);
                 w_nu = shift_in_sign(w_nu, sMU, Mref);
             }
             if constexpr (LOCAL) {
-                if constexpr (SINK != 1) w_stop = __builtin_amdgcn_alignbit(w_stop, __builtin_bit_cast(unsigned, M), 31);
+                if constexpr (SINK != 1 && SINK != 3) w_stop = __builtin_amdgcn_alignbit(w_stop, __builtin_bit_cast(unsigned, M), 31);
                 M = __builtin_fmaxf(M, 0.0f);                                    // cext.c:208-209
             }
             if constexpr (MK) {
@@ -208,7 +209,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
             // "from extend" bits = sign of (open - extend), shifted in with one v_alignbit each: no compare, so
             // no VCC write -> v_cndmask wait states (the compare form cost ~35 s_nop per step).  Column c lands
             // in bit 15 - c; reversed once per row below.  (-inf) - (-inf) only happens in cells no path enters.
-            if constexpr (SINK != 1) {
+            if constexpr (SINK != 1 && SINK != 3) {
                 w_u = shift_in_sign(w_u, uo, ue);
                 w_l = shift_in_sign(w_l, lo, le);
             }
@@ -314,7 +315,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         }
     }
     // match source as two bit planes, code = lo | hi << 1: 1 MM / 2 MU / 3 ML / 0 stop (masked cell, or the clamp won)
-    if constexpr (SINK != 1) {
+    if constexpr (SINK != 1 && SINK != 3) {
         const unsigned r_nm = __builtin_bitreverse32(w_nm) >> 16, r_nu = __builtin_bitreverse32(w_nu) >> 16;
         unsigned go_on = 0xffffu;
         if constexpr (LOCAL) go_on &= ~(__builtin_bitreverse32(w_stop) >> 16);
@@ -368,9 +369,11 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
     constexpr bool LOOKUP = BSRC == 3;
     constexpr bool DENSE = BSRC == 4;   // match scores from the task's dense tile (ar.dense): no operands, no MFMA
     constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0) && !LOOKUP && !DENSE;   // see split16_tb_step
-    constexpr int SINK = TWOPASS ? 1 : 0;
-    static_assert(!(CHAIN && TWOPASS), "the two-pass fill is a task-mode kernel");
-    static_assert(BSRC == 0 || (BSRC == 1 && TWOPASS && DM) || (LOOKUP && NTERM == 1 && !TWOPASS) || (DENSE && NTERM == 3 && !TWOPASS),
+    // CHAIN && TWOPASS: chain mode WITHOUT flags and checkpoints - the scores-only fill of plans of a few long sequences
+    // (one wave per task and strip where the score kernels would put four waves on a task)
+    constexpr bool FWD2 = TWOPASS && !CHAIN;   // the forward fill of the two-pass scheme proper
+    constexpr int SINK = TWOPASS ? (CHAIN ? 3 : 1) : 0;
+    static_assert(BSRC == 0 || (BSRC == 1 && FWD2 && DM) || (LOOKUP && NTERM == 1 && !TWOPASS) || (DENSE && NTERM == 3 && !TWOPASS),
                   "the one-hot table feeds the single-term forward fill; the lookup serves the single-pass integer-scoring fill; "
                   "dense tiles feed the single-pass fill with candidate sums");
     __shared__ __attribute__((aligned(16))) char lookup_all[LOOKUP ? 4 * lookup_bytes(NR) : 16];   // one table per wave of the block
@@ -431,9 +434,9 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
 
     if (CHAIN && chain_strip >= nstrips) return;
     // boundary columns: float4 [y][32]; chain mode keeps one per strip boundary, [strip][y][32]
-    const int64_t chain_col = CHAIN ? (int64_t)(max_l1 + 24) * 32 : (TWOPASS ? (int64_t)(max_l1 + PRALINE_TB2_PAD) * 32 : 0);
+    const int64_t chain_col = CHAIN ? (int64_t)(max_l1 + 24) * 32 : (FWD2 ? (int64_t)(max_l1 + PRALINE_TB2_PAD) * 32 : 0);
     const int ckpt_blocks = PRALINE_TB2_CKPT_BLOCKS(max_l1);
-    float *my_ckpt = TWOPASS ? reinterpret_cast<float *>(tb) + tk.tb_off + 4 * lane : nullptr;   // float4 [strip][block][3][4][64]
+    float *my_ckpt = FWD2 ? reinterpret_cast<float *>(tb) + tk.tb_off + 4 * lane : nullptr;   // float4 [strip][block][3][4][64]
     char *my_bnd = reinterpret_cast<char *>(bnd + tk.bnd_off + chain_col * chain_strip + j);          // read by this wave
     char *my_bnd_out = reinterpret_cast<char *>(bnd + tk.bnd_off + chain_col * (chain_strip + 1) + j);  // written (CHAIN)
     constexpr int BROW = 32 * (int)sizeof(float4);
@@ -603,10 +606,10 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
         // boundary states three rows ahead, in three rotating registers (one row = 0.7 us at one wave per SIMD is
         // not enough for a load that misses L2; measured with the 1-deep version: 27 % of the cycles waiting)
         // TWOPASS: strip s reads column s and writes column s + 1 (all of them stay for the recompute kernel)
-        const char *col_in = (TWOPASS && !(PRALINE_TB2_ABLATE & 2)) ? my_bnd + (int64_t)s * chain_col * (int64_t)sizeof(float4) : my_bnd;
+        const char *col_in = (FWD2 && !(PRALINE_TB2_ABLATE & 2)) ? my_bnd + (int64_t)s * chain_col * (int64_t)sizeof(float4) : my_bnd;
         const char *bnd_ld = col_in + 4 * BROW;
-        char *bnd_st = CHAIN ? my_bnd_out : ((TWOPASS && !(PRALINE_TB2_ABLATE & 2)) ? my_bnd + (int64_t)(s + 1) * chain_col * (int64_t)sizeof(float4) : my_bnd);   // upper half stores row yy = t - 1 (row 0: dummy)
-        float *ckpt_strip = TWOPASS ? my_ckpt + (int64_t)s * ckpt_blocks * PRALINE_TB2_CKPT_FLOATS : nullptr;
+        char *bnd_st = CHAIN ? my_bnd_out : ((FWD2 && !(PRALINE_TB2_ABLATE & 2)) ? my_bnd + (int64_t)(s + 1) * chain_col * (int64_t)sizeof(float4) : my_bnd);   // upper half stores row yy = t - 1 (row 0: dummy)
+        float *ckpt_strip = FWD2 ? my_ckpt + (int64_t)s * ckpt_blocks * PRALINE_TB2_CKPT_FLOATS : nullptr;
         if constexpr (CHAIN) {
             if (chain_in != nullptr) chain_seen = chain_wait(chain_in, 3, chain_seen);
         }

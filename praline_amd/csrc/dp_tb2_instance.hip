@@ -80,3 +80,30 @@ int praline_launch_keep_forward(const LaunchArgs &la, const Arena16Dev &a16, int
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }
+
+// chain mode without flags (k_dp_split16_tb<..., CHAIN, TWOPASS>): the scores-only fill of plans of a few long sequences
+template <int NR, int NTERM> static void launch_scores_chain(const LaunchArgs &la, const Arena16Dev &a16, bool local, int max_strips,
+                                                             int *flags, void *cand, int every)
+{
+    const dim3 grid(la.n_tasks * (unsigned)max_strips), block(64);
+    if (local)
+        hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, true, false, true, true>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,
+                           la.lane_pair, (float4 *)la.bnd, (uint2 *)nullptr, la.aux, la.rl, la.scores, la.end_cells, la.rp,
+                           (int)la.n_tasks, flags, max_strips + 1, (float4 *)cand, every);
+    else
+        hipLaunchKernelGGL((k_dp_split16_tb<NR, NTERM, false, false, true, true>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,
+                           la.lane_pair, (float4 *)la.bnd, (uint2 *)nullptr, la.aux, la.rl, la.scores, la.end_cells, la.rp,
+                           (int)la.n_tasks, flags, max_strips + 1, (float4 *)cand, every);
+}
+
+int praline_launch_scores_chain(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, int max_strips, int *flags,
+                                void *cand, int every)
+{
+    if (nr == 1 && nterm == 1) launch_scores_chain<1, 1>(la, a16, local, max_strips, flags, cand, every);
+    else if (nr == 1 && nterm == 3) launch_scores_chain<1, 3>(la, a16, local, max_strips, flags, cand, every);
+    else if (nr == 2 && nterm == 1) launch_scores_chain<2, 1>(la, a16, local, max_strips, flags, cand, every);
+    else if (nr == 2 && nterm == 3) launch_scores_chain<2, 3>(la, a16, local, max_strips, flags, cand, every);
+    else if (nr == 2 && nterm == 2) launch_scores_chain<2, 2>(la, a16, local, max_strips, flags, cand, every);
+    else return PRALINE_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? PRALINE_OK : PRALINE_ERR_DEVICE;
+}

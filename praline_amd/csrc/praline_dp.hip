@@ -824,6 +824,8 @@ struct praline_plan {
     std::vector<int64_t> aux_elems; // per task, floats
     int64_t bnd_elems = 0;
     DevBuf<WaveTask> d_tasks;
+    DevBuf<WaveTask> d_tasks_chain;   // scores-only chain mode: the tasks with chain-mode boundary offsets
+    int scores_chain = -1;            // -1: not decided, 0 / 1: this score plan runs in chain mode (plan_scores_chain_wanted)
     // small batches: four-wave workgroups whose waves share long tasks (k_dp_split16 WPG = 4, WgDesc)
     std::vector<WgDesc> wg;
     DevBuf<WgDesc> d_wg;
@@ -1022,6 +1024,8 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);
     }
     if (pl->ref_tile) pl->h_lane_one = sch.lane_one;
+    if (!want_paths && !pl->pipe.ok && pl->h_pairs.empty() && (int64_t)pl->tasks.size() <= chain_max_tasks())
+        pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);   // (score plans that may run in chain mode: k_semiglobal_end reads the pairs)
     const int64_t bnd = pl->bnd_elems, cap = pl->path_cap;
 
     hipStream_t st = g_rt.stream;
@@ -1400,6 +1404,97 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
     return PRALINE_OK;
 }
 
+// Score plans of a FEW LONG sequences: the score kernels put at most four waves on a task (its strips form a chain), so a
+// plan of a handful of tasks leaves the chip idle - a single 30 000 x 30 000 alignment took 2.7 s scores-only and 54 ms
+// with paths.  Such plans run the chain-mode fill (one wave per task and strip, pipelined across workgroups) in its
+// flag-free form (k_dp_split16_tb<..., CHAIN, TWOPASS>): same scores bit for bit.  The choice is an estimate from the
+// schedule, fitted to scripts/exp_scores_chain.py (all pairs of N x ~mu residues; chain wins from single alignments up to
+// about N = 64 x 400 and for every batch of long sequences that the pipeline workgroups do not take):
+//   shared waves: the longest task's ceil(strips / 4) x rows steps at 0.55 us (one-hot lookup instances: 0.45), in rounds
+//                 of 2048 waves;
+//   chain:        the larger of the longest task's rows + 24 x strips steps at 0.7 us and an even share of all strip-rows
+//                 over 2048 waves at 2.0 us per step (the waves of a chain wait for each other).
+static bool plan_scores_chain_wanted(const praline_plan &pl)
+{
+    if (const char *env = getenv("PRALINE_SCORES_CHAIN")) return atoi(env) != 0;
+    const size_t nt = pl.tasks.size();
+    if (nt == 0 || (int64_t)nt > chain_max_tasks()) return false;
+    double shared = 0.0, crit = 0.0, work = 0.0, bnd_bytes = 0.0;
+    int max_strips = 0;
+    for (const WaveTask &wt : pl.tasks) {
+        const double rows = wt.max_l1 + 1.0;
+        shared = std::max(shared, std::ceil(wt.nstrips / 4.0) * rows);
+        crit = std::max(crit, rows + 24.0 * wt.nstrips);
+        work += wt.nstrips * rows;
+        bnd_bytes += (wt.nstrips + 1.0) * (wt.max_l1 + 24.0) * 512.0;
+        max_strips = std::max(max_strips, (int)wt.nstrips);
+    }
+    if (max_strips < 2 || bnd_bytes > 64.0 * 1073741824.0) return false;
+    const bool lookup = pl.arena->onehot && pl.arena->nterm16 == 1;
+    const double t_shared = shared * std::ceil(4.0 * nt / 2048.0) * (lookup ? 0.45 : 0.55);   // us
+    const double t_chain = std::max(crit * 0.7, work / 2048.0 * 2.0);
+    return t_chain < 0.9 * t_shared;
+}
+
+static int plan_run_scores_chain(praline_plan &pl, LaunchArgs la, const Arena16Dev &a16, int mode, bool local)
+{
+    praline_arena &a = *pl.arena;
+    hipStream_t st = g_rt.stream;
+    const size_t nt = pl.tasks.size();
+    const bool semiglobal = mode >= 2;
+    std::vector<WaveTask> ct(pl.tasks.begin(), pl.tasks.end());
+    int64_t bnd_e = 0, aux_e = 0;
+    int max_strips = 0, rows = 0;
+    for (size_t t = 0; t < nt; ++t) {
+        WaveTask &wt = ct[t];
+        wt.bnd_off = bnd_e;
+        wt.tb_off = 0;
+        wt.aux_off = aux_e;
+        bnd_e += (int64_t)(wt.nstrips + 1) * (wt.max_l1 + 24) * 32;   // float4 elements, [strip boundary][row][32]
+        aux_e += semiglobal ? pl.aux_elems[t] : 0;
+        max_strips = std::max(max_strips, (int)wt.nstrips);
+        rows = std::max(rows, (int)wt.max_l1);
+    }
+    const size_t n_flags = nt * (size_t)(max_strips + 1);
+    if (pl.d_bnd_chain.n < (size_t)bnd_e * sizeof(float4)) RC(pl.d_bnd_chain.alloc((size_t)bnd_e * sizeof(float4)));
+    if (pl.d_chain_flags.n < n_flags) RC(pl.d_chain_flags.alloc(n_flags));
+    if (local && pl.d_chain_cand.n < n_flags * 32) RC(pl.d_chain_cand.alloc(n_flags * 32));
+    if (pl.d_aux.n < (size_t)std::max<int64_t>(aux_e, 1)) RC(pl.d_aux.alloc((size_t)std::max<int64_t>(aux_e, 1)));
+    if (pl.d_end_cells.n < (size_t)pl.n_pairs * 4) RC(pl.d_end_cells.alloc((size_t)pl.n_pairs * 4));
+    if (pl.d_tasks_chain.n < nt) RC(pl.d_tasks_chain.alloc(nt));
+    if (semiglobal && !pl.d_pairs.p) {
+        if (pl.h_pairs.size() != (size_t)pl.n_pairs * 2) return fail(PRALINE_ERR_UNSUPPORTED, "score plan without its pair list");
+        RC(pl.d_pairs.upload(pl.h_pairs, st));
+    }
+    HIPCHK(hipMemsetAsync(pl.d_chain_flags.p, 0, n_flags * sizeof(int), st));
+    HIPCHK(hipMemcpyAsync(pl.d_tasks_chain.p, ct.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // ct goes out of scope
+    la.tasks = pl.d_tasks_chain.p;
+    la.n_tasks = (unsigned)nt;
+    la.bnd = pl.d_bnd_chain.p;
+    la.tb = nullptr;
+    la.aux = pl.d_aux.p;
+    la.end_cells = pl.d_end_cells.p;
+    la.stream = st;
+    int every = nt >= 512 ? 96 : (nt >= 64 ? 24 : 6);
+    every = std::min(every, std::max(6, rows / 4));
+    if (const char *env = getenv("PRALINE_CHAIN_EVERY")) every = std::max(6, atoi(env));
+    int rc = praline_launch_scores_chain(la, a16, a.nr16, a.nterm16, local, max_strips, pl.d_chain_flags.p, pl.d_chain_cand.p, every);
+    if (rc != PRALINE_OK) return fail(rc, "no scores-only chain instance for nr=%d nterm=%d", a.nr16, a.nterm16);
+    if (local) {
+        const int64_t lanes = (int64_t)nt * 32;
+        hipLaunchKernelGGL(k_chain_local_end, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, la.tasks, la.lane_pair,
+                           pl.d_chain_cand.p, (int)nt, max_strips + 1, pl.d_end_cells.p, la.scores);
+    }
+    if (semiglobal) {
+        const int64_t lanes = (int64_t)nt * 32;
+        hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar, la.tasks, la.lane_one,
+                           la.lane_pair, pl.d_pairs.p, la.aux, pl.d_end_cells.p, la.scores, la.rp, (int32_t)0, (int32_t)nt, 1);
+    }
+    HIPCHK(hipGetLastError());
+    return PRALINE_OK;
+}
+
 extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, float gap_extend, void *d_scores)
 {
     if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
@@ -1501,6 +1596,18 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         HIPCHK(hipEventRecord(pl.ev1, st));
         HIPCHK(hipGetLastError());
         return PRALINE_OK;
+    }
+    if (!pl.want_paths && pl.split && la.a16 != nullptr && !pl.has_rects) {
+        if (pl.scores_chain < 0) pl.scores_chain = plan_scores_chain_wanted(pl) ? 1 : 0;
+        if (pl.scores_chain == 1) {
+            char kn[160];
+            snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, %d, %s, false, true, true, 0>", a.nr16, a.nterm16, local ? "true" : "false");
+            pl.last_kernel = kn;
+            HIPCHK(hipEventRecord(pl.ev0, st));
+            RC(plan_run_scores_chain(pl, la, a16, mode, local));
+            HIPCHK(hipEventRecord(pl.ev1, st));
+            return PRALINE_OK;
+        }
     }
     if (!pl.want_paths) {
         if (!pl.d_tasks.p) { RC(pl.d_tasks.upload(pl.tasks, st)); }

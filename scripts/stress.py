@@ -69,6 +69,10 @@ while time.time() < t_end:
             rects.append(rr)
     # path plans: a third through the two-pass scheme (forward fill + block recompute) whatever their size
     # (of those, the float-profile global plans with their forward fill on the scores kernel, PRALINE_TB_KEEP)
+    # score plans of few tasks: half on the shared-wave score kernels, half wherever the schedule's estimate sends them
+    # (mostly the flag-free chain fill)
+    if rng.random() < 0.5: os.environ["PRALINE_SCORES_CHAIN"] = "0"
+    else: os.environ.pop("PRALINE_SCORES_CHAIN", None)
     os.environ["PRALINE_TB_TWOPASS"] = "2" if rng.random() < 0.33 else "0"
     os.environ["PRALINE_TB_KEEP"] = "1" if rng.random() < 0.5 else "0"
     if os.environ.get("STRESS_VERBOSE") == "1":

@@ -437,11 +437,14 @@ def test_operand_stream_variants_agree_bitwise(nat, bba, kind, monkeypatch):
     results = {}
     # default: one-hot arenas look their match scores up (no MFMA; shared waves here, four singles with PRALINE_NO_W2);
     # "table": the one-hot operand table feeding MFMAs; "staged" / "lanes": the operand streams of float profiles
+    # (batches of this size would run the flag-free chain fill: held off for the score kernels' variants, and compared
+    # with them as the variant "chain")
     for variant, env in (("default", {}), ("lookup_singles", {"PRALINE_NO_W2": "1"}), ("table", {"PRALINE_NO_LOOKUP": "1"}),
                          ("table_singles", {"PRALINE_NO_LOOKUP": "1", "PRALINE_NO_W2": "1"}), ("staged", {"PRALINE_NO_ONEHOT": "1"}),
-                         ("lanes", {"PRALINE_NO_ONEHOT": "1", "PRALINE_NO_STAGE": "1"})):
+                         ("lanes", {"PRALINE_NO_ONEHOT": "1", "PRALINE_NO_STAGE": "1"}), ("chain", {"PRALINE_SCORES_CHAIN": "1"})):
         for k in ("PRALINE_NO_ONEHOT", "PRALINE_NO_STAGE", "PRALINE_NO_LOOKUP", "PRALINE_NO_W2"):
             monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("PRALINE_SCORES_CHAIN", "0")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         arena = nat.Arena(profs, S)
@@ -451,21 +454,26 @@ def test_operand_stream_variants_agree_bitwise(nat, bba, kind, monkeypatch):
             results[(variant, mode)] = plan.scores().copy()
         if kind != "profile" and variant in ("default", "lookup_singles") and not any(os.environ.get(k) for k in ("PRALINE_KERNEL", "PRALINE_MM")):
             assert ", 3, " in plan.kernel_name(), plan.kernel_name()       # the lookup instances ran
+        if variant == "chain" and not any(os.environ.get(k) for k in ("PRALINE_KERNEL", "PRALINE_MM")):
+            assert "true, true, 0>" in plan.kernel_name(), plan.kernel_name()   # k_dp_split16_tb<..., CHAIN, TWOPASS>: no flags
         plan.close()
         arena.close()
     for mode in MODES:
         ref = results[("lanes", mode)]
         assert np.isfinite(ref).all()
-        for variant in ("default", "lookup_singles", "table", "table_singles", "staged"):
+        for variant in ("default", "lookup_singles", "table", "table_singles", "staged", "chain"):
             assert np.array_equal(bits(results[(variant, mode)]), bits(ref)), (kind, variant, mode)
 
 
+@pytest.mark.parametrize("chain", ["0", "1"])
 @pytest.mark.parametrize("kind", ["onehot", "profile"])
-def test_shared_wave_boundaries_vs_oracle(nat, bba, kind):
+def test_shared_wave_boundaries_vs_oracle(nat, bba, kind, chain, monkeypatch):
     """Small batches run on four-wave workgroups whose waves share tasks (1, 2 or 4 waves per task,
-    chosen from the number of 12-row iterations and of 32-column strips).  Lengths sit on both sides
+    chosen from the number of 12-row iterations and of 32-column strips) - chain "0" - or, where the schedule's estimate
+    favours it, on the flag-free chain fill with one wave per task and strip - chain "1".  Lengths sit on both sides
     of every threshold; every score is checked against the oracle DP on the device's match scores
     (integer scoring: against the reference order too)."""
+    monkeypatch.setenv("PRALINE_SCORES_CHAIN", chain)
     rng = np.random.default_rng(17)
     S = bba["S"]
     # sequence two: 1..5 strips (+- 1 column around the strip edges); sequence one: 2..9 iterations
