@@ -185,8 +185,8 @@ class ReferenceCpuBaseline:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)     # (a step is ~2 ms: 50 + 10 steps keep the default run in seconds while the
+    ap.add_argument("--warmup", type=int, default=10)    #  timed region is no longer dominated by the first launches after idle)
     ap.add_argument("--mode", default="global")
     ap.add_argument("--workload", choices=["c2", "c4", "c5"], default=None,
                     help="default: c2 on one GPU (the metric's configuration), c4 split over the ranks on more")
