@@ -357,7 +357,8 @@ struct praline_arena {
     DevBuf<int32_t> d_set_lo;
     DevBuf<unsigned char> d_nzidx, d_nzcnt;
     DevBuf<float> d_reft;    // T[row][i][b] (k_build_reft), ref_tb floats per (row, symbol); ref_tb = 0: not built
-    int ref_tb = 0;
+    int ref_tb = 0;          // nonzeros per row, rounded up to 4 / 8 / 16 / 32 (0: more)
+    int reft_state = 0;      // d_reft: 0 not tried, 1 built, -1 not available (too large / too many nonzeros)
     bool ref_ready = false;
     // the same half-terms with two adjacent columns interleaved, for k_match_tile (dp_reftile.hip.h): T2[i][pair row][b][2]
     DevBuf<float> d_reft2;
@@ -651,19 +652,21 @@ extern "C" int praline_arena_set_gap_scores(praline_arena *arena, const float *g
 }
 
 static int arena_ensure_ref(praline_arena *a);
+static int arena_ensure_reft_table(praline_arena *a);
 
 // reference-order match scores of the pairs chunk_pairs[0 .. n_chunk) into mref + m_off[pair]
 static int launch_match_ref(praline_arena *a, const int32_t *d_pairs, const int32_t *d_chunk_pairs, size_t n_chunk, int max_l1,
                             const int64_t *d_m_off, float *d_mref)
 {
     RC(arena_ensure_ref(a));
+    RC(arena_ensure_reft_table(a));
     hipStream_t st = g_rt.stream;
     const dim3 grid((unsigned)n_chunk, (unsigned)((max_l1 + PRALINE_REF_ROWS - 1) / PRALINE_REF_ROWS)), block(256);
     const int n_sets = (int)a->set_lo.size() - 1;
 #define PRALINE_REFT(TB)                                                                                               \
     hipLaunchKernelGGL((k_match_reft<TB>), grid, block, 0, st, a->d_raw.p, a->A, a->d_reft.p, a->rows_raw, a->d_row_off_raw.p, a->d_len.p,  \
                        a->d_nzidx.p, a->d_nzcnt.p, a->d_set_lo.p, n_sets, d_pairs, d_chunk_pairs, d_m_off, d_mref)
-    switch (a->ref_tb) {
+    switch (a->reft_state == 1 ? a->ref_tb : 0) {
         case 4: PRALINE_REFT(4); break;
         case 8: PRALINE_REFT(8); break;
         case 16: PRALINE_REFT(16); break;
@@ -695,6 +698,18 @@ static int arena_ensure_ref(praline_arena *a)
     int max_nz = 1;
     for (unsigned char c : cnt) max_nz = std::max(max_nz, (int)c);
     a->ref_tb = max_nz <= 4 ? 4 : (max_nz <= 8 ? 8 : (max_nz <= 16 ? 16 : (max_nz <= 32 ? 32 : 0)));
+    a->reft_state = 0;
+    a->d_reft.release();
+    a->ref_ready = true;
+    return PRALINE_OK;
+}
+
+// the per-row tables of k_match_reft, built on the first launch that needs them (plans on the tile kernels never do)
+static int arena_ensure_reft_table(praline_arena *a)
+{
+    if (a->reft_state != 0) return PRALINE_OK;
+    hipStream_t st = g_rt.stream;
+    a->reft_state = -1;
     size_t table_limit = (size_t)16 << 30;
     if (const char *env = getenv("PRALINE_REF_TABLE_MB")) table_limit = (size_t)atoll(env) << 20;
     const size_t t_elems = (size_t)a->rows_raw * a->A * (size_t)a->ref_tb;
@@ -704,12 +719,8 @@ static int arena_ensure_ref(praline_arena *a)
         hipLaunchKernelGGL(k_build_reft, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->d_raw.p, a->d_S.p, a->A, a->rows_raw,
                            a->d_nzidx.p, a->d_nzcnt.p, a->d_set_lo.p, (int)a->set_lo.size() - 1, a->ref_tb, a->d_reft.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));
-    } else {
-        a->ref_tb = 0;
-        a->d_reft.release();
+        a->reft_state = 1;
     }
-    a->ref_ready = true;
     return PRALINE_OK;
 }
 
@@ -909,6 +920,8 @@ static size_t tb_budget_bytes()
     return (size_t)8 << 30;
 }
 
+static size_t reftile_budget_bytes();
+
 extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, int want_paths,
                                    const int32_t *rect_off, const int32_t *rects, praline_plan **out)
 {
@@ -963,7 +976,10 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         !(getenv("PRALINE_NO_REFTILE") && getenv("PRALINE_NO_REFTILE")[0] == '1')) {
         int rc = arena_ensure_reft2(arena);
         if (rc != PRALINE_OK) { delete pl; return rc; }
-        if (a.reft2_state == 1) { pl->ref = false; pl->ref_tile = true; }
+        // (a task's tile must fit a launch chunk: strips x rows x 4 KiB - sequences beyond ~16 000 positions keep the
+        // per-pair dense matrices of the per-cell path)
+        const double worst_tile = ((a.max_len + 31) / 32) * (a.max_len + (double)PRALINE_DENSE_PAD) * 4096.0;
+        if (a.reft2_state == 1 && worst_tile <= (double)reftile_budget_bytes()) { pl->ref = false; pl->ref_tile = true; }
     }
     if (pl->ref || pl->ppg) { opt.split_layout = false; opt.tp = 1; }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
