@@ -75,6 +75,16 @@ int praline_launch_match_tile(const RefTileArgs &g, int TB, unsigned n_blocks, h
 int praline_launch_dense(const LaunchArgs &la, const Arena16Dev &a16, bool local)
 {
     if (a16.dense == nullptr || a16.dense_off == nullptr) return PRALINE_ERR_ARG;
+    if (la.wg != nullptr) {   // small batch: four-wave workgroups whose waves share tasks (more tile rows in flight per task)
+        const dim3 g4(la.n_wg), b4(256);
+        if (local)
+            hipLaunchKernelGGL((k_dp_split16<1, 1, true, 4, 4>), g4, b4, 0, la.stream, a16, la.tasks, la.lane_one, la.lane_pair,
+                               (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
+        else
+            hipLaunchKernelGGL((k_dp_split16<1, 1, false, 4, 4>), g4, b4, 0, la.stream, a16, la.tasks, la.lane_one, la.lane_pair,
+                               (float2 *)la.bnd, la.scores, la.rp, (int)la.n_tasks, la.wg);
+        return hipGetLastError() == hipSuccess ? PRALINE_OK : PRALINE_ERR_DEVICE;
+    }
     const dim3 grid((unsigned)la.n_tasks), block(64);
     if (local)
         hipLaunchKernelGGL((k_dp_split16<1, 1, true, 4>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one, la.lane_pair,

@@ -493,11 +493,11 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
     static_assert(!KEEP || (BSRC == 2 && !LOCAL), "the kept-state forward fill runs on the staged stream (global / semiglobal recurrences)");
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;  // 16-byte operand slots held per lane
-    static_assert(WPG == 1 || (WPG == 4 && (BSRC == 2 || BSRC == 3)), "four-wave workgroups use the staged stream or the match-score lookup");
+    static_assert(WPG == 1 || (WPG == 4 && (BSRC == 2 || BSRC == 3 || BSRC == 4)), "four-wave workgroups use the staged stream, the match-score lookup or dense tiles");
     constexpr bool LOOKUP = BSRC == 3;
     constexpr bool DENSE = BSRC == 4;   // match scores from the task's dense tile (ar.dense, dp_reftile.hip.h): no operands at all
     static_assert(!LOOKUP || (NTERM == 1 && !KEEP), "the match-score lookup is an exact-mode path");
-    static_assert(!DENSE || (NTERM == 1 && !KEEP && WPG == 1), "the dense-tile instances are plain one-task waves");
+    static_assert(!DENSE || (NTERM == 1 && !KEEP), "the dense-tile instances take no operands");
     constexpr bool MW = WPG > 1;
     constexpr bool SNAPBR = LOCAL && !MW;   // see split16_step
 #ifdef PRALINE_TRACE
@@ -935,6 +935,12 @@ __global__ __launch_bounds__(256, KEEP ? 2 : (BSRC == 3 ? PRALINE_LOOKUP_WAVES :
             }
         } else if constexpr (DENSE) {
             for (int t = 2; t <= max_l1 + 1; t += 12) {
+                if constexpr (MW) {
+                    // shared task: the ranks meet every 12 rows; this wave's boundary rows of more than three steps ago are
+                    // complete (a step issues six memory operations, they retire in order) - the next rank, two iterations
+                    // behind, asks for nothing younger; the tile rows in flight stay in flight
+                    if (share > 1) { PRALINE_VMCNT(18); __builtin_amdgcn_s_barrier(); --mw_left; }
+                }
                 PRALINE_STEP16M(t, accB, accA, p1);
                 PRALINE_STEP16M(t + 1, accC, accB, p2);
                 PRALINE_STEP16M(t + 2, accD, accC, p0);

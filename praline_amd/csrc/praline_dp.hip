@@ -1407,6 +1407,17 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
         if (!pl.want_paths) {
             la.tb = nullptr;
             la.aux = nullptr;
+            la.wg = nullptr;
+            la.n_wg = 0;
+            if (chunks.size() == 1 && !pl.wg.empty() && !(getenv("PRALINE_NO_W2") && getenv("PRALINE_NO_W2")[0] == '1')) {
+                // (the shared-wave descriptors index the plan's task list: one chunk only)
+                if (!pl.d_wg.p) { RC(pl.d_wg.upload(pl.wg, st)); }
+                la.wg = pl.d_wg.p;
+                la.n_wg = (unsigned)pl.wg.size();
+                char kn[160];
+                snprintf(kn, sizeof(kn), "k_dp_split16<1, 1, %s, 4, 4, false>", local ? "true" : "false");
+                pl.last_kernel = kn;
+            }
             rc = praline_launch_dense(la, a16, local);
             if (rc != PRALINE_OK) return fail(rc, "dense-tile scores launch failed");
         } else {
@@ -1584,7 +1595,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     if (pl.ref_tile) {
         char kn[160];
         if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<1, 3, %s, %s, false, false, 4>", local ? "true" : "false", pl.has_rects ? "true" : "false");
-        else snprintf(kn, sizeof(kn), "k_dp_split16<1, 1, %s, 4, 1, false>", local ? "true" : "false");
+        else snprintf(kn, sizeof(kn), "k_dp_split16<1, 1, %s, 4, 1, false>", local ? "true" : "false");   // (refined by plan_run_reftile)
         pl.last_kernel = kn;
         HIPCHK(hipEventRecord(pl.ev0, st));
         RC(plan_run_reftile(pl, la, a16, mode, local));
