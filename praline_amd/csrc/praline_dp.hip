@@ -1004,6 +1004,10 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             int min_len = a.max_len;
             for (int64_t p = 0; p < n_pairs; ++p) min_len = std::min(min_len, std::min(a.len[pairs[2 * p]], a.len[pairs[2 * p + 1]]));
             PipeOptions po;
+            // sequences two per scheduler block: 32 while the whole plan is resident at once (up to ~2.5 tasks per workgroup
+            // slot: C2 1.90 ms against 2.09 with 16), 16 beyond (one rank's share of C4: 47.6 ms against 48.8 with 32 - the
+            // unions of 32 columns' sequences one leave more half-filled sets; scripts/exp_pipe_block2.py, exp_c4_block.py)
+            po.block_twos = n_pairs <= 40000 ? 32 : 16;
             if (const char *env = getenv("PRALINE_PIPE_BLOCK")) po.block_twos = atoi(env);
             if (const char *env = getenv("PRALINE_PIPE_SLOTS")) po.wg_slots = atoll(env);
             if (min_len >= 1) build_pipe_schedule(a.len.data(), a.n_seqs, n_pairs, pairs, po, pl->pipe);

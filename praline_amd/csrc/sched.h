@@ -44,8 +44,8 @@ struct PipeSchedule {
     int64_t lanes_used = 0, steps = 0;    // pairs placed; wave steps of the launch (4 x nrounds x rsteps summed over the items)
 };
 struct PipeOptions {
-    int block_twos = 32;                  // sequences two per block (their sequences one are pooled into the sets); measured on
-                                          // all pairs of N x ~400 aa, 8 / 16 / 32 / 64: N = 256 2.20 / 2.06 / 1.96 / 2.25 ms, equal within 1 % from N = 288 up
+    int block_twos = 32;                  // sequences two per block (their sequences one are pooled into the sets); praline_plan_create
+                                          // passes 32 for plans that are resident at once and 16 for larger ones
     int64_t wg_slots = 512;               // resident workgroups (256 CUs x 2)
     double min_fill = 0.55;               // give up below this share of occupied lanes
 };
