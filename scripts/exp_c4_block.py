@@ -13,11 +13,11 @@ pairs = pairs[allpairs.shard_columns(lens, pairs, 8)[3]]
 profs = [synth_profile(rng, int(L)) for L in lens]
 cells = int((lens[pairs[:, 0]].astype(np.int64) * lens[pairs[:, 1]]).sum())
 ar = nat.Arena(profs, S)
-for block in (8, 16, 32, 64, 16, 32):
-    os.environ["PRALINE_PIPE_BLOCK"] = str(block)
+for block, slots in ((16, 512), (16, 256), (16, 1024), (16, 2048), (16, 128), (16, 512)):
+    os.environ["PRALINE_PIPE_BLOCK"] = str(block); os.environ["PRALINE_PIPE_SLOTS"] = str(slots)
     pl = nat.Plan(ar, pairs); pl.run("global", -11, -1)
     ms = []
     for _ in range(4):
         pl.run("global", -11, -1); ms.append(pl.kernel_ms())
-    print("block %2d: tasks %6d steps %10d kernel %.2f ms %.0f GCUPS" % (block, pl.tasks, pl.steps, float(np.median(ms)), cells / float(np.median(ms)) / 1e6), flush=True)
+    print("block %2d slots %4d: tasks %6d steps %10d kernel %.2f ms %.0f GCUPS" % (block, slots, pl.tasks, pl.steps, float(np.median(ms)), cells / float(np.median(ms)) / 1e6), flush=True)
     pl.close()
