@@ -150,9 +150,14 @@ def test_reference_order_tiles(nat, bba, monkeypatch):
             for mode in MODES:
                 t_sc, _, t_kn, t_kind = run(arena, mode, False, True, twice=True)
                 o_sc, _, o_kn, _ = run(arena, mode, False, False)
-                assert "k_dp_split16<1, 1" in t_kn and ", 4, 1, false>" in t_kn and "k_dp_batch" in o_kn, (t_kn, o_kn)
+                # (dense-tile instance, BSRC = 4: one-task waves or - small one-chunk plans - shared-wave workgroups)
+                assert "k_dp_split16<1, 1" in t_kn and (", 4, 1, false>" in t_kn or ", 4, 4, false>" in t_kn) and "k_dp_batch" in o_kn, (t_kn, o_kn)
                 assert t_kind == 2
                 assert np.array_equal(bits(t_sc), bits(o_sc)), (name, mode)
+                monkeypatch.setenv("PRALINE_NO_W2", "1")                      # one-task waves instead of shared-wave workgroups
+                w_sc, _, w_kn, _ = run(arena, mode, False, True)
+                monkeypatch.delenv("PRALINE_NO_W2")
+                assert ", 4, 1, false>" in w_kn and np.array_equal(bits(w_sc), bits(t_sc)), (name, mode, w_kn)
                 t_sc2, t_paths, t_kn, _ = run(arena, mode, True, True)
                 o_sc2, o_paths, _, _ = run(arena, mode, True, False)
                 assert "k_dp_split16_tb<1, 3" in t_kn and t_kn.endswith(", 4>"), t_kn
