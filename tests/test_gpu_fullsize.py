@@ -255,6 +255,33 @@ def test_c4_rank_share_full_size(nat, bba, monkeypatch):
         plan.close()
         monkeypatch.delenv("PRALINE_NO_PIPE")
     arena.close()
+    # the same shard in the reference-order mode (k_match_tile + dense-tile instances; ~700 GB of tiles in 32 GiB launch
+    # chunks, groups of several hundred tasks): 16 pairs bit-identical to the oracle's reference-order evaluation, and a
+    # 2 000-pair sample bit for bit against the one-cell-per-thread kernels + k_dp_batch
+    nat.set_match_mode("ref")
+    try:
+        arena = nat.Arena(profs, S)
+        plan = nat.Plan(arena, mine)
+        plan.run("global", GO, GE)
+        scr = plan.scores().copy()
+        assert plan.match_kind() == 2 and ", 4, " in plan.kernel_name(), plan.kernel_name()
+        plan.close()
+        for k in rng.choice(len(mine), 16, replace=False):
+            i, j = mine[k]
+            assert scr[k] == np.float32(orc.pairwise_score_fast("global", profs[i], profs[j], S, GO, GE)), (i, j)
+        rel = np.abs(scr - scf) / np.maximum(1.0, np.abs(scf))
+        assert rel.max() <= 1e-5, rel.max()                      # (and the default mode agrees with it to north_star's tolerance)
+        monkeypatch.setenv("PRALINE_NO_REFTILE", "1")
+        sample = np.sort(rng.choice(len(mine), 2000, replace=False))
+        plan = nat.Plan(arena, mine[sample])
+        plan.run("global", GO, GE)
+        assert "k_dp_batch" in plan.kernel_name()
+        assert np.array_equal(bits(plan.scores()), bits(scr[sample]))
+        plan.close()
+        monkeypatch.delenv("PRALINE_NO_REFTILE")
+        arena.close()
+    finally:
+        nat.set_match_mode(None)
 
 
 def test_c5_long_dna_full_size(nat):
