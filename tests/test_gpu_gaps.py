@@ -131,3 +131,42 @@ def test_pairwise_batch_with_gap_score_models(nat, bba):
         orc.cext_build_scores([p1], [p2], [orc.build_nonzero_matrix(p1)], [orc.build_nonzero_matrix(p2)], [S], m)
         s_or, p_or = orc.raw_pairwise_align(mode, m, gaps[i], gaps[j])
         assert np.float32(s_dev) == np.float32(s_or) and np.array_equal(p_dev, p_or), (mode, i, j)
+
+
+def test_per_position_gap_scores_c2_sample(nat, bba):
+    """BASELINE C2's float profiles (256 seqs ~400 aa), 2 048 sampled pairs with per-position gap scores - several launch
+    chunks of dense match scores under a small budget: scores-only and path plans agree bit for bit, 24 pairs per mode equal
+    the oracle on the device's match scores."""
+    import os
+    from conftest import synth_lengths
+    rng = np.random.default_rng(2)
+    N = 256
+    lens = synth_lengths(rng, N, 400).astype(np.int32)
+    profs = [synth_profile(rng, int(L))[0] for L in lens]
+    gaps = [random_gaps(rng, int(L), exact=False) for L in lens]
+    allp = np.array([(i, j) for i in range(N) for j in range(i + 1, N)], dtype=np.int32)
+    pairs = allp[np.sort(np.random.default_rng(7).choice(len(allp), 2048, replace=False))]
+    arena = nat.Arena(profs, bba["S"])
+    arena.set_gap_scores(gaps)
+    old = os.environ.get("PRALINE_REF_BUDGET_MB")
+    os.environ["PRALINE_REF_BUDGET_MB"] = "256"          # 1.3 GB of dense match scores: six chunks
+    try:
+        for mode in ("global", "local", "semiglobal_both"):
+            plan = nat.Plan(arena, pairs, want_paths=True)
+            plan.run_gaps(mode)
+            sc, paths, kind = plan.scores().copy(), plan.paths(), plan.match_kind()
+            plan.close()
+            plan0 = nat.Plan(arena, pairs, want_paths=False)
+            plan0.run_gaps(mode)
+            assert np.array_equal(bits(plan0.scores()), bits(sc)), mode
+            plan0.close()
+            for k in np.random.default_rng(11).choice(len(pairs), 24, replace=False):
+                i, j = pairs[k]
+                s_or, p_or = orc.raw_pairwise_align(mode, arena.match_scores(int(i), int(j), kind), gaps[i], gaps[j])
+                assert sc[k] == np.float32(s_or) and np.array_equal(paths[k], p_or), (mode, i, j)
+    finally:
+        if old is None:
+            os.environ.pop("PRALINE_REF_BUDGET_MB", None)
+        else:
+            os.environ["PRALINE_REF_BUDGET_MB"] = old
+        arena.close()
