@@ -1,4 +1,5 @@
-"""One rank's share of C4 (column shard 3 of 8, float profiles): k_dp_pipe kernel time against the scheduler's block size."""
+"""One rank's share of C4 (column shard 3 of 8, float profiles): k_dp_pipe kernel time against the scheduler's block size
+(PRALINE_PIPE_BLOCK: 8 3567, 16 3526, 32 3445, 64 3258 GCUPS) and the workgroup slots it assumes (PRALINE_PIPE_SLOTS: flat)."""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
