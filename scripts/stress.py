@@ -15,8 +15,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 n_cases = n_pairs_checked = 0
 t_progress = time.time()
-def dp_on_m(mode, m, rects=None):
-    g1, g2 = orc.gap_arrays(m.shape[0], m.shape[1], (-11.0, -1.0))
+def dp_on_m(mode, m, rects=None, gaps=None):
+    g1, g2 = gaps if gaps is not None else orc.gap_arrays(m.shape[0], m.shape[1], (-11.0, -1.0))
     zero = None
     if rects:
         zero = [(y, x) for (y0, y1, x0, x1) in rects for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
@@ -80,15 +80,23 @@ while time.time() < t_end:
             n_cases, kind, ref_mode, N, mu, len(pairs), mode, want_paths, rects is not None, os.environ["PRALINE_TB_TWOPASS"],
             os.environ["PRALINE_TB_KEEP"]), flush=True)
     arena = nat.Arena(profs, S)
+    # one batch in eight with per-position gap scores (praline_plan_run_gaps: k_dp_batch<..., PPG> on dense match scores)
+    ppg = None
+    if rng.random() < 0.125 and N <= 64:
+        exact = kind in ("onehot", "dna")
+        ppg = [np.stack([-rng.integers(8, 60, int(L)) / 4.0, -rng.integers(1, 12, int(L)) / 4.0], axis=1).astype(np.float32) if exact
+               else np.stack([-rng.uniform(2.0, 15.0, int(L)), -rng.uniform(0.1, 3.0, int(L))], axis=1).astype(np.float32) for L in lens]
+        arena.set_gap_scores(ppg)
     plan = nat.Plan(arena, pairs, want_paths=want_paths, rects=rects)
     mk = plan.match_kind()
-    plan.run(mode, -11.0, -1.0)
+    if ppg is not None: plan.run_gaps(mode)
+    else: plan.run(mode, -11.0, -1.0)
     sc = plan.scores()
     paths = plan.paths() if want_paths else None
     kname = plan.kernel_name()
     packed = plan.paths_packed() if want_paths else None
     plan.close()
-    if want_paths and rng.random() < 0.25:
+    if want_paths and ppg is None and rng.random() < 0.25:
         # the same plan under another configuration (other pass scheme, other scratch budget = other chunking): EVERY
         # score and path must be identical (races between chunks show up here, not in 24 sampled pairs)
         keep_env = {k: os.environ.get(k) for k in ("PRALINE_TB_TWOPASS", "PRALINE_TB_BUDGET_MB")}
@@ -125,7 +133,7 @@ while time.time() < t_end:
     for k in check:
         i, j = pairs[k]
         m = arena.match_scores(int(i), int(j), mk)
-        s_or, p_or = dp_on_m(mode, m, rects[k] if rects else None)
+        s_or, p_or = dp_on_m(mode, m, rects[k] if rects else None, (ppg[i], ppg[j]) if ppg is not None else None)
         if sc[k] != np.float32(s_or) or (want_paths and not np.array_equal(paths[k], p_or)):
             print("MISMATCH kind=%s N=%d mu=%d mode=%s paths=%s rects=%s pair=(%d,%d) lens=(%d,%d) dev=%r oracle=%r" % (
                 kind, N, mu, mode, want_paths, rects[k] if rects else None, i, j, lens[i], lens[j], sc[k], s_or), flush=True)
@@ -144,7 +152,7 @@ while time.time() < t_end:
                                 or_path=np.asarray(p_or) if want_paths else 0, p_i=profs[i], p_j=profs[j], m=m,
                                 profs=np.concatenate(profs, axis=0))
             sys.exit(1)
-        if kind not in ("profile", "wide") and rects is None and k % 3 == 0:
+        if kind not in ("profile", "wide") and rects is None and ppg is None and k % 3 == 0:
             ref = orc.pairwise_score_fast(mode, profs[i], profs[j], S, -11.0, -1.0)
             assert sc[k] == np.float32(ref), ("reference order", kind, mode, i, j)
         if mk == 2 and k % 2 == 0:

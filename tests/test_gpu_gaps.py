@@ -104,6 +104,41 @@ def test_per_position_gap_scores_plans(nat, bba, kind):
         nat.set_match_mode(None)
 
 
+def test_per_position_gap_scores_with_many_rectangles(nat, bba):
+    """Per-position gap scores on plans with more rectangles per pair than the register-resident masks hold (column-mask
+    words, MASK = 2): the <LOCAL, traceback, MASK = 2, PPG> instance of k_dp_batch was miscompiled at -O3 (wrong local
+    scores, also for pairs without rectangles; scripts/debug_ppg_mask2.py) - its translation unit is built -O1.  Scores
+    and paths against the oracle, local and global."""
+    rng = np.random.default_rng(5)
+    lens = [60, 75, 48, 66, 90, 170, 159]
+    profs = [one_hot(rng.integers(0, 20, L), 27) for L in lens]
+    gaps = [random_gaps(rng, L, exact=True) for L in lens]
+    n = len(lens)
+    pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32)
+    rects = []
+    for k, (i, j) in enumerate(pairs):
+        r = []
+        for _ in range([0, 1, 3, 9][k % 4]):
+            y0, x0 = int(rng.integers(1, lens[i])), int(rng.integers(1, lens[j]))
+            r.append((y0, min(lens[i], y0 + int(rng.integers(0, 12))), x0, min(lens[j], x0 + int(rng.integers(0, 12)))))
+        rects.append(r)
+    assert max(len(r) for r in rects) > nat.MAX_RECTS
+    arena = nat.Arena(profs, bba["S"])
+    arena.set_gap_scores(gaps)
+    for mode in ("local", "global"):
+        plan = nat.Plan(arena, pairs, want_paths=True, rects=rects)
+        mk = plan.match_kind()
+        plan.run_gaps(mode)
+        sc, paths = plan.scores(), plan.paths()
+        assert ", 2, 1, true>" in plan.kernel_name(), plan.kernel_name()
+        plan.close()
+        for k, (i, j) in enumerate(pairs):
+            s_or, p_or = orc.raw_pairwise_align(mode, arena.match_scores(int(i), int(j), mk), gaps[i], gaps[j],
+                                                zero_idxs=zero_cells(rects[k], lens[i], lens[j]) or None)
+            assert sc[k] == np.float32(s_or) and np.array_equal(paths[k], p_or), (mode, i, j, len(rects[k]))
+    arena.close()
+
+
 def test_pairwise_batch_with_gap_score_models(nat, bba):
     """The host mirror: PairwiseBatch.set_gap_scores hands per-sequence GapScoreModels to the device; sequences without
     one keep the gap series."""
