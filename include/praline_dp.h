@@ -79,6 +79,11 @@ const char *praline_last_error(void);         /* message of the last failure on 
 int praline_pool_trim(void);
 int64_t praline_pool_cached_bytes(void);
 void *praline_stream(void);                   /* the hipStream_t all kernels are launched on */
+/* Page-locked host memory for the caller's staging of inputs: profiles handed to praline_arena_create from such a
+ * buffer go up by DMA as they lie (11 MB of C2: 0.2 ms), without the runtime's copy through its own staging pages
+ * that a pageable buffer costs.  Optional - every entry point takes any host pointer. */
+int praline_host_alloc(size_t bytes, void **out);
+int praline_host_free(void *p);
 int praline_set_match_mode(int kind);         /* PRALINE_MATCH_*; -1 = back to the PRALINE_MM default */
 int praline_get_match_mode(void);
 
@@ -204,6 +209,8 @@ int64_t praline_plan_cells(const praline_plan *plan);      /* sum L1*L2 over the
  * strip = 1024 cells incl. padding) and the number of 32-pair tasks; bench.py prices VALU issue with them. */
 int64_t praline_plan_steps(const praline_plan *plan);
 int64_t praline_plan_tasks(const praline_plan *plan);
+/* ... and the number of tasks the scheduler cut between two workgroups of the pipeline kernel (0 for other plans). */
+int64_t praline_plan_cut_tasks(const praline_plan *plan);
 int64_t praline_plan_path_capacity(const praline_plan *plan); /* rows: sum (L1+L2+2) */
 
 /* Launches the fused match-score + affine DP fill for every pair of the plan (asynchronous on

@@ -60,6 +60,7 @@ struct Runtime {
     // the traceback and the tail of chunk k overlap the fill of chunk k + 1
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int *h_flags = nullptr;   // page-locked: small read-backs that must not block the host when they are enqueued (256 ints)
 };
 static Runtime g_rt;
 
@@ -82,6 +83,7 @@ static int ensure_runtime(int device)
     HIPCHK(hipStreamCreateWithFlags(&g_rt.stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&g_rt.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&g_rt.ev_join, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void **)&g_rt.h_flags, 256 * sizeof(int), hipHostMallocDefault));
     g_rt.device = device;
     g_rt.ready = true;
     return PRALINE_OK;
@@ -111,6 +113,7 @@ extern "C" int praline_shutdown(void)
     pool_clear();
     (void)hipEventDestroy(g_rt.ev_fork);
     (void)hipEventDestroy(g_rt.ev_join);
+    (void)hipHostFree(g_rt.h_flags);
     (void)hipStreamDestroy(g_rt.stream2);
     (void)hipStreamDestroy(g_rt.stream);
     g_rt = Runtime();
@@ -152,6 +155,26 @@ extern "C" int praline_pool_trim(void)
     HIPCHK(hipStreamSynchronize(g_rt.stream));
     HIPCHK(hipStreamSynchronize(g_rt.stream2));
     pool_clear();
+    return PRALINE_OK;
+}
+
+extern "C" int praline_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (int rc = ensure_runtime(-1)) return rc;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return fail(PRALINE_ERR_NOMEM, "page-locked host allocation of %zu bytes failed", bytes);
+    }
+    return PRALINE_OK;
+}
+
+extern "C" int praline_host_free(void *p)
+{
+    if (!p) return PRALINE_OK;
+    HIPCHK(hipHostFree(p));
     return PRALINE_OK;
 }
 
@@ -476,11 +499,13 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         if (u & 0x7fffffffu) inexact_bits = (u & 0x1fffu) | (unsigned)(e < 113u) | (unsigned)(e > 142u);
     }
     hipStream_t st = g_rt.stream;
+    // the raw profiles go up first; the scan of their rows (mass per symbol, one-hot rows) runs on the device - one
+    // small read-back instead of 0.6 ms of host time for the 11 MB of C2.  Everything the host can prepare without the
+    // scan's answer is done while the upload is in flight (a DMA when the caller's buffer is page-locked:
+    // praline_host_alloc).
+    DevBuf<int> d_flags;
+    int *flags = g_rt.h_flags;   // (A <= 254)
     {
-        // the raw profiles go up first; the scan of their rows (mass per symbol, one-hot rows) runs on the device - one
-        // small read-back instead of 0.6 ms of host time for the 11 MB of C2
-        DevBuf<int> d_flags;
-        std::vector<int> flags((size_t)A + 1, 0);
         int rc0 = PRALINE_OK;
         if ((rc0 = a->d_raw.alloc((size_t)rr * A)) || (rc0 = a->d_raw.upload(profiles, (size_t)rr * A, st)) ||
             (rc0 = a->d_sym_raw.alloc((size_t)rr)) || (rc0 = d_flags.alloc((size_t)A + 1))) {
@@ -492,13 +517,10 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
             hipLaunchKernelGGL(k_scan_profiles, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, st, a->d_raw.p, rr, A, a->d_sym_raw.p, d_flags.p);
             e0 = hipGetLastError();
         }
-        if (e0 == hipSuccess) e0 = hipMemcpyAsync(flags.data(), d_flags.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, st);
-        if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
-        if (e0 != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena scan: %s", hipGetErrorString(e0)); }
-        for (int i = 0; i < A; ++i) has_mass[i] = (char)(flags[(size_t)i] != 0);
-        all_onehot_rows = flags[(size_t)A] == 0;
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(flags, d_flags.p, ((size_t)A + 1) * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e0 != hipSuccess) { (void)hipStreamSynchronize(st); delete a; return fail(PRALINE_ERR_DEVICE, "arena scan: %s", hipGetErrorString(e0)); }
     }
-    pt.mark("upload + device scan of the profiles");
+    pt.mark("upload + device scan enqueued");
     for (int i = 0; i < A; ++i)
         for (int j = 0; j < A; ++j)
             if (S[i * A + j] != 0.0f) has_score[i] = 1;
@@ -511,6 +533,28 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         if (ok) a->s_scale_bits = k;
     }
     for (int i = 0; i < A * A; ++i) a->s_absmax = std::max(a->s_absmax, std::fabs(S[i]));
+    std::vector<int32_t> seq_of_rowp((size_t)a->rows_pad, -1);
+    for (int64_t s = 0; s < n_seqs; ++s)
+        std::fill(seq_of_rowp.begin() + a->row_off_pad[s], seq_of_rowp.begin() + a->row_off_pad[s] + (lens[s] + 31) / 32 * 32, (int32_t)s);
+    {
+        int rc0 = PRALINE_OK;
+        if ((rc0 = a->d_S.alloc((size_t)A * A)) || (rc0 = a->d_S.upload(S, (size_t)A * A, st)) ||
+            (rc0 = a->d_len.upload(a->len, st)) || (rc0 = a->d_row_off_pad.upload(a->row_off_pad, st)) ||
+            (rc0 = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc0 = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
+            (rc0 = a->d_flag16.alloc(1))) {
+            (void)hipStreamSynchronize(st);
+            delete a;
+            return rc0;
+        }
+    }
+    pt.mark("host tables");
+    {
+        const hipError_t e0 = hipStreamSynchronize(st);
+        if (e0 != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena scan: %s", hipGetErrorString(e0)); }
+        for (int i = 0; i < A; ++i) has_mass[i] = (char)(flags[(size_t)i] != 0);
+        all_onehot_rows = flags[(size_t)A] == 0;
+    }
+    pt.mark("wait for the scan");
     for (int i = 0; i < A; ++i)
         if (has_mass[i] && has_score[i]) a->active.push_back(i);
     a->n_active = (int)a->active.size();
@@ -544,20 +588,13 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         }
     }
 
-    std::vector<int32_t> seq_of_rowp((size_t)a->rows_pad, -1);
-    for (int64_t s = 0; s < n_seqs; ++s)
-        for (int r = 0; r < (lens[s] + 31) / 32 * 32; ++r) seq_of_rowp[a->row_off_pad[s] + r] = (int32_t)s;
-
-    pt.mark("host tables");
     int rc = PRALINE_OK;
-    if ((rc = a->d_S.alloc((size_t)A * A)) || (rc = a->d_S.upload(S, (size_t)A * A, st)) ||
-        (rc = a->d_len.upload(a->len, st)) || (rc = a->d_row_off_pad.upload(a->row_off_pad, st)) ||
-        (rc = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
-        (rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
+    if ((rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
         (rc = a->d_P.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) ||
-        (rc = a->d_flag16.alloc(1)) || (a->onehot && (rc = a->d_sym8.alloc((size_t)a->rows_pad + 64))) ||
+        (a->onehot && (rc = a->d_sym8.alloc((size_t)a->rows_pad + 64))) ||
         (a->nr16 > 0 && ((rc = a->d_P16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)) ||
                          (rc = a->d_Q16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16))))) {
+        (void)hipStreamSynchronize(st);
         delete a;
         return rc;
     }
@@ -851,6 +888,9 @@ struct praline_plan {
     DevBuf<int32_t> d_pipe_set_one, d_pipe_lane_pair;
     DevBuf<float2> d_pipe_bnd, d_pipe_analytic;
     int pipe_analytic_rows = 0;
+    DevBuf<int> d_pipe_cut_flags;      // cut tasks (dp_types.h): flag word per cut, zero at creation, = pipe_gen once the head is done
+    DevBuf<float> d_pipe_cut_res;      // [n_cuts][2][32]
+    int pipe_gen = 0;
     DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
@@ -1010,6 +1050,8 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             po.block_twos = n_pairs <= 40000 ? 32 : 16;
             if (const char *env = getenv("PRALINE_PIPE_BLOCK")) po.block_twos = atoi(env);
             if (const char *env = getenv("PRALINE_PIPE_SLOTS")) po.wg_slots = atoll(env);
+            if (const char *env = getenv("PRALINE_PIPE_CUTS")) po.cuts = env[0] != '0';   // (A/B: whole tasks only)
+            if (const char *env = getenv("PRALINE_PIPE_CUT_MARGIN")) po.cut_margin = atoi(env);   // (tests: 0 = cuts wherever they fit)
             if (min_len >= 1) build_pipe_schedule(a.len.data(), a.n_seqs, n_pairs, pairs, po, pl->pipe);
             // below ~200 tasks (all pairs of ~110 sequences) the shared-wave task schedule is as fast or faster
             // (scripts/exp_pipe_sweep.py): a pipeline item cannot be smaller than one task
@@ -1065,6 +1107,14 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             (rc = pl->d_pipe_bnd.alloc((size_t)pl->pipe.bnd_elems))) {
             delete pl;
             return rc;
+        }
+        {
+            const size_t nc = (size_t)std::max<int64_t>(pl->pipe.n_cuts, 1);
+            if ((rc = pl->d_pipe_cut_flags.alloc(nc)) || (rc = pl->d_pipe_cut_res.alloc(nc * 64))) { delete pl; return rc; }
+            if (hipMemsetAsync(pl->d_pipe_cut_flags.p, 0, nc * sizeof(int), st) != hipSuccess) {
+                delete pl;
+                return fail(PRALINE_ERR_DEVICE, "plan upload: memset failed");
+            }
         }
         for (const PipeItem &pi : pl->pipe.items) pl->pipe_analytic_rows = std::max(pl->pipe_analytic_rows, pi.rsteps + 16);
         if ((rc = pl->d_pipe_analytic.alloc((size_t)pl->pipe_analytic_rows * 32))) { delete pl; return rc; }
@@ -1137,6 +1187,7 @@ extern "C" int64_t praline_plan_tasks(const praline_plan *plan)
     for (const WaveTask &wt : plan->tasks) n += wt.max_l1 > 0;
     return n;
 }
+extern "C" int64_t praline_plan_cut_tasks(const praline_plan *plan) { return plan && plan->pipe.ok ? plan->pipe.n_cuts : 0; }
 extern "C" int64_t praline_plan_path_capacity(const praline_plan *plan) { return plan ? plan->path_cap : 0; }
 extern "C" void *praline_plan_device_scores(praline_plan *plan) { return plan ? (void *)plan->d_scores.p : nullptr; }
 
@@ -1621,6 +1672,10 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         pp.analytic_rows = pl.pipe_analytic_rows;
         pp.scores = la.scores;
         pp.rp = la.rp;
+        pp.cut_flags = pl.d_pipe_cut_flags.p;
+        pp.cut_res = pl.d_pipe_cut_res.p;
+        pl.pipe_gen = pl.pipe_gen == 0x7fffffff ? 1 : pl.pipe_gen + 1;
+        pp.gen = pl.pipe_gen;
         pp.stream = st;
         HIPCHK(hipEventRecord(pl.ev0, st));
         RC(praline_launch_pipe(pp, a16, a.nr16, a.nterm16));

@@ -62,6 +62,9 @@ def lib():
     L.praline_raw_align.argtypes = [i32, pa, pa, pa, pa, ctypes.POINTER(f32), vp,
                                     ctypes.POINTER(i64)]
     L.praline_arena_create.argtypes = [i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
+    if hasattr(L, "praline_host_alloc"):
+        L.praline_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+        L.praline_host_free.argtypes = [vp]
     L.praline_arena_destroy.argtypes = [vp]
     L.praline_arena_set_track_sets.argtypes = [vp, i32, vp]
     L.praline_arena_set_counts.argtypes = [vp, vp, i64, i64]
@@ -82,7 +85,9 @@ def lib():
     for name in ("praline_arena_counts_reset", "praline_plan_add_counts", "praline_arena_counts_read",
                  "praline_plan_path_bounds"):
         getattr(L, name).restype = ctypes.c_int
-    for name in ("praline_plan_steps", "praline_plan_tasks"):
+    for name in ("praline_plan_steps", "praline_plan_tasks", "praline_plan_cut_tasks"):
+        if not hasattr(L, name):
+            continue   # (A/B runs against older builds of the library: PRALINE_LIB)
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i64
     L.praline_plan_path_capacity.argtypes = [vp]
@@ -255,6 +260,47 @@ def raw_align(mode, m, g1, g2, z=None):
 
 
 # ---- batched path --------------------------------------------------------------------------------
+# Page-locked staging for the profiles of an arena (praline_host_alloc): the list of per-sequence arrays is concatenated
+# straight into it and goes up by DMA.  One buffer per process, grown on demand, reused by every Arena (the upload has
+# finished when praline_arena_create returns); lists beyond the cap take the pageable path.
+_STAGE_CAP = 1 << 30
+_stage = {"ptr": None, "view": None}
+
+
+def _stage_view(n_floats):
+    if n_floats * 4 > _STAGE_CAP or not hasattr(lib(), "praline_host_alloc"):
+        return None
+    v = _stage["view"]
+    if v is None or v.size < n_floats:
+        if _stage["ptr"] is not None:
+            _stage["view"] = None
+            lib().praline_host_free(_stage["ptr"])
+            _stage["ptr"] = None
+        want = max(1 << 22, 1 << int(n_floats - 1).bit_length())
+        p = ctypes.c_void_p()
+        if lib().praline_host_alloc(want * 4, ctypes.byref(p)) != OK:
+            return None
+        _stage["ptr"] = p
+        v = _stage["view"] = np.ctypeslib.as_array((ctypes.c_float * want).from_address(p.value))
+    return v[:n_floats]
+
+
+def _stage_profiles(profiles, A):
+    """The float32 [sum L, A] concatenation of `profiles`, in page-locked memory when they are float32 already."""
+    first = profiles[0]
+    if isinstance(first, np.ndarray) and first.dtype == np.float32 and first.ndim == 2 and first.shape[1] == A:
+        rows = 0
+        for p in profiles:
+            rows += len(p)
+        v = _stage_view(rows * A)
+        if v is not None:
+            try:
+                return np.concatenate(profiles, axis=0, out=v.reshape(rows, A), casting="no")
+            except (TypeError, ValueError):
+                pass   # (mixed dtypes or shapes: the general path below reports what is wrong)
+    return np.ascontiguousarray(np.concatenate(profiles, axis=0), dtype=np.float32)
+
+
 class Arena(object):
     """Profiles of N sequences resident in HBM (praline_arena_create)."""
 
@@ -263,7 +309,7 @@ class Arena(object):
         sets concatenated along the alphabet axis (only the "ref" match mode needs them)."""
         A = int(score_matrix.shape[0])
         self.lens = np.array([p.shape[0] for p in profiles], dtype=np.int32)
-        cat = np.ascontiguousarray(np.concatenate(profiles, axis=0), dtype=np.float32)
+        cat = _stage_profiles(profiles, A)
         if cat.shape[1] != A:
             raise ValueError("profile width %d != score matrix size %d" % (cat.shape[1], A))
         S = np.ascontiguousarray(score_matrix, dtype=np.float32)
@@ -396,6 +442,8 @@ class Plan(object):
         self.cells = int(lib().praline_plan_cells(h))
         self.steps = int(lib().praline_plan_steps(h))   # wavefront steps per run (1024 cells each, incl. padding)
         self.tasks = int(lib().praline_plan_tasks(h))   # 32-pair tasks
+        # ... of which the pipeline schedule cut between two workgroups
+        self.cut_tasks = int(lib().praline_plan_cut_tasks(h)) if hasattr(lib(), "praline_plan_cut_tasks") else 0
 
     def run(self, mode, gap_open, gap_extend, d_scores=None):
         """Asynchronous launch on the library stream.  d_scores: optional DEVICE pointer (int)."""
