@@ -209,8 +209,6 @@ int64_t praline_plan_cells(const praline_plan *plan);      /* sum L1*L2 over the
  * strip = 1024 cells incl. padding) and the number of 32-pair tasks; bench.py prices VALU issue with them. */
 int64_t praline_plan_steps(const praline_plan *plan);
 int64_t praline_plan_tasks(const praline_plan *plan);
-/* ... and the number of tasks the scheduler cut between two workgroups of the pipeline kernel (0 for other plans). */
-int64_t praline_plan_cut_tasks(const praline_plan *plan);
 int64_t praline_plan_path_capacity(const praline_plan *plan); /* rows: sum (L1+L2+2) */
 
 /* Launches the fused match-score + affine DP fill for every pair of the plan (asynchronous on

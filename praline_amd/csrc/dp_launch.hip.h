@@ -56,9 +56,6 @@ struct PipeLaunch {
     int analytic_rows;
     float *scores;
     RunParams rp;
-    int *cut_flags;         // one word per cut task (dp_types.h): the launch generation once its head is done
-    float *cut_res;         // float [n_cuts][2][32]: the heads' shares of the results
-    int gen;                // this launch's generation (never 0)
     hipStream_t stream;
 };
 bool praline_pipe_supported(int nr, int nterm);

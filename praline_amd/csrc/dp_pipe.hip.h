@@ -30,21 +30,17 @@
 // ring slot p % 12 = u % 12: static per unrolled step, the same for every wave.  Boundary rows live in slot row % 12 of
 // the consumer's ring.
 //
-// Rows that leave through memory (wave 3's, and those of a strip that ends the HEAD of a cut task - dp_types.h - on any
-// wave) are staged in the wave's OWN incoming ring: slot u % 12 held the incoming row u, consumed a step earlier, and is
-// not refilled before step u + 4 (DMA) / u + 10 (LDS hand-off); every fourth step the four staged rows go out in one store.
-//
-// LDS per workgroup (77.5 KiB: two workgroups per CU): [12 x 4 KiB operand ring][4 x 4 KiB A tiles of the next strips]
-// [4 x 3 KiB boundary rings][1.5 KiB results].
+// LDS per workgroup (80 KiB: two workgroups per CU): [12 x 4 KiB operand ring][4 x 4 KiB A tiles of the next strips]
+// [4 x 3 KiB boundary rings][3 KiB wave 3's outgoing rows][1 KiB results].
 #pragma once
 #include "dp_split16.hip.h"
 
 __host__ __device__ constexpr int pipe_ring_bytes() { return PRALINE_PIPE_RING * 4096; }
 __host__ __device__ constexpr int pipe_bring_bytes() { return 12 * 256; }
-__host__ __device__ constexpr int pipe_res_bytes() { return PRALINE_PIPE_MAX_PIECES * 2 * 32 * 4; }
+__host__ __device__ constexpr int pipe_res_bytes() { return PRALINE_PIPE_MAX_TASKS * 2 * 32 * 4; }
 __host__ __device__ constexpr int pipe_lds_bytes()
 {
-    return pipe_ring_bytes() + 4 * 4096 + 4 * pipe_bring_bytes() + pipe_res_bytes();
+    return pipe_ring_bytes() + 4 * 4096 + 5 * pipe_bring_bytes() + pipe_res_bytes();
 }
 static_assert(pipe_lds_bytes() <= 80 * 1024, "two pipeline workgroups per CU");
 
@@ -96,41 +92,21 @@ __device__ __forceinline__ void pipe_issue(PipeDma &d)
 __device__ __forceinline__ void pipe_issue_block(unsigned long long src, unsigned dst, unsigned lane16)
 {
     unsigned keep;
-    // (sc1: agent scope - a cut column was written by a workgroup that may sit on another XCD, behind another L2)
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 sc1\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
                  : "=&s"(keep)
                  : "v"(lane16), "s"(src), "s"(dst)
                  : "memory");
-}
-// four staged boundary rows (1 KiB) to memory, written through to where every XCD sees them
-__device__ __forceinline__ void pipe_store_block(unsigned long long dst, unsigned lane16, const f4n &v)
-{
-    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" : : "v"(lane16), "v"(v), "s"(dst) : "memory");
-}
-
-typedef __attribute__((address_space(1))) unsigned pipe_u32;
-// the head of a cut task has stored its boundary column and published its results (cut flag = this launch's generation)
-__device__ __forceinline__ void pipe_cut_wait(const int *flag, int gen)
-{
-    for (;;) {
-        int v = (int)__hip_atomic_load((const pipe_u32 *)(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = __builtin_amdgcn_readfirstlane(v);
-        if (v == gen) break;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    // (no cache maintenance: the column and the results were written through - sc1 stores, drained before the flag - and
-    // are read with agent-scope loads; this kernel has not touched their lines before)
 }
 
 // Boundary traffic of a wave, per strip (wave-uniform).
 struct PipeBnd {
     unsigned long long in_src;   // next block of the incoming column to fetch (analytic column or the wrap-around column)
     bool in_dma;                 // this strip's boundary column comes from memory (wave 0, or the task's first strip)
-    unsigned long long out_dst;  // next block of the outgoing column to store (wave 3: wrap-around column; a head's last strip: cut column)
-    bool out_mem;                // this strip's rows go to memory (four at a time)
+    unsigned long long out_dst;  // wave 3: next block of the wrap-around column to store
+    bool out_mem;                // wave 3: rows go to memory (four at a time)
     unsigned ring_addr;          // LDS address of this wave's incoming ring
-    const char *out_stage;       // the staged outgoing rows: this wave's own ring (+ lane * 16)
+    const char *out_stage;       // wave 3: its outgoing rows in LDS (+ lane * 16)
 };
 
 // One step.  K = u % 12.  Register roles as in split16_step (BSRC = 2 without DM):
@@ -222,7 +198,7 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
         }
         if (pb.out_mem) {
             const f4n v = *reinterpret_cast<const f4n *>(pb.out_stage + (K - 3) * 256);
-            pipe_store_block(pb.out_dst, lane16, v);
+            __builtin_nontemporal_store(v, reinterpret_cast<f4n *>(pb.out_dst + lane16));
             pb.out_dst += 1024;
         }
     }
@@ -260,7 +236,7 @@ template <int NR, int NTERM, bool LOCAL, bool SEMI>
 __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeItem *__restrict__ items, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ set_one, const int32_t *__restrict__ lane_pair,
                                                     float2 *bnd, const float2 *__restrict__ analytic, float *__restrict__ scores,
-                                                    RunParams rp, int *cut_flags, float *cut_res, int gen)
+                                                    RunParams rp)
 {
     static_assert(!(LOCAL && SEMI), "one mode at a time");
     __shared__ __attribute__((aligned(16))) char lds[pipe_lds_bytes()];
@@ -268,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
     const int rank = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform (SGPR)
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     char *atile = lds + pipe_ring_bytes() + rank * 4096;
-    char *bring_all = lds + pipe_ring_bytes() + 4 * 4096;          // boundary rings [wave 0..3][12 rows][32] float2
-    float *res = reinterpret_cast<float *>(bring_all + 4 * pipe_bring_bytes());   // [piece][2][32]
+    char *bring_all = lds + pipe_ring_bytes() + 4 * 4096;          // boundary rings [wave 0..3][12 rows][32] float2, then wave 3's outgoing rows
+    float *res = reinterpret_cast<float *>(bring_all + 5 * pipe_bring_bytes());   // [task][2][32]
     const PipeItem it = items[blockIdx.x];
     const int rsteps = it.rsteps, nrounds = it.nrounds, nstrips_all = it.nstrips;
     const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
@@ -279,9 +255,9 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
     const float h00 = max3f(0.0f, o001, o002);
 
     // defined LDS contents before the first DMA / hand-off; results start at -inf
-    for (int i = threadIdx.x * 16; i < pipe_ring_bytes() + 4 * 4096 + 4 * pipe_bring_bytes(); i += 256 * 16)
+    for (int i = threadIdx.x * 16; i < pipe_ring_bytes() + 4 * 4096 + 5 * pipe_bring_bytes(); i += 256 * 16)
         *reinterpret_cast<float4 *>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = threadIdx.x; i < PRALINE_PIPE_MAX_PIECES * 2 * 32; i += 256) res[i] = PRALINE_NEG_INF;
+    for (int i = threadIdx.x; i < PRALINE_PIPE_MAX_TASKS * 2 * 32; i += 256) res[i] = PRALINE_NEG_INF;
     __syncthreads();
 
     const int my_one = set_one[it.set * 32 + j];
@@ -323,13 +299,12 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
     PipeBnd pb;
     pb.ring_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(bring_all + rank * pipe_bring_bytes()));
     pb.out_mem = rank == 3;
-    pb.out_stage = bring_all + rank * pipe_bring_bytes() + lane * 16;
+    pb.out_stage = bring_all + 4 * pipe_bring_bytes() + lane * 16;
     pb.out_dst = wrap_col;
     pb.in_dma = false;
     pb.in_src = 0;
     const char *bnd_in = bring_all + rank * pipe_bring_bytes() + j * 8;           // rows handed to this wave
-    char *bnd_own = bring_all + rank * pipe_bring_bytes() + j * 8;                // ... whose consumed slots stage the rows that leave through memory
-    char *bnd_next = bring_all + ((rank + 1) & 3) * pipe_bring_bytes() + j * 8;   // rows this wave hands to the next one
+    char *bnd_out = bring_all + (rank + 1) * pipe_bring_bytes() + j * 8;          // rows this wave hands on (wave 3: its staging ring)
 
     // ---- this wave's strips ----
     int ti = 0, s = rank;          // task (inside the item) and strip of this wave's current strip
@@ -343,16 +318,10 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
 #pragma unroll
     for (int i = 0; i < PRALINE_PIPE_AHEAD; ++i) pipe_issue(dma);
     if (any && s == 0) {
-        unsigned long long src = analytic_col;
-        const long long cut_in = tasks[it.task0 + ti].bnd_off;
-        if (cut_in >= 0) {   // the item starts with (or its first round reaches) the tail of a cut task
-            pipe_cut_wait(cut_flags + (int)tasks[it.task0 + ti].aux_off, gen);
-            src = uniform64(reinterpret_cast<unsigned long long>(bnd + cut_in));
-        }
-        pipe_issue_block(src, pb.ring_addr, lane16);
-        pipe_issue_block(src + 1024, pb.ring_addr + 1024, lane16);
+        pipe_issue_block(analytic_col, pb.ring_addr, lane16);
+        pipe_issue_block(analytic_col + 1024, pb.ring_addr + 1024, lane16);
         pb.in_dma = true;
-        pb.in_src = src + 2048;
+        pb.in_src = analytic_col + 2048;
     }
     PRALINE_VMCNT(0);
     PRALINE_PIPE_BARRIER();
@@ -376,25 +345,19 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
         const WaveTask tk = tasks[it.task0 + ti];
         const int two = tk.two[0];
         const int L2 = ar.len[two];
-        const int nstrips = tk.nstrips;          // of this piece (dp_types.h): strips sg = tk.two[1] + s of the task
-        const int sg = tk.two[1] + s;
+        const int nstrips = tk.nstrips;
         const int clast = (L2 - 1) & 31;
         const bool own_last = (clast >> 4) == h;
-        const int x0 = sg * 32;
-        const bool last_owner = (sg == ((L2 + 31) >> 5) - 1) && own_last;
+        const int x0 = s * 32;
+        const bool last_owner = (s == nstrips - 1) && own_last;
         const int xb = x0 + 16 * h;
         cidx = clast & 15;
         asm volatile("" : "+v"(cidx));
         const bool have_pair = have_one && lane_pair[(it.task0 + ti) * 32 + j] >= 0;
-        // the upper half hands its rows on - unless this strip ends its piece: the next strip then starts from the
-        // analytic column (or a cut column), which its wave fetches into the same ring.  Wave 3's rows and those of a
-        // strip that ends the head of a cut task leave through memory, staged in the wave's own ring.
-        const bool cut_out = s == nstrips - 1 && tk.tb_off >= 0;
-        const bool to_mem = rank == 3 || cut_out;
-        const bool wr_lane = h == 1 && (s < nstrips - 1 || to_mem);
-        char *bnd_out = to_mem ? bnd_own : bnd_next;
-        pb.out_mem = to_mem;
-        pb.out_dst = cut_out ? uniform64(reinterpret_cast<unsigned long long>(bnd + tk.tb_off)) : wrap_col;
+        // the upper half hands its rows on - unless this strip ends its task: the next strip then starts from the
+        // analytic column, which its wave fetches into the same ring
+        const bool wr_lane = h == 1 && (s < nstrips - 1 || rank == 3);
+        pb.out_dst = wrap_col;
 
         if (!started) {
             // pipeline prologue of the wave's first strip: A tile straight from memory, operand rows 1 and 2 from the
@@ -429,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
             Hs[c + 1] = boundary_value(xb + c + 1, go, ge, free_two);   // H[0][x] = o[0,x,2]
             Uc[c] = PRALINE_NEG_INF;                                     // U[1][x]
         }
-        float dH = (sg == 0) ? h00 : boundary_value(x0, go, ge, free_two);
+        float dH = (s == 0) ? h00 : boundary_value(x0, go, ge, free_two);
         float hd_x = PRALINE_NEG_INF, l_x = PRALINE_NEG_INF;
         // per-strip results (folded into the task's table at the end of the strip); the column-0 / row-0 cells and
         // o[0,0] enter at finalisation
@@ -445,11 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
             while (s_n >= tasks[it.task0 + ti_n].nstrips) { s_n -= tasks[it.task0 + ti_n].nstrips; ++ti_n; }
         }
         const bool in_dma_next = more && (rank == 0 || s_n == 0);
-        // (a piece's first strip: the analytic column, or - the tail of a cut task - the column its head has stored)
-        const long long cut_in_next = (more && s_n == 0) ? (long long)tasks[it.task0 + ti_n].bnd_off : -1ll;
-        const int cut_wait = cut_in_next >= 0 ? (int)tasks[it.task0 + ti_n].aux_off : -1;
-        const unsigned long long in_src_next =
-            s_n == 0 ? (cut_in_next >= 0 ? uniform64(reinterpret_cast<unsigned long long>(bnd + cut_in_next)) : analytic_col) : wrap_col;
+        const unsigned long long in_src_next = s_n == 0 ? analytic_col : wrap_col;
 
 #define PRALINE_PIPE_STEP(KK, SN, CURA, PREVA, BUSE, BFIL)                                                             \
         pipe_step<NR, NTERM, LOCAL, SEMI, KK, SN>(u0 + KK, L1, have_pair, h, CURA, PREVA, BUSE, BFIL, aop, ring, stage_rd, bnd_in, \
@@ -463,7 +422,6 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
             PRALINE_PIPE_STEP(5, SN, accB, accA, b1, b0);                                                              \
             PRALINE_PIPE_STEP(6, SN, accA, accB, b0, b1);                                                              \
             if (last_it) {   /* the block requested at step 7 (rows rsteps .. rsteps + 3) is the next strip's rows 0 .. 3 */ \
-                if (cut_wait >= 0) pipe_cut_wait(cut_flags + cut_wait, gen);                                           \
                 pb.in_dma = in_dma_next;                                                                               \
                 pb.in_src = in_src_next;                                                                               \
             }                                                                                                          \
@@ -500,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
             if (a_fetch) {                                                                                             \
                 /* A tile of strip q + 4 (rows x0' .. x0' + 31 of its sequence two, this lane's 64 bytes) -> LDS */    \
                 const unsigned long long qs = uniform64(reinterpret_cast<unsigned long long>(ar.Q16) +                 \
-                                              ((unsigned long long)ar.row_off[tasks[it.task0 + ti_n].two[0]] + (unsigned long long)((tasks[it.task0 + ti_n].two[1] + s_n) * 32)) * 128ull); \
+                                              ((unsigned long long)ar.row_off[tasks[it.task0 + ti_n].two[0]] + (unsigned long long)(s_n * 32)) * 128ull); \
                 _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                                                     \
                     unsigned keep;                                                                                     \
                     const unsigned go_ = a_gofs + 16u * qq, dst = a_lds + 1024u * qq;                                  \
@@ -537,21 +495,6 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
                 if (SEMI && colmax_all != PRALINE_NEG_INF) atomicMax(r0 + 32, colmax_all);
             }
         }
-        if (cut_out) {
-            // the head of a cut task is complete (its earlier strips ran on waves that are ahead of this one, or in earlier
-            // rounds: their shares are in the table): publish its results, then - its column and results written back
-            // for every XCD to see - the flag its tail waits for
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (h == 0) {
-                float *cr = cut_res + (int64_t)tk.aux_off * 64 + j;
-                __hip_atomic_store((pipe_u32 *)(cr), __builtin_bit_cast(unsigned, res[ti * 64 + j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store((pipe_u32 *)(cr + 32), __builtin_bit_cast(unsigned, res[ti * 64 + 32 + j]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // column and results are in memory before the flag says so
-            if (lane == 0)
-                __hip_atomic_store((pipe_u32 *)(cut_flags + tk.aux_off), (unsigned)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         ti = ti_n;
         s = s_n;
     }
@@ -564,18 +507,11 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
 
     // ---- scores: wave r finalises the tasks r, r + 4, ... ----
     for (int t = rank; t < it.ntasks; t += 4) {
-        const WaveTask tf = tasks[it.task0 + t];
-        if (tf.tb_off >= 0) continue;   // the head of a cut task: the item that holds its tail reports the scores
         if (h != 0 || !have_one) continue;
         const int pair = lane_pair[(it.task0 + t) * 32 + j];
         if (pair < 0) continue;
-        const int L2 = ar.len[tf.two[0]];
-        float v0 = res[t * 64 + j], v1 = res[t * 64 + 32 + j];
-        if (tf.bnd_off >= 0) {   // the tail of a cut task: its head's share
-            const float *cr = cut_res + (int64_t)tf.aux_off * 64 + j;
-            v0 = __builtin_fmaxf(v0, __builtin_bit_cast(float, __hip_atomic_load((const pipe_u32 *)(cr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-            v1 = __builtin_fmaxf(v1, __builtin_bit_cast(float, __hip_atomic_load((const pipe_u32 *)(cr + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-        }
+        const int L2 = ar.len[tasks[it.task0 + t].two[0]];
+        const float v0 = res[t * 64 + j], v1 = res[t * 64 + 32 + j];
         float score;
         if (LOCAL) score = __builtin_fmaxf(v0, h00);
         else if (SEMI) {

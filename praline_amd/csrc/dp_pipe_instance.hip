@@ -10,7 +10,7 @@ template <int NR, int NTERM> static void launch_pipe(const PipeLaunch &pl, const
                        (float2 *)pl.analytic, pl.analytic_rows, pl.rp);
 #define PRALINE_PIPE_LAUNCH(LOC, SEMI)                                                                                  \
     hipLaunchKernelGGL((k_dp_pipe<NR, NTERM, LOC, SEMI>), grid, block, 0, pl.stream, a16, pl.items, pl.tasks, pl.set_one, \
-                       pl.lane_pair, (float2 *)pl.bnd, (const float2 *)pl.analytic, pl.scores, pl.rp, pl.cut_flags, pl.cut_res, pl.gen)
+                       pl.lane_pair, (float2 *)pl.bnd, (const float2 *)pl.analytic, pl.scores, pl.rp)
     if (pl.rp.mode == PRALINE_MODE_LOCAL) PRALINE_PIPE_LAUNCH(true, false);
     else if (pl.rp.mode >= 2) PRALINE_PIPE_LAUNCH(false, true);
     else PRALINE_PIPE_LAUNCH(false, false);

@@ -40,18 +40,7 @@ struct PipeItem {
 #define PRALINE_PIPE_LAG 2          // steps between consecutive waves of a pipeline workgroup
 #define PRALINE_PIPE_RING 12        // operand rows held by the workgroup's LDS ring
 #define PRALINE_PIPE_MIN_STEPS 36   // shortest round: the wrap-around hand-off (wave 3 -> wave 0) goes through memory
-#define PRALINE_PIPE_MAX_TASKS 4    // whole tasks per item
-// A task may be CUT between two items of its list (plans that are resident at once: the cut lets every item of a list take
-// the same number of rounds): the HEAD piece (strips 0 .. k - 1) is the first piece of one item, the TAIL piece (strips
-// k ..) the last piece of an item further down the launch order.  The head's last strip stores its boundary column to
-// memory (any wave can: its outgoing rows are staged in the consumed slots of its own incoming ring), publishes the
-// head's share of the results and raises the cut's flag; the tail's first strip waits for the flag and reads the column
-// the way a task's first strip reads the analytic column.  Pieces are WaveTask entries of the item's list:
-//   two[1]  = first strip of the piece inside its task (0: whole task or head)
-//   nstrips = strips of the piece
-//   bnd_off = float2 element offset of the cut column a TAIL reads (-1: none), tb_off = ... a HEAD writes (-1: none)
-//   aux_off = index of the cut (flag word, partial results) or -1
-#define PRALINE_PIPE_MAX_PIECES 6   // pieces per item (the per-piece result table lives in LDS: 256 bytes per piece)
+#define PRALINE_PIPE_MAX_TASKS 4    // tasks per item (the per-task result table lives in LDS: 256 bytes per task)
 
 // two-pass alignments with paths: rows per kept boundary column beyond max_l1, and checkpoint blocks per strip (one
 // per 32 rows; the unrolled loops compute rows up to max_l1 + 12; block 0 is never written)

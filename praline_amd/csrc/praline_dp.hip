@@ -888,9 +888,6 @@ struct praline_plan {
     DevBuf<int32_t> d_pipe_set_one, d_pipe_lane_pair;
     DevBuf<float2> d_pipe_bnd, d_pipe_analytic;
     int pipe_analytic_rows = 0;
-    DevBuf<int> d_pipe_cut_flags;      // cut tasks (dp_types.h): flag word per cut, zero at creation, = pipe_gen once the head is done
-    DevBuf<float> d_pipe_cut_res;      // [n_cuts][2][32]
-    int pipe_gen = 0;
     DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
@@ -1050,8 +1047,6 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             po.block_twos = n_pairs <= 40000 ? 32 : 16;
             if (const char *env = getenv("PRALINE_PIPE_BLOCK")) po.block_twos = atoi(env);
             if (const char *env = getenv("PRALINE_PIPE_SLOTS")) po.wg_slots = atoll(env);
-            if (const char *env = getenv("PRALINE_PIPE_CUTS")) po.cuts = env[0] != '0';   // (A/B: whole tasks only)
-            if (const char *env = getenv("PRALINE_PIPE_CUT_MARGIN")) po.cut_margin = atoi(env);   // (tests: 0 = cuts wherever they fit)
             if (min_len >= 1) build_pipe_schedule(a.len.data(), a.n_seqs, n_pairs, pairs, po, pl->pipe);
             // below ~200 tasks (all pairs of ~110 sequences) the shared-wave task schedule is as fast or faster
             // (scripts/exp_pipe_sweep.py): a pipeline item cannot be smaller than one task
@@ -1107,14 +1102,6 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
             (rc = pl->d_pipe_bnd.alloc((size_t)pl->pipe.bnd_elems))) {
             delete pl;
             return rc;
-        }
-        {
-            const size_t nc = (size_t)std::max<int64_t>(pl->pipe.n_cuts, 1);
-            if ((rc = pl->d_pipe_cut_flags.alloc(nc)) || (rc = pl->d_pipe_cut_res.alloc(nc * 64))) { delete pl; return rc; }
-            if (hipMemsetAsync(pl->d_pipe_cut_flags.p, 0, nc * sizeof(int), st) != hipSuccess) {
-                delete pl;
-                return fail(PRALINE_ERR_DEVICE, "plan upload: memset failed");
-            }
         }
         for (const PipeItem &pi : pl->pipe.items) pl->pipe_analytic_rows = std::max(pl->pipe_analytic_rows, pi.rsteps + 16);
         if ((rc = pl->d_pipe_analytic.alloc((size_t)pl->pipe_analytic_rows * 32))) { delete pl; return rc; }
@@ -1187,7 +1174,6 @@ extern "C" int64_t praline_plan_tasks(const praline_plan *plan)
     for (const WaveTask &wt : plan->tasks) n += wt.max_l1 > 0;
     return n;
 }
-extern "C" int64_t praline_plan_cut_tasks(const praline_plan *plan) { return plan && plan->pipe.ok ? plan->pipe.n_cuts : 0; }
 extern "C" int64_t praline_plan_path_capacity(const praline_plan *plan) { return plan ? plan->path_cap : 0; }
 extern "C" void *praline_plan_device_scores(praline_plan *plan) { return plan ? (void *)plan->d_scores.p : nullptr; }
 
@@ -1672,10 +1658,6 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         pp.analytic_rows = pl.pipe_analytic_rows;
         pp.scores = la.scores;
         pp.rp = la.rp;
-        pp.cut_flags = pl.d_pipe_cut_flags.p;
-        pp.cut_res = pl.d_pipe_cut_res.p;
-        pl.pipe_gen = pl.pipe_gen == 0x7fffffff ? 1 : pl.pipe_gen + 1;
-        pp.gen = pl.pipe_gen;
         pp.stream = st;
         HIPCHK(hipEventRecord(pl.ev0, st));
         RC(praline_launch_pipe(pp, a16, a.nr16, a.nterm16));

@@ -613,8 +613,7 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
     // items of one list under the bound c*: bin packing of its tasks (<= PRALINE_PIPE_MAX_TASKS per item) into bins of
     // floor(c* / rsteps) rounds = 4 x that many strips, first fit decreasing - long and short sequences two end up
     // together, so the strip totals come out near the multiples of four that the rounds are made of
-    struct Piece { int32_t task, s0, n, cut_in, cut_out; };   // strips s0 .. s0 + n - 1 of a task; cut ids or -1 (dp_types.h)
-    struct Cut { int32_t list; std::vector<Piece> piece; };
+    struct Cut { int32_t list; std::vector<int32_t> task; };
     // max_tasks: tasks per item; n_single: per list, this share (in 1/1024) of its tasks - the shortest - become items
     // of their own (large batches: the short items the dispatcher fills the tail of the launch with)
     // (every list's tasks by descending strip count, once: the bisection below packs them a dozen times)
@@ -627,7 +626,7 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
         int64_t n = 0;
         std::vector<int64_t> load;
         std::vector<int32_t> count;
-        std::vector<std::vector<Piece>> member;
+        std::vector<std::vector<int32_t>> member;
         for (size_t li = 0; li < lists.size(); ++li) {
             const PipeList &l = lists[li];
             const int64_t cap = std::max<int64_t>(1, cstar / l.rsteps) * 4;   // strips per item
@@ -646,7 +645,7 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
                 if (b == load.size()) { load.push_back(0); count.push_back(0); if (cuts) member.emplace_back(); }
                 load[b] += q; ++count[b];
                 if (k >= n_packed) count[b] = max_tasks;   // closed
-                if (cuts) member[b].push_back(Piece{t, 0, (int32_t)q, -1, -1});
+                if (cuts) member[b].push_back(t);
             }
             n += (int64_t)load.size();
             if (cuts)
@@ -656,68 +655,8 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
     };
     auto item_cost = [&](const Cut &c) {
         int64_t q = 0;
-        for (const Piece &pc : c.piece) q += pc.n;
+        for (int32_t t : c.task) q += st[(size_t)t].nstrips;
         return (q + 3) / 4 * (int64_t)lists[(size_t)c.list].rsteps;
-    };
-    // The same with CUT tasks (plans resident at once): a list's strips are dealt out item after item, floor(c* / rsteps)
-    // rounds each; the task that crosses an item's end is cut there - its head becomes the FIRST piece of that item, its
-    // tail the LAST piece of the next one (so the head is long done when the tail's first strip asks for its column).
-    // Every item of a list but the last takes exactly that many rounds.  A task is cut at most once (the bound is at least
-    // the longest task's cost) and an item holds at most PRALINE_PIPE_MAX_PIECES pieces.
-    int32_t n_cut_ids = 0;
-    auto cut_pack = [&](int64_t cstar, std::vector<Cut> *cuts) {
-        int64_t n = 0;
-        n_cut_ids = 0;
-        for (size_t li = 0; li < lists.size(); ++li) {
-            const PipeList &l = lists[li];
-            const int64_t cap = std::max<int64_t>(1, cstar / l.rsteps) * 4;   // strips per item
-            const std::vector<int32_t> &order = sorted_tasks[li];
-            int64_t used = 0;
-            int pieces = 0;
-            Cut cur;
-            cur.list = (int32_t)li;
-            Piece tail{-1, 0, 0, -1, -1};   // the tail this item ends with (emitted last)
-            auto close = [&]() {
-                if (pieces == 0) return;
-                if (cuts) {
-                    if (tail.task >= 0) cur.piece.push_back(tail);
-                    cuts->push_back(cur);
-                }
-                cur.piece.clear();
-                tail.task = -1;
-                used = 0; pieces = 0;
-                ++n;
-            };
-            for (size_t k = 0; k < order.size(); ++k) {
-                const int32_t t = order[k];
-                const int64_t q = st[(size_t)t].nstrips;
-                if (used + q <= cap && pieces < PRALINE_PIPE_MAX_PIECES) {
-                    cur.piece.push_back(Piece{t, 0, (int32_t)q, -1, -1});
-                    used += q; ++pieces;
-                } else {
-                    const int64_t room = cap - used;
-                    // (a tail only starts once its head is complete - the hand-over is per column, not per row: the head runs
-                    // in its item's first rounds, the tail in the last ones of an item that starts at the same time, so an
-                    // item must be two rounds longer than the task or the tail's workgroup sits waiting)
-                    if (room >= 1 && room < q && pieces < PRALINE_PIPE_MAX_PIECES && q - room <= cap && cap >= q + opt.cut_margin) {
-                        const int32_t id = n_cut_ids++;
-                        // (the head goes to the front of this item)
-                        cur.piece.insert(cur.piece.begin(), Piece{t, 0, (int32_t)room, -1, id});
-                        ++pieces;
-                        close();
-                        tail = Piece{t, (int32_t)room, (int32_t)(q - room), id, -1};
-                        used = q - room; pieces = 1;
-                    } else {
-                        close();
-                        cur.piece.push_back(Piece{t, 0, (int32_t)q, -1, -1});
-                        used = q; pieces = 1;
-                    }
-                }
-                if (used >= cap || pieces >= PRALINE_PIPE_MAX_PIECES) close();
-            }
-            close();
-        }
-        return n;
     };
     int64_t total = 0, one_max = 0;
     for (const PipeList &l : lists) {
@@ -729,56 +668,19 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
     // PRALINE_PIPE_MAX_TASKS: the strip total of a long list wastes less of its last round), and two slots' worth of
     // single-task items from the short end of every list to even out the tail of the launch.
     std::vector<Cut> cuts;
-    bool used_cuts = false;
     {
         const int64_t n_tasks = (int64_t)st.size(), slots = std::max<int64_t>(opt.wg_slots, 1);
         if (2 * n_tasks <= 5 * slots) {
             // the bound only acts through floor(c* / rsteps) and every rsteps is a multiple of 12: search the multiples of
-            // 12, from the larger of the longest task and an even share upwards
-            const int64_t base = (std::max(one_max, (total + slots - 1) / slots) + 11) / 12;
+            // 12, from the larger of the longest task and an even share upwards (galloping, then bisection)
+            int64_t lo = (std::max(one_max, (total + slots - 1) / slots) + 11) / 12, hi = lo;
             const int64_t top = (std::max(one_max, total) + 11) / 12;
-            bool done = false;
-            if (opt.cuts) {
-                // with cuts a list of S strips needs ceil(S / (4 floor(c* / rsteps))) items whatever its tasks are: bisect on
-                // that, then pack (the piece limit can ask for a little more).  Whole tasks are kept when they fit the same
-                // bound.
-                std::vector<int64_t> strips(lists.size(), 0);
-                for (size_t li = 0; li < lists.size(); ++li)
-                    for (int32_t t : lists[li].task) strips[li] += st[(size_t)t].nstrips;
-                auto ideal = [&](int64_t cstar) {
-                    int64_t n = 0;
-                    for (size_t li = 0; li < lists.size(); ++li) {
-                        const int64_t cap = std::max<int64_t>(1, cstar / lists[li].rsteps) * 4;
-                        n += (strips[li] + cap - 1) / cap;
-                    }
-                    return n;
-                };
-                int64_t clo = base, chi = top;
-                while (clo < chi) {
-                    const int64_t mid = (clo + chi) / 2;
-                    if (ideal(12 * mid) <= slots) chi = mid; else clo = mid + 1;
-                }
-                const int64_t give_up = clo + clo / 8;
-                while (clo < give_up && cut_pack(12 * clo, nullptr) > slots) ++clo;
-                if (clo < give_up) {
-                    if (cut_count(12 * clo, PRALINE_PIPE_MAX_TASKS, 0, nullptr) <= slots) {
-                        cut_count(12 * clo, PRALINE_PIPE_MAX_TASKS, 0, &cuts);
-                    } else {
-                        cut_pack(12 * clo, &cuts);
-                        used_cuts = n_cut_ids > 0;
-                    }
-                    done = true;
-                }
+            while (hi < top && cut_count(12 * hi, PRALINE_PIPE_MAX_TASKS, 0, nullptr) > slots) { lo = hi + 1; hi = std::min(top, hi + std::max<int64_t>(1, hi / 8)); }
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) / 2;
+                if (cut_count(12 * mid, PRALINE_PIPE_MAX_TASKS, 0, nullptr) <= slots) hi = mid; else lo = mid + 1;
             }
-            if (!done) {   // whole tasks: galloping, then bisection
-                int64_t lo = base, hi = lo;
-                while (hi < top && cut_count(12 * hi, PRALINE_PIPE_MAX_TASKS, 0, nullptr) > slots) { lo = hi + 1; hi = std::min(top, hi + std::max<int64_t>(1, hi / 8)); }
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) / 2;
-                    if (cut_count(12 * mid, PRALINE_PIPE_MAX_TASKS, 0, nullptr) <= slots) hi = mid; else lo = mid + 1;
-                }
-                cut_count(12 * lo, PRALINE_PIPE_MAX_TASKS, 0, &cuts);
-            }
+            cut_count(12 * lo, PRALINE_PIPE_MAX_TASKS, 0, &cuts);
         } else {
             const int k = (int)std::min<int64_t>(PRALINE_PIPE_MAX_TASKS, std::max<int64_t>(1, n_tasks / (3 * slots)));
             const int share = k == 1 ? 0 : (int)std::min<int64_t>(1024, 2 * slots * 1024 / n_tasks);
@@ -799,60 +701,31 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
         order.swap(snake);
     }
 
-    if (used_cuts) {
-        // a cut's head must be dispatched before its tail (workgroups are dispatched in index order: a tail that polls
-        // the flag of a head that has not started could otherwise hold its slot for ever): the items of a list - equal
-        // cost but for the last - keep their launch positions, taken in list order
-        std::vector<std::vector<int32_t>> pos_of_list(lists.size());
-        for (size_t k = 0; k < order.size(); ++k) pos_of_list[(size_t)cuts[(size_t)order[k]].list].push_back((int32_t)k);
-        std::vector<size_t> next(lists.size(), 0);
-        for (size_t c = 0; c < cuts.size(); ++c) {   // (cut_pack emits a list's items in chain order)
-            const size_t li = (size_t)cuts[c].list;
-            order[(size_t)pos_of_list[li][next[li]++]] = (int32_t)c;
-        }
-    }
     out.set_one.swap(set_one);
     out.tasks.reserve(st.size());
     out.lane_pair.reserve(st.size() * 32);
     int64_t bnd = 0;
-    // cut columns (float2 [rsteps + 16][32] each) follow the items' wrap-around columns
-    std::vector<int64_t> cut_col;
-    int64_t cut_elems = 0;
-    if (used_cuts) {
-        int64_t wrap_total = 0;
-        for (const Cut &c : cuts) wrap_total += (int64_t)(lists[(size_t)c.list].rsteps + 16) * 32;
-        cut_col.assign((size_t)n_cut_ids, -1);
-        for (const Cut &c : cuts)
-            for (const Piece &pc : c.piece)
-                if (pc.cut_out >= 0) {
-                    cut_col[(size_t)pc.cut_out] = wrap_total + cut_elems;
-                    cut_elems += (int64_t)(lists[(size_t)c.list].rsteps + 16) * 32;
-                }
-        out.n_cuts = n_cut_ids;
-    }
     for (int32_t c : order) {
         const PipeList &l = lists[(size_t)cuts[(size_t)c].list];
         PipeItem it;
         it.set = l.set;
         it.task0 = (int32_t)out.tasks.size();
-        it.ntasks = (int32_t)cuts[(size_t)c].piece.size();
+        it.ntasks = (int32_t)cuts[(size_t)c].task.size();
         it.nstrips = 0;
         it.rsteps = l.rsteps;
-        for (const Piece &pc : cuts[(size_t)c].piece) {
-            const ScratchTask &t = st[(size_t)pc.task];
+        for (int32_t tsk : cuts[(size_t)c].task) {
+            const ScratchTask &t = st[(size_t)tsk];
             WaveTask wt;
-            wt.two[0] = t.two; wt.two[1] = pc.s0;
+            wt.two[0] = t.two; wt.two[1] = -1;
             wt.max_l1 = lens[out.set_one[(size_t)l.set * 32]];
-            wt.nstrips = pc.n;
-            wt.bnd_off = pc.cut_in >= 0 ? cut_col[(size_t)pc.cut_in] : -1;
-            wt.tb_off = pc.cut_out >= 0 ? cut_col[(size_t)pc.cut_out] : -1;
-            wt.aux_off = pc.cut_in >= 0 ? pc.cut_in : pc.cut_out;
+            wt.nstrips = t.nstrips;
+            wt.bnd_off = 0; wt.tb_off = 0; wt.aux_off = 0;
             out.tasks.push_back(wt);
             for (int q = 0; q < 32; ++q) {
                 out.lane_pair.push_back(t.pair[q]);
-                out.lanes_used += t.pair[q] >= 0 && pc.cut_in < 0;
+                out.lanes_used += t.pair[q] >= 0;
             }
-            it.nstrips += pc.n;
+            it.nstrips += t.nstrips;
         }
         it.nrounds = (it.nstrips + 3) / 4;
         it.bnd_off = bnd;
@@ -860,21 +733,18 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
         out.steps += 4 * (int64_t)it.nrounds * it.rsteps;
         out.items.push_back(it);
     }
-    out.bnd_elems = bnd + cut_elems;
+    out.bnd_elems = bnd;
     out.ok = true;
 }
 
 extern "C" int praline_sched_pipe_test(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int block_twos,
                                        int64_t wg_slots, int64_t cap_items, int64_t cap_tasks, int64_t cap_sets, int64_t *n_items_out,
                                        int64_t *n_tasks_out, int64_t *n_sets_out, int32_t *item_fields /* [cap_items][6]: set, task0, ntasks, nstrips, rsteps, nrounds */,
-                                       int32_t *task_fields /* [cap_tasks][6]: two, max_l1, nstrips, first strip, cut read (-1), cut written (-1) */,
-                                       int32_t *lane_pair /* [cap_tasks][32] */,
+                                       int32_t *task_fields /* [cap_tasks][3]: two, max_l1, nstrips */, int32_t *lane_pair /* [cap_tasks][32] */,
                                        int32_t *set_one /* [cap_sets][32] */)
 {
     PipeOptions opt;
     if (block_twos > 0) opt.block_twos = block_twos;
-    if (block_twos < 0) { opt.block_twos = -block_twos; opt.cuts = false; }   // (negative: whole tasks only)
-    if (block_twos > 1000) { opt.block_twos = block_twos - 1000; opt.cut_margin = 0; }   // (+ 1000: cuts wherever they fit)
     if (wg_slots > 0) opt.wg_slots = wg_slots;
     PipeSchedule s;
     build_pipe_schedule(lens, n_seqs, n_pairs, pairs, opt, s);
@@ -889,10 +759,7 @@ extern "C" int praline_sched_pipe_test(const int32_t *lens, int64_t n_seqs, int6
         f[0] = it.set; f[1] = it.task0; f[2] = it.ntasks; f[3] = it.nstrips; f[4] = it.rsteps; f[5] = it.nrounds;
     }
     for (size_t t = 0; t < s.tasks.size(); ++t) {
-        int32_t *f = task_fields + 6 * t;
-        f[0] = s.tasks[t].two[0]; f[1] = s.tasks[t].max_l1; f[2] = s.tasks[t].nstrips; f[3] = s.tasks[t].two[1];
-        f[4] = s.tasks[t].bnd_off >= 0 ? (int32_t)s.tasks[t].aux_off : -1;
-        f[5] = s.tasks[t].tb_off >= 0 ? (int32_t)s.tasks[t].aux_off : -1;
+        task_fields[3 * t] = s.tasks[t].two[0]; task_fields[3 * t + 1] = s.tasks[t].max_l1; task_fields[3 * t + 2] = s.tasks[t].nstrips;
     }
     std::copy(s.lane_pair.begin(), s.lane_pair.end(), lane_pair);
     std::copy(s.set_one.begin(), s.set_one.end(), set_one);

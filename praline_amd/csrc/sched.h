@@ -40,8 +40,7 @@ struct PipeSchedule {
     std::vector<WaveTask> tasks;          // two[0], max_l1 (of the set), nstrips; the tasks of an item are consecutive
     std::vector<int32_t> set_one;         // [n_sets][32] arena index of each lane's sequence one (-1: no sequence)
     std::vector<int32_t> lane_pair;       // [n_tasks][32] pair index, -1 = no pair in this lane
-    int64_t bnd_elems = 0;                // float2 elements of the wrap-around boundary columns and the cut columns
-    int64_t n_cuts = 0;                   // tasks cut between two items (dp_types.h)
+    int64_t bnd_elems = 0;                // float2 elements of the wrap-around boundary columns
     int64_t lanes_used = 0, steps = 0;    // pairs placed; wave steps of the launch (4 x nrounds x rsteps summed over the items)
 };
 struct PipeOptions {
@@ -49,8 +48,6 @@ struct PipeOptions {
                                           // passes 32 for plans that are resident at once and 16 for larger ones
     int64_t wg_slots = 512;               // resident workgroups (256 CUs x 2)
     double min_fill = 0.55;               // give up below this share of occupied lanes
-    bool cuts = true;                     // plans resident at once: tasks may be cut between two items (dp_types.h)
-    int cut_margin = 8;                   // ... when an item holds this many strips more than the task (tests: 0)
 };
 void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, const PipeOptions &opt,
                          PipeSchedule &out);

@@ -85,9 +85,7 @@ def lib():
     for name in ("praline_arena_counts_reset", "praline_plan_add_counts", "praline_arena_counts_read",
                  "praline_plan_path_bounds"):
         getattr(L, name).restype = ctypes.c_int
-    for name in ("praline_plan_steps", "praline_plan_tasks", "praline_plan_cut_tasks"):
-        if not hasattr(L, name):
-            continue   # (A/B runs against older builds of the library: PRALINE_LIB)
+    for name in ("praline_plan_steps", "praline_plan_tasks"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i64
     L.praline_plan_path_capacity.argtypes = [vp]
@@ -442,8 +440,6 @@ class Plan(object):
         self.cells = int(lib().praline_plan_cells(h))
         self.steps = int(lib().praline_plan_steps(h))   # wavefront steps per run (1024 cells each, incl. padding)
         self.tasks = int(lib().praline_plan_tasks(h))   # 32-pair tasks
-        # ... of which the pipeline schedule cut between two workgroups
-        self.cut_tasks = int(lib().praline_plan_cut_tasks(h)) if hasattr(lib(), "praline_plan_cut_tasks") else 0
 
     def run(self, mode, gap_open, gap_extend, d_scores=None):
         """Asynchronous launch on the library stream.  d_scores: optional DEVICE pointer (int)."""

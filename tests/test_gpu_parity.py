@@ -728,48 +728,6 @@ def test_two_pass_forward_on_the_scores_kernel(nat, bba, monkeypatch):
         arena.close()
 
 
-@pytest.mark.parametrize("shape", [(100, 260, "100", "8"), (100, 260, "100", "0"), (150, 200, "200", "0"), (120, 150, "160", "0")])
-def test_pipeline_cut_tasks_agree_bitwise(nat, bba, shape, monkeypatch):
-    """Tasks CUT between two pipeline workgroups (dp_types.h; plans with two to three tasks per workgroup slot): the
-    head's last strip hands its boundary column over through memory from whichever wave it runs on and publishes the
-    head's share of the results, the tail - the last piece of a workgroup launched later - waits for the flag.  Scores
-    equal the whole-task schedule's bit for bit in all five modes, run after run on the same plan (the flags carry the
-    launch generation); PRALINE_PIPE_CUT_MARGIN=0 also cuts where the tail has to wait for its head."""
-    N, mu, slots, margin = shape
-    rng = np.random.default_rng(31)
-    lens = synth_lengths(rng, N, mu)
-    profs = [synth_profile(rng, int(L))[0] for L in lens]
-    pairs = all_pairs(N)
-    for k in ("PRALINE_NO_PIPE", "PRALINE_PIPE_MIN_TASKS", "PRALINE_PIPE_BLOCK", "PRALINE_PIPE_SLOTS", "PRALINE_PIPE_CUTS", "PRALINE_PIPE_CUT_MARGIN"):
-        monkeypatch.delenv(k, raising=False)
-    arena = nat.Arena(profs, bba["S"])
-    if arena.info()["f16_terms"] not in (2, 3) or any(os.environ.get(k) for k in ("PRALINE_KERNEL", "PRALINE_MM", "PRALINE_NO_STAGE")):
-        arena.close()
-        pytest.skip("the pipeline workgroups run the float-profile instances of the staged stream")
-    monkeypatch.setenv("PRALINE_PIPE_SLOTS", slots)
-    monkeypatch.setenv("PRALINE_PIPE_CUTS", "0")
-    plan = nat.Plan(arena, pairs)
-    assert plan.cut_tasks == 0
-    want = {}
-    for mode in MODES:
-        plan.run(mode, *GAPS)
-        want[mode] = plan.scores().copy()
-    assert "k_dp_pipe" in plan.kernel_name()
-    plan.close()
-    monkeypatch.setenv("PRALINE_PIPE_CUTS", "1")
-    monkeypatch.setenv("PRALINE_PIPE_CUT_MARGIN", margin)
-    plan = nat.Plan(arena, pairs)
-    assert plan.cut_tasks >= 50, plan.cut_tasks
-    for rep in range(3):
-        for mode in MODES:
-            plan.run(mode, *GAPS)
-            got = plan.scores()
-            assert "k_dp_pipe" in plan.kernel_name()
-            assert np.array_equal(bits(got), bits(want[mode])), (shape, rep, mode, int((bits(got) != bits(want[mode])).sum()))
-    plan.close()
-    arena.close()
-
-
 @pytest.mark.parametrize("lists", ["triangle", "ordered", "subset"])
 def test_pipeline_workgroups_agree_bitwise(nat, bba, lists, monkeypatch):
     """k_dp_pipe (dp_pipe.hip.h: four waves pipeline the strips of tasks that share a set of 32 sequences one; shared
@@ -788,7 +746,7 @@ def test_pipeline_workgroups_agree_bitwise(nat, bba, lists, monkeypatch):
         pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j], dtype=np.int32)
         if lists == "subset":
             pairs = pairs[rng.random(len(pairs)) < 0.9]
-    for k in ("PRALINE_NO_PIPE", "PRALINE_PIPE_MIN_TASKS", "PRALINE_PIPE_BLOCK", "PRALINE_PIPE_SLOTS", "PRALINE_PIPE_CUTS"):
+    for k in ("PRALINE_NO_PIPE", "PRALINE_PIPE_MIN_TASKS", "PRALINE_PIPE_BLOCK", "PRALINE_PIPE_SLOTS"):
         monkeypatch.delenv(k, raising=False)
     arena = nat.Arena(profs, bba["S"])
     if arena.info()["f16_terms"] not in (2, 3) or any(os.environ.get(k) for k in ("PRALINE_KERNEL", "PRALINE_MM", "PRALINE_NO_STAGE")):
@@ -805,15 +763,10 @@ def test_pipeline_workgroups_agree_bitwise(nat, bba, lists, monkeypatch):
     plan.close()
     monkeypatch.delenv("PRALINE_NO_PIPE")
     monkeypatch.setenv("PRALINE_PIPE_MIN_TASKS", "1")
-    n_cut = 0
-    for env in ({}, {"PRALINE_PIPE_BLOCK": "3", "PRALINE_PIPE_SLOTS": "16"}, {"PRALINE_PIPE_BLOCK": "64", "PRALINE_PIPE_SLOTS": "100000"},
-                {"PRALINE_PIPE_SLOTS": "100"}, {"PRALINE_PIPE_BLOCK": "16", "PRALINE_PIPE_SLOTS": "150"},
-                {"PRALINE_PIPE_SLOTS": "100", "PRALINE_PIPE_CUTS": "0"}):
+    for env in ({}, {"PRALINE_PIPE_BLOCK": "3", "PRALINE_PIPE_SLOTS": "16"}, {"PRALINE_PIPE_BLOCK": "64", "PRALINE_PIPE_SLOTS": "100000"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         plan = nat.Plan(arena, pairs)
-        assert plan.cut_tasks == 0 or env.get("PRALINE_PIPE_CUTS") != "0"
-        n_cut += plan.cut_tasks
         for mode in MODES:
             plan.run(mode, *GAPS)
             got = plan.scores()

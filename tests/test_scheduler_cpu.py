@@ -150,7 +150,7 @@ def test_four_singles_keep_the_xcd_queues(sched):
 
 
 # ---- pipeline workgroups (k_dp_pipe): sets of 32 sequences one, tasks, workgroup items ------------------------------
-PIPE_MAX_TASKS, PIPE_MIN_STEPS, PIPE_MAX_PIECES = 4, 36, 6   # PRALINE_PIPE_MAX_TASKS, _MIN_STEPS, _MAX_PIECES (dp_types.h)
+PIPE_MAX_TASKS, PIPE_MIN_STEPS = 4, 36   # PRALINE_PIPE_MAX_TASKS, PRALINE_PIPE_MIN_STEPS (dp_types.h)
 
 
 @pytest.fixture(scope="module")
@@ -166,7 +166,7 @@ def pipe_sched(sched):
         cap = len(pairs) + 4096
         n_i, n_t, n_s = i64(0), i64(0), i64(0)
         items = np.zeros((cap, 6), np.int32)
-        tasks = np.zeros((cap, 6), np.int32)   # two, max_l1, strips, first strip, cut read, cut written
+        tasks = np.zeros((cap, 3), np.int32)
         lp = np.zeros((cap, 32), np.int32)
         so = np.zeros((cap, 32), np.int32)
         rc = lib.praline_sched_pipe_test(lens.ctypes.data, len(lens), len(pairs), pairs.ctypes.data, block_twos, wg_slots, cap, cap,
@@ -178,15 +178,11 @@ def pipe_sched(sched):
 
 
 def check_pipe(lens, pairs, items, tasks, lp, so):
-    """Every pair in exactly one lane of one task; a task is whole, or cut ONCE into a head (the first piece of its item)
-    and a tail (the last piece of an item launched later) that together cover its strips."""
-    whole_or_head = tasks[:, 4] < 0
-    seen = lp[whole_or_head][lp[whole_or_head] >= 0]
+    seen = lp[lp >= 0]
     assert np.array_equal(np.sort(seen), np.arange(len(pairs)))            # every pair in exactly one lane of one task
     covered = np.zeros(len(tasks), bool)
-    head_at, tail_at = {}, {}
-    for pos, (set_id, task0, ntasks, nstrips, rsteps, nrounds) in enumerate(items):
-        assert 1 <= ntasks <= PIPE_MAX_PIECES
+    for set_id, task0, ntasks, nstrips, rsteps, nrounds in items:
+        assert 1 <= ntasks <= PIPE_MAX_TASKS
         assert not covered[task0:task0 + ntasks].any()
         covered[task0:task0 + ntasks] = True
         ones = so[set_id]
@@ -196,31 +192,13 @@ def check_pipe(lens, pairs, items, tasks, lp, so):
         assert rsteps % 12 == 0 and rsteps >= max(PIPE_MIN_STEPS, max_l1 + 1) and rsteps < max(PIPE_MIN_STEPS, max_l1 + 1) + 12
         assert nstrips == tasks[task0:task0 + ntasks, 2].sum() and nrounds == (nstrips + 3) // 4
         for t in range(task0, task0 + ntasks):
-            two, t_max_l1, t_strips, s0, cut_in, cut_out = tasks[t]
-            total = (lens[two] + 31) // 32
-            assert t_max_l1 == max_l1 and t_strips >= 1 and s0 >= 0 and s0 + t_strips <= total
-            assert not (cut_in >= 0 and cut_out >= 0)                       # a task is cut at most once
-            if cut_out >= 0:
-                assert t == task0 and s0 == 0 and t_strips < total         # a head is the first piece of its item
-                assert cut_out not in head_at
-                head_at[cut_out] = (pos, set_id, two, t_strips, t)
-            elif cut_in >= 0:
-                assert t == task0 + ntasks - 1 and s0 + t_strips == total  # a tail is the last piece of its item
-                assert cut_in not in tail_at
-                tail_at[cut_in] = (pos, set_id, two, s0, t)
-            else:
-                assert s0 == 0 and t_strips == total
+            two, t_max_l1, t_strips = tasks[t]
+            assert t_max_l1 == max_l1 and t_strips == (lens[two] + 31) // 32
             lanes = np.nonzero(lp[t] >= 0)[0]
             assert len(lanes) >= 1
             assert np.all(pairs[lp[t][lanes], 1] == two)                    # one shared sequence two per task
             assert np.array_equal(pairs[lp[t][lanes], 0], ones[lanes])      # lane l of every task of the set = sequence ones[l]
     assert covered.all()
-    assert set(head_at) == set(tail_at) == set(range(len(head_at)))
-    for c, (hpos, hset, htwo, hstrips, ht) in head_at.items():
-        tpos, tset, ttwo, ts0, tt = tail_at[c]
-        assert hpos < tpos and hset == tset and htwo == ttwo and ts0 == hstrips   # the head is launched first; same task
-        assert np.array_equal(lp[ht], lp[tt])
-    return len(head_at)
 
 
 def test_pipe_schedule_covers_the_pair_list(pipe_sched):
@@ -242,9 +220,6 @@ def test_pipe_schedule_covers_the_pair_list(pipe_sched):
             ok, items, tasks, lp, so = pipe_sched(lens, pairs, block_twos=5, wg_slots=64)
             if ok:
                 check_pipe(lens, pairs, items, tasks, lp, so)
-            ok, items, tasks, lp, so = pipe_sched(lens, pairs, block_twos=-32)   # whole tasks only
-            if ok:
-                assert check_pipe(lens, pairs, items, tasks, lp, so) == 0
 
 
 def test_pipe_schedule_fits_the_slots_for_small_batches(pipe_sched):
@@ -253,16 +228,10 @@ def test_pipe_schedule_fits_the_slots_for_small_batches(pipe_sched):
     rng = np.random.default_rng(2)
     lens = synth_lengths(rng, 256, 400)
     pairs = all_pairs(256)
-    ok, items, tasks, lp, so = pipe_sched(lens, pairs, block_twos=-32)
+    ok, items, tasks, lp, so = pipe_sched(lens, pairs)
     assert ok and len(items) <= 512
     cost = items[:, 5].astype(np.int64) * items[:, 4]
-    assert cost.max() <= 1.3 * cost.sum() / 512                             # C2, whole tasks: longest item within 30 % of the mean load
-    # tasks cut between items: every item of a list but its last takes the same number of rounds
-    ok, items, tasks, lp, so = pipe_sched(lens, pairs, block_twos=32)
-    assert ok and len(items) <= 512
-    assert check_pipe(lens, pairs, items, tasks, lp, so) > 100
-    cost_cut = items[:, 5].astype(np.int64) * items[:, 4]
-    assert cost_cut.max() <= 0.92 * cost.max() and cost_cut.max() <= 1.12 * cost_cut.sum() / 512
+    assert cost.max() <= 1.3 * cost.sum() / 512                             # C2: longest item within 30 % of the mean load
     # large batch: short single-task items exist for the tail of the launch, the bulk sits in PIPE_MAX_TASKS-task items
     lens = synth_lengths(rng, 1024, 300)
     ok, items, tasks, lp, so = pipe_sched(lens, all_pairs(1024))
