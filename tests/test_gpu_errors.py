@@ -89,3 +89,52 @@ def test_component_errors_match_reference_types(nat, bba):
     tracks = comp.build_preprofiles([a, b], ct.TRACK_ID_INPUT, blosum, mode="local", waterman_eggert_iterations=7)
     prof = run(comp.ProfileBuilder, alignment=out['alignment'], track_id=ct.TRACK_ID_INPUT)
     assert np.array_equal(np.asarray(tracks[0].counts), np.asarray(prof['profile_track'].counts))
+
+
+def test_arena_inputs_staged_or_not_give_the_same_arena(nat, bba):
+    """native.Arena concatenates a list of float32 profiles into page-locked staging (praline_host_alloc: the upload is
+    a DMA); float64 / mixed lists and lists beyond the staging cap take the pageable road.  Same arena either way -
+    scores bit for bit - and the staging buffer is reused (and grown) across arenas."""
+    rng = np.random.default_rng(11)
+    lens = rng.integers(5, 90, 40)
+    profs = []
+    for L in lens:
+        c = rng.integers(0, 5, (int(L), 27)).astype(np.float32) + np.eye(27, dtype=np.float32)[rng.integers(0, 20, int(L))]
+        profs.append((c / c.sum(axis=1, keepdims=True)).astype(np.float32))
+    pairs = np.array([(i, j) for i in range(40) for j in range(i + 1, 40)], dtype=np.int32)
+
+    def scores(plist):
+        a = nat.Arena(plist, bba["S"])
+        p = nat.Plan(a, pairs)
+        p.run("global", -11.0, -1.0)
+        s = p.scores().copy()
+        p.close(); a.close()
+        return s
+
+    want = scores(profs)                                                   # float32 list: staged
+    assert nat._stage["ptr"] is not None
+    ptr0 = nat._stage["ptr"].value
+    assert np.array_equal(want.view(np.uint32), scores([p.astype(np.float64) for p in profs]).view(np.uint32))   # cast on the way
+    mixed = [p.astype(np.float64) if i % 3 == 0 else p for i, p in enumerate(profs)]
+    assert np.array_equal(want.view(np.uint32), scores(mixed).view(np.uint32))
+    assert np.array_equal(want.view(np.uint32), scores([np.asfortranarray(p) for p in profs]).view(np.uint32))  # any strides
+    cap = nat._STAGE_CAP
+    try:
+        nat._STAGE_CAP = 1024                                              # nothing fits: pageable upload
+        assert np.array_equal(want.view(np.uint32), scores(profs).view(np.uint32))
+    finally:
+        nat._STAGE_CAP = cap
+    assert np.array_equal(want.view(np.uint32), scores(profs).view(np.uint32))
+    assert nat._stage["ptr"].value == ptr0                                 # the same staging buffer again
+    big = [np.tile(p, (40, 1)) for p in profs]                             # 40 x the rows: the staging buffer grows
+    a = nat.Arena(big + big + big, bba["S"])
+    assert int(a.lens.sum()) == 120 * int(lens.sum())
+    a.close()
+    # the allocator itself
+    import ctypes
+    p = ctypes.c_void_p()
+    assert nat.lib().praline_host_alloc(1 << 20, ctypes.byref(p)) == 0 and p.value
+    np.ctypeslib.as_array((ctypes.c_float * 16).from_address(p.value))[:] = 1.0
+    assert nat.lib().praline_host_free(p) == 0
+    assert nat.lib().praline_host_free(None) == 0
+    assert nat.lib().praline_host_alloc(16, None) != 0
