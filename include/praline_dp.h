@@ -204,6 +204,17 @@ int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pa
                         int want_paths, const int32_t *rect_off, const int32_t *rects,
                         praline_plan **out);
 int praline_plan_destroy(praline_plan *plan);
+/* The host scheduling of a scores-only plan ahead of its arena: praline_sched_prepare needs the sequence lengths and the
+ * pair list only and touches no device - it may run on another host thread while praline_arena_create uploads and
+ * packs the same sequences (C2: 0.4 ms of scheduling beside 0.7 ms of arena creation).  praline_plan_create_prepared
+ * is praline_plan_create(arena, n_pairs, pairs, 0, NULL, NULL, out) that takes the prepared schedule when it fits the
+ * arena (same lengths, same pair list, a kernel that runs that kind of schedule) and schedules itself otherwise;
+ * `sched` may be NULL.  The caller destroys the schedule object either way. */
+typedef struct praline_sched praline_sched;
+int praline_sched_prepare(int64_t n_seqs, const int32_t *lens, int64_t n_pairs, const int32_t *pairs, praline_sched **out);
+int praline_sched_destroy(praline_sched *sched);
+int praline_plan_create_prepared(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, praline_sched *sched,
+                                 praline_plan **out);
 int64_t praline_plan_cells(const praline_plan *plan);      /* sum L1*L2 over the pairs */
 /* Diagnostics: wavefront steps one praline_plan_run executes (one step = one DP row of a 32-pair x 32-column
  * strip = 1024 cells incl. padding) and the number of 32-pair tasks; bench.py prices VALU issue with them. */

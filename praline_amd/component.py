@@ -158,14 +158,24 @@ class PairwiseBatch(object):
         if len(ii) == 0:
             return out
         idx = np.array([self._arena_index(seq, 0) for seq in sequences], dtype=np.int32)
+        # one mode for the whole list (the guide tree, a rescoring pass): its plan is scheduled on a second host thread
+        # while the arena is created (native.prepare_schedule_async)
+        prep = None
+        if len(ii) >= 1024 and bool(np.all(modes == modes[0])):
+            pairs0 = np.stack([idx[ii], idx[jj]], axis=1).astype(np.int32)
+            prep = native.prepare_schedule_async([p.shape[0] for p in self._profiles], pairs0)
         arena = native.Arena(self._profiles, self.S, set_sizes=self.sizes)
         try:
             for mode in MODES:
                 sel = np.flatnonzero(modes == mode)
                 if len(sel) == 0:
                     continue
-                pairs = np.stack([idx[ii[sel]], idx[jj[sel]]], axis=1).astype(np.int32)
-                plan = native.Plan(arena, pairs, want_paths=False)
+                if prep is not None:
+                    plan = native.Plan(arena, pairs0, prepared=prep)
+                    prep = None
+                else:
+                    pairs = np.stack([idx[ii[sel]], idx[jj[sel]]], axis=1).astype(np.int32)
+                    plan = native.Plan(arena, pairs, want_paths=False)
                 try:
                     if on_device and len(sel) == len(ii):
                         plan.run(mode, self.gap_open, self.gap_extend, d_scores=out.data_ptr())

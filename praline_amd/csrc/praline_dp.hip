@@ -356,6 +356,10 @@ struct praline_arena {
     int64_t rows_raw = 0, rows_pad = 0;
     int max_len = 0;
     std::vector<int32_t> len, row_off_pad, row_off_raw, active;
+    // host sources of the creation's asynchronous uploads (kept: praline_arena_create does not wait for them)
+    std::vector<float> h_S;
+    std::vector<int32_t> h_seq_of_rowp, h_active_up;
+    std::vector<unsigned char> h_slot_of;
     DevBuf<float> d_raw, d_S, d_P, d_Q;
     DevBuf<int32_t> d_len, d_row_off_pad, d_row_off_raw, d_seq_of_rowp, d_active;
     // f16 split operands for k_dp_split16 (matrix-pipe MFMA)
@@ -533,12 +537,14 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         if (ok) a->s_scale_bits = k;
     }
     for (int i = 0; i < A * A; ++i) a->s_absmax = std::max(a->s_absmax, std::fabs(S[i]));
-    std::vector<int32_t> seq_of_rowp((size_t)a->rows_pad, -1);
+    std::vector<int32_t> &seq_of_rowp = a->h_seq_of_rowp;
+    seq_of_rowp.assign((size_t)a->rows_pad, -1);
     for (int64_t s = 0; s < n_seqs; ++s)
         std::fill(seq_of_rowp.begin() + a->row_off_pad[s], seq_of_rowp.begin() + a->row_off_pad[s] + (lens[s] + 31) / 32 * 32, (int32_t)s);
+    a->h_S.assign(S, S + (size_t)A * A);
     {
         int rc0 = PRALINE_OK;
-        if ((rc0 = a->d_S.alloc((size_t)A * A)) || (rc0 = a->d_S.upload(S, (size_t)A * A, st)) ||
+        if ((rc0 = a->d_S.alloc((size_t)A * A)) || (rc0 = a->d_S.upload(a->h_S.data(), (size_t)A * A, st)) ||
             (rc0 = a->d_len.upload(a->len, st)) || (rc0 = a->d_row_off_pad.upload(a->row_off_pad, st)) ||
             (rc0 = a->d_row_off_raw.upload(a->row_off_raw, st)) || (rc0 = a->d_seq_of_rowp.upload(seq_of_rowp, st)) ||
             (rc0 = a->d_flag16.alloc(1))) {
@@ -576,7 +582,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
 
     // one-hot arenas (every row: a single 1, zeros elsewhere): active-symbol bytes for the one-hot operand table (built
     // on the device below: k_build_sym8)
-    std::vector<unsigned char> slot_of;
+    std::vector<unsigned char> &slot_of = a->h_slot_of;
     {
         const bool want_table = a->nr16 > 0 && !(getenv("PRALINE_NO_ONEHOT") && getenv("PRALINE_NO_ONEHOT")[0] == '1');
         a->all_onehot = all_onehot_rows;
@@ -589,7 +595,8 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     }
 
     int rc = PRALINE_OK;
-    if ((rc = a->d_active.upload(a->active.empty() ? std::vector<int32_t>(1, 0) : a->active, st)) ||
+    a->h_active_up = a->active.empty() ? std::vector<int32_t>(1, 0) : a->active;
+    if ((rc = a->d_active.upload(a->h_active_up, st)) ||
         (rc = a->d_P.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) || (rc = a->d_Q.alloc(a->wide ? 1 : (size_t)a->rows_pad * a->KP)) ||
         (a->onehot && (rc = a->d_sym8.alloc((size_t)a->rows_pad + 64))) ||
         (a->nr16 > 0 && ((rc = a->d_P16.alloc((size_t)a->rows_pad * 4 * a->nr16 * 16)) ||
@@ -598,7 +605,7 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
         delete a;
         return rc;
     }
-    DevBuf<unsigned char> d_slot_of;
+    DevBuf<unsigned char> d_slot_of;   // (read by k_build_sym8 below; released to the stream-ordered pool at return)
     if (a->onehot) {
         if ((rc = d_slot_of.upload(slot_of, st))) { delete a; return rc; }
         const int64_t rows_out = a->rows_pad + 64;
@@ -617,10 +624,15 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     } else {
         rc = arena_launch_premultiply(a, true);
     }
-    if (rc != PRALINE_OK) { delete a; return rc; }
+    if (rc != PRALINE_OK) { (void)hipStreamSynchronize(st); delete a; return rc; }
     pt.mark("premultiply launches");
-    hipError_t e = hipStreamSynchronize(st);  // host vectors above go out of scope
-    pt.mark("stream sync");
+    // Float profiles: nothing to read back - the packing launch and the small uploads (their host sources live in the
+    // arena) finish under whatever the caller does next on this stream (plan creation waits for its own uploads).
+    hipError_t e = hipSuccess;
+    if (!host_knows_split) {
+        e = hipStreamSynchronize(st);
+        pt.mark("stream sync");
+    }
     if (e != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "arena upload: %s", hipGetErrorString(e)); }
     if (a->nr16 > 0 && !host_knows_split) {
         int flag = 1;
@@ -959,8 +971,90 @@ static size_t tb_budget_bytes()
 
 static size_t reftile_budget_bytes();
 
+// scheduler options of the pipeline workgroups for a pair list of this size (plan creation and praline_sched_prepare)
+static PipeOptions pipe_options_for(int64_t n_pairs)
+{
+    PipeOptions po;
+    // sequences two per scheduler block: 32 while the whole plan is resident at once (up to ~2.5 tasks per workgroup
+    // slot: C2 1.90 ms against 2.09 with 16), 16 beyond (one rank's share of C4: 47.6 ms against 48.8 with 32 - the
+    // unions of 32 columns' sequences one leave more half-filled sets; scripts/exp_pipe_block2.py, exp_c4_block.py)
+    po.block_twos = n_pairs <= 40000 ? 32 : 16;
+    if (const char *env = getenv("PRALINE_PIPE_BLOCK")) po.block_twos = atoi(env);
+    if (const char *env = getenv("PRALINE_PIPE_SLOTS")) po.wg_slots = atoll(env);
+    return po;
+}
+
+// the pipeline schedule of a scores-only plan over `pairs` (everything praline_plan_create derives from the pair list and
+// the sequence lengths alone); below ~200 tasks (all pairs of ~110 sequences) the shared-wave task schedule is as fast
+// or faster (scripts/exp_pipe_sweep.py): a pipeline item cannot be smaller than one task
+static void pipe_schedule_for(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int max_len, PipeSchedule &pipe)
+{
+    int min_len = max_len;
+    for (int64_t p = 0; p < n_pairs; ++p) min_len = std::min(min_len, std::min(lens[pairs[2 * p]], lens[pairs[2 * p + 1]]));
+    if (min_len >= 1) build_pipe_schedule(lens, n_seqs, n_pairs, pairs, pipe_options_for(n_pairs), pipe);
+    int64_t min_tasks = 200;
+    if (const char *env = getenv("PRALINE_PIPE_MIN_TASKS")) min_tasks = atoll(env);
+    if (pipe.ok && (int64_t)pipe.tasks.size() < min_tasks) pipe = PipeSchedule();
+}
+
+// praline_sched_prepare: host-only, may run on another host thread while the arena of the same sequences is created
+struct praline_sched {
+    std::vector<int32_t> lens;
+    int64_t n_pairs = 0;
+    int32_t first[2] = {0, 0}, last[2] = {0, 0};   // (a cheap identity check of the pair list)
+    PipeSchedule pipe;
+};
+
+extern "C" int praline_sched_prepare(int64_t n_seqs, const int32_t *lens, int64_t n_pairs, const int32_t *pairs, praline_sched **out)
+{
+    if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_seqs <= 0 || !lens || n_pairs < 0 || (n_pairs > 0 && !pairs)) return fail(PRALINE_ERR_ARG, "bad schedule arguments");
+    int max_len = 0;
+    for (int64_t s = 0; s < n_seqs; ++s) {
+        if (lens[s] <= 0) return fail(PRALINE_ERR_ARG, "sequence %lld has length %d (must be >= 1)", (long long)s, lens[s]);
+        max_len = std::max(max_len, lens[s]);
+    }
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int32_t o = pairs[2 * p], t = pairs[2 * p + 1];
+        if (o < 0 || o >= n_seqs || t < 0 || t >= n_seqs)
+            return fail(PRALINE_ERR_ARG, "pair %lld = (%d, %d) out of range", (long long)p, o, t);
+    }
+    praline_sched *sc = new praline_sched();
+    sc->lens.assign(lens, lens + n_seqs);
+    sc->n_pairs = n_pairs;
+    if (n_pairs > 0) {
+        sc->first[0] = pairs[0]; sc->first[1] = pairs[1];
+        sc->last[0] = pairs[2 * n_pairs - 2]; sc->last[1] = pairs[2 * n_pairs - 1];
+        pipe_schedule_for(lens, n_seqs, n_pairs, pairs, max_len, sc->pipe);
+    }
+    *out = sc;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_sched_destroy(praline_sched *sched)
+{
+    delete sched;
+    return PRALINE_OK;
+}
+
+static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, int want_paths, const int32_t *rect_off,
+                            const int32_t *rects, praline_sched *prep, praline_plan **out);
+
 extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, int want_paths,
                                    const int32_t *rect_off, const int32_t *rects, praline_plan **out)
+{
+    return plan_create_impl(arena, n_pairs, pairs, want_paths, rect_off, rects, nullptr, out);
+}
+
+extern "C" int praline_plan_create_prepared(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, praline_sched *sched,
+                                            praline_plan **out)
+{
+    return plan_create_impl(arena, n_pairs, pairs, 0, nullptr, nullptr, sched, out);
+}
+
+static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t *pairs, int want_paths, const int32_t *rect_off,
+                            const int32_t *rects, praline_sched *prep, praline_plan **out)
 {
     if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
     *out = nullptr;
@@ -1038,21 +1132,12 @@ extern "C" int praline_plan_create(praline_arena *arena, int64_t n_pairs, const 
         const Arena16Dev v16 = a.view16();
         if (!want_paths && !pl->ref && opt.split_layout && a.nr16 > 0 && v16.stage && v16.sym8 == nullptr &&
             praline_pipe_supported(a.nr16, a.nterm16) && match_mode() == PRALINE_MATCH_FAST && !(np && np[0] == '1') && n_pairs > 0) {
-            int min_len = a.max_len;
-            for (int64_t p = 0; p < n_pairs; ++p) min_len = std::min(min_len, std::min(a.len[pairs[2 * p]], a.len[pairs[2 * p + 1]]));
-            PipeOptions po;
-            // sequences two per scheduler block: 32 while the whole plan is resident at once (up to ~2.5 tasks per workgroup
-            // slot: C2 1.90 ms against 2.09 with 16), 16 beyond (one rank's share of C4: 47.6 ms against 48.8 with 32 - the
-            // unions of 32 columns' sequences one leave more half-filled sets; scripts/exp_pipe_block2.py, exp_c4_block.py)
-            po.block_twos = n_pairs <= 40000 ? 32 : 16;
-            if (const char *env = getenv("PRALINE_PIPE_BLOCK")) po.block_twos = atoi(env);
-            if (const char *env = getenv("PRALINE_PIPE_SLOTS")) po.wg_slots = atoll(env);
-            if (min_len >= 1) build_pipe_schedule(a.len.data(), a.n_seqs, n_pairs, pairs, po, pl->pipe);
-            // below ~200 tasks (all pairs of ~110 sequences) the shared-wave task schedule is as fast or faster
-            // (scripts/exp_pipe_sweep.py): a pipeline item cannot be smaller than one task
-            int64_t min_tasks = 200;
-            if (const char *env = getenv("PRALINE_PIPE_MIN_TASKS")) min_tasks = atoll(env);
-            if (pl->pipe.ok && (int64_t)pl->pipe.tasks.size() < min_tasks) pl->pipe = PipeSchedule();
+            // (a schedule prepared from the same lengths and pair list while the arena was being created: take it)
+            const bool prepared = prep != nullptr && prep->n_pairs == n_pairs && prep->lens == a.len && prep->first[0] == pairs[0] &&
+                                  prep->first[1] == pairs[1] && prep->last[0] == pairs[2 * n_pairs - 2] && prep->last[1] == pairs[2 * n_pairs - 1];
+            if (prepared) pl->pipe = std::move(prep->pipe);
+            else pipe_schedule_for(a.len.data(), a.n_seqs, n_pairs, pairs, a.max_len, pl->pipe);
+            if (prepared) { prep->pipe = PipeSchedule(); prep->n_pairs = -1; }   // (consumed)
         }
     }
     if (pl->pipe.ok) {

@@ -74,6 +74,10 @@ def lib():
     L.praline_arena_premultiply.argtypes = [vp]
     L.praline_plan_create.argtypes = [vp, i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
     L.praline_plan_destroy.argtypes = [vp]
+    if hasattr(L, "praline_sched_prepare"):
+        L.praline_sched_prepare.argtypes = [i64, vp, i64, vp, ctypes.POINTER(vp)]
+        L.praline_sched_destroy.argtypes = [vp]
+        L.praline_plan_create_prepared.argtypes = [vp, i64, vp, vp, ctypes.POINTER(vp)]
     L.praline_plan_cells.argtypes = [vp]
     L.praline_plan_cells.restype = i64
     L.praline_arena_counts_reset.argtypes = [vp]
@@ -403,14 +407,58 @@ class Arena(object):
             pass
 
 
+class PreparedSchedule(object):
+    """The host scheduling of a scores-only plan, computed from the sequence lengths and the pair list alone
+    (praline_sched_prepare) - before, or on another thread beside, the creation of the arena."""
+
+    def __init__(self, lens, pairs):
+        self.lens = np.ascontiguousarray(lens, dtype=np.int32)
+        self.pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        h = ctypes.c_void_p()
+        _check(lib().praline_sched_prepare(len(self.lens), self.lens.ctypes.data, self.pairs.shape[0], self.pairs.ctypes.data,
+                                           ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().praline_sched_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_sched_pool = None
+
+
+def prepare_schedule_async(lens, pairs):
+    """PreparedSchedule(lens, pairs) on a worker thread (the call spends its time in the library, outside the
+    interpreter lock): start it, create the Arena of the same sequences, then Plan(arena, pairs, prepared=future)."""
+    global _sched_pool
+    if _sched_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _sched_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="praline-sched")
+    lib()   # (loaded on the calling thread)
+    return _sched_pool.submit(PreparedSchedule, lens, pairs)
+
+
 class Plan(object):
     """A scheduled pair list (praline_plan_create)."""
 
-    def __init__(self, arena, pairs, want_paths=False, rects=None):
+    def __init__(self, arena, pairs, want_paths=False, rects=None, prepared=None):
         """pairs: int [n, 2] (sequence_one, sequence_two); rects: optional list (one entry per
-        pair) of lists of (y0, y1, x0, x1) inclusive zero rectangles, or an int array [n, k, 4]."""
+        pair) of lists of (y0, y1, x0, x1) inclusive zero rectangles, or an int array [n, k, 4];
+        prepared: a PreparedSchedule of the same lengths and pairs (or the future of one) for a scores-only plan."""
         self.arena = arena
-        self.pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        if prepared is not None and hasattr(prepared, "result"):
+            prepared = prepared.result()
+        if prepared is not None and (want_paths or rects is not None):
+            raise ValueError("a prepared schedule serves scores-only plans")
+        self.pairs = prepared.pairs if prepared is not None and pairs is prepared.pairs else \
+            np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
         self.n = self.pairs.shape[0]
         self.want_paths = bool(want_paths)
         ro = rv = None
@@ -432,10 +480,14 @@ class Plan(object):
                 rv = np.zeros((1, 4), dtype=np.int32)
         self._keep = (ro, rv)
         h = ctypes.c_void_p()
-        _check(lib().praline_plan_create(arena._h, self.n, self.pairs.ctypes.data, int(want_paths),
-                                         ro.ctypes.data if ro is not None else None,
-                                         rv.ctypes.data if rv is not None else None,
-                                         ctypes.byref(h)))
+        if prepared is not None:
+            _check(lib().praline_plan_create_prepared(arena._h, self.n, self.pairs.ctypes.data, prepared._h, ctypes.byref(h)))
+            prepared.close()
+        else:
+            _check(lib().praline_plan_create(arena._h, self.n, self.pairs.ctypes.data, int(want_paths),
+                                             ro.ctypes.data if ro is not None else None,
+                                             rv.ctypes.data if rv is not None else None,
+                                             ctypes.byref(h)))
         self._h = h
         self.cells = int(lib().praline_plan_cells(h))
         self.steps = int(lib().praline_plan_steps(h))   # wavefront steps per run (1024 cells each, incl. padding)

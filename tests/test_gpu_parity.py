@@ -787,3 +787,49 @@ def test_pipeline_workgroups_agree_bitwise(nat, bba, lists, monkeypatch):
         s_or, _ = oracle_dp_on_m("global", arena.match_scores(int(i), int(j), kind), gaps=(-3.5, -0.25))
         assert got[p] == np.float32(s_or), (i, j)
     arena.close()
+
+
+def test_prepared_schedule_gives_the_same_plan(nat, bba):
+    """praline_sched_prepare / praline_plan_create_prepared: a score plan whose host scheduling ran ahead of the arena
+    (on a worker thread: native.prepare_schedule_async) is the plan praline_plan_create builds - same kernel, same
+    scores bit for bit; a schedule that does not fit the arena (other lengths, another pair list, an arena whose plans
+    run another kernel) is ignored, misuse is refused."""
+    rng = np.random.default_rng(41)
+    N = 160
+    lens = synth_lengths(rng, N, 120)
+    profs = [synth_profile(rng, int(L))[0] for L in lens]
+    pairs = all_pairs(N)
+    arena = nat.Arena(profs, bba["S"])
+    plan = nat.Plan(arena, pairs)
+    plan.run("global", *GAPS)
+    want, kernel = plan.scores().copy(), plan.kernel_name()
+    plan.close()
+    for how in ("sync", "async"):
+        prep = nat.PreparedSchedule(lens, pairs) if how == "sync" else nat.prepare_schedule_async(lens, pairs)
+        arena2 = nat.Arena(profs, bba["S"])
+        plan = nat.Plan(arena2, pairs, prepared=prep)
+        plan.run("global", *GAPS)
+        assert plan.kernel_name() == kernel and np.array_equal(bits(plan.scores()), bits(want)), how
+        plan.run("local", *GAPS)
+        plan.close(); arena2.close()
+    # schedules that do not belong to the arena / pair list are not used
+    for bad in (nat.PreparedSchedule(lens[::-1].copy(), pairs), nat.PreparedSchedule(lens, pairs[::-1].copy()),
+                nat.PreparedSchedule(lens, pairs[:-1])):
+        plan = nat.Plan(arena, pairs, prepared=bad)
+        plan.run("global", *GAPS)
+        assert np.array_equal(bits(plan.scores()), bits(want))
+        plan.close()
+    # an arena of plain sequences runs the lookup kernels: the prepared pipeline schedule is dropped
+    onehot = [one_hot(rng.integers(0, 20, int(L)), 27) for L in lens]
+    a3 = nat.Arena(onehot, bba["S"])
+    p_ref = nat.Plan(a3, pairs); p_ref.run("global", *GAPS)
+    p_pre = nat.Plan(a3, pairs, prepared=nat.PreparedSchedule(lens, pairs)); p_pre.run("global", *GAPS)
+    assert p_pre.kernel_name() == p_ref.kernel_name() and np.array_equal(bits(p_pre.scores()), bits(p_ref.scores()))
+    p_ref.close(); p_pre.close(); a3.close()
+    with pytest.raises(nat.NativeError):
+        nat.PreparedSchedule(lens, np.array([[0, N]], dtype=np.int32))          # pair out of range
+    with pytest.raises(nat.NativeError):
+        nat.PreparedSchedule(np.array([5, 0, 3], dtype=np.int32), np.array([[0, 2]], dtype=np.int32))   # empty sequence
+    with pytest.raises(ValueError):
+        nat.Plan(arena, pairs, want_paths=True, prepared=nat.PreparedSchedule(lens, pairs))
+    arena.close()
