@@ -675,3 +675,50 @@ def test_score_shard_stays_on_the_device_through_the_exchange(env, seqs):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_all_pairs_scores_with_the_schedule_prepared_beside_the_arena(env):
+    """PairwiseBatch.scores_for_pairs on a one-mode list of 1024 pairs and more (a guide tree's all-pairs stage)
+    schedules the plan on a second host thread while the arena is created (native.prepare_schedule_async): the scores
+    equal those of plans scheduled the ordinary way - for profile tracks (the prepared pipeline schedule is used) and for
+    plain sequences (their kernels take another kind of schedule: the prepared one is dropped)."""
+    from praline_amd import native
+    rng = np.random.default_rng(77)
+    n = 130
+    plain, profile = [], []
+    for i in range(n):
+        L = int(rng.integers(60, 180))
+        idx = rng.integers(0, 20, L)
+        plain.append(ct.Sequence("p%03d" % i, [(ct.TRACK_ID_INPUT, ct.PlainTrack(None, ct.ALPHABET_AA, raw_indices=idx))]))
+        counts = np.zeros((L, 27), dtype=int)
+        counts[np.arange(L), idx] += 3
+        counts[np.arange(L), rng.integers(0, 20, L)] += rng.integers(0, 3, L)
+        profile.append(ct.Sequence("q%03d" % i, [(ct.TRACK_ID_INPUT, ct.ProfileTrack(counts, ct.ALPHABET_AA))]))
+    ii, jj = np.triu_indices(n, k=1)
+    assert len(ii) >= 1024
+    modes = np.array(["global"] * len(ii))
+    calls = []
+    real = native.prepare_schedule_async
+
+    def counted(lens, pairs):
+        calls.append(len(pairs))
+        return real(lens, pairs)
+
+    native.prepare_schedule_async = counted
+    try:
+        for seqs_ in (profile, plain):
+            batch = comp.PairwiseBatch(T_IN, T_IN, [env["blosum"]], [-11.0, -1.0])
+            got = batch.scores_for_pairs(seqs_, ii, jj, modes)
+            # the same list in two modes takes the ordinary road (one plan per mode)
+            half = np.array(["global", "local"])[(np.arange(len(ii)) % 2)]
+            batch2 = comp.PairwiseBatch(T_IN, T_IN, [env["blosum"]], [-11.0, -1.0])
+            mixed = batch2.scores_for_pairs(seqs_, ii, jj, half)
+            sel = half == "global"
+            assert np.array_equal(got[sel], mixed[sel])
+            for k in rng.choice(len(ii), 6, replace=False):
+                out = run_one(env["serial"], comp.PairwiseAligner, mode="global", sequence_one=seqs_[ii[k]], sequence_two=seqs_[jj[k]],
+                              track_id_sets_one=T_IN, track_id_sets_two=T_IN, score_matrices=[env["blosum"]])
+                assert np.float32(out['score']) == got[k]
+    finally:
+        native.prepare_schedule_async = real
+    assert calls == [len(ii), len(ii)]
