@@ -233,7 +233,7 @@ __device__ __forceinline__ void premultiply_block(int64_t rowp0, int c0, const f
                                                      int A, int KP, int KS, int64_t rows_pad,
                                                      float *__restrict__ Q)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int64_t rowp = rowp0 + j;
     const float *src = nullptr;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void k_premultiply(const float *__restrict__ ra
 
 // Everything praline_arena_premultiply does, for 32 rows per wave in ONE launch: pack P, Q = P . S^T (MFMA), and the
 // f16 hi/lo pieces of both (the four separate launches cost ~0.1 ms of a 2.3 ms bench step in launch gaps).
-__global__ __launch_bounds__(64) void k_prepare_rows(const float *__restrict__ raw, const float *__restrict__ S,
+__global__ __launch_bounds__(256) void k_prepare_rows(const float *__restrict__ raw, const float *__restrict__ S,
                                                       const int32_t *__restrict__ seq_of_rowp,
                                                       const int32_t *__restrict__ row_off_pad,
                                                       const int32_t *__restrict__ row_off_raw,
@@ -288,22 +288,25 @@ __global__ __launch_bounds__(64) void k_prepare_rows(const float *__restrict__ r
                                                       _Float16 *__restrict__ P16, _Float16 *__restrict__ Q16, int64_t block0 = 0,
                                                       int packed = 0)
 {
+    // (four waves per 32 rows: the element-wise passes are chains of dependent loads - their length, not the traffic, is
+    // what the launch lasts; the MFMA pre-multiply of a 32-column block is one wave's work)
     const int64_t rowp0 = ((int64_t)blockIdx.x + block0) * 32;   // block0: first 32-row block (appended sequences only)
-    for (int i = threadIdx.x; i < 32 * KP; i += 64)
+    const int nthr = (int)blockDim.x, wave = (int)(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 32 * KP; i += nthr)
         pack_entry(rowp0 * KP + i, raw, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, P);
-    for (int c0 = 0; c0 < KP; c0 += 32)
+    for (int c0 = 32 * wave; c0 < KP; c0 += 32 * (nthr >> 6))
         premultiply_block(rowp0, c0, raw, S, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, rows_pad, Q);
     if (NR > 0) {
-        __syncthreads();   // this wave's P and Q rows are visible to all its lanes
+        __syncthreads();   // the block's P and Q rows are visible to all its lanes
         if (packed) {   // K-packed three-term layout (NR = 2, n_active <= 21): 64 halves per row and side
-            for (int i = threadIdx.x; i < 32 * 64; i += 64) {
+            for (int i = threadIdx.x; i < 32 * 64; i += nthr) {
                 split_f16_entry_packed(P, KP, KS, n_active, 1, rowp0 * 64 + i, P16);
                 split_f16_entry_packed(Q, KP, KS, n_active, 0, rowp0 * 64 + i, Q16);
             }
             return;
         }
         const int per_row = 2 * NR * 8;
-        for (int i = threadIdx.x; i < 32 * per_row; i += 64) {
+        for (int i = threadIdx.x; i < 32 * per_row; i += nthr) {
             split_f16_entry(P, KP, KS, n_active, NR, rowp0 * per_row + i, P16);
             split_f16_entry(Q, KP, KS, n_active, NR, rowp0 * per_row + i, Q16);
         }

@@ -52,8 +52,9 @@ struct PipeLaunch {
     const WaveTask *tasks;
     const int32_t *set_one, *lane_pair;
     void *bnd;
-    void *analytic;         // float2 [analytic_rows][32]: the analytic column 0, rewritten by every launch
+    void *analytic;         // float2 [analytic_rows][32]: the analytic column 0 of this run's mode and gap scores
     int analytic_rows;
+    bool analytic_valid;    // the buffer already holds it (the plan's previous run had the same mode and gap scores)
     float *scores;
     RunParams rp;
     hipStream_t stream;

@@ -6,8 +6,9 @@ template <int NR, int NTERM> static void launch_pipe(const PipeLaunch &pl, const
 {
     const dim3 grid(pl.n_items), block(256);
     // the analytic column 0 (gap scores and mode of this run) that every task's first strip reads
-    hipLaunchKernelGGL(k_pipe_analytic, dim3((unsigned)((pl.analytic_rows * 32 + 255) / 256)), dim3(256), 0, pl.stream,
-                       (float2 *)pl.analytic, pl.analytic_rows, pl.rp);
+    if (!pl.analytic_valid)
+        hipLaunchKernelGGL(k_pipe_analytic, dim3((unsigned)((pl.analytic_rows * 32 + 255) / 256)), dim3(256), 0, pl.stream,
+                           (float2 *)pl.analytic, pl.analytic_rows, pl.rp);
 #define PRALINE_PIPE_LAUNCH(LOC, SEMI)                                                                                  \
     hipLaunchKernelGGL((k_dp_pipe<NR, NTERM, LOC, SEMI>), grid, block, 0, pl.stream, a16, pl.items, pl.tasks, pl.set_one, \
                        pl.lane_pair, (float2 *)pl.bnd, (const float2 *)pl.analytic, pl.scores, pl.rp)

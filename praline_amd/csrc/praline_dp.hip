@@ -425,7 +425,7 @@ static int arena_launch_premultiply(praline_arena *a, bool check_f16 = false)
 {
     if (a->wide) return PRALINE_OK;   // no packed operands: plans on this arena read the raw profiles (k_match_ref)
     if (!check_f16) {   // the recurring call: everything in one launch
-        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)(a->rows_pad / 32)), dim3(64), 0, g_rt.stream, a->d_raw.p, a->d_S.p,
+        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)(a->rows_pad / 32)), dim3(256), 0, g_rt.stream, a->d_raw.p, a->d_S.p,
                            a->d_seq_of_rowp.p, a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, a->d_active.p, a->n_active,
                            a->A, a->KP, a->KS, a->rows_pad, a->d_P.p, a->d_Q.p, a->nr16, (_Float16 *)a->d_P16.p,
                            (_Float16 *)a->d_Q16.p, (int64_t)0, a->nterm16 == 2 ? 1 : 0);
@@ -900,6 +900,8 @@ struct praline_plan {
     DevBuf<int32_t> d_pipe_set_one, d_pipe_lane_pair;
     DevBuf<float2> d_pipe_bnd, d_pipe_analytic;
     int pipe_analytic_rows = 0;
+    int pipe_analytic_mode = -1;            // mode and gap scores the analytic column was last written for (-1: never)
+    float pipe_analytic_go = 0.0f, pipe_analytic_ge = 0.0f;
     DevBuf<int32_t> d_lane_one, d_lane_pair, d_pairs, d_rect_off, d_rects, d_end_cells, d_path_rows, d_paths;
     DevBuf<PairLoc> d_loc;
     DevBuf<float> d_scores, d_aux;
@@ -1741,6 +1743,8 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         pp.bnd = pl.d_pipe_bnd.p;
         pp.analytic = pl.d_pipe_analytic.p;
         pp.analytic_rows = pl.pipe_analytic_rows;
+        pp.analytic_valid = pl.pipe_analytic_mode == mode && pl.pipe_analytic_go == la.rp.go1 && pl.pipe_analytic_ge == la.rp.ge1;
+        pl.pipe_analytic_mode = mode; pl.pipe_analytic_go = la.rp.go1; pl.pipe_analytic_ge = la.rp.ge1;
         pp.scores = la.scores;
         pp.rp = la.rp;
         pp.stream = st;
@@ -2392,7 +2396,7 @@ extern "C" int praline_arena_append_merged_many(praline_arena *arena, praline_pl
     a->d_counts.release();
     a->counts_ext = nullptr;
     if (!a->wide) {   // packed operands of the new rows only (they are contiguous in the padded row space)
-        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)((a->rp_end - rp0) / 32)), dim3(64), 0, st, a->d_raw.p, a->d_S.p, a->d_seq_of_rowp.p,
+        hipLaunchKernelGGL(k_prepare_rows, dim3((unsigned)((a->rp_end - rp0) / 32)), dim3(256), 0, st, a->d_raw.p, a->d_S.p, a->d_seq_of_rowp.p,
                            a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, a->d_active.p, a->n_active, a->A, a->KP, a->KS,
                            a->rows_pad, a->d_P.p, a->d_Q.p, a->nr16, (_Float16 *)a->d_P16.p, (_Float16 *)a->d_Q16.p,
                            (int64_t)(rp0 / 32), a->nterm16 == 2 ? 1 : 0);
