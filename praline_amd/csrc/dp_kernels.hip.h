@@ -299,9 +299,33 @@ __global__ __launch_bounds__(256) void k_prepare_rows(const float *__restrict__ 
     if (NR > 0) {
         __syncthreads();   // the block's P and Q rows are visible to all its lanes
         if (packed) {   // K-packed three-term layout (NR = 2, n_active <= 21): 64 halves per row and side
-            for (int i = threadIdx.x; i < 32 * 64; i += nthr) {
-                split_f16_entry_packed(P, KP, KS, n_active, 1, rowp0 * 64 + i, P16);
-                split_f16_entry_packed(Q, KP, KS, n_active, 0, rowp0 * 64 + i, Q16);
+            // one 16-byte slot (eight consecutive entries of split_f16_entry_packed) per thread and side: 256 slots per
+            // side in a block, written with one store each instead of eight 2-byte ones
+            for (int c = threadIdx.x; c < 32 * 8; c += nthr) {
+                const int64_t idx0 = rowp0 * 64 + (int64_t)c * 8;
+                const int64_t rowp = idx0 / 64;
+                const int rem = (int)(idx0 % 64);
+                const int hh = rem / 32, q = (rem / 8) % 4;
+                _Float16 op[8], oq[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int kp = 16 * q + 8 * hh + jj;
+                    _Float16 vp = (_Float16)0.0f, vq = (_Float16)0.0f;
+                    if (kp < 3 * n_active) {
+                        const int term = kp / n_active, k = kp % n_active;
+                        const float fp = P[rowp * KP + (k & 1) * KS + (k >> 1)], fq = Q[rowp * KP + (k & 1) * KS + (k >> 1)];
+                        const _Float16 hp = (_Float16)fp, hq = (_Float16)fq;
+                        const _Float16 lp = (_Float16)(fp - (float)hp), lq = (_Float16)(fq - (float)hq);
+                        vp = term == 1 ? lp : hp;   // side 1 (B operand, P): hi, lo, hi
+                        vq = term == 0 ? lq : hq;   // side 0 (A operand, Q): lo, hi, hi
+                    }
+                    op[jj] = vp; oq[jj] = vq;
+                }
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                const h8 wp = {op[0], op[1], op[2], op[3], op[4], op[5], op[6], op[7]};
+                const h8 wq = {oq[0], oq[1], oq[2], oq[3], oq[4], oq[5], oq[6], oq[7]};
+                *reinterpret_cast<h8 *>(P16 + (rowp * 2 + hh) * 32 + q * 8) = wp;
+                *reinterpret_cast<h8 *>(Q16 + (rowp * 2 + hh) * 32 + q * 8) = wq;
             }
             return;
         }
