@@ -292,8 +292,19 @@ __global__ __launch_bounds__(256) void k_prepare_rows(const float *__restrict__ 
     // what the launch lasts; the MFMA pre-multiply of a 32-column block is one wave's work)
     const int64_t rowp0 = ((int64_t)blockIdx.x + block0) * 32;   // block0: first 32-row block (appended sequences only)
     const int nthr = (int)blockDim.x, wave = (int)(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < 32 * KP; i += nthr)
-        pack_entry(rowp0 * KP + i, raw, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, P);
+    {
+        // pack_entry for the block's 32 rows: they belong to ONE sequence (sequences are padded to multiples of 32 rows),
+        // so the row bookkeeping is looked up once
+        const int seq = seq_of_rowp[rowp0];
+        const int r0 = seq >= 0 ? (int)(rowp0 - row_off_pad[seq]) : 0;
+        const int n_rows = seq >= 0 ? len[seq] - r0 : 0;   // rows of the block that hold profile rows
+        const float *src = raw + (seq >= 0 ? (int64_t)(row_off_raw[seq] + r0) * A : 0);
+        for (int i = threadIdx.x; i < 32 * KP; i += nthr) {
+            const int r = i / KP, c = i % KP;
+            const int k = 2 * (c % KS) + c / KS;
+            P[rowp0 * KP + i] = (r < n_rows && k < n_active) ? src[(int64_t)r * A + active[k]] : 0.0f;
+        }
+    }
     for (int c0 = 32 * wave; c0 < KP; c0 += 32 * (nthr >> 6))
         premultiply_block(rowp0, c0, raw, S, seq_of_rowp, row_off_pad, row_off_raw, len, active, n_active, A, KP, KS, rows_pad, Q);
     if (NR > 0) {
