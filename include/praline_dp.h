@@ -16,7 +16,8 @@
  * owns its device memory and streams.  There is NO CPU fallback: without a usable HIP device
  * every compute entry point fails with PRALINE_ERR_DEVICE.
  *
- * Threading: one host thread per device (praline_init binds the calling process to a device).
+ * Threading: one host thread per device (praline_init binds the calling process to a device).  The one exception is
+ * praline_sched_prepare / praline_sched_destroy: host-only, no shared state - they may run on any other thread.
  */
 #ifndef PRALINE_DP_H
 #define PRALINE_DP_H
