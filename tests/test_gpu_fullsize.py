@@ -11,6 +11,7 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 GO, GE = -11.0, -1.0
+MODES5 = ("global", "local", "semiglobal_both", "semiglobal_one", "semiglobal_two")
 GAPS = (GO, GE)
 
 
@@ -465,3 +466,46 @@ def test_scratch_growth_between_back_to_back_path_runs(nat, monkeypatch):
         for p in plans:
             p.close()
     arena.close()
+
+
+def test_single_long_alignments(nat, bba):
+    """The long end of the size range: ONE alignment of 6 211 x 9 001 nucleotides (55.9 M cells; lengths that are no
+    multiple of the 32-column strips or the 12-row loop iterations), scores-only and with paths in all five modes, and
+    one of 2 345 x 3 111 float profiles - plans of a single task, which the library runs with one wave per strip
+    (chain mode; the scores-only form without flags).  Scores and paths equal the oracle's, which walks the whole
+    matrices on the host."""
+    d = load_golden("synthetic_dna.npz")
+    Sd = d["matrix"]
+    rng = np.random.default_rng(91)
+    # integer scoring: the oracle computes match scores and alignment from the sequences alone
+    v1, v2 = rng.integers(0, 4, 6211), rng.integers(0, 4, 9001)
+    v2[1000:5000] = v1[800:4800]                      # a long common stretch: paths with long diagonals and real gaps
+    profs = [one_hot(v1, 15), one_hot(v2, 15)]
+    lens = np.array([len(v1), len(v2)], dtype=np.int32)
+    arena = nat.Arena(profs, Sd)
+    pair = np.array([[0, 1]], dtype=np.int32)
+    cat = np.concatenate(profs, axis=0)
+    row_off = np.array([0, len(v1)], dtype=np.int64)
+    sc_or, paths_or = orc.batch_align(MODES5, cat, row_off, lens, Sd, pair, GO, GE, threads=min(5, host_threads()))
+    p_scores = nat.Plan(arena, pair)
+    p_paths = nat.Plan(arena, pair, want_paths=True)
+    for q, mode in enumerate(MODES5):
+        p_scores.run(mode, GO, GE)
+        assert p_scores.scores()[0] == sc_or[0, q], (mode, "scores only")
+        p_paths.run(mode, GO, GE)
+        assert p_paths.scores()[0] == sc_or[0, q], (mode, "with paths")
+        assert np.array_equal(p_paths.paths()[0], paths_or[0][q]), mode
+    p_scores.close(); p_paths.close(); arena.close()
+    # float profiles: the oracle's DP on the device's own match scores
+    f1, f2 = synth_profile(rng, 2345)[0], synth_profile(rng, 3111)[0]
+    arena = nat.Arena([f1, f2], bba["S"])
+    p_scores = nat.Plan(arena, pair)
+    p_paths = nat.Plan(arena, pair, want_paths=True)
+    m = arena.match_scores(0, 1, p_paths.match_kind())
+    for mode in MODES5:
+        s_or, path_or = oracle_dp_on_m(mode, m)
+        p_scores.run(mode, GO, GE)
+        p_paths.run(mode, GO, GE)
+        assert p_scores.scores()[0] == np.float32(s_or) and p_paths.scores()[0] == np.float32(s_or), mode
+        assert np.array_equal(p_paths.paths()[0], path_or), mode
+    p_scores.close(); p_paths.close(); arena.close()
