@@ -340,10 +340,27 @@ __global__ __launch_bounds__(256) void k_prepare_rows(const float *__restrict__ 
             }
             return;
         }
-        const int per_row = 2 * NR * 8;
-        for (int i = threadIdx.x; i < 32 * per_row; i += nthr) {
-            split_f16_entry(P, KP, KS, n_active, NR, rowp0 * per_row + i, P16);
-            split_f16_entry(Q, KP, KS, n_active, NR, rowp0 * per_row + i, Q16);
+        // hi / lo layout (split_f16_entry): one (row, half, 16-symbol range) per thread - eight hi and eight lo halves of
+        // each side, four 16-byte stores instead of thirty-two 2-byte ones
+        for (int c = threadIdx.x; c < 32 * 2 * NR; c += nthr) {
+            const int64_t rowp = rowp0 + c / (2 * NR);
+            const int hh = (c / NR) % 2, r = c % NR;
+            _Float16 ph[8], pl[8], qh[8], ql[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int k = 16 * r + 8 * hh + jj;
+                float fp = 0.0f, fq = 0.0f;
+                if (k < n_active) { fp = P[rowp * KP + (k & 1) * KS + (k >> 1)]; fq = Q[rowp * KP + (k & 1) * KS + (k >> 1)]; }
+                ph[jj] = (_Float16)fp; pl[jj] = (_Float16)(fp - (float)ph[jj]);
+                qh[jj] = (_Float16)fq; ql[jj] = (_Float16)(fq - (float)qh[jj]);
+            }
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            const int64_t half_elems = 2 * NR * 8;  // halves per (rowp, hh): [piece][r][8]
+            _Float16 *op = P16 + (rowp * 2 + hh) * half_elems, *oq = Q16 + (rowp * 2 + hh) * half_elems;
+            *reinterpret_cast<h8 *>(op + (0 * NR + r) * 8) = h8{ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]};
+            *reinterpret_cast<h8 *>(op + (1 * NR + r) * 8) = h8{pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6], pl[7]};
+            *reinterpret_cast<h8 *>(oq + (0 * NR + r) * 8) = h8{qh[0], qh[1], qh[2], qh[3], qh[4], qh[5], qh[6], qh[7]};
+            *reinterpret_cast<h8 *>(oq + (1 * NR + r) * 8) = h8{ql[0], ql[1], ql[2], ql[3], ql[4], ql[5], ql[6], ql[7]};
         }
     }
 }

@@ -833,3 +833,47 @@ def test_prepared_schedule_gives_the_same_plan(nat, bba):
     with pytest.raises(ValueError):
         nat.Plan(arena, pairs, want_paths=True, prepared=nat.PreparedSchedule(lens, pairs))
     arena.close()
+
+
+def test_float_profiles_with_more_than_21_active_symbols(nat):
+    """Float profiles with mass on all 27 symbols and a score matrix without empty rows: 27 active symbols - past the 21
+    that the K-packed three-term layout holds - so the hi / lo pieces of P and Q = P . S^T are laid out unpacked (six
+    MFMAs per step).  The device's match scores agree with float64 to 1e-5 of the matrix's range (the north star's
+    float tolerance), and the plans' scores and paths are the oracle's on those match scores."""
+    rng = np.random.default_rng(57)
+    A = 27
+    S = rng.integers(-4, 12, (A, A)).astype(np.float32)
+    S = np.maximum(S, S.T)
+    np.fill_diagonal(S, rng.integers(4, 12, A))
+    N = 40
+    profs = []
+    for L in rng.integers(50, 121, N):
+        c = rng.random((int(L), A)).astype(np.float32) ** 3 + np.eye(A, dtype=np.float32)[rng.integers(0, A, int(L))]
+        profs.append((c / c.sum(axis=1, keepdims=True)).astype(np.float32))
+    arena = nat.Arena(profs, S)
+    info = arena.info()
+    assert info["n_active"] == 27 and info["f16_terms"] == 3, info
+    pairs = all_pairs(N)
+    plan = nat.Plan(arena, pairs, want_paths=True)
+    kind = plan.match_kind()
+    for (i, j) in ((0, 1), (3, 17), (38, 39), (11, 5)):
+        m = arena.match_scores(i, j, kind)
+        want = profs[i].astype(np.float64) @ S.astype(np.float64) @ profs[j].astype(np.float64).T
+        assert np.abs(m - want).max() <= 1e-5 * np.abs(want).max(), (i, j, float(np.abs(m - want).max()))
+    for mode in MODES:
+        plan.run(mode, *GAPS)
+        sc, paths = plan.scores().copy(), plan.paths()
+        for p in rng.choice(len(pairs), 5, replace=False):
+            i, j = pairs[p]
+            s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(int(i), int(j), kind))
+            assert sc[p] == np.float32(s_or) and np.array_equal(paths[p], p_or), (mode, i, j)
+    plan.close()
+    plan = nat.Plan(arena, pairs)
+    plan.run("global", *GAPS)
+    s2 = plan.scores().copy()
+    plan.close()
+    plan = nat.Plan(arena, pairs, want_paths=True)
+    plan.run("global", *GAPS)
+    assert np.array_equal(bits(s2), bits(plan.scores()))      # scores-only and path kernels agree
+    plan.close()
+    arena.close()
