@@ -165,6 +165,15 @@ typedef struct praline_plan praline_plan;   /* a scheduled pair list (wave tasks
  * alphabet, bit-identical to the reference, an order of magnitude slower). */
 int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t A, const float *profiles,
                          const float *S, praline_arena **out);
+/* The same in three steps, for callers that assemble `profiles` piece by piece (a binding that concatenates per-sequence
+ * arrays into page-locked staging): begin sizes the arena, put_rows uploads rows [row0, row0 + n_rows) of the
+ * concatenation - asynchronously: the upload of the first part runs while the caller copies the second; `rows` must stay
+ * valid until praline_arena_finish returns, and part 0 (row0 = 0) is where the library looks for non-float16 values -,
+ * finish does the rest of praline_arena_create.  Between begin and finish only put_rows and destroy may be called;
+ * a failing finish destroys the arena. */
+int praline_arena_begin(int64_t n_seqs, const int32_t *lens, int32_t A, praline_arena **out);
+int praline_arena_put_rows(praline_arena *arena, int64_t row0, int64_t n_rows, const float *rows);
+int praline_arena_finish(praline_arena *arena, const float *S);
 int praline_arena_destroy(praline_arena *arena);
 /* Tells the arena how its alphabet axis is partitioned into track sets (sizes[0] + ... + sizes[n_sets-1] = A).
  * Only PRALINE_MATCH_REFERENCE needs it: the reference keeps one running sum per set and adds the sets in list

@@ -357,6 +357,8 @@ struct praline_arena {
     int max_len = 0;
     std::vector<int32_t> len, row_off_pad, row_off_raw, active;
     // host sources of the creation's asynchronous uploads (kept: praline_arena_create does not wait for them)
+    bool building = false;       // between praline_arena_begin and praline_arena_finish: only praline_arena_put_rows may touch it
+    unsigned inexact_bits = 0;   // some value of the first rows is not a normal float16 (praline_arena_put_rows)
     std::vector<float> h_S;
     std::vector<int32_t> h_seq_of_rowp, h_active_up;
     std::vector<unsigned char> h_slot_of;
@@ -452,16 +454,17 @@ static int arena_launch_premultiply(praline_arena *a, bool check_f16 = false)
     return PRALINE_OK;
 }
 
-extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t A, const float *profiles,
-                                    const float *S, praline_arena **out)
+// Arena creation in three steps (praline_arena_create is begin + one put + finish): begin sizes the arena and allocates
+// the raw rows, put uploads a range of rows (asynchronously: a caller that concatenates per-sequence arrays into
+// page-locked staging uploads the first half while it copies the second), finish scans, packs and pre-multiplies.
+static int arena_begin(int64_t n_seqs, const int32_t *lens, int32_t A, praline_arena **out)
 {
     if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (n_seqs <= 0 || !lens || !profiles || !S) return fail(PRALINE_ERR_ARG, "NULL or empty arena input");
+    if (n_seqs <= 0 || !lens) return fail(PRALINE_ERR_ARG, "NULL or empty arena input");
     // the raw (concatenated) alphabet may be wide; what the kernels bound is the number of ACTIVE symbols (<= 32)
     if (A <= 0 || A > 254) return fail(PRALINE_ERR_ARG, "alphabet size %d not in 1..254 (concatenated track sets)", A);
     RC(ensure_runtime(-1));
-    PhaseTimer pt("arena_create");
     praline_arena *a = new praline_arena();
     a->n_seqs = n_seqs;
     a->A = A;
@@ -483,25 +486,53 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     a->rp_end = rp;
     // tail padding: the kernels prefetch one row past the longest sequence and read whole strips
     a->rows_pad = rp + (a->max_len + 31) / 32 * 32 + 64;
+    int rc0 = PRALINE_OK;
+    if ((rc0 = a->d_raw.alloc((size_t)rr * A)) || (rc0 = a->d_sym_raw.alloc((size_t)rr))) { delete a; return rc0; }
+    a->building = true;
+    *out = a;
+    return PRALINE_OK;
+}
 
+static int arena_put(praline_arena *a, int64_t row0, int64_t n_rows, const float *rows)
+{
+    if (!a || !a->building) return fail(PRALINE_ERR_ARG, "rows can only be put into an arena between begin and finish");
+    if (!rows || row0 < 0 || n_rows < 0 || row0 + n_rows > a->rows_raw) return fail(PRALINE_ERR_ARG, "row range %lld + %lld outside the arena's %lld rows", (long long)row0, (long long)n_rows, (long long)a->rows_raw);
+    if (row0 == 0) {
+        // ... whether some value is NOT a normal float16 (13 low mantissa bits set, or an exponent outside -14 .. 15): such
+        // an arena needs the hi/lo split whatever S is, so the device-side exactness check (and the second packing launch
+        // that follows its read-back) can be skipped - float profiles, i.e. every preprofile / profile-profile stage
+        // (looked for in the first 64 K values only: float profiles show one in their first rows, and arenas that show none
+        // there keep the device-side check)
+        unsigned inexact_bits = 0;
+        for (int64_t k = 0, n = std::min<int64_t>(n_rows * a->A, 65536); k < n && !inexact_bits; ++k) {
+            unsigned u;
+            memcpy(&u, &rows[k], 4);
+            const unsigned e = (u >> 23) & 0xffu;
+            if (u & 0x7fffffffu) inexact_bits = (u & 0x1fffu) | (unsigned)(e < 113u) | (unsigned)(e > 142u);
+        }
+        a->inexact_bits = inexact_bits;
+    }
+    // (a DMA when the caller's buffer is page-locked: praline_host_alloc)
+    if (n_rows > 0) HIPCHK(hipMemcpyAsync(a->d_raw.p + row0 * a->A, rows, (size_t)n_rows * a->A * sizeof(float), hipMemcpyHostToDevice, g_rt.stream));
+    return PRALINE_OK;
+}
+
+// (destroys the arena when it fails)
+static int arena_finish(praline_arena *a, const float *S)
+{
+    if (!a || !a->building) return fail(PRALINE_ERR_ARG, "the arena is not being built");
+    if (!S) { (void)hipStreamSynchronize(g_rt.stream); delete a; return fail(PRALINE_ERR_ARG, "NULL score matrix"); }
+    PhaseTimer pt("arena_create");
+    const int64_t n_seqs = a->n_seqs, rr = a->rows_raw;
+    const int A = a->A;
+    const int32_t *lens = a->len.data();
+    const unsigned inexact_bits = a->inexact_bits;
     // active symbols: i contributes to m = sum_i P1[y,i] * Q2[x,i] only if some profile has mass on
     // it and row i of S is not all zero; dropping the others is exact (their terms are +-0).
     // One pass over the raw profiles gathers everything the host needs from them: which symbols carry mass, and per
     // row whether it is one-hot and on which symbol (counted branch-free so that the loop vectorises).
     std::vector<char> has_mass(A, 0), has_score(A, 0);
     bool all_onehot_rows = true;
-    // ... and whether some value is NOT a normal float16 (13 low mantissa bits set, or an exponent outside -14 .. 15): such
-    // an arena needs the hi/lo split whatever S is, so the device-side exactness check (and the second packing launch
-    // that follows its read-back) can be skipped - float profiles, i.e. every preprofile / profile-profile stage
-    // (looked for in the first 64 K values only: float profiles show one in their first rows, and arenas that show none
-    // there keep the device-side check)
-    unsigned inexact_bits = 0;
-    for (int64_t k = 0, n = std::min<int64_t>(rr * A, 65536); k < n && !inexact_bits; ++k) {
-        unsigned u;
-        memcpy(&u, &profiles[k], 4);
-        const unsigned e = (u >> 23) & 0xffu;
-        if (u & 0x7fffffffu) inexact_bits = (u & 0x1fffu) | (unsigned)(e < 113u) | (unsigned)(e > 142u);
-    }
     hipStream_t st = g_rt.stream;
     // the raw profiles go up first; the scan of their rows (mass per symbol, one-hot rows) runs on the device - one
     // small read-back instead of 0.6 ms of host time for the 11 MB of C2.  Everything the host can prepare without the
@@ -511,8 +542,8 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
     int *flags = g_rt.h_flags;   // (A <= 254)
     {
         int rc0 = PRALINE_OK;
-        if ((rc0 = a->d_raw.alloc((size_t)rr * A)) || (rc0 = a->d_raw.upload(profiles, (size_t)rr * A, st)) ||
-            (rc0 = a->d_sym_raw.alloc((size_t)rr)) || (rc0 = d_flags.alloc((size_t)A + 1))) {
+        if ((rc0 = d_flags.alloc((size_t)A + 1))) {
+            (void)hipStreamSynchronize(st);
             delete a;
             return rc0;
         }
@@ -648,9 +679,36 @@ extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t
             if (rc != PRALINE_OK) { delete a; return rc; }
         }
     }
+    a->building = false;
+    return PRALINE_OK;
+}
+
+extern "C" int praline_arena_create(int64_t n_seqs, const int32_t *lens, int32_t A, const float *profiles,
+                                    const float *S, praline_arena **out)
+{
+    if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_seqs <= 0 || !lens || !profiles || !S) return fail(PRALINE_ERR_ARG, "NULL or empty arena input");
+    praline_arena *a = nullptr;
+    RC(arena_begin(n_seqs, lens, A, &a));
+    int rc = arena_put(a, 0, a->rows_raw, profiles);
+    if (rc != PRALINE_OK) { (void)hipStreamSynchronize(g_rt.stream); delete a; return rc; }
+    RC(arena_finish(a, S));
     *out = a;
     return PRALINE_OK;
 }
+
+extern "C" int praline_arena_begin(int64_t n_seqs, const int32_t *lens, int32_t A, praline_arena **out)
+{
+    return arena_begin(n_seqs, lens, A, out);
+}
+
+extern "C" int praline_arena_put_rows(praline_arena *arena, int64_t row0, int64_t n_rows, const float *rows)
+{
+    return arena_put(arena, row0, n_rows, rows);
+}
+
+extern "C" int praline_arena_finish(praline_arena *arena, const float *S) { return arena_finish(arena, S); }
 
 extern "C" int praline_arena_destroy(praline_arena *arena)
 {
@@ -662,6 +720,7 @@ extern "C" int praline_arena_destroy(praline_arena *arena)
 
 extern "C" int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets, const int32_t *sizes)
 {
+    if (arena && arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
     if (!arena || n_sets <= 0 || !sizes) return fail(PRALINE_ERR_ARG, "bad track-set arguments");
     std::vector<int32_t> lo(1, 0);
     for (int n = 0; n < n_sets; ++n) {
@@ -679,6 +738,7 @@ extern "C" int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets
 // (open, extend) of every position of every sequence, in arena order; NULL: back to constant gap scores.
 extern "C" int praline_arena_set_gap_scores(praline_arena *arena, const float *g)
 {
+    if (arena && arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
     if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
     RC(ensure_runtime(-1));
     if (!g) { arena->has_gaps = false; arena->d_gaps.release(); return PRALINE_OK; }
@@ -846,6 +906,7 @@ static int arena_reserve(praline_arena *a, int64_t need_seqs, int64_t need_rows_
 
 extern "C" int praline_arena_set_counts(praline_arena *arena, const int32_t *counts, int64_t reserve_seqs, int64_t reserve_rows)
 {
+    if (arena && arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
     if (!arena || !counts) return fail(PRALINE_ERR_ARG, "NULL argument");
     RC(ensure_runtime(-1));
     praline_arena *a = arena;
@@ -861,6 +922,7 @@ extern "C" int praline_arena_set_counts(praline_arena *arena, const int32_t *cou
 
 extern "C" int praline_arena_premultiply(praline_arena *arena)
 {
+    if (arena && arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
     if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
     return arena_launch_premultiply(arena);
 }
@@ -1061,6 +1123,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!arena || n_pairs < 0 || (n_pairs > 0 && !pairs)) return fail(PRALINE_ERR_ARG, "bad plan arguments");
+    if (arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
     if ((rect_off != nullptr) != (rects != nullptr) && rect_off && rect_off[n_pairs] > 0)
         return fail(PRALINE_ERR_ARG, "rect_off given without rects");
     if (rect_off && !want_paths && rect_off[n_pairs] > 0)

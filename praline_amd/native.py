@@ -62,6 +62,10 @@ def lib():
     L.praline_raw_align.argtypes = [i32, pa, pa, pa, pa, ctypes.POINTER(f32), vp,
                                     ctypes.POINTER(i64)]
     L.praline_arena_create.argtypes = [i64, vp, i32, vp, vp, ctypes.POINTER(vp)]
+    if hasattr(L, "praline_arena_begin"):
+        L.praline_arena_begin.argtypes = [i64, vp, i32, ctypes.POINTER(vp)]
+        L.praline_arena_put_rows.argtypes = [vp, i64, i64, vp]
+        L.praline_arena_finish.argtypes = [vp, vp]
     if hasattr(L, "praline_host_alloc"):
         L.praline_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
         L.praline_host_free.argtypes = [vp]
@@ -266,6 +270,7 @@ def raw_align(mode, m, g1, g2, z=None):
 # straight into it and goes up by DMA.  One buffer per process, grown on demand, reused by every Arena (the upload has
 # finished when praline_arena_create returns); lists beyond the cap take the pageable path.
 _STAGE_CAP = 1 << 30
+_PARTS_MIN_BYTES = 4 << 20   # arenas from this size on are uploaded in two parts (Arena._create_in_parts)
 _stage = {"ptr": None, "view": None}
 
 
@@ -311,19 +316,49 @@ class Arena(object):
         sets concatenated along the alphabet axis (only the "ref" match mode needs them)."""
         A = int(score_matrix.shape[0])
         self.lens = np.array([p.shape[0] for p in profiles], dtype=np.int32)
-        cat = _stage_profiles(profiles, A)
-        if cat.shape[1] != A:
-            raise ValueError("profile width %d != score matrix size %d" % (cat.shape[1], A))
         S = np.ascontiguousarray(score_matrix, dtype=np.float32)
         self.n_seqs = len(profiles)
         self.A = A
-        h = ctypes.c_void_p()
-        _check(lib().praline_arena_create(self.n_seqs, self.lens.ctypes.data, A, cat.ctypes.data,
-                                          S.ctypes.data, ctypes.byref(h)))
+        h = self._create_in_parts(profiles, A, S)
+        if h is None:
+            cat = _stage_profiles(profiles, A)
+            if cat.shape[1] != A:
+                raise ValueError("profile width %d != score matrix size %d" % (cat.shape[1], A))
+            h = ctypes.c_void_p()
+            _check(lib().praline_arena_create(self.n_seqs, self.lens.ctypes.data, A, cat.ctypes.data,
+                                              S.ctypes.data, ctypes.byref(h)))
         self._h = h
         if set_sizes is not None and len(set_sizes) > 1:
             sz = np.ascontiguousarray(set_sizes, dtype=np.int32)
             _check(lib().praline_arena_set_track_sets(h, len(sz), sz.ctypes.data))
+
+    def _create_in_parts(self, profiles, A, S):
+        """Large lists of float32 profiles: the concatenation into page-locked staging is done in two halves, and the
+        first half goes up (praline_arena_put_rows, a DMA) while numpy copies the second.  Returns the arena handle, or
+        None when this road does not apply (small or mixed inputs, no staging)."""
+        rows = int(self.lens.sum())
+        if rows * A * 4 < _PARTS_MIN_BYTES or len(profiles) < 8 or not hasattr(lib(), "praline_arena_begin"):
+            return None
+        if not all(isinstance(p, np.ndarray) and p.dtype == np.float32 and p.ndim == 2 and p.shape[1] == A for p in profiles):
+            return None
+        v = _stage_view(rows * A)
+        if v is None:
+            return None
+        out = v.reshape(rows, A)
+        half = len(profiles) // 2
+        r0 = int(self.lens[:half].sum())
+        h = ctypes.c_void_p()
+        _check(lib().praline_arena_begin(self.n_seqs, self.lens.ctypes.data, A, ctypes.byref(h)))
+        try:
+            np.concatenate(profiles[:half], axis=0, out=out[:r0], casting="no")
+            _check(lib().praline_arena_put_rows(h, 0, r0, out.ctypes.data))
+            np.concatenate(profiles[half:], axis=0, out=out[r0:], casting="no")
+            _check(lib().praline_arena_put_rows(h, r0, rows - r0, out[r0:].ctypes.data))
+        except Exception:
+            lib().praline_arena_destroy(h)
+            raise
+        _check(lib().praline_arena_finish(h, S.ctypes.data))   # (destroys the arena when it fails)
+        return h
 
     def set_gap_scores(self, gap_scores):
         """Per-position gap scores (praline_arena_set_gap_scores): a list of float32 [L_s, 2] arrays, one per sequence,

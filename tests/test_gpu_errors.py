@@ -126,12 +126,46 @@ def test_arena_inputs_staged_or_not_give_the_same_arena(nat, bba):
         nat._STAGE_CAP = cap
     assert np.array_equal(want.view(np.uint32), scores(profs).view(np.uint32))
     assert nat._stage["ptr"].value == ptr0                                 # the same staging buffer again
+    parts_min = nat._PARTS_MIN_BYTES
+    try:
+        nat._PARTS_MIN_BYTES = 0                                           # begin / put first half / put second half / finish
+        assert np.array_equal(want.view(np.uint32), scores(profs).view(np.uint32))
+        onehots = [np.eye(27, dtype=np.float32)[rng.integers(0, 20, int(L))] for L in lens]
+        got_parts = scores(onehots)
+    finally:
+        nat._PARTS_MIN_BYTES = parts_min
+    assert np.array_equal(got_parts.view(np.uint32), scores(onehots).view(np.uint32))   # (an exact-mode arena both ways)
     big = [np.tile(p, (40, 1)) for p in profs]                             # 40 x the rows: the staging buffer grows
     a = nat.Arena(big + big + big, bba["S"])
     assert int(a.lens.sum()) == 120 * int(lens.sum())
     a.close()
-    # the allocator itself
+    # the three-step creation, misused
     import ctypes
+    L = nat.lib()
+    lens32 = np.ascontiguousarray(lens, dtype=np.int32)
+    cat = np.ascontiguousarray(np.concatenate(profs, axis=0))
+    h = ctypes.c_void_p()
+    assert L.praline_arena_begin(len(lens32), lens32.ctypes.data, 27, ctypes.byref(h)) == 0
+    assert L.praline_arena_put_rows(h, 5, len(cat), cat.ctypes.data) != 0          # past the end
+    assert L.praline_arena_put_rows(h, 0, 10, None) != 0
+    hp = ctypes.c_void_p()
+    assert L.praline_plan_create(h, len(pairs), pairs.ctypes.data, 0, None, None, ctypes.byref(hp)) != 0   # still being built
+    assert L.praline_arena_premultiply(h) != 0
+    assert L.praline_arena_put_rows(h, 0, len(cat), cat.ctypes.data) == 0
+    S32 = np.ascontiguousarray(bba["S"], dtype=np.float32)
+    assert L.praline_arena_finish(h, S32.ctypes.data) == 0
+    assert L.praline_arena_finish(h, S32.ctypes.data) != 0                         # not being built any more
+    assert L.praline_arena_put_rows(h, 0, 1, cat.ctypes.data) != 0
+    assert L.praline_plan_create(h, len(pairs), pairs.ctypes.data, 0, None, None, ctypes.byref(hp)) == 0
+    assert L.praline_plan_run(hp, 0, -11.0, -1.0, None) == 0
+    got = np.zeros(len(pairs), dtype=np.float32)
+    assert L.praline_plan_scores(hp, got.ctypes.data) == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    L.praline_plan_destroy(hp); L.praline_arena_destroy(h)
+    assert L.praline_arena_begin(len(lens32), lens32.ctypes.data, 27, ctypes.byref(h)) == 0
+    assert L.praline_arena_destroy(h) == 0                                        # an arena that was never finished
+    assert L.praline_arena_begin(0, lens32.ctypes.data, 27, ctypes.byref(h)) != 0
+    # the allocator itself
     p = ctypes.c_void_p()
     assert nat.lib().praline_host_alloc(1 << 20, ctypes.byref(p)) == 0 and p.value
     np.ctypeslib.as_array((ctypes.c_float * 16).from_address(p.value))[:] = 1.0
