@@ -1061,11 +1061,32 @@ static void pipe_schedule_for(const int32_t *lens, int64_t n_seqs, int64_t n_pai
     if (pipe.ok && (int64_t)pipe.tasks.size() < min_tasks) pipe = PipeSchedule();
 }
 
+// a 64-bit digest of a pair list (four interleaved multiply-add chains over its 8-byte entries): a prepared schedule is
+// only taken for the pair list it was computed from
+static uint64_t pairs_digest(const int32_t *pairs, int64_t n_pairs)
+{
+    const uint64_t K = 0x9E3779B97F4A7C15ull;
+    uint64_t h[4] = {1, 2, 3, 4};
+    int64_t p = 0;
+    for (; p + 4 <= n_pairs; p += 4)
+        for (int q = 0; q < 4; ++q) {
+            uint64_t w;
+            memcpy(&w, pairs + 2 * (p + q), 8);
+            h[q] = (h[q] ^ w) * K + (h[q] >> 29);
+        }
+    for (; p < n_pairs; ++p) {
+        uint64_t w;
+        memcpy(&w, pairs + 2 * p, 8);
+        h[0] = (h[0] ^ w) * K + (h[0] >> 29);
+    }
+    return (h[0] * K) ^ (h[1] * (K + 2)) ^ (h[2] * (K + 4)) ^ (h[3] * (K + 6)) ^ (uint64_t)n_pairs;
+}
+
 // praline_sched_prepare: host-only, may run on another host thread while the arena of the same sequences is created
 struct praline_sched {
     std::vector<int32_t> lens;
     int64_t n_pairs = 0;
-    int32_t first[2] = {0, 0}, last[2] = {0, 0};   // (a cheap identity check of the pair list)
+    uint64_t digest = 0;   // of the pair list the schedule belongs to
     PipeSchedule pipe;
 };
 
@@ -1088,8 +1109,7 @@ extern "C" int praline_sched_prepare(int64_t n_seqs, const int32_t *lens, int64_
     sc->lens.assign(lens, lens + n_seqs);
     sc->n_pairs = n_pairs;
     if (n_pairs > 0) {
-        sc->first[0] = pairs[0]; sc->first[1] = pairs[1];
-        sc->last[0] = pairs[2 * n_pairs - 2]; sc->last[1] = pairs[2 * n_pairs - 1];
+        sc->digest = pairs_digest(pairs, n_pairs);
         pipe_schedule_for(lens, n_seqs, n_pairs, pairs, max_len, sc->pipe);
     }
     *out = sc;
@@ -1198,8 +1218,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         if (!want_paths && !pl->ref && opt.split_layout && a.nr16 > 0 && v16.stage && v16.sym8 == nullptr &&
             praline_pipe_supported(a.nr16, a.nterm16) && match_mode() == PRALINE_MATCH_FAST && !(np && np[0] == '1') && n_pairs > 0) {
             // (a schedule prepared from the same lengths and pair list while the arena was being created: take it)
-            const bool prepared = prep != nullptr && prep->n_pairs == n_pairs && prep->lens == a.len && prep->first[0] == pairs[0] &&
-                                  prep->first[1] == pairs[1] && prep->last[0] == pairs[2 * n_pairs - 2] && prep->last[1] == pairs[2 * n_pairs - 1];
+            const bool prepared = prep != nullptr && prep->n_pairs == n_pairs && prep->lens == a.len && prep->digest == pairs_digest(pairs, n_pairs);
             if (prepared) pl->pipe = std::move(prep->pipe);
             else pipe_schedule_for(a.len.data(), a.n_seqs, n_pairs, pairs, a.max_len, pl->pipe);
             if (prepared) { prep->pipe = PipeSchedule(); prep->n_pairs = -1; }   // (consumed)

@@ -813,8 +813,10 @@ def test_prepared_schedule_gives_the_same_plan(nat, bba):
         plan.run("local", *GAPS)
         plan.close(); arena2.close()
     # schedules that do not belong to the arena / pair list are not used
+    shuffled = pairs.copy()
+    shuffled[1:-1] = shuffled[1:-1][rng.permutation(len(pairs) - 2)]          # same first / last pair, same count
     for bad in (nat.PreparedSchedule(lens[::-1].copy(), pairs), nat.PreparedSchedule(lens, pairs[::-1].copy()),
-                nat.PreparedSchedule(lens, pairs[:-1])):
+                nat.PreparedSchedule(lens, pairs[:-1]), nat.PreparedSchedule(lens, shuffled)):
         plan = nat.Plan(arena, pairs, prepared=bad)
         plan.run("global", *GAPS)
         assert np.array_equal(bits(plan.scores()), bits(want))
