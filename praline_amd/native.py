@@ -292,6 +292,28 @@ def _stage_view(n_floats):
     return v[:n_floats]
 
 
+_result = {"ptr": None, "view": None}
+
+
+def _result_view(n_floats):
+    """A page-locked float32 buffer for score read-backs (grown on demand, at most 64 MB)."""
+    if n_floats * 4 > (64 << 20) or not hasattr(lib(), "praline_host_alloc"):
+        return None
+    v = _result["view"]
+    if v is None or v.size < n_floats:
+        if _result["ptr"] is not None:
+            _result["view"] = None
+            lib().praline_host_free(_result["ptr"])
+            _result["ptr"] = None
+        want = max(1 << 16, 1 << int(n_floats - 1).bit_length())
+        p = ctypes.c_void_p()
+        if lib().praline_host_alloc(want * 4, ctypes.byref(p)) != OK:
+            return None
+        _result["ptr"] = p
+        v = _result["view"] = np.ctypeslib.as_array((ctypes.c_float * want).from_address(p.value))
+    return v[:n_floats]
+
+
 def _stage_profiles(profiles, A):
     """The float32 [sum L, A] concatenation of `profiles`, in page-locked memory when they are float32 already."""
     first = profiles[0]
@@ -542,6 +564,11 @@ class Plan(object):
         _check(lib().praline_plan_run_gaps(self._h, MODES[mode], ctypes.c_void_p(d_scores) if d_scores else None))
 
     def scores(self):
+        # (read back into page-locked memory - a DMA the host only waits for - and copied out)
+        v = _result_view(self.n) if self.n else None
+        if v is not None:
+            _check(lib().praline_plan_scores(self._h, v.ctypes.data))
+            return v.copy()
         out = np.zeros(self.n, dtype=np.float32)
         _check(lib().praline_plan_scores(self._h, out.ctypes.data))
         return out
