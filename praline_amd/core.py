@@ -11,6 +11,7 @@ Only the surface the reference's callers use to reach the pairwise aligner is re
 Parallel / remote managers, the TaskNode progress tree and LogBundle are orchestration and out of
 scope.
 """
+import warnings
 import uuid
 
 MESSAGE_KIND_BEGIN = "begin"
@@ -245,7 +246,7 @@ class TypeIndex(object):
             raise ComponentError("component with type id '{0}' not registered".format(component_class.tid))
         del self._types[component_class.tid]
 
-    def autoregister(self):
+    def autoregister(self, strict=False):
         """Register every component published under the `praline.type` entry-point group - what the reference does
         (manager.py:72-85): this package's own components (setup.py) and any third-party aligner installed beside it.
         Without packaging metadata (a bare source tree) the in-package list is registered."""
@@ -261,19 +262,39 @@ class TypeIndex(object):
             from importlib import metadata
             eps = metadata.entry_points()
             group = eps.select(group=ENTRY_POINT_GROUP) if hasattr(eps, "select") else eps.get(ENTRY_POINT_GROUP, [])
-        except Exception:
+        except Exception as exc:   # no packaging metadata machinery: the in-package list stands
+            warnings.warn("praline_amd: entry-point discovery failed (%s): only the package's own components are "
+                          "registered" % (exc,), RuntimeWarning, stacklevel=2)
             return
+        # Every entry point that is NOT taken is reported (the reference, manager.py:72-85, propagates load errors and
+        # lets the last registration win; here the package's own tids are never displaced - INTEGRATION.md section 4 - so
+        # a user whose replacement aligner is ignored must be told).  `strict=True` restores the reference's behaviour
+        # for load errors: they propagate.
         for entry_point in group:
             try:
                 cls = entry_point.load()
-            except Exception:
-                continue   # a distribution whose import fails here (the reference without its dependencies) is skipped
+            except Exception as exc:
+                if strict:
+                    raise
+                # a distribution whose import fails here (the reference itself without its dependencies) is skipped
+                warnings.warn("praline_amd: entry point %r of group %r could not be loaded (%s: %s) - skipped"
+                              % (getattr(entry_point, "name", entry_point), ENTRY_POINT_GROUP, type(exc).__name__, exc),
+                              RuntimeWarning, stacklevel=2)
+                continue
             # third-party components must be written against THIS runtime (a subclass of its Component) and may
             # add tids, not replace the package's own
             if not (isinstance(cls, type) and issubclass(cls, Component)):
+                if getattr(cls, "__module__", "").split(".")[0] != "praline":   # (the reference's own classes: expected)
+                    warnings.warn("praline_amd: entry point %r is not a praline_amd.core.Component subclass - skipped"
+                                  % (getattr(entry_point, "name", entry_point),), RuntimeWarning, stacklevel=2)
                 continue
             tid = getattr(cls, "tid", None)
-            if tid is None or (tid in own and own[tid] is not cls):
+            if tid is None:
+                continue
+            if tid in own and own[tid] is not cls:
+                warnings.warn("praline_amd: entry point %r publishes type id %r, which belongs to this package: its own "
+                              "component is kept (register the replacement explicitly with TypeIndex.register to override)"
+                              % (getattr(entry_point, "name", entry_point), tid), RuntimeWarning, stacklevel=2)
                 continue
             self.register(cls)
 

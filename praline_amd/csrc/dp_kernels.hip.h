@@ -648,7 +648,9 @@ __global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__
         for (int y = 1; y <= tk.max_l1; ++y) {
             // PPG: gy1 = scores of position y - 1 (U[y][x], the boundary cell o[y,0,1]), gy = those of position y (U[y+1][x])
             const float2 gy1 = g1a, gy = g1b;
-            if constexpr (PPG) { g1a = g1b; g1b = make_float2(g1p[2 * (y + 1)], g1p[2 * (y + 1) + 1]); }
+            // (one row ahead, never past row L1 of this lane's own sequence - a row whose values no cell uses: a short lane
+            // of a task with a much longer one does not walk on through other sequences' rows towards the buffer's end)
+            if constexpr (PPG) { const int yn = y + 1 <= L1 ? y + 1 : L1; g1a = g1b; g1b = make_float2(g1p[2 * yn], g1p[2 * yn + 1]); }
             // MASK == 2: bit c of zrow = cell (y, x0 + c + 1) lies in one of this pair's rectangles; the words were
             // prepared by k_build_zmask (walking the rectangle list here, in a loop, miscompiled the LOCAL instance with
             // ROCm 7.2: wrong scores even with empty lists)

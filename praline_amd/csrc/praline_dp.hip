@@ -61,6 +61,11 @@ struct Runtime {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int *h_flags = nullptr;   // page-locked: small read-backs that must not block the host when they are enqueued (256 ints)
+    // device twins used by arena creation (praline_arena_finish), allocated once: a per-call buffer of this size would be
+    // hipFree'd at return - a device-wide wait - and the call could never return ahead of its packing launch.  Every use
+    // is ordered on `stream` (the next arena's memset / upload follows the previous arena's kernels).
+    int *d_scan_flags = nullptr;          // 256 ints
+    unsigned char *d_slot_of = nullptr;   // 256 bytes
 };
 static Runtime g_rt;
 
@@ -84,6 +89,8 @@ static int ensure_runtime(int device)
     HIPCHK(hipEventCreateWithFlags(&g_rt.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&g_rt.ev_join, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void **)&g_rt.h_flags, 256 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&g_rt.d_scan_flags, 256 * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&g_rt.d_slot_of, 256));
     g_rt.device = device;
     g_rt.ready = true;
     return PRALINE_OK;
@@ -114,6 +121,8 @@ extern "C" int praline_shutdown(void)
     (void)hipEventDestroy(g_rt.ev_fork);
     (void)hipEventDestroy(g_rt.ev_join);
     (void)hipHostFree(g_rt.h_flags);
+    (void)hipFree(g_rt.d_scan_flags);
+    (void)hipFree(g_rt.d_slot_of);
     (void)hipStreamDestroy(g_rt.stream2);
     (void)hipStreamDestroy(g_rt.stream);
     g_rt = Runtime();
@@ -423,6 +432,15 @@ struct praline_arena {
     }
 };
 
+// Every arena entry point but praline_arena_put_rows / _finish / _destroy goes through this: an arena between
+// praline_arena_begin and praline_arena_finish has no tables, no operands and no lengths on the device yet.
+static int arena_ready(const praline_arena *a)
+{
+    if (!a) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    if (a->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
+    return PRALINE_OK;
+}
+
 static int arena_launch_premultiply(praline_arena *a, bool check_f16 = false)
 {
     if (a->wide) return PRALINE_OK;   // no packed operands: plans on this arena read the raw profiles (k_match_ref)
@@ -538,21 +556,15 @@ static int arena_finish(praline_arena *a, const float *S)
     // small read-back instead of 0.6 ms of host time for the 11 MB of C2.  Everything the host can prepare without the
     // scan's answer is done while the upload is in flight (a DMA when the caller's buffer is page-locked:
     // praline_host_alloc).
-    DevBuf<int> d_flags;
-    int *flags = g_rt.h_flags;   // (A <= 254)
+    int *const d_flags = g_rt.d_scan_flags;   // (A <= 254; owned by the runtime: nothing is freed when this call returns)
+    int *flags = g_rt.h_flags;
     {
-        int rc0 = PRALINE_OK;
-        if ((rc0 = d_flags.alloc((size_t)A + 1))) {
-            (void)hipStreamSynchronize(st);
-            delete a;
-            return rc0;
-        }
-        hipError_t e0 = hipMemsetAsync(d_flags.p, 0, ((size_t)A + 1) * sizeof(int), st);
+        hipError_t e0 = hipMemsetAsync(d_flags, 0, ((size_t)A + 1) * sizeof(int), st);
         if (e0 == hipSuccess) {
-            hipLaunchKernelGGL(k_scan_profiles, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, st, a->d_raw.p, rr, A, a->d_sym_raw.p, d_flags.p);
+            hipLaunchKernelGGL(k_scan_profiles, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, st, a->d_raw.p, rr, A, a->d_sym_raw.p, d_flags);
             e0 = hipGetLastError();
         }
-        if (e0 == hipSuccess) e0 = hipMemcpyAsync(flags, d_flags.p, ((size_t)A + 1) * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(flags, d_flags, ((size_t)A + 1) * sizeof(int), hipMemcpyDeviceToHost, st);
         if (e0 != hipSuccess) { (void)hipStreamSynchronize(st); delete a; return fail(PRALINE_ERR_DEVICE, "arena scan: %s", hipGetErrorString(e0)); }
     }
     pt.mark("upload + device scan enqueued");
@@ -636,13 +648,17 @@ static int arena_finish(praline_arena *a, const float *S)
         delete a;
         return rc;
     }
-    DevBuf<unsigned char> d_slot_of;   // (read by k_build_sym8 below; released to the stream-ordered pool at return)
     if (a->onehot) {
-        if ((rc = d_slot_of.upload(slot_of, st))) { delete a; return rc; }
+        // (the table is read by k_build_sym8 below from the runtime's 256-byte buffer; its host source lives in the arena)
+        if (hipMemcpyAsync(g_rt.d_slot_of, slot_of.data(), 256, hipMemcpyHostToDevice, st) != hipSuccess) {
+            (void)hipStreamSynchronize(st);
+            delete a;
+            return fail(PRALINE_ERR_DEVICE, "symbol table upload failed");
+        }
         const int64_t rows_out = a->rows_pad + 64;
         hipLaunchKernelGGL(k_build_sym8, dim3((unsigned)((rows_out + 255) / 256)), dim3(256), 0, st, a->d_sym_raw.p, a->d_seq_of_rowp.p,
-                           a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, d_slot_of.p, a->rows_pad, rows_out, a->d_sym8.p);
-        if (hipGetLastError() != hipSuccess) { delete a; return fail(PRALINE_ERR_DEVICE, "k_build_sym8 launch failed"); }
+                           a->d_row_off_pad.p, a->d_row_off_raw.p, a->d_len.p, g_rt.d_slot_of, a->rows_pad, rows_out, a->d_sym8.p);
+        if (hipGetLastError() != hipSuccess) { (void)hipStreamSynchronize(st); delete a; return fail(PRALINE_ERR_DEVICE, "k_build_sym8 launch failed"); }
     }
     pt.mark("allocations + uploads (async)");
     const bool host_knows_split = a->nr16 > 0 && inexact_bits != 0;
@@ -720,7 +736,7 @@ extern "C" int praline_arena_destroy(praline_arena *arena)
 
 extern "C" int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets, const int32_t *sizes)
 {
-    if (arena && arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
+    RC(arena_ready(arena));
     if (!arena || n_sets <= 0 || !sizes) return fail(PRALINE_ERR_ARG, "bad track-set arguments");
     std::vector<int32_t> lo(1, 0);
     for (int n = 0; n < n_sets; ++n) {
@@ -738,11 +754,14 @@ extern "C" int praline_arena_set_track_sets(praline_arena *arena, int32_t n_sets
 // (open, extend) of every position of every sequence, in arena order; NULL: back to constant gap scores.
 extern "C" int praline_arena_set_gap_scores(praline_arena *arena, const float *g)
 {
-    if (arena && arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
+    RC(arena_ready(arena));
     if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
     RC(ensure_runtime(-1));
     if (!g) { arena->has_gaps = false; arena->d_gaps.release(); return PRALINE_OK; }
-    if (arena->cap_seqs != 0) return fail(PRALINE_ERR_UNSUPPORTED, "gap scores on a growing arena (praline_arena_set_counts) are not supported");
+    // gap rows exist for the sequences the arena holds NOW: an arena that grows (praline_arena_set_counts /
+    // praline_arena_append_merged) would leave its appended sequences without any - the two are mutually exclusive
+    if (arena->have_cnt || arena->cap_seqs != 0)
+        return fail(PRALINE_ERR_UNSUPPORTED, "gap scores on a growing arena (praline_arena_set_counts) are not supported");
     const size_t rows = (size_t)arena->rows_pad + 64;
     std::vector<float> pad(rows * 2, 0.0f);
     for (int64_t q = 0; q < arena->n_seqs; ++q) {
@@ -906,8 +925,10 @@ static int arena_reserve(praline_arena *a, int64_t need_seqs, int64_t need_rows_
 
 extern "C" int praline_arena_set_counts(praline_arena *arena, const int32_t *counts, int64_t reserve_seqs, int64_t reserve_rows)
 {
-    if (arena && arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
+    RC(arena_ready(arena));
     if (!arena || !counts) return fail(PRALINE_ERR_ARG, "NULL argument");
+    if (arena->has_gaps)
+        return fail(PRALINE_ERR_UNSUPPORTED, "the arena holds per-position gap scores (praline_arena_set_gap_scores): it cannot grow");
     RC(ensure_runtime(-1));
     praline_arena *a = arena;
     RC(a->d_cnt.alloc((size_t)a->rows_raw * a->A));
@@ -922,7 +943,7 @@ extern "C" int praline_arena_set_counts(praline_arena *arena, const int32_t *cou
 
 extern "C" int praline_arena_premultiply(praline_arena *arena)
 {
-    if (arena && arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
+    RC(arena_ready(arena));
     if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
     return arena_launch_premultiply(arena);
 }
@@ -1061,32 +1082,11 @@ static void pipe_schedule_for(const int32_t *lens, int64_t n_seqs, int64_t n_pai
     if (pipe.ok && (int64_t)pipe.tasks.size() < min_tasks) pipe = PipeSchedule();
 }
 
-// a 64-bit digest of a pair list (four interleaved multiply-add chains over its 8-byte entries): a prepared schedule is
-// only taken for the pair list it was computed from
-static uint64_t pairs_digest(const int32_t *pairs, int64_t n_pairs)
-{
-    const uint64_t K = 0x9E3779B97F4A7C15ull;
-    uint64_t h[4] = {1, 2, 3, 4};
-    int64_t p = 0;
-    for (; p + 4 <= n_pairs; p += 4)
-        for (int q = 0; q < 4; ++q) {
-            uint64_t w;
-            memcpy(&w, pairs + 2 * (p + q), 8);
-            h[q] = (h[q] ^ w) * K + (h[q] >> 29);
-        }
-    for (; p < n_pairs; ++p) {
-        uint64_t w;
-        memcpy(&w, pairs + 2 * p, 8);
-        h[0] = (h[0] ^ w) * K + (h[0] >> 29);
-    }
-    return (h[0] * K) ^ (h[1] * (K + 2)) ^ (h[2] * (K + 4)) ^ (h[3] * (K + 6)) ^ (uint64_t)n_pairs;
-}
-
 // praline_sched_prepare: host-only, may run on another host thread while the arena of the same sequences is created
 struct praline_sched {
     std::vector<int32_t> lens;
     int64_t n_pairs = 0;
-    uint64_t digest = 0;   // of the pair list the schedule belongs to
+    std::vector<int32_t> pairs;   // the pair list the schedule belongs to (compared entry by entry when the plan is created)
     PipeSchedule pipe;
 };
 
@@ -1109,7 +1109,7 @@ extern "C" int praline_sched_prepare(int64_t n_seqs, const int32_t *lens, int64_
     sc->lens.assign(lens, lens + n_seqs);
     sc->n_pairs = n_pairs;
     if (n_pairs > 0) {
-        sc->digest = pairs_digest(pairs, n_pairs);
+        sc->pairs.assign(pairs, pairs + 2 * n_pairs);
         pipe_schedule_for(lens, n_seqs, n_pairs, pairs, max_len, sc->pipe);
     }
     *out = sc;
@@ -1143,7 +1143,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!arena || n_pairs < 0 || (n_pairs > 0 && !pairs)) return fail(PRALINE_ERR_ARG, "bad plan arguments");
-    if (arena->building) return fail(PRALINE_ERR_ARG, "the arena is still being built (praline_arena_finish)");
+    RC(arena_ready(arena));
     if ((rect_off != nullptr) != (rects != nullptr) && rect_off && rect_off[n_pairs] > 0)
         return fail(PRALINE_ERR_ARG, "rect_off given without rects");
     if (rect_off && !want_paths && rect_off[n_pairs] > 0)
@@ -1218,7 +1218,8 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         if (!want_paths && !pl->ref && opt.split_layout && a.nr16 > 0 && v16.stage && v16.sym8 == nullptr &&
             praline_pipe_supported(a.nr16, a.nterm16) && match_mode() == PRALINE_MATCH_FAST && !(np && np[0] == '1') && n_pairs > 0) {
             // (a schedule prepared from the same lengths and pair list while the arena was being created: take it)
-            const bool prepared = prep != nullptr && prep->n_pairs == n_pairs && prep->lens == a.len && prep->digest == pairs_digest(pairs, n_pairs);
+            const bool prepared = prep != nullptr && prep->n_pairs == n_pairs && prep->lens == a.len &&
+                                  memcmp(prep->pairs.data(), pairs, (size_t)n_pairs * 2 * sizeof(int32_t)) == 0;
             if (prepared) pl->pipe = std::move(prep->pipe);
             else pipe_schedule_for(a.len.data(), a.n_seqs, n_pairs, pairs, a.max_len, pl->pipe);
             if (prepared) { prep->pipe = PipeSchedule(); prep->n_pairs = -1; }   // (consumed)
@@ -2348,7 +2349,7 @@ extern "C" int praline_plan_paths(praline_plan *plan, int32_t *paths, int64_t *p
 // ---- preprofile stage on the device: counts and path bounding boxes (k_path_counts / k_path_bounds) ----------
 extern "C" int praline_arena_counts_reset(praline_arena *arena)
 {
-    if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    RC(arena_ready(arena));
     if (!arena->counts_ext && !arena->d_counts.p) RC(arena->d_counts.alloc((size_t)arena->rows_raw * arena->A));
     HIPCHK(hipMemsetAsync(arena->counts_ptr(), 0, (size_t)arena->rows_raw * arena->A * sizeof(int32_t), g_rt.stream));
     return PRALINE_OK;
@@ -2356,7 +2357,7 @@ extern "C" int praline_arena_counts_reset(praline_arena *arena)
 
 extern "C" int praline_arena_counts_bind(praline_arena *arena, void *d_counts)
 {
-    if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    RC(arena_ready(arena));
     arena->counts_ext = (int32_t *)d_counts;
     return PRALINE_OK;
 }
@@ -2384,6 +2385,7 @@ extern "C" int praline_plan_add_counts(praline_plan *plan, int use_threshold, fl
 extern "C" int praline_arena_counts_read(praline_arena *arena, int32_t *counts)
 {
     if (!arena || !counts) return fail(PRALINE_ERR_ARG, "NULL argument");
+    RC(arena_ready(arena));
     if (!arena->counts_ptr()) return fail(PRALINE_ERR_ARG, "praline_arena_counts_reset has not been called");
     HIPCHK(hipMemcpyAsync(counts, arena->counts_ptr(), (size_t)arena->rows_raw * arena->A * sizeof(int32_t),
                           hipMemcpyDeviceToHost, g_rt.stream));
@@ -2412,6 +2414,7 @@ extern "C" int praline_arena_append_merged_many(praline_arena *arena, praline_pl
                                                 int32_t *new_index, int32_t *new_len)
 {
     if (!arena || !plan || !new_index || !new_len || (n > 0 && !pair_index)) return fail(PRALINE_ERR_ARG, "NULL argument");
+    RC(arena_ready(arena));
     if (plan->arena != arena) return fail(PRALINE_ERR_ARG, "the plan belongs to another arena");
     if (!plan->want_paths || plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "the plan has no paths (want_paths + praline_plan_run first)");
     if (plan->last_mode == PRALINE_MODE_LOCAL) return fail(PRALINE_ERR_UNSUPPORTED, "clusters are merged along global / semiglobal paths");
@@ -2420,6 +2423,7 @@ extern "C" int praline_arena_append_merged_many(praline_arena *arena, praline_pl
         if (pair_index[q] < 0 || pair_index[q] >= plan->n_pairs) return fail(PRALINE_ERR_ARG, "pair index out of range");
     praline_arena *a = arena;
     if (!a->have_cnt) return fail(PRALINE_ERR_ARG, "praline_arena_set_counts has not been called");
+    if (a->has_gaps) return fail(PRALINE_ERR_UNSUPPORTED, "the arena holds per-position gap scores: it cannot grow");
     hipStream_t st = g_rt.stream;
     // where the paths are: one round trip for the whole plan (a level of the guide tree is one plan)
     const int64_t np = plan->n_pairs;
@@ -2782,6 +2786,7 @@ __global__ __launch_bounds__(64) void k_debug_tile(ArenaDev ar, const int32_t *l
 extern "C" int praline_debug_tile(praline_arena *arena, const int32_t *lane_one, int two0, int two1, int x0, int y, int tp,
                                   float *out)
 {
+    RC(arena_ready(arena));
     RC(ensure_runtime(-1));
     DevBuf<int32_t> d_l;
     DevBuf<float> d_o;
@@ -2801,6 +2806,7 @@ extern "C" int praline_debug_tile(praline_arena *arena, const int32_t *lane_one,
 extern "C" int praline_arena_match_scores(praline_arena *arena, int32_t one, int32_t two, int kind, float *m)
 {
     if (!arena || !m) return fail(PRALINE_ERR_ARG, "NULL argument");
+    RC(arena_ready(arena));
     if (one < 0 || one >= arena->n_seqs || two < 0 || two >= arena->n_seqs) return fail(PRALINE_ERR_ARG, "index out of range");
     RC(ensure_runtime(-1));
     const int L1 = arena->len[one], L2 = arena->len[two];
@@ -2836,7 +2842,7 @@ extern "C" int praline_arena_match_scores(praline_arena *arena, int32_t one, int
 extern "C" int praline_arena_info(const praline_arena *arena, int32_t *n_active, int32_t *mfma_steps_f32, int32_t *f16_ranges,
                                   int32_t *f16_terms)
 {
-    if (!arena) return fail(PRALINE_ERR_ARG, "arena is NULL");
+    RC(arena_ready(arena));
     if (n_active) *n_active = arena->n_active;
     if (mfma_steps_f32) *mfma_steps_f32 = arena->nstep;
     if (f16_ranges) *f16_ranges = arena->nr16;

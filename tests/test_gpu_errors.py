@@ -54,6 +54,24 @@ def test_c_abi_rejects_misuse(nat, bba):
     with pytest.raises(nat.NativeError):
         nat.Plan(arena, np.array([(0, 1)], np.int32), want_paths=False, rects=[[(1, 1, 1, 1)]])   # masks need paths
     arena.close()
+    # per-position gap scores and a growing arena exclude each other, in both orders (the gap rows exist for the
+    # sequences present when they were set: an appended sequence would read zeros or past the buffer)
+    gaps = [np.tile(np.float32([-11, -1]), (len(q), 1)) for q in p]
+    counts = np.concatenate(p).astype(np.int32)
+    grow = nat.Arena(p, S)
+    grow.set_counts(counts)                                              # no reserve: cap_seqs stays 0
+    with pytest.raises(nat.NativeError) as e:
+        grow.set_gap_scores(gaps)
+    assert e.value.code == -4 and "growing" in str(e.value)
+    grow.close()
+    gapped = nat.Arena(p, S)
+    gapped.set_gap_scores(gaps)
+    with pytest.raises(nat.NativeError) as e:
+        gapped.set_counts(counts, reserve_seqs=2, reserve_rows=16)
+    assert e.value.code == -4 and "cannot grow" in str(e.value)
+    gapped.set_gap_scores(None)                                          # removing them makes the arena growable again
+    gapped.set_counts(counts, reserve_seqs=2, reserve_rows=16)
+    gapped.close()
 
 
 def test_component_errors_match_reference_types(nat, bba):

@@ -433,12 +433,27 @@ def test_autoregister_is_not_displaced_by_a_second_distribution(tmp_path):
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "from praline_amd import core, component\n"
             "import fakepraline\n"
+            "import warnings\n"
             "idx = core.TypeIndex()\n"
-            "idx.autoregister()\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always')\n"
+            "    idx.autoregister()\n"
             "for cls in component.COMPONENTS:\n"
             "    assert idx.resolve(cls.tid) is cls, cls.tid\n"
             "assert idx.resolve('third.party.MyAligner') is fakepraline.MyAligner\n"
-            "assert len(idx._types) == len(component.COMPONENTS) + 1\n" % (str(other), str(tmp_path), root))
+            "assert len(idx._types) == len(component.COMPONENTS) + 1\n"
+            "# nothing is dropped silently: the failed import, the foreign class and the colliding tid are all reported\n"
+            "msgs = ' | '.join(str(x.message) for x in w)\n"
+            "assert 'Broken' in msgs and 'could not be loaded' in msgs, msgs\n"
+            "assert 'not a praline_amd.core.Component subclass' in msgs, msgs\n"
+            "assert 'praline.component.GuideTreeBuilder' in msgs and 'is kept' in msgs, msgs\n"
+            "# strict: load errors propagate as in the reference (manager.py:72-85)\n"
+            "try:\n"
+            "    core.TypeIndex().autoregister(strict=True)\n"
+            "except ImportError:\n"
+            "    pass\n"
+            "else:\n"
+            "    raise AssertionError('strict autoregister swallowed a load error')\n" % (str(other), str(tmp_path), root))
     subprocess.check_call([sys.executable, "-c", code])
 
 
