@@ -62,6 +62,11 @@ struct PipeLaunch {
 bool praline_pipe_supported(int nr, int nterm);
 int praline_pipe_attrs(int nr, int nterm, int mode, int *vgprs, int *lds_bytes);
 int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm);
+// k_dp_pipe<..., KEEP>: the forward fill of the two-pass alignments with paths on the pipeline (global mode); backward:
+// praline_launch_tb2_backward with keep_in_aux = 2 (blocks of PRALINE_KEEP_BH rows, analytic column 0)
+int praline_launch_pipe_keep(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm, void *keep_bnd, float *ckpt,
+                             int32_t *end_cells, void *analytic4);
+int praline_pipe_keep_attrs(int nr, int nterm, int *vgprs, int *lds_bytes);
 // two-pass alignments with paths (dp_tb2_instance.hip): flag-free forward fill, then block recompute + traceback
 struct Trace2Args {
     const int64_t *slot_off;
@@ -70,8 +75,10 @@ struct Trace2Args {
     int32_t *path_rows;
 };
 int praline_launch_tb2_forward(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, bool mask);
+// keep_in_aux: 0 the forward was k_dp_split16_tb<..., TWOPASS>; 1 k_dp_split16<..., KEEP> (kept columns at tk.aux_off);
+// 2 k_dp_pipe<..., KEEP> (the same, blocks of PRALINE_KEEP_BH rows, column 0 of every task = analytic4)
 int praline_launch_tb2_backward(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, int nr, int nterm, bool local,
-                                bool mask, int keep_in_aux = 0);
+                                bool mask, int keep_in_aux = 0, const void *analytic4 = nullptr);
 // chain mode without flags: scores only (score plans of a few long sequences)
 int praline_launch_scores_chain(const LaunchArgs &la, const Arena16Dev &a16, int nr, int nterm, bool local, int max_strips, int *flags,
                                 void *cand, int every);

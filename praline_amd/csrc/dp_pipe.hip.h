@@ -47,6 +47,31 @@ static_assert(pipe_lds_bytes() <= 80 * 1024, "two pipeline workgroups per CU");
 // barrier of the pipeline: every LDS access of this wave (the hand-off write above all) has completed before it
 #define PRALINE_PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PRALINE_PIPE_AHEAD 6   // the operand stream runs this many positions ahead of wave 0's step
+
+// KEEP: the pipeline as the FORWARD fill of the two-pass alignments with paths (dp_trace2.hip.h; global mode).  Besides its
+// (H, L) hand-off a strip writes what k_trace_recompute starts from, in the layout of k_dp_split16<..., KEEP>:
+//   * its last column as three states, float4 (M, U, L, 0) [strip + 1][row][32 pairs] per task at tk.aux_off - the
+//     recurrence's own intermediates (M before the maximum, U and L on entry to the cell), bit for bit the values the
+//     three-state kernels carry: fl(max3(Mp, Up, Lp) + m) = max3 of the three rounded sums;
+//   * the (M, U, L) states of every PRALINE_KEEP_BH-th row, float4 [row / BH][3][4][64] per strip at tk.tb_off.  BH is a
+//     multiple of 12, so the two steps per block that hold such a row (lower half: u = 11 mod 12, upper half: u = 0 mod 12)
+//     are static positions of the 12x unrolled loop: only they carry the (wave-uniform) test;
+//   * M and U of the corner cell (the end state k is the first of M, U, L that equals the score, align.py:428-430).
+static_assert(PRALINE_KEEP_BH % 12 == 0, "checkpoint rows sit at static positions of the unrolled loop");
+// checkpoint blocks per strip: the rounds compute rows up to rsteps <= max(max_l1 + 12, PRALINE_PIPE_MIN_STEPS); block 0 is never written
+__host__ __device__ constexpr int pipe_keep_blocks(int max_l1)
+{
+    return ((max_l1 + 12 > PRALINE_PIPE_MIN_STEPS) ? max_l1 + 12 : PRALINE_PIPE_MIN_STEPS) / PRALINE_KEEP_BH + 1;
+}
+#ifndef PRALINE_PIPE_KEEP_ABLATE
+#define PRALINE_PIPE_KEEP_ABLATE 0   // timing experiments only: 1 no checkpoint stores, 2 no kept columns
+#endif
+struct PipeKeep {
+    char *st = nullptr;        // kept column being written: this lane's float4 of the row this step stores
+    f4n *ckpt = nullptr;       // this strip's checkpoint blocks (+ lane)
+    float snap_m = 0.0f, snap_u = 0.0f;
+    bool st_lane = false;      // upper half of a strip that has a strip to its right
+};
 #ifndef PRALINE_PIPE_ABLATE
 #define PRALINE_PIPE_ABLATE 0   // timing experiments only (results invalid): 1 no half select, 2 four more MFMAs per step
 #endif
@@ -59,6 +84,15 @@ __global__ void k_pipe_analytic(float2 *col, int rows, RunParams rp)
     const int y = i >> 5;
     if (y >= rows) return;
     col[i] = make_float2(y >= 1 ? boundary_value(y, rp.go1, rp.ge1, mode_free_one(rp.mode)) : 0.0f, PRALINE_NEG_INF);
+}
+// the same column as three states, float4 (-inf, o[y,0,1], -inf, 0) [rows][32]: what k_trace_recompute reads as the boundary
+// column of every task's first strip behind the KEEP forward fill
+__global__ void k_pipe_analytic4(float4 *col, int rows, RunParams rp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = i >> 5;
+    if (y >= rows) return;
+    col[i] = make_float4(PRALINE_NEG_INF, y >= 1 ? boundary_value(y, rp.go1, rp.ge1, mode_free_one(rp.mode)) : 0.0f, PRALINE_NEG_INF, 0.0f);
 }
 
 struct PipeDma {
@@ -111,16 +145,19 @@ struct PipeBnd {
 
 // One step.  K = u % 12.  Register roles as in split16_step (BSRC = 2 without DM):
 //   CUR row u + 1's scores, PREV row u's (receives row u + 2's); BOPS operands of row u + 2, BFILL receives row u + 3.
-template <int NR, int NTERM, bool LOCAL, bool SEMI, int K, bool SNAP>
+// KEEP: 0 scores only; 1 kept column (+ corner snapshot); 2 the same with the checkpoint stores of a row u + 1 - h = 0 (mod BH)
+template <int NR, int NTERM, bool LOCAL, bool SEMI, int K, bool SNAP, int KEEP = 0>
 __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                           const float4 (&BOPS)[4], float4 (&BFILL)[4], const float4 (&aop)[4],
                                           const char *ring, const unsigned (&stage_rd)[4], const char *bnd_in, char *bnd_out,
                                           bool wr_lane, PipeDma &dma, PipeBnd &pb, unsigned lane16,
                                           float (&Hs)[17], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
                                           float &best_run, float &col_run, float &out_best, float &out_rowmax, float &out_colmax,
-                                          float &out_corner, float go, float ge, int cidx, bool last_owner, int xb, int L2)
+                                          float &out_corner, float go, float ge, int cidx, bool last_owner, int xb, int L2,
+                                          PipeKeep *ks = nullptr)
 {
     static_assert(NR == 2 && (NTERM == 2 || NTERM == 3), "k_dp_pipe is built for the 128-byte operand rows of float-profile arenas");
+    static_assert(KEEP == 0 || (!LOCAL && !SEMI), "the kept-state forward fill serves global alignments");
     constexpr int NM = NTERM * NR;
     // every memory operation of this wave but the three youngest has completed: its pieces of the rows read below (issued
     // >= 4 steps ago; a block DMA / store or the A-tile fetch among the youngest only makes the wait stricter), then
@@ -150,6 +187,22 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
     const float hd_out = Hs[16];
     const f2 go2 = {go, go}, ge2 = {ge, ge};
     f2 hs = {Hs[0], Hs[1]};
+    bool ck_mine = false;
+    f4n ckM, ckU, ckL;         // KEEP == 2: the states of four columns, stored once complete
+    float kM = 0.0f, kU = 0.0f, kL = 0.0f;   // KEEP: states of this lane's last column
+    if constexpr (KEEP != 0) {
+        const int yy = u + 1 - h;
+        if constexpr (KEEP == 2) ck_mine = yy >= PRALINE_KEEP_BH && (yy % PRALINE_KEEP_BH) == 0;
+        if constexpr (SNAP) {
+            if (have_pair && yy == L1 && last_owner) {   // the corner cell is in this row: its M and U (split16_step, KEEP)
+                float hw[16], mw[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) { hw[c] = Hs[c]; mw[c] = (c & 1) ? m2[c >> 1].y : m2[c >> 1].x; }
+                ks->snap_m = select16(hw, cidx) + select16(mw, cidx);
+                ks->snap_u = select16(Uc, cidx);
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -171,8 +224,24 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
             const f2 U = {Uc[2 * cp], Uc[2 * cp + 1]};
             const f2 Ug = pk_add(U, ge2);
             const float H0 = max3f(M.x, U.x, lrun);
+            const float lin0 = lrun;
             lrun = __builtin_fmaxf(Mo.x, lrun + ge);      // L[y][x+1]   (cext.c:169-183,276-283)
             const float H1 = max3f(M.y, U.y, lrun);
+            if constexpr (KEEP != 0) {
+                if (cp == 7) { kM = M.y; kU = U.y; kL = lrun; }
+            }
+            if constexpr (KEEP == 2) {
+                if ((cp & 1) == 0) { ckM.x = M.x; ckM.y = M.y; ckU.x = U.x; ckU.y = U.y; ckL.x = lin0; ckL.y = lrun; }
+                else {
+                    ckM.z = M.x; ckM.w = M.y; ckU.z = U.x; ckU.w = U.y; ckL.z = lin0; ckL.w = lrun;
+                    if (ck_mine && !(PRALINE_PIPE_KEEP_ABLATE & 1)) {
+                        f4n *q = ks->ckpt + (int64_t)((u + 1 - h) / PRALINE_KEEP_BH) * PRALINE_CKPT_BLOCK_F4 + (cp >> 1) * 64;
+                        __builtin_nontemporal_store(ckM, q);
+                        __builtin_nontemporal_store(ckU, q + 4 * 64);
+                        __builtin_nontemporal_store(ckL, q + 8 * 64);
+                    }
+                }
+            }
             lrun = __builtin_fmaxf(Mo.y, lrun + ge);
             if (LOCAL) best_run = max3f(best_run, H0, H1);
             Uc[2 * cp] = __builtin_fmaxf(Mo.x, Ug.x);        // U[y+1][x]   (cext.c:152-166,247-254)
@@ -187,6 +256,14 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
     // hand row yy = u of the last column to the next strip (ring slot u % 12 of the next wave; wave 3: its own staging
     // ring; lanes of the lower half and strips that end a task write nothing)
     if (wr_lane) *reinterpret_cast<float2 *>(bnd_out + (K % 12) * 256) = make_float2(Hs[16], lrun);
+    if constexpr (KEEP != 0) {
+        // (M, U, L) of the cell (u, last column): what the NEXT strip's recompute reads as its boundary column
+        if (ks->st_lane && !(PRALINE_PIPE_KEEP_ABLATE & 2)) {
+            const f4n kv = {kM, kU, kL, 0.0f};
+            __builtin_nontemporal_store(kv, reinterpret_cast<f4n *>(ks->st));
+        }
+        ks->st += 32 * sizeof(float4);
+    }
     pipe_issue(dma);
     if constexpr ((K & 3) == 3) {
         // every fourth step: the next four rows of a boundary column that lives in memory -
@@ -232,13 +309,15 @@ __device__ __forceinline__ void pipe_idle_step(PipeDma &dma)
     pipe_issue(dma);
 }
 
-template <int NR, int NTERM, bool LOCAL, bool SEMI>
+template <int NR, int NTERM, bool LOCAL, bool SEMI, bool KEEP = false>
 __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeItem *__restrict__ items, const WaveTask *__restrict__ tasks,
                                                     const int32_t *__restrict__ set_one, const int32_t *__restrict__ lane_pair,
                                                     float2 *bnd, const float2 *__restrict__ analytic, float *__restrict__ scores,
-                                                    RunParams rp)
+                                                    RunParams rp, float4 *keep_bnd = nullptr, float *ckpt = nullptr,
+                                                    int32_t *__restrict__ end_cells = nullptr)
 {
     static_assert(!(LOCAL && SEMI), "one mode at a time");
+    static_assert(!KEEP || (!LOCAL && !SEMI), "the kept-state forward fill serves global alignments");
     __shared__ __attribute__((aligned(16))) char lds[pipe_lds_bytes()];
     char *ring = lds;
     const int rank = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform (SGPR)
@@ -358,6 +437,14 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
         // analytic column, which its wave fetches into the same ring
         const bool wr_lane = h == 1 && (s < nstrips - 1 || rank == 3);
         pb.out_dst = wrap_col;
+        PipeKeep ks;
+        if constexpr (KEEP) {
+            // this strip's kept column (index s + 1 of the task, row 0 = the dummy row of step 0's upper half) and checkpoints
+            const int64_t keep_col = (int64_t)(tk.max_l1 + PRALINE_TB2_PAD) * 32 * (int64_t)sizeof(float4);
+            ks.st = reinterpret_cast<char *>(keep_bnd + tk.aux_off + j) + (int64_t)(s + 1) * keep_col;
+            ks.ckpt = reinterpret_cast<f4n *>(ckpt + tk.tb_off) + (int64_t)s * pipe_keep_blocks(tk.max_l1) * PRALINE_CKPT_BLOCK_F4 + lane;
+            ks.st_lane = h == 1 && s < nstrips - 1;
+        }
 
         if (!started) {
             // pipeline prologue of the wave's first strip: A tile straight from memory, operand rows 1 and 2 from the
@@ -410,10 +497,19 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
         const bool in_dma_next = more && (rank == 0 || s_n == 0);
         const unsigned long long in_src_next = s_n == 0 ? analytic_col : wrap_col;
 
-#define PRALINE_PIPE_STEP(KK, SN, CURA, PREVA, BUSE, BFIL)                                                             \
-        pipe_step<NR, NTERM, LOCAL, SEMI, KK, SN>(u0 + KK, L1, have_pair, h, CURA, PREVA, BUSE, BFIL, aop, ring, stage_rd, bnd_in, \
+#define PRALINE_PIPE_STEPK(KK, SN, KP, CURA, PREVA, BUSE, BFIL)                                                        \
+        pipe_step<NR, NTERM, LOCAL, SEMI, KK, SN, KP>(u0 + KK, L1, have_pair, h, CURA, PREVA, BUSE, BFIL, aop, ring, stage_rd, bnd_in, \
                                                   bnd_out, wr_lane, dma, pb, lane16, Hs, Uc, dH, hd_x, l_x, best_run, col_run, \
-                                                  out_best, out_rowmax, out_colmax, out_corner, go, ge, cidx, last_owner, xb, L2)
+                                                  out_best, out_rowmax, out_colmax, out_corner, go, ge, cidx, last_owner, xb, L2, &ks)
+#define PRALINE_PIPE_STEP(KK, SN, CURA, PREVA, BUSE, BFIL) PRALINE_PIPE_STEPK(KK, SN, (KEEP ? 1 : 0), CURA, PREVA, BUSE, BFIL)
+        // KEEP: the step at which a half reaches a checkpoint row (wave-uniform test, see PipeKeep)
+#define PRALINE_PIPE_STEPC(KK, SN, CK, CURA, PREVA, BUSE, BFIL)                                                        \
+        do {                                                                                                           \
+            if constexpr (KEEP) {                                                                                      \
+                if (CK) PRALINE_PIPE_STEPK(KK, SN, 2, CURA, PREVA, BUSE, BFIL);                                        \
+                else PRALINE_PIPE_STEPK(KK, SN, 1, CURA, PREVA, BUSE, BFIL);                                           \
+            } else PRALINE_PIPE_STEPK(KK, SN, 0, CURA, PREVA, BUSE, BFIL);                                             \
+        } while (0)
 #define PRALINE_PIPE_TAIL(SN)                                                                                          \
             PRALINE_PIPE_STEP(1, SN, accB, accA, b1, b0);                                                              \
             PRALINE_PIPE_STEP(2, SN, accA, accB, b0, b1);                                                              \
@@ -434,12 +530,15 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
                 _Pragma("unroll") for (int qq = 0; qq < 4; ++qq)                                                       \
                     aop[qq] = *reinterpret_cast<const float4 *>(atile + 1024 * qq + lane * 16);                        \
             }                                                                                                          \
-            PRALINE_PIPE_STEP(11, SN, accB, accA, b1, b0)
+            PRALINE_PIPE_STEPC(11, SN, ck11, accB, accA, b1, b0)
         // one 12-step iteration; SN: with the snapshot test (the iterations that can contain a sequence's last row)
 #define PRALINE_PIPE_ITER(SN)                                                                                          \
         {                                                                                                              \
             const bool last_it = u0 + 12 >= rsteps;                                                                    \
             const bool a_fetch = last_it && more;                                                                      \
+            /* KEEP: step 0's upper half is at row u0, step 11's lower half at row u0 + 12 */                           \
+            const bool ck0 = KEEP && u0 > 0 && (u0 % PRALINE_KEEP_BH) == 0;                                             \
+            const bool ck11 = KEEP && ((u0 + 12) % PRALINE_KEEP_BH) == 0;                                               \
             if (u0 == 0) {                                                                                             \
                 /* step 0: only the lower half has a row (row 1); the upper half's garbage is undone right after */    \
                 float Hsave[17];                                                                                       \
@@ -453,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
                     col_run = col_s;                                                                                   \
                 }                                                                                                      \
             } else {                                                                                                   \
-                PRALINE_PIPE_STEP(0, SN, accA, accB, b0, b1);                                                          \
+                PRALINE_PIPE_STEPC(0, SN, ck0, accA, accB, b0, b1);                                                    \
             }                                                                                                          \
             if (a_fetch) {                                                                                             \
                 /* A tile of strip q + 4 (rows x0' .. x0' + 31 of its sequence two, this lane's 64 bytes) -> LDS */    \
@@ -481,6 +580,8 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
 #undef PRALINE_PIPE_ITER
 #undef PRALINE_PIPE_TAIL
 #undef PRALINE_PIPE_STEP
+#undef PRALINE_PIPE_STEPC
+#undef PRALINE_PIPE_STEPK
 
         // ---- fold this strip's share into the task's results ----
         {
@@ -493,6 +594,14 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
                 const float v0 = LOCAL ? best_all : (SEMI ? rowmax_all : corner_all);
                 if (v0 != PRALINE_NEG_INF) atomicMax(r0, v0);
                 if (SEMI && colmax_all != PRALINE_NEG_INF) atomicMax(r0 + 32, colmax_all);
+            }
+            if constexpr (KEEP) {
+                // global end state: the first of (M, U, L) of the corner cell that equals its maximum (np.argmax, align.py:428-430);
+                // only the half of the strip that owns the corner holds a finite out_corner
+                if (out_corner != PRALINE_NEG_INF) {
+                    const float kf = (ks.snap_m == out_corner) ? 0.0f : ((ks.snap_u == out_corner) ? 1.0f : 2.0f);
+                    atomicMax(res + ti * 64 + 32 + j, kf);
+                }
             }
         }
         ti = ti_n;
@@ -521,5 +630,9 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
             score = (rowmax > colmax && free_two) ? rowmax : colmax;
         } else score = v0;
         scores[pair] = score;
+        if constexpr (KEEP) {
+            int32_t *ec = end_cells + (int64_t)pair * 4;
+            ec[0] = L1; ec[1] = L2; ec[2] = (int)v1; ec[3] = 0;
+        }
     }
 }

@@ -29,9 +29,18 @@ template <int NR, int NTERM> static void launch_fwd(const LaunchArgs &la, const 
 }
 
 template <int NR, int NTERM> static void launch_bwd(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, bool local,
-                                                    bool mask, int keep_in_aux)
+                                                    bool mask, int keep_in_aux, const void *analytic4)
 {
     const dim3 grid(la.n_tasks), block(64);
+    if (keep_in_aux == 2) {
+        // behind the pipeline forward fill (global mode, no rectangles): blocks of PRALINE_KEEP_BH rows
+        if constexpr (NR == 2 && NTERM != 1)
+            hipLaunchKernelGGL((k_trace_recompute<NR, NTERM, false, false, PRALINE_KEEP_BH>), grid, block, 0, la.stream, a16, la.tasks,
+                               la.lane_one, la.lane_pair, (const float4 *)la.bnd, (const float *)la.tb, la.rl, la.end_cells,
+                               ta.slot_off, ta.paths, ta.path_start, ta.path_rows, la.rp, (int)la.n_tasks, 1,
+                               (const float4 *)analytic4, 1);
+        return;
+    }
 #define PRALINE_BWD(LOC, MSK)                                                                                            \
     hipLaunchKernelGGL((k_trace_recompute<NR, NTERM, LOC, MSK>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one,    \
                        la.lane_pair, (const float4 *)la.bnd, (const float *)la.tb, la.rl, la.end_cells, ta.slot_off,       \
@@ -53,13 +62,14 @@ int praline_launch_tb2_forward(const LaunchArgs &la, const Arena16Dev &a16, int 
 }
 
 int praline_launch_tb2_backward(const LaunchArgs &la, const Arena16Dev &a16, const Trace2Args &ta, int nr, int nterm, bool local,
-                                bool mask, int keep_in_aux)
+                                bool mask, int keep_in_aux, const void *analytic4)
 {
-    if (nr == 1 && nterm == 1) launch_bwd<1, 1>(la, a16, ta, local, mask, keep_in_aux);
-    else if (nr == 1 && nterm == 3) launch_bwd<1, 3>(la, a16, ta, local, mask, keep_in_aux);
-    else if (nr == 2 && nterm == 1) launch_bwd<2, 1>(la, a16, ta, local, mask, keep_in_aux);
-    else if (nr == 2 && nterm == 3) launch_bwd<2, 3>(la, a16, ta, local, mask, keep_in_aux);
-    else if (nr == 2 && nterm == 2) launch_bwd<2, 2>(la, a16, ta, local, mask, keep_in_aux);
+    if (keep_in_aux == 2 && (nr != 2 || nterm == 1 || local || mask || analytic4 == nullptr)) return PRALINE_ERR_UNSUPPORTED;
+    if (nr == 1 && nterm == 1) launch_bwd<1, 1>(la, a16, ta, local, mask, keep_in_aux, analytic4);
+    else if (nr == 1 && nterm == 3) launch_bwd<1, 3>(la, a16, ta, local, mask, keep_in_aux, analytic4);
+    else if (nr == 2 && nterm == 1) launch_bwd<2, 1>(la, a16, ta, local, mask, keep_in_aux, analytic4);
+    else if (nr == 2 && nterm == 3) launch_bwd<2, 3>(la, a16, ta, local, mask, keep_in_aux, analytic4);
+    else if (nr == 2 && nterm == 2) launch_bwd<2, 2>(la, a16, ta, local, mask, keep_in_aux, analytic4);
     else return PRALINE_ERR_UNSUPPORTED;
     return PRALINE_OK;
 }

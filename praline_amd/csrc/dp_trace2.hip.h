@@ -19,9 +19,13 @@
 #ifndef PRALINE_TB2_BWD_WAVES
 #define PRALINE_TB2_BWD_WAVES 2
 #endif
-#define PRALINE_TB2_ROWS 40   // LDS flag rows per block: 32 + the pipeline's overshoot
+#define PRALINE_TB2_ROWS(BH) ((BH) + 8)   // LDS flag rows per block: the block's rows + the pipeline's overshoot
 
-template <int NR, int NTERM, bool LOCAL, bool MASK>
+// BH: rows per recomputed block = the forward fill's checkpoint spacing (32: k_dp_split16_tb<..., TWOPASS> and
+// k_dp_split16<..., KEEP>; PRALINE_KEEP_BH: k_dp_pipe<..., KEEP>, whose checkpoints are float4 [row / BH][3][4][64] per strip
+// with pipe_keep_blocks() blocks).  analytic4 (k_dp_pipe forward): the column 0 of EVERY task, float4 (-inf, o[y,0,1], -inf)
+// [row][32], written once per launch - that forward fill keeps no copy per task.
+template <int NR, int NTERM, bool LOCAL, bool MASK, int BH = 32>
 __global__ __launch_bounds__(64, MASK ? 1 : PRALINE_TB2_BWD_WAVES) void k_trace_recompute(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                         const int32_t *__restrict__ lane_one,
                                                         const int32_t *__restrict__ lane_pair, const float4 *__restrict__ bnd,
@@ -29,14 +33,16 @@ __global__ __launch_bounds__(64, MASK ? 1 : PRALINE_TB2_BWD_WAVES) void k_trace_
                                                         const int32_t *__restrict__ end_cells,
                                                         const int64_t *__restrict__ slot_off, int32_t *__restrict__ paths,
                                                         int64_t *__restrict__ path_start, int32_t *__restrict__ path_rows,
-                                                        RunParams rp, int n_tasks, int keep_in_aux = 0)
+                                                        RunParams rp, int n_tasks, int keep_in_aux = 0,
+                                                        const float4 *__restrict__ analytic4 = nullptr, int ckpt_blocks_arg = 0)
 {
+    static_assert(BH == 32 || BH % 6 == 0, "the six-step rotation covers a block exactly, or BH = 32 with its two tail steps");
     // keep_in_aux: the forward fill was k_dp_split16<..., KEEP> - the kept columns sit at tk.aux_off (tk.bnd_off is
     // that kernel's own (H, L) hand-off column)
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
     constexpr bool DM = NTERM == 1 && (PRALINE_TB_DM != 0);
-    __shared__ __attribute__((aligned(16))) char lds_flags_all[PRALINE_TB2_ROWS * 512];
+    __shared__ __attribute__((aligned(16))) char lds_flags_all[PRALINE_TB2_ROWS(BH) * 512];
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
     const int lane = threadIdx.x & 63;
@@ -65,7 +71,8 @@ __global__ __launch_bounds__(64, MASK ? 1 : PRALINE_TB2_BWD_WAVES) void k_trace_
     const int64_t col_elems = (int64_t)(max_l1 + PRALINE_TB2_PAD) * 32;   // float4 elements per boundary column
     const char *my_bnd = reinterpret_cast<const char *>(bnd + (keep_in_aux ? tk.aux_off : tk.bnd_off) + j);
     constexpr int BROW = 32 * (int)sizeof(float4);
-    const int ckpt_blocks = PRALINE_TB2_CKPT_BLOCKS(max_l1);
+    const int ckpt_blocks = ckpt_blocks_arg > 0 ? ((max_l1 + 12 > PRALINE_PIPE_MIN_STEPS ? max_l1 + 12 : PRALINE_PIPE_MIN_STEPS) / BH + 1)
+                                                : PRALINE_TB2_CKPT_BLOCKS(max_l1);   // (ckpt_blocks_arg: the pipeline forward's count, pipe_keep_blocks)
     const float4 *my_ckpt = reinterpret_cast<const float4 *>(ckpt + tk.tb_off) + lane;   // float4 [strip][block][3][4][64]
     char *lds_flags = lds_flags_all + lane * 8;
 
@@ -143,13 +150,14 @@ __global__ __launch_bounds__(64, MASK ? 1 : PRALINE_TB2_BWD_WAVES) void k_trace_
                                      __uint_as_float(__float_as_uint(a.z) & ml), __uint_as_float(__float_as_uint(a.w) & ml));
             }
         }
-        const char *col_in = my_bnd + (int64_t)s * col_elems * (int64_t)sizeof(float4);
+        const char *col_in = (s == 0 && analytic4 != nullptr) ? reinterpret_cast<const char *>(analytic4 + j)
+                                                              : my_bnd + (int64_t)s * col_elems * (int64_t)sizeof(float4);
         const float4 *ckpt_strip = my_ckpt + (int64_t)s * ckpt_blocks * (PRALINE_TB2_CKPT_FLOATS / 4);
 
         for (;;) {
             const bool act = !stopped && y >= 1 && x > x0;      // (x <= x0 + 32 holds: the strips are walked downwards)
             if (__ballot(act) == 0ull) break;
-            const int yb0 = act ? ((y - 1) & ~31) : 0;           // this lane's block: rows yb0 + 1 .. yb0 + 32
+            const int yb0 = act ? ((y - 1) / BH) * BH : 0;       // this lane's block: rows yb0 + 1 .. yb0 + BH
 
             // ---- recompute the block with the single pass's flag logic ----
             float Mp[16], Up[16], Lp[16];
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(64, MASK ? 1 : PRALINE_TB2_BWD_WAVES) void k_trace_
                         Mp[c] = PRALINE_NEG_INF; Up[c] = PRALINE_NEG_INF; Lp[c] = boundary_value(xb + c + 1, go, ge, free_two);
                     }
                 } else {
-                    const float4 *q = ckpt_strip + (int64_t)(yb0 >> 5) * (PRALINE_TB2_CKPT_FLOATS / 4);
+                    const float4 *q = ckpt_strip + (int64_t)(yb0 / BH) * (PRALINE_TB2_CKPT_FLOATS / 4);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 vm = q[g * 64], vu = q[(4 + g) * 64], vl = q[(8 + g) * 64];
@@ -224,9 +232,10 @@ __global__ __launch_bounds__(64, MASK ? 1 : PRALINE_TB2_BWD_WAVES) void k_trace_
             if constexpr (DM) PRALINE_TB2_STEP(1, accA, accB, bX, bZ, bnd_prefA);
             else PRALINE_TB2_STEP(1, accA, accB, bX, bX, bnd_prefA);
             if (h) load_top();
-            // steps 2 .. 33 (the upper half's row 32 is computed at step 33): five full rounds of the six-step
-            // rotation and the first two steps of a sixth
-            for (int t = 2; t <= 31; t += 6) {
+            // steps 2 .. BH + 1 (the upper half's row BH is computed at step BH + 1): full rounds of the six-step rotation
+            // (BH = 32: five of them and the first two steps of a sixth)
+            constexpr int T_ROT = (BH == 32) ? 31 : BH + 1;
+            for (int t = 2; t <= T_ROT; t += 6) {
                 if constexpr (DM) {
                     PRALINE_TB2_STEP(t, accB, accA, bY, bX, bnd_prefB);
                     PRALINE_TB2_STEP(t + 1, accA, accB, bZ, bY, bnd_prefC);
@@ -243,12 +252,14 @@ __global__ __launch_bounds__(64, MASK ? 1 : PRALINE_TB2_BWD_WAVES) void k_trace_
                     PRALINE_TB2_STEP(t + 5, accA, accB, bX, bX, bnd_prefA);
                 }
             }
-            if constexpr (DM) {
-                PRALINE_TB2_STEP(32, accB, accA, bY, bX, bnd_prefB);
-                PRALINE_TB2_STEP(33, accA, accB, bZ, bY, bnd_prefC);
-            } else {
-                PRALINE_TB2_STEP(32, accB, accA, bY, bY, bnd_prefB);
-                PRALINE_TB2_STEP(33, accA, accB, bX, bX, bnd_prefC);
+            if constexpr (BH == 32) {
+                if constexpr (DM) {
+                    PRALINE_TB2_STEP(32, accB, accA, bY, bX, bnd_prefB);
+                    PRALINE_TB2_STEP(33, accA, accB, bZ, bY, bnd_prefC);
+                } else {
+                    PRALINE_TB2_STEP(32, accB, accA, bY, bY, bnd_prefB);
+                    PRALINE_TB2_STEP(33, accA, accB, bX, bX, bnd_prefC);
+                }
             }
 #undef PRALINE_TB2_STEP
             // the flag words of all lanes are in LDS before any lane walks them

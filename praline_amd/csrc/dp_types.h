@@ -48,5 +48,11 @@ struct PipeItem {
 #define PRALINE_TB2_CKPT_BLOCKS(max_l1) (((max_l1) + 12) / 32 + 1)
 #define PRALINE_TB2_CKPT_FLOATS (3 * 16 * 64)   // floats per checkpoint block: float4 [state][four-column group][64 lanes]
 
+// the pipeline kernel as the forward fill of the two-pass scheme (k_dp_pipe<..., KEEP>, dp_pipe.hip.h): rows between two
+// kept (M, U, L) rows = rows per block k_trace_recompute rebuilds; a multiple of 12 (the pipeline's unrolled loop)
+#ifndef PRALINE_KEEP_BH
+#define PRALINE_KEEP_BH 36
+#endif
+
 #define PRALINE_MAX_RECTS 4   // zero rectangles per pair carried by the batched kernels
 #define PRALINE_MW_LAG 2      // 12-row iterations between consecutive ranks of a shared task

@@ -982,6 +982,12 @@ struct praline_plan {
     DevBuf<WaveTask> d_pipe_tasks;
     DevBuf<int32_t> d_pipe_set_one, d_pipe_lane_pair;
     DevBuf<float2> d_pipe_bnd, d_pipe_analytic;
+    // path plans (global mode): the pipeline as the forward fill of the two-pass scheme (k_dp_pipe<..., KEEP> +
+    // k_trace_recompute): per-task sequences one, the float4 analytic column, scratch sizes (kept columns in d_bnd2, row
+    // checkpoints in d_tb); the tasks carry aux_off / tb_off into them
+    DevBuf<int32_t> d_pipe_lane_one;
+    DevBuf<float4> d_pipe_analytic4;
+    int64_t pipe_keep_bnd_elems = 0, pipe_keep_ck_floats = 0;
     int pipe_analytic_rows = 0;
     int pipe_analytic_mode = -1;            // mode and gap scores the analytic column was last written for (-1: never)
     float pipe_analytic_go = 0.0f, pipe_analytic_ge = 0.0f;
@@ -1215,7 +1221,11 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     {
         const char *np = getenv("PRALINE_NO_PIPE");
         const Arena16Dev v16 = a.view16();
-        if (!want_paths && !pl->ref && opt.split_layout && a.nr16 > 0 && v16.stage && v16.sym8 == nullptr &&
+        // path plans without rectangles get the pipeline schedule BESIDE their task schedule: global runs take it as the
+        // forward fill of the two-pass scheme (PRALINE_TB_PIPE=0: never), the other modes keep chain / task mode
+        const char *tpp = getenv("PRALINE_TB_PIPE");
+        const bool paths_ok = !want_paths || (!pl->has_rects && !pl->ref_tile && !pl->ppg && !(tpp && tpp[0] == '0'));
+        if (paths_ok && !pl->ref && opt.split_layout && a.nr16 > 0 && v16.stage && v16.sym8 == nullptr &&
             praline_pipe_supported(a.nr16, a.nterm16) && match_mode() == PRALINE_MATCH_FAST && !(np && np[0] == '1') && n_pairs > 0) {
             // (a schedule prepared from the same lengths and pair list while the arena was being created: take it)
             const bool prepared = prep != nullptr && prep->n_pairs == n_pairs && prep->lens == a.len &&
@@ -1225,7 +1235,21 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
             if (prepared) { prep->pipe = PipeSchedule(); prep->n_pairs = -1; }   // (consumed)
         }
     }
-    if (pl->pipe.ok) {
+    if (pl->pipe.ok && want_paths) {
+        // scratch of the KEEP forward fill: per task (nstrips + 1) kept columns of max_l1 + PRALINE_TB2_PAD rows and
+        // nstrips x pipe_keep_blocks row checkpoints; plans beyond the scratch budget keep chain / task mode
+        int64_t bnd_e = 0, ck_e = 0;
+        for (WaveTask &wt : pl->pipe.tasks) {
+            wt.aux_off = bnd_e;
+            wt.tb_off = ck_e;
+            bnd_e += (int64_t)(wt.nstrips + 1) * (wt.max_l1 + PRALINE_TB2_PAD_ROWS) * 32;
+            const int rows_top = std::max(wt.max_l1 + 12, PRALINE_PIPE_MIN_STEPS);
+            ck_e += (int64_t)wt.nstrips * (rows_top / PRALINE_KEEP_BH + 1) * PRALINE_TB2_CKPT_FLOATS;
+        }
+        if ((size_t)(bnd_e * 16 + ck_e * 4) > tb_budget_bytes()) pl->pipe = PipeSchedule();
+        else { pl->pipe_keep_bnd_elems = bnd_e; pl->pipe_keep_ck_floats = ck_e; }
+    }
+    if (pl->pipe.ok && !want_paths) {
         // the pipeline schedule is all a scores-only run needs: no task schedule, no per-task boundary scratch
         sch.split = opt.split_layout;
         for (int64_t p = 0; p < n_pairs; ++p) sch.cells += (int64_t)a.len[pairs[2 * p]] * a.len[pairs[2 * p + 1]];
@@ -1274,6 +1298,21 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
             return rc;
         }
         for (const PipeItem &pi : pl->pipe.items) pl->pipe_analytic_rows = std::max(pl->pipe_analytic_rows, pi.rsteps + 16);
+        if (want_paths) {
+            // (k_trace_recompute prefetches up to a block and a few rows beyond a sequence's last row)
+            pl->pipe_analytic_rows += PRALINE_KEEP_BH + 16;
+            // sequences one per task: the set's, for the lanes that hold a pair
+            std::vector<int32_t> l1(pl->pipe.lane_pair.size(), -1);
+            for (const PipeItem &pi : pl->pipe.items)
+                for (int t = pi.task0; t < pi.task0 + pi.ntasks; ++t)
+                    for (int q = 0; q < 32; ++q)
+                        if (pl->pipe.lane_pair[(size_t)t * 32 + q] >= 0) l1[(size_t)t * 32 + q] = pl->pipe.set_one[(size_t)pi.set * 32 + q];
+            if ((rc = pl->d_pipe_lane_one.upload(l1, st)) || (rc = pl->d_pipe_analytic4.alloc((size_t)pl->pipe_analytic_rows * 32))) {
+                delete pl;
+                return rc;
+            }
+            if (hipStreamSynchronize(st) != hipSuccess) { delete pl; return fail(PRALINE_ERR_DEVICE, "plan upload failed"); }   // (l1 goes out of scope)
+        }
         if ((rc = pl->d_pipe_analytic.alloc((size_t)pl->pipe_analytic_rows * 32))) { delete pl; return rc; }
         // (rows the kernels never write only feed padding rows; keep them free of NaN bit patterns)
         if (hipMemsetAsync(pl->d_pipe_bnd.p, 0, (size_t)pl->pipe.bnd_elems * sizeof(float2), st) != hipSuccess) {
@@ -1330,7 +1369,7 @@ extern "C" int64_t praline_plan_cells(const praline_plan *plan) { return plan ? 
 extern "C" int64_t praline_plan_steps(const praline_plan *plan)
 {
     if (!plan) return 0;
-    if (plan->pipe.ok) return plan->pipe.steps;   // wave steps of the pipeline launch (idle waves of the last rounds included)
+    if (plan->pipe.ok && !plan->want_paths) return plan->pipe.steps;   // wave steps of the pipeline launch (idle waves of the last rounds included)
     int64_t steps = 0;
     for (const WaveTask &wt : plan->tasks)
         if (wt.max_l1 > 0) steps += (int64_t)wt.nstrips * (wt.max_l1 + 1);
@@ -1339,7 +1378,7 @@ extern "C" int64_t praline_plan_steps(const praline_plan *plan)
 extern "C" int64_t praline_plan_tasks(const praline_plan *plan)
 {
     if (!plan) return 0;
-    if (plan->pipe.ok) return (int64_t)plan->pipe.tasks.size();
+    if (plan->pipe.ok && !plan->want_paths) return (int64_t)plan->pipe.tasks.size();
     int64_t n = 0;
     for (const WaveTask &wt : plan->tasks) n += wt.max_l1 > 0;
     return n;
@@ -1918,6 +1957,51 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             budget = (size_t)std::min<int64_t>((int64_t)48 << 30, 2 * all);   // (twice: chunked plans cut at half the budget)
     }
     HIPCHK(hipEventRecord(pl.ev0, st));
+    // ---- two passes with the PIPELINE as the forward fill (k_dp_pipe<..., KEEP>: operand rows streamed once per
+    // workgroup, boundary hand-off through LDS, H recurrence) and k_trace_recompute on blocks of PRALINE_KEEP_BH rows:
+    // float-profile arenas, global mode, no rectangles, plans whose scratch fits the budget (praline_plan_create)
+    if (pl.pipe.ok && mode == PRALINE_MODE_GLOBAL && la.a16 != nullptr && !pl.has_rects &&
+        !(getenv("PRALINE_TB_PIPE") && getenv("PRALINE_TB_PIPE")[0] == '0')) {
+        char kn[160];
+        snprintf(kn, sizeof(kn), "k_dp_pipe<%d, %d, false, false, true>", a.nr16, a.nterm16);
+        pl.last_kernel = kn;
+        if (pl.d_bnd2.n < (size_t)pl.pipe_keep_bnd_elems) RC(pl.d_bnd2.alloc((size_t)pl.pipe_keep_bnd_elems));
+        if (pl.d_tb.n < (size_t)pl.pipe_keep_ck_floats * 4) RC(pl.d_tb.alloc((size_t)pl.pipe_keep_ck_floats * 4));
+        PipeLaunch pp;
+        pp.items = pl.d_pipe_items.p;
+        pp.n_items = (unsigned)pl.pipe.items.size();
+        pp.tasks = pl.d_pipe_tasks.p;
+        pp.set_one = pl.d_pipe_set_one.p;
+        pp.lane_pair = pl.d_pipe_lane_pair.p;
+        pp.bnd = pl.d_pipe_bnd.p;
+        pp.analytic = pl.d_pipe_analytic.p;
+        pp.analytic_rows = pl.pipe_analytic_rows;
+        pp.analytic_valid = pl.pipe_analytic_mode == mode && pl.pipe_analytic_go == la.rp.go1 && pl.pipe_analytic_ge == la.rp.ge1;
+        pl.pipe_analytic_mode = mode; pl.pipe_analytic_go = la.rp.go1; pl.pipe_analytic_ge = la.rp.ge1;
+        pp.scores = la.scores;
+        pp.rp = la.rp;
+        pp.stream = st;
+        int rc2 = praline_launch_pipe_keep(pp, a16, a.nr16, a.nterm16, pl.d_bnd2.p, (float *)pl.d_tb.p, pl.d_end_cells.p,
+                                           pl.d_pipe_analytic4.p);
+        if (rc2 != PRALINE_OK) return fail(rc2, "no kept-state pipeline instance for nr=%d nterm=%d", a.nr16, a.nterm16);
+        Trace2Args ta;
+        ta.slot_off = pl.d_slot_off.p;
+        ta.paths = pl.d_paths.p;
+        ta.path_start = pl.d_path_start.p;
+        ta.path_rows = pl.d_path_rows.p;
+        LaunchArgs lb = la;
+        lb.tasks = pl.d_pipe_tasks.p;
+        lb.n_tasks = (unsigned)pl.pipe.tasks.size();
+        lb.lane_one = pl.d_pipe_lane_one.p;
+        lb.lane_pair = pl.d_pipe_lane_pair.p;
+        lb.tb = (uint4 *)pl.d_tb.p;
+        lb.bnd = pl.d_bnd2.p;
+        rc2 = praline_launch_tb2_backward(lb, a16, ta, a.nr16, a.nterm16, false, false, 2, pl.d_pipe_analytic4.p);
+        if (rc2 != PRALINE_OK) return fail(rc2, "no two-pass backward instance for nr=%d nterm=%d", a.nr16, a.nterm16);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(pl.ev1, st));
+        return PRALINE_OK;
+    }
     // ---- two passes (dp_trace2.hip.h) for plans too large for chain mode: a flag-free forward fill that keeps the
     // strip boundary columns and (M, U, L) of every 32nd row, then k_trace_recompute rebuilds the flags of only the
     // 32 x 32 blocks each path crosses.  PRALINE_TB_TWOPASS=0 keeps the single pass.
@@ -2298,6 +2382,11 @@ extern "C" int praline_plan_kernel_resources(const praline_plan *plan, int32_t *
     *vgprs = *lds_bytes = *waves_per_simd = 0;
     if (!plan->pipe.ok || plan->last_mode < 0) return PRALINE_OK;   // (reported for the pipeline workgroups only)
     int v = 0, l = 0;
+    if (plan->want_paths) {
+        // (path plans: the pipeline is the forward fill of global runs only)
+        if (plan->last_mode != PRALINE_MODE_GLOBAL || plan->last_kernel.compare(0, 9, "k_dp_pipe") != 0) return PRALINE_OK;
+        RC(praline_pipe_keep_attrs(plan->arena->nr16, plan->arena->nterm16, &v, &l));
+    } else
     RC(praline_pipe_attrs(plan->arena->nr16, plan->arena->nterm16, plan->last_mode, &v, &l));
     *vgprs = v;
     *lds_bytes = l;
