@@ -70,7 +70,6 @@ struct PipeKeep {
     char *st = nullptr;        // kept column being written: this lane's float4 of the row this step stores
     f4n *ckpt = nullptr;       // this strip's checkpoint blocks (+ lane)
     float snap_m = 0.0f, snap_u = 0.0f;
-    bool st_lane = false;      // upper half of a strip that has a strip to its right
 };
 #ifndef PRALINE_PIPE_ABLATE
 #define PRALINE_PIPE_ABLATE 0   // timing experiments only (results invalid): 1 no half select, 2 four more MFMAs per step
@@ -154,7 +153,7 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
                                           float (&Hs)[17], float (&Uc)[16], float &dH, float &hd_x, float &l_x,
                                           float &best_run, float &col_run, float &out_best, float &out_rowmax, float &out_colmax,
                                           float &out_corner, float go, float ge, int cidx, bool last_owner, int xb, int L2,
-                                          PipeKeep *ks = nullptr)
+                                          PipeKeep *ks = nullptr, bool ck_near = false)
 {
     static_assert(NR == 2 && (NTERM == 2 || NTERM == 3), "k_dp_pipe is built for the 128-byte operand rows of float-profile arenas");
     static_assert(KEEP == 0 || (!LOCAL && !SEMI), "the kept-state forward fill serves global alignments");
@@ -162,7 +161,19 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
     // every memory operation of this wave but the three youngest has completed: its pieces of the rows read below (issued
     // >= 4 steps ago; a block DMA / store or the A-tile fetch among the youngest only makes the wait stricter), then
     // the barrier: the other waves' pieces too, and the previous step's boundary hand-off
-    PRALINE_VMCNT(3);
+    // KEEP: every step - idle steps included - issues exactly one kept-column store in front of its operand DMA, so six
+    // operations are younger than the piece issued four steps ago (vmcnt counts loads and stores together, in order: with
+    // the scores kernel's vmcnt(3) every step would wait for the stores of the last two steps to reach memory)
+    // The 12 checkpoint stores of a step (KEEP == 2, at K = 11 and at K = 0 of the next iteration - the same wave-uniform
+    // condition ck_near: row u0 = 0 mod BH) are also younger than the pieces the next steps wait for: waiting for all but 6
+    // would park the wave until those stores have reached memory (measured: +0.7 ms on C2).  Operations younger than the
+    // piece of step u - 4 when ck_near: K = 0: 2 + 2 + 14; K = 1, 2: 2 + 14 + 14 (the order varies); K = 3: 14 + 2 + 2.
+    if constexpr (KEEP != 0) {
+        constexpr int WBIG = (K == 0 || K == 3) ? 18 : 30;
+        if constexpr (K <= 3) {
+            if (ck_near) PRALINE_VMCNT(WBIG); else PRALINE_VMCNT(6);
+        } else PRALINE_VMCNT(6);
+    } else PRALINE_VMCNT(3);
     PRALINE_PIPE_BARRIER();
     // boundary column of row u + 1: (H[y][x0], L[y][x0 + 1]); u = K (mod 12), so every ring slot is static
     const float2 bv = *reinterpret_cast<const float2 *>(bnd_in + ((K + 1) % 12) * 256);
@@ -258,7 +269,9 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
     if (wr_lane) *reinterpret_cast<float2 *>(bnd_out + (K % 12) * 256) = make_float2(Hs[16], lrun);
     if constexpr (KEEP != 0) {
         // (M, U, L) of the cell (u, last column): what the NEXT strip's recompute reads as its boundary column
-        if (ks->st_lane && !(PRALINE_PIPE_KEEP_ABLATE & 2)) {
+        // (the upper half of EVERY strip stores - a task's last strip into the spare column behind it - so that the count of
+        // memory operations per step is the same for all waves: see the vmcnt above)
+        if (h) {
             const f4n kv = {kM, kU, kL, 0.0f};
             __builtin_nontemporal_store(kv, reinterpret_cast<f4n *>(ks->st));
         }
@@ -302,10 +315,18 @@ __device__ __forceinline__ void pipe_step(int u, int L1, bool have_pair, int h, 
 }
 
 // a step of a wave that has no strip (lead-in, the last round's spare waves): its share of the operand stream only
-__device__ __forceinline__ void pipe_idle_step(PipeDma &dma)
+template <bool KEEP = false>
+__device__ __forceinline__ void pipe_idle_step(PipeDma &dma, char *dummy = nullptr, int h = 0)
 {
-    PRALINE_VMCNT(3);
+    if constexpr (KEEP) PRALINE_VMCNT(6); else PRALINE_VMCNT(3);
     PRALINE_PIPE_BARRIER();
+    if constexpr (KEEP) {
+        // the store a real step issues in front of its DMA (pipe_step): same operation count per step for every wave
+        if (h) {
+            const f4n z = {0.0f, 0.0f, 0.0f, 0.0f};
+            __builtin_nontemporal_store(z, reinterpret_cast<f4n *>(dummy));
+        }
+    }
     pipe_issue(dma);
 }
 
@@ -404,7 +425,10 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
     }
     PRALINE_VMCNT(0);
     PRALINE_PIPE_BARRIER();
-    for (int i = 0; i < PRALINE_PIPE_LAG * rank; ++i) pipe_idle_step(dma);
+    // KEEP: where idle steps put their store - row 0 of column 0 of the item's first task (column 0 is never read: the
+    // recompute kernel takes the analytic column; row 0 of any kept column is the dummy row of step 0)
+    char *idle_st = KEEP ? reinterpret_cast<char *>(keep_bnd + tasks[it.task0].aux_off + j) : nullptr;
+    for (int i = 0; i < PRALINE_PIPE_LAG * rank; ++i) pipe_idle_step<KEEP>(dma, idle_st, h);
 
     int cidx = 0;
     float4 aop[4], b0[4], b1[4];
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
     for (int round = 0; round < nrounds; ++round) {
         const int q = 4 * round + rank;
         if (q >= nstrips_all) {   // no strip left for this wave (last round only)
-            for (int u = 0; u < rsteps; ++u) pipe_idle_step(dma);
+            for (int u = 0; u < rsteps; ++u) pipe_idle_step<KEEP>(dma, idle_st, h);
             continue;
         }
         const WaveTask tk = tasks[it.task0 + ti];
@@ -443,7 +467,6 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
             const int64_t keep_col = (int64_t)(tk.max_l1 + PRALINE_TB2_PAD) * 32 * (int64_t)sizeof(float4);
             ks.st = reinterpret_cast<char *>(keep_bnd + tk.aux_off + j) + (int64_t)(s + 1) * keep_col;
             ks.ckpt = reinterpret_cast<f4n *>(ckpt + tk.tb_off) + (int64_t)s * pipe_keep_blocks(tk.max_l1) * PRALINE_CKPT_BLOCK_F4 + lane;
-            ks.st_lane = h == 1 && s < nstrips - 1;
         }
 
         if (!started) {
@@ -500,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_dp_pipe(Arena16Dev ar, const PipeIte
 #define PRALINE_PIPE_STEPK(KK, SN, KP, CURA, PREVA, BUSE, BFIL)                                                        \
         pipe_step<NR, NTERM, LOCAL, SEMI, KK, SN, KP>(u0 + KK, L1, have_pair, h, CURA, PREVA, BUSE, BFIL, aop, ring, stage_rd, bnd_in, \
                                                   bnd_out, wr_lane, dma, pb, lane16, Hs, Uc, dH, hd_x, l_x, best_run, col_run, \
-                                                  out_best, out_rowmax, out_colmax, out_corner, go, ge, cidx, last_owner, xb, L2, &ks)
+                                                  out_best, out_rowmax, out_colmax, out_corner, go, ge, cidx, last_owner, xb, L2, &ks, ck0)
 #define PRALINE_PIPE_STEP(KK, SN, CURA, PREVA, BUSE, BFIL) PRALINE_PIPE_STEPK(KK, SN, (KEEP ? 1 : 0), CURA, PREVA, BUSE, BFIL)
         // KEEP: the step at which a half reaches a checkpoint row (wave-uniform test, see PipeKeep)
 #define PRALINE_PIPE_STEPC(KK, SN, CK, CURA, PREVA, BUSE, BFIL)                                                        \

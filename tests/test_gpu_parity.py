@@ -322,6 +322,46 @@ def test_path_plan_execution_forms_agree(nat, bba, kind, monkeypatch):
     arena.close()
 
 
+def test_pipeline_two_pass_paths_equal_single_pass(nat, bba, monkeypatch):
+    """Global alignments with paths of float-profile plans run two passes with the PIPELINE kernel as the forward fill
+    (k_dp_pipe<..., KEEP>: kept strip columns, (M, U, L) of every PRALINE_KEEP_BH-th row, corner states) and
+    k_trace_recompute on the blocks each path crosses.  Scores, end states and paths must equal the single pass (chain mode,
+    PRALINE_TB_PIPE=0) bit for bit and the oracle's walk on the device's match scores: ragged lengths (1 .. 3 blocks of
+    rows, sequences shorter than a strip), sets with empty lanes, a pair list with holes, several items per set."""
+    rng = np.random.default_rng(41)
+    N = 70
+    lens = synth_lengths(rng, N, 90)
+    lens[:6] = [1, 2, 31, 33, 35, 37]
+    lens[6], lens[7] = 150, 73
+    profs = [synth_profile(rng, int(L))[0] for L in lens]
+    arena = nat.Arena(profs, bba["S"])
+    allp = np.array([(i, j) for i in range(N) for j in range(N) if i != j], dtype=np.int32)
+    for case, pairs in (("all ordered pairs", allp), ("with holes", allp[rng.random(len(allp)) < 0.8])):
+        out = {}
+        for form, env in (("single", {"PRALINE_TB_PIPE": "0"}), ("pipeline", {"PRALINE_TB_PIPE": "1", "PRALINE_PIPE_MIN_TASKS": "1"})):
+            for key, val in env.items():
+                monkeypatch.setenv(key, val)
+            plan = nat.Plan(arena, pairs, want_paths=True)
+            pk = plan.match_kind()
+            plan.run("global", *GAPS)
+            out[form] = (plan.scores().copy(), [p.copy() for p in plan.paths()], plan.kernel_name())
+            # a second run of the same plan (the analytic column is reused) and another gap pair (it is rewritten)
+            plan.run("global", -7.5, -0.5)
+            out[form + "2"] = (plan.scores().copy(), [p.copy() for p in plan.paths()])
+            plan.close()
+        assert out["pipeline"][2].startswith("k_dp_pipe<") and "true>" in out["pipeline"][2], out["pipeline"][2]
+        assert not out["single"][2].startswith("k_dp_pipe"), out["single"][2]
+        for a, b in (("single", "pipeline"), ("single2", "pipeline2")):
+            assert np.array_equal(bits(out[a][0]), bits(out[b][0])), (case, a)
+            assert all(np.array_equal(x, y) for x, y in zip(out[a][1], out[b][1])), (case, a)
+        for k in range(0, len(pairs), 97):
+            i, j = pairs[k]
+            s_or, p_or = oracle_dp_on_m("global", arena.match_scores(i, j, pk), GAPS, None)
+            assert out["pipeline"][0][k] == np.float32(s_or), (case, i, j)
+            assert np.array_equal(out["pipeline"][1][k], p_or), (case, i, j)
+    arena.close()
+
+
 def test_batch_waterman_eggert_masks(nat, bba):
     """LocalMasterSlaveAligner's inner calls (praline/component/preprofile.py:227-267)."""
     d = load_golden("preprofile.npz")
