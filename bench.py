@@ -244,7 +244,7 @@ def main():
 
     arena = native.Arena(profs, S)
     plan = native.Plan(arena, my_pairs)
-    # two score buffers: step k + 1 computes into the other one while step k's slice is still being gathered
+    # two score buffers: step k + 1 computes into the other one while step k's slice is still being gathered / copied out
     d_slices = [torch.zeros(slice_len, dtype=torch.float32, device="cuda") for _ in range(2)]
     gathered = [None, None]
     d_slice = d_slices[0]
@@ -253,23 +253,38 @@ def main():
     if dist is not None:
         d_src = torch.as_tensor(src, device="cuda")
         d_dst = torch.as_tensor(dst, device="cuda")
-        d_ordered = torch.zeros(len(pairs), dtype=torch.float32, device="cuda")
+        d_ordered = [torch.zeros(len(pairs), dtype=torch.float32, device="cuda") for _ in range(2)]
     lib_stream = torch.cuda.ExternalStream(native.stream_handle())
+    # the metric's wall time runs from the submission to the scores in HOST memory - every step ends with an
+    # asynchronous copy of the stage's score list (this rank's slice on one GPU, the gathered and re-ordered list on
+    # several) into page-locked host memory on a second stream, under the next step's kernel (C2: 130 KB)
+    copy_stream = torch.cuda.Stream()
+    n_out = len(pairs) if dist is not None else slice_len
+    h_scores = [torch.empty(n_out, dtype=torch.float32, pin_memory=True) for _ in range(2)]
 
     def step(k):
         buf = d_slices[k & 1]
         if gathered[k & 1] is not None:
-            lib_stream.wait_event(gathered[k & 1])   # the gather that last read this buffer has finished
+            lib_stream.wait_event(gathered[k & 1])   # the gather / copy that last read this buffer has finished
         arena.premultiply()
         plan.run(args.mode, GAP_OPEN, GAP_EXTEND, d_scores=buf.data_ptr())
         if dist is not None:
             # the exchange step: all ranks obtain every score slice (RCCL all-gather over xGMI)
             cur = torch.cuda.current_stream()
             cur.wait_stream(lib_stream)
+            if gathered[k & 1] is not None:
+                cur.wait_event(gathered[k & 1])      # (the ordered list of step k - 2 has left for the host)
             dist.all_gather_into_tensor(d_all, buf)
-            d_ordered[d_dst] = d_all[d_src]   # back into the reference's pair order (tree.py:142-145)
+            d_ordered[k & 1][d_dst] = d_all[d_src]   # back into the reference's pair order (tree.py:142-145)
+            copy_stream.wait_stream(cur)
+            src_t = d_ordered[k & 1]
+        else:
+            copy_stream.wait_stream(lib_stream)
+            src_t = buf
+        with torch.cuda.stream(copy_stream):
+            h_scores[k & 1].copy_(src_t, non_blocking=True)
             gathered[k & 1] = torch.cuda.Event()
-            gathered[k & 1].record(cur)
+            gathered[k & 1].record(copy_stream)
 
     def fence():
         if dist is not None:
@@ -293,11 +308,18 @@ def main():
 
     if dist is not None:
         # untimed sanity check of the exchange: this rank's slice sits at its pairs' positions of the gathered list
-        last = d_slices[(args.warmup + args.steps - 1) & 1]
-        if not (torch.equal(d_ordered[torch.as_tensor(my_idx, device="cuda")], last[:len(my_idx)])
-                and bool(torch.isfinite(d_ordered).all())):
+        kl = (args.warmup + args.steps - 1) & 1
+        last = d_slices[kl]
+        if not (torch.equal(d_ordered[kl][torch.as_tensor(my_idx, device="cuda")], last[:len(my_idx)])
+                and bool(torch.isfinite(d_ordered[kl]).all())
+                and torch.equal(h_scores[kl], d_ordered[kl].cpu())):
             raise SystemExit("bench.py: the gathered score list does not hold this rank's slice at its pairs' positions")
 
+    if dist is None:
+        # untimed: the host copy of the last step holds what the kernel wrote
+        kl = (args.warmup + args.steps - 1) & 1
+        if not (torch.equal(h_scores[kl], d_slices[kl].cpu()) and bool(torch.isfinite(h_scores[kl][:len(my_idx)]).all())):
+            raise SystemExit("bench.py: the host copy of the scores differs from the device buffer")
     # separate untimed pass: average DP-kernel duration over a few launches (HIP events on the library's stream)
     kms = []
     for _ in range(5):
@@ -363,6 +385,9 @@ def main():
         # arithmetic type of the DP; float-profile match scores come from f16 hi/lo MFMAs with fp32 accumulation
         # (roofline.mfma.dtype), the fp32-chain figure is variants.f32_chain_gcups
         "dtype": "f32", "data": "synthetic",
+        # a step = pre-multiply + DP kernel over all pairs (inputs resident in HBM) + the score list copied to page-locked
+        # host memory (asynchronously, under the next step); kernel-only: roofline.kernel_ms
+        "scores_to_host": True,
         "config": {"workload": "%s: %s, all %d pairs%s, %s, %s, gaps -11/-1, score-only" % (
                        wl["name"], wl["desc"], len(pairs), " split over %d ranks" % world if world > 1 else "",
                        args.mode, wl["matrix"]),

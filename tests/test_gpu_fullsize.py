@@ -285,6 +285,51 @@ def test_c4_rank_share_full_size(nat, bba, monkeypatch):
         nat.set_match_mode(None)
 
 
+@pytest.mark.parametrize("kind", ["float", "onehot"])
+def test_c4_eight_column_shards_equal_one_plan(nat, bba, kind):
+    """BASELINE config 4 split as `bench.py --gpus 8` splits it, short of the RCCL call: the eight column shards
+    (allpairs.shard_columns) run one after the other on this GPU, their score slices are padded and lined up rank by rank as
+    the all-gather lines them up, `out[dst] = gathered[src]` (allpairs.gather_maps) puts them back into the reference's
+    row-major pair order (tree.py:105-129,142-145) - and the result equals, bit for bit, ONE plan over all 8 386 560 pairs.
+    Float profiles (k_dp_pipe on every shard and on the whole list) and plain sequences (the lookup kernel)."""
+    from praline_amd import allpairs
+    rng = np.random.default_rng(4)
+    N = 4096
+    lens = synth_lengths(rng, N, 400)
+    pairs = allpairs.enumerate_pairs(N)
+    if kind == "float":
+        profs = [synth_profile(rng, int(L))[0] for L in lens]
+    else:
+        profs = [one_hot(rng.integers(0, 20, int(L)), 27) for L in lens]
+    arena = nat.Arena(profs, bba["S"])
+    del profs
+    shards = allpairs.shard_columns(lens, pairs, 8)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(len(pairs)))      # a partition of the pair list
+    cells = lens[pairs[:, 0]].astype(np.int64) * lens[pairs[:, 1]]
+    loads = np.array([cells[ix].sum() for ix in shards], dtype=np.float64)
+    assert loads.max() / loads.mean() < 1.01                                        # balanced by DP cells
+    src, dst, shard_len = allpairs.gather_maps(shards)
+    gathered = np.full(8 * shard_len, np.nan, dtype=np.float32)
+    kernels = set()
+    for r, ix in enumerate(shards):
+        plan = nat.Plan(arena, pairs[ix])
+        plan.run("global", GO, GE)
+        gathered[r * shard_len:r * shard_len + len(ix)] = plan.scores()
+        kernels.add(plan.kernel_name())
+        plan.close()
+    ordered = np.empty(len(pairs), dtype=np.float32)
+    ordered[dst] = gathered[src]
+    plan = nat.Plan(arena, pairs)
+    plan.run("global", GO, GE)
+    whole = plan.scores().copy()
+    kernels.add(plan.kernel_name())
+    plan.close()
+    arena.close()
+    assert np.isfinite(whole).all()
+    assert np.array_equal(bits(ordered), bits(whole)), kernels
+    assert all(("k_dp_pipe" in k) == (kind == "float") for k in kernels), kernels
+
+
 def test_c5_long_dna_full_size(nat):
     """BASELINE config 4 at its stated size: 512 nucleotide seqs ~5 kb, ALL 130 816 pairs (3.3e12 cells) in global,
     local and semiglobal_both mode; exact against the oracle on 24 sampled pairs per mode; symmetry of the scores under

@@ -336,7 +336,9 @@ def test_pipeline_two_pass_paths_equal_single_pass(nat, bba, monkeypatch):
     profs = [synth_profile(rng, int(L))[0] for L in lens]
     arena = nat.Arena(profs, bba["S"])
     allp = np.array([(i, j) for i in range(N) for j in range(N) if i != j], dtype=np.int32)
-    for case, pairs in (("all ordered pairs", allp), ("with holes", allp[rng.random(len(allp)) < 0.8])):
+    # (a few holes only: lists that leave the sets of 32 sequences one much emptier than the per-column tasks would be keep
+    # the task schedule - sched.cpp, build_pipe_schedule)
+    for case, pairs in (("all ordered pairs", allp), ("with holes", allp[rng.random(len(allp)) < 0.97])):
         out = {}
         for form, env in (("single", {"PRALINE_TB_PIPE": "0"}), ("pipeline", {"PRALINE_TB_PIPE": "1", "PRALINE_PIPE_MIN_TASKS": "1"})):
             for key, val in env.items():

@@ -224,10 +224,10 @@ def exact_path_score(path, p1, p2, S, mode, L1, L2):
 
 
 def test_c2_float_profile_alignments_vs_reference_order(nat, bba):
-    """BASELINE C2's own float profiles (256 seqs ~400 aa, seed 2), 2 048 sampled pairs x 5 modes with paths, checked
-    against the oracle on the REFERENCE-order match scores:
-      * ref mode: every score bit-identical and every path identical to the reference's;
-      * default (matrix-pipe) mode: every score within 1e-5 relative; a path may differ only where the choice is a tie
+    """BASELINE C2's own float profiles (256 seqs ~400 aa, seed 2) x 5 modes with paths, checked against the oracle on the
+    REFERENCE-order match scores:
+      * ref mode, ALL 32 640 pairs: every score bit-identical and every path identical to the reference's;
+      * default (matrix-pipe) mode, 2 048 sampled pairs: every score within 1e-5 relative; a path may differ only where the choice is a tie
         up to float32 rounding - each differing path's score in EXACT rational arithmetic is within 1e-5 relative of
         the reference path's exact score.  The mismatch statistics are written to gpurun_out/ for profiles/."""
     rng = np.random.default_rng(2)
@@ -242,19 +242,28 @@ def test_c2_float_profile_alignments_vs_reference_order(nat, bba):
     row_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
     sc_ref, paths_ref = orc.batch_align(MODES, cat, row_off, lens, S, pairs, GO, GE, threads=host_threads())
 
+    # ref mode: ALL 32 640 pairs x 5 modes = 163 200 alignments (in chunks: the oracle's paths of a chunk are a few hundred
+    # MB), every score bit for bit and every path row for row
     nat.set_match_mode("ref")
+    n_strict = 0
     try:
         arena = nat.Arena(profs, S)
-        strict = run_device(nat, arena, pairs, MODES)
+        for c0 in range(0, len(allp), 8192):
+            chunk = allp[c0:c0 + 8192]
+            sc_c, paths_c = orc.batch_align(MODES, cat, row_off, lens, S, chunk, GO, GE, threads=host_threads())
+            strict = run_device(nat, arena, chunk, MODES)
+            for q, mode in enumerate(MODES):
+                sc, paths, kind = strict[mode]
+                assert kind == 2
+                assert np.array_equal(bits(sc), bits(sc_c[:, q])), (mode, c0)
+                bad = [k for k in range(len(chunk)) if not np.array_equal(paths[k], paths_c[k][q])]
+                assert not bad, (mode, c0, len(bad), chunk[bad[:3]].tolist())
+                n_strict += len(chunk)
+            del strict, sc_c, paths_c
         arena.close()
     finally:
         nat.set_match_mode(None)
-    for q, mode in enumerate(MODES):
-        sc, paths, kind = strict[mode]
-        assert kind == 2
-        assert np.array_equal(bits(sc), bits(sc_ref[:, q])), mode
-        bad = [k for k in range(len(pairs)) if not np.array_equal(paths[k], paths_ref[k][q])]
-        assert not bad, (mode, len(bad), pairs[bad[:3]].tolist())
+    assert n_strict == len(allp) * len(MODES)
 
     arena = nat.Arena(profs, S)
     fast = run_device(nat, arena, pairs, MODES)
@@ -281,7 +290,8 @@ def test_c2_float_profile_alignments_vs_reference_order(nat, bba):
                                 "max_rel_score_diff": float(rel.max())}
     stats["paths_differing_total"] = int(sum(v["paths_differing"] for v in stats["modes"].values()))
     stats["max_rel_score_diff"] = worst_rel
-    stats["ref_mode"] = "all %d scores bit-identical, all paths identical" % (len(pairs) * len(MODES))
+    stats["ref_mode"] = "all %d alignments of the WHOLE workload (%d pairs x %d modes): scores bit-identical, paths identical" % (
+        n_strict, len(allp), len(MODES))
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
