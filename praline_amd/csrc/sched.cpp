@@ -12,8 +12,103 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
+#include <chrono>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 
 namespace {
+
+// Host threads of the scheduler's passes over a large pair list (the counting and scatter loops are independent per slice
+// of the list).  Small lists stay on the calling thread; PRALINE_SCHED_THREADS overrides (1: serial).
+int sched_threads(int64_t n_pairs)
+{
+    static int cached = -1;
+    if (cached < 0) {
+        int hw = (int)std::thread::hardware_concurrency();
+        if (const char *env = getenv("PRALINE_SCHED_THREADS")) hw = atoi(env);
+        cached = std::max(1, std::min(16, hw));
+    }
+    return n_pairs < (1 << 16) ? 1 : cached;
+}
+
+// A small persistent pool (created on first use, lives as long as the library): a pass over the pair list is a few
+// hundred microseconds of work per thread, which spawning threads per pass would eat.  One caller at a time (the library is
+// for one host thread per device; praline_sched_prepare may run beside it on another thread: the mutex serialises them).
+class SchedPool {
+public:
+    static SchedPool &get() { static SchedPool p; return p; }
+    void run(int nt, const std::function<void(int, int)> &fn)
+    {
+        std::lock_guard<std::mutex> whole(one_caller_);
+        ensure(nt - 1);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn; job_nt_ = nt; pending_ = nt - 1; ++gen_;
+        }
+        cv_.notify_all();
+        fn(0, nt);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    ~SchedPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    void ensure(int n)
+    {
+        while ((int)th_.size() < n) {
+            const int id = (int)th_.size() + 1;
+            uint64_t seen;
+            { std::lock_guard<std::mutex> lk(m_); seen = gen_; }
+            th_.emplace_back([this, id, seen]() mutable {
+                for (;;) {
+                    const std::function<void(int, int)> *job = nullptr;
+                    int nt = 0;
+                    {
+                        std::unique_lock<std::mutex> lk(m_);
+                        cv_.wait(lk, [&] { return gen_ != seen; });
+                        seen = gen_;
+                        if (stop_) return;
+                        job = job_; nt = job_nt_;
+                    }
+                    if (job && id < nt) {
+                        (*job)(id, nt);
+                        std::lock_guard<std::mutex> lk(m_);
+                        if (--pending_ == 0) done_.notify_one();
+                    }
+                }
+            });
+        }
+    }
+    std::mutex one_caller_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(int, int)> *job_ = nullptr;
+    int job_nt_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+template <class F> void run_threads(int nt, F &&fn)   // fn(thread, n_threads)
+{
+    if (nt <= 1) { fn(0, 1); return; }
+    const std::function<void(int, int)> f = [&fn](int t, int n) { fn(t, n); };
+    SchedPool::get().run(nt, f);
+}
+
+inline void slice_of(int64_t n, int t, int nt, int64_t &lo, int64_t &hi)
+{
+    lo = n * t / nt;
+    hi = n * (t + 1) / nt;
+}
+
 
 struct HalfTask {
     int32_t two;
@@ -38,42 +133,85 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
     // counting sorts, least significant key first - by length (descending), then by sequence two.  (A comparison sort of
     // the whole list cost 15 of the 19 ms of a 261 632-pair plan, per-group std::stable_sort still 40 of the 98 ms of
     // C3's 1 047 552 pairs; this is linear.)
+    const int nt = sched_threads(n_pairs);
     std::vector<int64_t> order((size_t)n_pairs);
+    int32_t max_two = -1, max_len = 0;
     {
-        int32_t max_two = -1, max_len = 0;
-        for (int64_t i = 0; i < n_pairs; ++i) {
-            max_two = std::max(max_two, pairs[2 * i + 1]);
-            max_len = std::max(max_len, lens[pairs[2 * i]]);
-        }
+        std::vector<int32_t> mt((size_t)nt, -1), ml((size_t)nt, 0);
+        run_threads(nt, [&](int t, int n) {
+            int64_t lo, hi;
+            slice_of(n_pairs, t, n, lo, hi);
+            int32_t a = -1, b = 0;
+            for (int64_t i = lo; i < hi; ++i) { a = std::max(a, pairs[2 * i + 1]); b = std::max(b, lens[pairs[2 * i]]); }
+            mt[(size_t)t] = a; ml[(size_t)t] = b;
+        });
+        for (int t = 0; t < nt; ++t) { max_two = std::max(max_two, mt[(size_t)t]); max_len = std::max(max_len, ml[(size_t)t]); }
+    }
+    // a stable counting sort whose passes run per slice of the input: thread t's share of bucket b starts after the shares
+    // of the threads before it, so equal keys keep their input order whatever the number of threads
+    auto counting_sort = [&](int64_t n_buckets, auto key_of, auto item_of, auto put) {
+        std::vector<std::vector<int64_t>> cnt((size_t)nt);
+        run_threads(nt, [&](int t, int n) {
+            int64_t lo, hi;
+            slice_of(n_pairs, t, n, lo, hi);
+            std::vector<int64_t> &c = cnt[(size_t)t];
+            c.assign((size_t)n_buckets, 0);
+            for (int64_t q = lo; q < hi; ++q) ++c[(size_t)key_of(item_of(q))];
+        });
+        int64_t run = 0;
+        for (int64_t b = 0; b < n_buckets; ++b)
+            for (int t = 0; t < nt; ++t) { const int64_t c = cnt[(size_t)t][(size_t)b]; cnt[(size_t)t][(size_t)b] = run; run += c; }
+        run_threads(nt, [&](int t, int n) {
+            int64_t lo, hi;
+            slice_of(n_pairs, t, n, lo, hi);
+            std::vector<int64_t> &c = cnt[(size_t)t];
+            for (int64_t q = lo; q < hi; ++q) { const int64_t i = item_of(q); put(c[(size_t)key_of(i)]++, i); }
+        });
+    };
+    {
         std::vector<int32_t> by_len((size_t)n_pairs);
-        {
-            // bucket b = max_len - len: longer first
-            std::vector<int64_t> start((size_t)max_len + 2, 0);
-            for (int64_t i = 0; i < n_pairs; ++i) ++start[(size_t)(max_len - lens[pairs[2 * i]]) + 1];
-            for (size_t t = 1; t < start.size(); ++t) start[t] += start[t - 1];
-            for (int64_t i = 0; i < n_pairs; ++i) by_len[(size_t)start[(size_t)(max_len - lens[pairs[2 * i]])]++] = (int32_t)i;
-        }
-        std::vector<int64_t> start((size_t)max_two + 2, 0);
-        for (int64_t i = 0; i < n_pairs; ++i) ++start[(size_t)pairs[2 * i + 1] + 1];
-        for (size_t t = 1; t < start.size(); ++t) start[t] += start[t - 1];
-        for (int64_t q = 0; q < n_pairs; ++q) {
-            const int64_t i = by_len[(size_t)q];
-            order[(size_t)start[(size_t)pairs[2 * i + 1]]++] = i;
-        }
+        // bucket b = max_len - len: longer first
+        counting_sort((int64_t)max_len + 1, [&](int64_t i) { return (int64_t)(max_len - lens[pairs[2 * i]]); },
+                      [&](int64_t q) { return q; }, [&](int64_t at, int64_t i) { by_len[(size_t)at] = (int32_t)i; });
+        counting_sort((int64_t)max_two + 1, [&](int64_t i) { return (int64_t)pairs[2 * i + 1]; },
+                      [&](int64_t q) { return (int64_t)by_len[(size_t)q]; }, [&](int64_t at, int64_t i) { order[(size_t)at] = i; });
     }
-    std::vector<HalfTask> halves;
-    for (int64_t i = 0; i < n_pairs;) {
-        const int32_t two = pairs[2 * order[i] + 1];
-        HalfTask h = empty_half(two);
-        int n = 0;
-        while (i < n_pairs && n < 32 && pairs[2 * order[i] + 1] == two) {
-            h.one[n] = pairs[2 * order[i]];
-            h.pair[n] = (int32_t)order[i];
-            h.max_l1 = std::max(h.max_l1, lens[h.one[n]]);
-            ++n; ++i;
-        }
-        halves.push_back(h);
+    // half tasks: every sequence two's run of `order` in pieces of 32, the columns cut on several threads
+    std::vector<int64_t> col_start;      // first position in `order` of every run of equal sequence two, and the end
+    {
+        std::vector<std::vector<int64_t>> part((size_t)nt);
+        run_threads(nt, [&](int t, int n) {
+            int64_t lo, hi;
+            slice_of(n_pairs, t, n, lo, hi);
+            for (int64_t q = lo; q < hi; ++q)
+                if (q == 0 || pairs[2 * order[(size_t)q] + 1] != pairs[2 * order[(size_t)q - 1] + 1]) part[(size_t)t].push_back(q);
+        });
+        for (const std::vector<int64_t> &v : part) col_start.insert(col_start.end(), v.begin(), v.end());
+        col_start.push_back(n_pairs);
     }
+    const int64_t n_cols = (int64_t)col_start.size() - 1;
+    std::vector<int64_t> half0((size_t)n_cols + 1, 0);
+    for (int64_t c = 0; c < n_cols; ++c) half0[(size_t)c + 1] = half0[(size_t)c] + (col_start[(size_t)c + 1] - col_start[(size_t)c] + 31) / 32;
+    std::vector<HalfTask> halves((size_t)half0[(size_t)n_cols]);
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of(n_cols, t, n, lo, hi);
+        for (int64_t c = lo; c < hi; ++c) {
+            int64_t i = col_start[(size_t)c];
+            const int64_t end = col_start[(size_t)c + 1];
+            const int32_t two = pairs[2 * order[(size_t)i] + 1];
+            for (int64_t hix = half0[(size_t)c]; i < end; ++hix) {
+                HalfTask h = empty_half(two);
+                int k = 0;
+                for (; i < end && k < 32; ++i, ++k) {
+                    h.one[k] = pairs[2 * order[(size_t)i]];
+                    h.pair[k] = (int32_t)order[(size_t)i];
+                    h.max_l1 = std::max(h.max_l1, lens[h.one[k]]);
+                }
+                halves[(size_t)hix] = h;
+            }
+        }
+    });
     // longest work first; equal-shaped halves end up adjacent (paired into one wave when TP = 2).  Sort indices, not
     // the 264-byte structs.
     std::vector<int32_t> idx(halves.size());
@@ -442,8 +580,18 @@ std::vector<int64_t> xcd_group_order(int64_t n0, int G)
 
 void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, const SchedOptions &opt, Schedule &out)
 {
+    const bool timing = getenv("PRALINE_SCHED_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sched] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     std::vector<HalfTask> halves = cut_half_tasks(lens, n_pairs, pairs);
+    mark("half tasks");
     place_on_xcds(halves, opt.xcd_group);
+    mark("xcd placement");
 
     out.split = opt.split_layout;
     int tp = halves.size() >= 4096 ? 2 : 1;
@@ -461,35 +609,44 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
     out.loc.assign((size_t)n_pairs, PairLoc());
     out.tb_elems.assign(n_tasks, 0);
     out.aux_elems.assign(n_tasks, 0);
+    const int nt = sched_threads(n_pairs);
+    run_threads(nt, [&](int th, int n) {
+        int64_t lo, hi;
+        slice_of((int64_t)n_tasks, th, n, lo, hi);
+        for (size_t t = (size_t)lo; t < (size_t)hi; ++t) {
+            WaveTask &wt = out.tasks[t];
+            wt.two[0] = wt.two[1] = -1;
+            wt.max_l1 = 0;
+            wt.nstrips = 0;
+            for (int hh = 0; hh < tp; ++hh) {
+                const size_t hi2 = t * tp + hh;
+                if (hi2 >= halves.size()) break;
+                const HalfTask &h = halves[hi2];
+                wt.two[hh] = h.two;
+                wt.max_l1 = std::max(wt.max_l1, h.max_l1);
+                wt.nstrips = std::max(wt.nstrips, (lens[h.two] + 31) / 32);
+                for (int q = 0; q < 32; ++q) {
+                    out.lane_one[t * lanes + hh * 32 + q] = h.one[q];
+                    out.lane_pair[t * lanes + hh * 32 + q] = h.pair[q];
+                    if (h.pair[q] >= 0) { out.loc[h.pair[q]].task = (int32_t)t; out.loc[h.pair[q]].lane = hh * 32 + q; }
+                }
+            }
+            wt.tb_off = 0;
+            wt.aux_off = 0;
+            // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]
+            out.tb_elems[t] = out.split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
+            out.aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * (out.split ? 32 : 64);
+        }
+    });
     int64_t bnd = 0;
     for (size_t t = 0; t < n_tasks; ++t) {
         WaveTask &wt = out.tasks[t];
-        wt.two[0] = wt.two[1] = -1;
-        wt.max_l1 = 0;
-        wt.nstrips = 0;
-        for (int hh = 0; hh < tp; ++hh) {
-            const size_t hi = t * tp + hh;
-            if (hi >= halves.size()) break;
-            const HalfTask &h = halves[hi];
-            wt.two[hh] = h.two;
-            wt.max_l1 = std::max(wt.max_l1, h.max_l1);
-            wt.nstrips = std::max(wt.nstrips, (lens[h.two] + 31) / 32);
-            for (int q = 0; q < 32; ++q) {
-                out.lane_one[t * lanes + hh * 32 + q] = h.one[q];
-                out.lane_pair[t * lanes + hh * 32 + q] = h.pair[q];
-                if (h.pair[q] >= 0) { out.loc[h.pair[q]].task = (int32_t)t; out.loc[h.pair[q]].lane = hh * 32 + q; }
-            }
-        }
         wt.bnd_off = bnd;
         // strip-boundary rows: the 12x unrolled loops of the split kernels read ahead
         bnd += out.split ? (int64_t)(wt.max_l1 + 24) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
-        wt.tb_off = 0;
-        wt.aux_off = 0;
-        // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]
-        out.tb_elems[t] = out.split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
-        out.aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * (out.split ? 32 : 64);
     }
     out.bnd_elems = bnd;
+    mark("tasks");
 
     out.wg.clear();
     out.wg_singles.clear();
@@ -499,16 +656,38 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
         if (out.wg.empty()) out.wg_singles = four_singles(out.tasks);
     }
 
+    mark("workgroup lists");
+    // path slots (capacity l1 + l2 + 2 rows per pair) and the cell count: a prefix sum in two passes over slices
     out.slot_off.assign((size_t)n_pairs, 0);
     int64_t cap = 0, cells = 0;
-    for (int64_t p = 0; p < n_pairs; ++p) {
-        const int64_t l1 = lens[pairs[2 * p]], l2 = lens[pairs[2 * p + 1]];
-        out.slot_off[p] = cap;
-        cap += l1 + l2 + 2;
-        cells += l1 * l2;
+    {
+        std::vector<int64_t> pcap((size_t)nt, 0), pcells((size_t)nt, 0);
+        run_threads(nt, [&](int th, int n) {
+            int64_t lo, hi;
+            slice_of(n_pairs, th, n, lo, hi);
+            int64_t c = 0, ce = 0;
+            for (int64_t p = lo; p < hi; ++p) {
+                const int64_t l1 = lens[pairs[2 * p]], l2 = lens[pairs[2 * p + 1]];
+                out.slot_off[(size_t)p] = c;
+                c += l1 + l2 + 2;
+                ce += l1 * l2;
+            }
+            pcap[(size_t)th] = c; pcells[(size_t)th] = ce;
+        });
+        std::vector<int64_t> base((size_t)nt, 0);
+        for (int t = 0; t < nt; ++t) { base[(size_t)t] = cap; cap += pcap[(size_t)t]; cells += pcells[(size_t)t]; }
+        if (nt > 1)
+            run_threads(nt, [&](int th, int n) {
+                int64_t lo, hi;
+                slice_of(n_pairs, th, n, lo, hi);
+                const int64_t b = base[(size_t)th];
+                if (b == 0) return;
+                for (int64_t p = lo; p < hi; ++p) out.slot_off[(size_t)p] += b;
+            });
     }
     out.path_cap = cap;
     out.cells = cells;
+    mark("path slots");
 }
 
 // ---- pipeline workgroups (k_dp_pipe) ---------------------------------------------------------------------------
@@ -530,11 +709,194 @@ struct PipeList { int32_t set; int32_t rsteps; std::vector<int32_t> task; };   /
 
 }  // namespace
 
-void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, const PipeOptions &opt,
-                         PipeSchedule &out)
+namespace {
+
+struct ScratchTask { int32_t two, set, nstrips; int32_t pair[32]; };
+
+// Step 1 of build_pipe_schedule - sets of 32 sequences one per block of sequences two, one task per (set, sequence two)
+// that holds a pair - in passes over the pair list that are independent per slice of it (no pair-index permutation, no
+// random gathers through one: at 8.4 M pairs the permutation version spent 0.3 s in cache misses):
+//   a. pairs per sequence two -> the distinct sequences two, their block and place in it;
+//   b. which sequences one occur in each block (a byte table [block][sequence]);
+//   c. per block: its sequences one by descending length, cut into sets of 32 -> position of every sequence in its block;
+//   d. pairs per (block, sequence two, set) slot -> the tasks, numbered by (sequence two, set);
+//   e. every pair into its lane of its task.
+// The lists (one per set: its tasks by ascending sequence two) and set_one come out exactly as the serial version's.
+// Returns false when the byte table would be too large (the caller takes the serial version); dup: the same pair twice.
+bool pipe_front_sliced(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int B, int nt,
+                       std::vector<ScratchTask> &st, std::vector<PipeList> &lists, std::vector<int32_t> &set_one,
+                       int64_t &old_tasks, bool &dup)
 {
-    out = PipeSchedule();
-    if (n_pairs <= 0 || n_seqs <= 0) return;
+    dup = false;
+    old_tasks = 0;
+    const bool timing = getenv("PRALINE_SCHED_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sched] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    // a.
+    std::vector<int32_t> cnt((size_t)n_seqs, 0);
+    {
+        std::vector<std::vector<int32_t>> part((size_t)nt);
+        run_threads(nt, [&](int t, int n) {
+            int64_t lo, hi;
+            slice_of(n_pairs, t, n, lo, hi);
+            std::vector<int32_t> &h = part[(size_t)t];
+            h.assign((size_t)n_seqs, 0);
+            for (int64_t i = lo; i < hi; ++i) ++h[(size_t)pairs[2 * i + 1]];
+        });
+        for (const std::vector<int32_t> &h : part)
+            for (int64_t q = 0; q < n_seqs; ++q) cnt[(size_t)q] += h[(size_t)q];
+    }
+    std::vector<int32_t> twos, block_of((size_t)n_seqs, -1), place_of((size_t)n_seqs, 0);
+    for (int64_t t = 0; t < n_seqs; ++t)
+        if (cnt[(size_t)t] > 0) {
+            block_of[(size_t)t] = (int32_t)(twos.size() / (size_t)B);
+            place_of[(size_t)t] = (int32_t)(twos.size() % (size_t)B);
+            twos.push_back((int32_t)t);
+            old_tasks += (cnt[(size_t)t] + 31) / 32;
+        }
+    const int64_t n_blocks = ((int64_t)twos.size() + B - 1) / B;
+    if (n_blocks * n_seqs > ((int64_t)16 << 20)) return false;
+    mark("a. pairs per sequence two");
+    // b.
+    std::vector<uint8_t> member((size_t)(n_blocks * n_seqs), 0);
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of(n_pairs, t, n, lo, hi);
+        for (int64_t i = lo; i < hi; ++i) {
+            uint8_t &m = member[(size_t)((int64_t)block_of[(size_t)pairs[2 * i + 1]] * n_seqs + pairs[2 * i])];
+            if (!m) m = 1;   // (benign race: every writer stores 1)
+        }
+    });
+    mark("b. membership");
+    // c.  (one global order by descending length serves every block: a block's sequences one are its members in that order)
+    std::vector<int32_t> by_len((size_t)n_seqs);
+    std::iota(by_len.begin(), by_len.end(), 0);
+    std::sort(by_len.begin(), by_len.end(), [&](int32_t x, int32_t y) { return lens[x] != lens[y] ? lens[x] > lens[y] : x < y; });
+    std::vector<std::vector<int32_t>> uni((size_t)n_blocks);
+    std::vector<int32_t> pos((size_t)(n_blocks * n_seqs), -1);
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of(n_blocks, t, n, lo, hi);
+        for (int64_t b = lo; b < hi; ++b) {
+            std::vector<int32_t> &u = uni[(size_t)b];
+            const uint8_t *m = member.data() + b * n_seqs;
+            int32_t *pb = pos.data() + b * n_seqs;
+            for (int64_t q = 0; q < n_seqs; ++q) {
+                const int32_t sq = by_len[(size_t)q];
+                if (m[sq]) { pb[sq] = (int32_t)u.size(); u.push_back(sq); }
+            }
+        }
+    });
+    // slots: (block b, set g, lane, place of the sequence two) -> tmp[tbase[b] + (g * 32 + lane) * n_twos(b) + place]; for a
+    // fixed sequence one (= lane) consecutive sequences two of a block are consecutive words: an all-pairs list in
+    // row-major order writes them one after the other
+    std::vector<int64_t> set0((size_t)n_blocks + 1, 0), tbase((size_t)n_blocks + 1, 0);
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        const int64_t nsets = ((int64_t)uni[(size_t)b].size() + 31) / 32;
+        const int64_t n_twos = std::min<int64_t>(B, (int64_t)twos.size() - b * B);
+        set0[(size_t)b + 1] = set0[(size_t)b] + nsets;
+        tbase[(size_t)b + 1] = tbase[(size_t)b] + nsets * 32 * n_twos;
+    }
+    const int64_t n_sets = set0[(size_t)n_blocks];
+    set_one.assign((size_t)n_sets * 32, -1);
+    lists.assign((size_t)n_sets, PipeList());
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        const std::vector<int32_t> &u = uni[(size_t)b];
+        std::copy(u.begin(), u.end(), set_one.begin() + set0[(size_t)b] * 32);
+        for (int64_t g = 0; g < set0[(size_t)b + 1] - set0[(size_t)b]; ++g) {
+            lists[(size_t)(set0[(size_t)b] + g)].set = (int32_t)(set0[(size_t)b] + g);
+            lists[(size_t)(set0[(size_t)b] + g)].rsteps = pipe_rsteps(lens[u[(size_t)g * 32]]);
+        }
+    }
+    mark("c. sets");
+    // d.  every pair into its word
+    // (uninitialised: the threads that fill it touch its pages first)
+    const int64_t n_tmp = tbase[(size_t)n_blocks];
+    std::unique_ptr<int32_t[]> tmp_mem(new int32_t[(size_t)std::max<int64_t>(n_tmp, 1)]);
+    int32_t *tmp = tmp_mem.get();
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of(n_tmp, t, n, lo, hi);
+        std::fill(tmp + lo, tmp + hi, -1);
+    });
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of(n_pairs, t, n, lo, hi);
+        for (int64_t i = lo; i < hi; ++i) {
+            const int32_t one = pairs[2 * i], two = pairs[2 * i + 1];
+            const int64_t bq = block_of[(size_t)two];
+            const int64_t n_twos = std::min<int64_t>(B, (int64_t)twos.size() - bq * B);
+            tmp[(size_t)(tbase[(size_t)bq] + (int64_t)pos[(size_t)(bq * n_seqs + one)] * n_twos + place_of[(size_t)two])] = (int32_t)i;
+        }
+    });
+    mark("d. pairs into lanes");
+    // e.  tasks: the (set, sequence two) columns that hold a pair, numbered block by block, set by set, by sequence two
+    std::vector<int64_t> task0((size_t)n_blocks + 1, 0);
+    std::vector<int64_t> filled((size_t)n_blocks, 0);
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of(n_blocks, t, n, lo, hi);
+        for (int64_t b = lo; b < hi; ++b) {
+            const int64_t nsets = set0[(size_t)b + 1] - set0[(size_t)b];
+            const int64_t n_twos = std::min<int64_t>(B, (int64_t)twos.size() - b * B);
+            int64_t nt_b = 0;
+            for (int64_t g = 0; g < nsets; ++g)
+                for (int64_t q = 0; q < n_twos; ++q) {
+                    const int32_t *w = tmp + tbase[(size_t)b] + g * 32 * n_twos + q;
+                    bool any = false;
+                    for (int l = 0; l < 32 && !any; ++l) any = w[l * n_twos] >= 0;
+                    nt_b += any;
+                }
+            task0[(size_t)b + 1] = nt_b;
+        }
+    });
+    for (int64_t b = 0; b < n_blocks; ++b) task0[(size_t)b + 1] += task0[(size_t)b];
+    st.resize((size_t)task0[(size_t)n_blocks]);
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of(n_blocks, t, n, lo, hi);
+        for (int64_t b = lo; b < hi; ++b) {
+            const int64_t nsets = set0[(size_t)b + 1] - set0[(size_t)b];
+            const int64_t n_twos = std::min<int64_t>(B, (int64_t)twos.size() - b * B);
+            int64_t tk = task0[(size_t)b], got = 0;
+            for (int64_t g = 0; g < nsets; ++g)
+                for (int64_t q = 0; q < n_twos; ++q) {
+                    const int32_t *w = tmp + tbase[(size_t)b] + g * 32 * n_twos + q;
+                    int cnt_l = 0;
+                    ScratchTask x;
+                    for (int l = 0; l < 32; ++l) { x.pair[l] = w[l * n_twos]; cnt_l += x.pair[l] >= 0; }
+                    if (!cnt_l) continue;
+                    x.two = twos[(size_t)(b * B + q)];
+                    x.set = (int32_t)(set0[(size_t)b] + g);
+                    x.nstrips = (lens[x.two] + 31) / 32;
+                    st[(size_t)tk] = x;
+                    lists[(size_t)x.set].task.push_back((int32_t)tk);   // (a set's tasks belong to one block: no other thread touches it)
+                    ++tk;
+                    got += cnt_l;
+                }
+            filled[(size_t)b] = got;
+        }
+    });
+    // (two pairs on one word - the same pair twice in the list - leave fewer filled lanes than pairs)
+    int64_t all = 0;
+    for (int64_t b = 0; b < n_blocks; ++b) all += filled[(size_t)b];
+    dup = all != n_pairs;
+    mark("e. tasks");
+    return true;
+}
+
+// the same step with one permutation of the pair list by sequence two (any list size, any number of sequences)
+void pipe_front_serial(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int B,
+                       std::vector<ScratchTask> &st, std::vector<PipeList> &lists, std::vector<int32_t> &set_one,
+                       int64_t &old_tasks, bool &dup)
+{
+    dup = false;
+    old_tasks = 0;
     // pairs by sequence two (counting sort, stable: list order inside a column)
     std::vector<int64_t> start((size_t)n_seqs + 1, 0);
     for (int64_t i = 0; i < n_pairs; ++i) ++start[(size_t)pairs[2 * i + 1] + 1];
@@ -547,14 +909,7 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
     std::vector<int32_t> twos;
     for (int64_t t = 0; t < n_seqs; ++t)
         if (start[(size_t)t + 1] > start[(size_t)t]) twos.push_back((int32_t)t);
-
-    struct ScratchTask { int32_t two, set, nstrips; int32_t pair[32]; };
-    std::vector<ScratchTask> st;
-    std::vector<PipeList> lists;
-    std::vector<int32_t> set_one;
     std::vector<int32_t> pos_of((size_t)n_seqs, -1), stamp((size_t)n_seqs, -1);
-    const int B = std::max(1, opt.block_twos);
-    int64_t old_tasks = 0;   // what the per-column schedule would need
     for (size_t b0 = 0; b0 < twos.size(); b0 += (size_t)B) {
         const size_t b1 = std::min(twos.size(), b0 + (size_t)B);
         std::vector<int32_t> uni;
@@ -594,11 +949,40 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
                     lists[list0 + g].task.push_back(task_of[g]);
                 }
                 int32_t &slot = st[(size_t)task_of[g]].pair[pos % 32];
-                if (slot >= 0) return;   // the same pair twice in the list: not for this layout
+                if (slot >= 0) { dup = true; return; }   // the same pair twice in the list: not for this layout
                 slot = (int32_t)pi;
             }
         }
     }
+}
+
+}  // namespace
+
+void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, const PipeOptions &opt,
+                         PipeSchedule &out)
+{
+    out = PipeSchedule();
+    if (n_pairs <= 0 || n_seqs <= 0) return;
+    std::vector<ScratchTask> st;
+    std::vector<PipeList> lists;
+    std::vector<int32_t> set_one;
+    const int B = std::max(1, opt.block_twos);
+    int64_t old_tasks = 0;   // what the per-column schedule would need
+    bool dup = false;
+    const int nt = sched_threads(n_pairs);
+    if (opt.serial_front || !pipe_front_sliced(lens, n_seqs, n_pairs, pairs, B, nt, st, lists, set_one, old_tasks, dup)) {
+        st.clear(); lists.clear(); set_one.clear();
+        pipe_front_serial(lens, n_seqs, n_pairs, pairs, B, st, lists, set_one, old_tasks, dup);
+    }
+    const bool timing = getenv("PRALINE_SCHED_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sched] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    if (dup) return;
     if (st.empty() || lens == nullptr) return;
     for (const ScratchTask &t : st)
         if (t.nstrips <= 0) return;   // empty sequence two
@@ -653,6 +1037,7 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
         }
         return n;
     };
+    mark("f. lists sorted");
     auto item_cost = [&](const Cut &c) {
         int64_t q = 0;
         for (int32_t t : c.task) q += st[(size_t)t].nstrips;
@@ -687,6 +1072,7 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
             cut_count(INT64_MAX / 8, k, share, &cuts);
         }
     }
+    mark("g. items cut");
     // launch order: longest first; when everything is resident at once (two workgroups per CU: launch positions b and
     // b + 256 share a CU), the longest share their CUs with the shortest.  (Measured and dropped: keeping the items of one
     // list on one XCD - positions of equal b % 8 - so that its L2 serves their common operand rows: C2 1.90 -> 2.06 ms.)
@@ -701,39 +1087,54 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
         order.swap(snake);
     }
 
+    mark("h. launch order");
     out.set_one.swap(set_one);
-    out.tasks.reserve(st.size());
-    out.lane_pair.reserve(st.size() * 32);
-    int64_t bnd = 0;
-    for (int32_t c : order) {
-        const PipeList &l = lists[(size_t)cuts[(size_t)c].list];
-        PipeItem it;
-        it.set = l.set;
-        it.task0 = (int32_t)out.tasks.size();
-        it.ntasks = (int32_t)cuts[(size_t)c].task.size();
-        it.nstrips = 0;
-        it.rsteps = l.rsteps;
-        for (int32_t tsk : cuts[(size_t)c].task) {
-            const ScratchTask &t = st[(size_t)tsk];
-            WaveTask wt;
-            wt.two[0] = t.two; wt.two[1] = -1;
-            wt.max_l1 = lens[out.set_one[(size_t)l.set * 32]];
-            wt.nstrips = t.nstrips;
-            wt.bnd_off = 0; wt.tb_off = 0; wt.aux_off = 0;
-            out.tasks.push_back(wt);
-            for (int q = 0; q < 32; ++q) {
-                out.lane_pair.push_back(t.pair[q]);
-                out.lanes_used += t.pair[q] >= 0;
-            }
-            it.nstrips += t.nstrips;
+    // items in launch order: task ranges and boundary offsets by prefix sums, then the tasks' records on several threads
+    out.items.resize(order.size());
+    {
+        int64_t t0 = 0, bnd = 0;
+        for (size_t k = 0; k < order.size(); ++k) {
+            const Cut &cut = cuts[(size_t)order[k]];
+            const PipeList &l = lists[(size_t)cut.list];
+            PipeItem &it = out.items[k];
+            it.set = l.set;
+            it.task0 = (int32_t)t0;
+            it.ntasks = (int32_t)cut.task.size();
+            it.nstrips = 0;
+            it.rsteps = l.rsteps;
+            for (int32_t tsk : cut.task) it.nstrips += st[(size_t)tsk].nstrips;
+            it.nrounds = (it.nstrips + 3) / 4;
+            it.bnd_off = bnd;
+            bnd += (int64_t)(it.rsteps + 16) * 32;
+            out.steps += 4 * (int64_t)it.nrounds * it.rsteps;
+            t0 += it.ntasks;
         }
-        it.nrounds = (it.nstrips + 3) / 4;
-        it.bnd_off = bnd;
-        bnd += (int64_t)(it.rsteps + 16) * 32;
-        out.steps += 4 * (int64_t)it.nrounds * it.rsteps;
-        out.items.push_back(it);
+        out.bnd_elems = bnd;
+        out.tasks.resize((size_t)t0);
+        out.lane_pair.resize((size_t)t0 * 32);
     }
-    out.bnd_elems = bnd;
+    std::vector<int64_t> used((size_t)nt, 0);
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of((int64_t)order.size(), t, n, lo, hi);
+        for (int64_t k = lo; k < hi; ++k) {
+            const Cut &cut = cuts[(size_t)order[(size_t)k]];
+            const PipeItem &it = out.items[(size_t)k];
+            const int32_t max_l1 = lens[out.set_one[(size_t)it.set * 32]];
+            for (size_t q = 0; q < cut.task.size(); ++q) {
+                const ScratchTask &x = st[(size_t)cut.task[q]];
+                WaveTask &wt = out.tasks[(size_t)it.task0 + q];
+                wt.two[0] = x.two; wt.two[1] = -1;
+                wt.max_l1 = max_l1;
+                wt.nstrips = x.nstrips;
+                wt.bnd_off = 0; wt.tb_off = 0; wt.aux_off = 0;
+                int32_t *lp = out.lane_pair.data() + ((size_t)it.task0 + q) * 32;
+                for (int l = 0; l < 32; ++l) { lp[l] = x.pair[l]; used[(size_t)t] += x.pair[l] >= 0; }
+            }
+        }
+    });
+    for (int64_t v : used) out.lanes_used += v;
+    mark("i. output");
     out.ok = true;
 }
 
@@ -744,6 +1145,7 @@ extern "C" int praline_sched_pipe_test(const int32_t *lens, int64_t n_seqs, int6
                                        int32_t *set_one /* [cap_sets][32] */)
 {
     PipeOptions opt;
+    if (block_twos < 0) { opt.serial_front = true; block_twos = -block_twos; }   // (tests: the one-thread permutation version)
     if (block_twos > 0) opt.block_twos = block_twos;
     if (wg_slots > 0) opt.wg_slots = wg_slots;
     PipeSchedule s;

@@ -48,6 +48,7 @@ struct PipeOptions {
                                           // passes 32 for plans that are resident at once and 16 for larger ones
     int64_t wg_slots = 512;               // resident workgroups (256 CUs x 2)
     double min_fill = 0.55;               // give up below this share of occupied lanes
+    bool serial_front = false;            // tests: build the sets and tasks with the one-thread permutation version
 };
 void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, const PipeOptions &opt,
                          PipeSchedule &out);
