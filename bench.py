@@ -242,8 +242,12 @@ def main():
     my_pairs = pairs[my_idx]
     src, dst, slice_len = gather_maps(shards)
 
+    t_a = time.perf_counter()
     arena = native.Arena(profs, S)
+    t_b = time.perf_counter()
     plan = native.Plan(arena, my_pairs)
+    t_c = time.perf_counter()
+    rank_arena_ms, rank_plan_ms = (t_b - t_a) * 1e3, (t_c - t_b) * 1e3   # host side of the stage (outside the timed steps)
     # two score buffers: step k + 1 computes into the other one while step k's slice is still being gathered / copied out
     d_slices = [torch.zeros(slice_len, dtype=torch.float32, device="cuda") for _ in range(2)]
     gathered = [None, None]
@@ -327,6 +331,27 @@ def main():
         kms.append(plan.kernel_ms())
     kernel_ms_avg = float(np.mean(kms))
     kernel_name = plan.kernel_name()
+    # per rank: pairs, DP cells, plan creation, DP kernel, exchange (all-gather + reorder, CUDA events around 5 untimed
+    # repeats) - the driver computes scaling from `value`; this makes a curve readable (who waits for whom)
+    gather_ms = None
+    if dist is not None:
+        cur = torch.cuda.current_stream()
+        native.synchronize(); torch.cuda.synchronize(); dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for _ in range(5):
+            dist.all_gather_into_tensor(d_all, d_slice)
+            d_ordered[0][d_dst] = d_all[d_src]
+        e1.record(cur)
+        torch.cuda.synchronize()
+        gather_ms = e0.elapsed_time(e1) / 5
+    my_cells_rank = int(cells[my_idx].sum())
+    mine = {"rank": rank, "pairs": int(len(my_idx)), "cells": my_cells_rank, "arena_ms": rank_arena_ms, "plan_ms": rank_plan_ms,
+            "kernel_ms": kernel_ms_avg, "gather_ms": gather_ms, "kernel": kernel_name}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     ms_per_step = elapsed / args.steps * 1e3
     gcups = total_cells / (elapsed / args.steps) / 1e9
@@ -394,6 +419,8 @@ def main():
                    "n_seqs": n_seqs, "pairs": int(len(pairs)), "cells": total_cells,
                    "pairs_per_gpu": int(len(my_pairs)), "parallelism": "pairs sharded x%d" % world},
         "roofline": roofline,
+        "per_rank": per_rank,
+        "cell_imbalance": (max(r["cells"] for r in per_rank) / (sum(r["cells"] for r in per_rank) / len(per_rank))),
     }
 
     side = rank == 0 and world == 1 and not args.no_variants
@@ -491,7 +518,9 @@ def main():
         p3 = np.stack([i3[i3 != j3], j3[i3 != j3]], axis=1).astype(np.int32)
         c3 = int((l3[p3[:, 0]].astype(np.int64) * l3[p3[:, 1]]).sum())
         for m3 in ("global", "local", "semiglobal_both"):
+            t_b = time.perf_counter()
             pl3 = native.Plan(a3, p3, want_paths=True)
+            variants["c3_path_plan_ms"] = min(variants.get("c3_path_plan_ms", 1e9), (time.perf_counter() - t_b) * 1e3)
             variants["c3_with_paths_%s_gcups" % m3] = c3 / timed(lambda: pl3.run(m3, GAP_OPEN, GAP_EXTEND), reps=3) / 1e9
             pl3.close()
         a3.close()
@@ -502,11 +531,31 @@ def main():
         c4 = int((w4["lens"][s4[:, 0]].astype(np.int64) * w4["lens"][s4[:, 1]]).sum())
         a4 = native.Arena(w4["profs"], w4["S"])
         pl4 = native.Plan(a4, s4)
+        pl4.close()
+        # what one rank of the 8-way split pays host-to-host for its stage: arena (4096 profiles, 177 MB over PCIe, packing,
+        # pre-multiply) + plan (host scheduling on the scheduler's thread pool + uploads) + run + its score slice in host memory
+        t_a = time.perf_counter()
+        a4b = native.Arena(w4["profs"], w4["S"])
+        t_b = time.perf_counter()
+        pl4 = native.Plan(a4b, s4)
+        t_c = time.perf_counter()
+        pl4.run("global", GAP_OPEN, GAP_EXTEND)
+        sc4 = pl4.scores()
+        t_d = time.perf_counter()
+        assert np.isfinite(sc4).all()
+        variants["c4_rank_share_e2e_ms"] = (t_d - t_a) * 1e3
+        variants["c4_rank_share_arena_ms"] = (t_b - t_a) * 1e3
+        variants["c4_rank_share_plan_ms"] = (t_c - t_b) * 1e3
+        variants["c4_rank_share_run_and_scores_d2h_ms"] = (t_d - t_c) * 1e3
+        pl4.close(); a4b.close()
+        pl4 = native.Plan(a4, s4)
         variants["c4_rank_share_float_gcups"] = c4 / timed(lambda: (a4.premultiply(), pl4.run("global", GAP_OPEN, GAP_EXTEND)), reps=3) / 1e9
         variants["c4_rank_share_kernel"] = pl4.kernel_name()
         pl4.close()
         # ... and ALL of C4 on this one GPU (8 386 560 pairs, 1.34e12 cells): the like-for-like base of the N > 1 runs
+        t_b = time.perf_counter()
         pl4 = native.Plan(a4, p4)
+        variants["c4_all_pairs_plan_ms"] = (time.perf_counter() - t_b) * 1e3
         c4_all = int((w4["lens"][p4[:, 0]].astype(np.int64) * w4["lens"][p4[:, 1]]).sum())
         variants["c4_all_pairs_one_gpu_gcups"] = c4_all / timed(lambda: (a4.premultiply(), pl4.run("global", GAP_OPEN, GAP_EXTEND)), reps=2) / 1e9
         pl4.close(); a4.close()

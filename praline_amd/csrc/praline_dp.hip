@@ -1081,7 +1081,8 @@ static PipeOptions pipe_options_for(int64_t n_pairs)
 static void pipe_schedule_for(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int max_len, PipeSchedule &pipe)
 {
     int min_len = max_len;
-    for (int64_t p = 0; p < n_pairs; ++p) min_len = std::min(min_len, std::min(lens[pairs[2 * p]], lens[pairs[2 * p + 1]]));
+    (void)max_len;
+    sched_pair_stats(lens, n_seqs, n_pairs, pairs, nullptr, &min_len, nullptr);
     if (min_len >= 1) build_pipe_schedule(lens, n_seqs, n_pairs, pairs, pipe_options_for(n_pairs), pipe);
     int64_t min_tasks = 200;
     if (const char *env = getenv("PRALINE_PIPE_MIN_TASKS")) min_tasks = atoll(env);
@@ -1106,10 +1107,10 @@ extern "C" int praline_sched_prepare(int64_t n_seqs, const int32_t *lens, int64_
         if (lens[s] <= 0) return fail(PRALINE_ERR_ARG, "sequence %lld has length %d (must be >= 1)", (long long)s, lens[s]);
         max_len = std::max(max_len, lens[s]);
     }
-    for (int64_t p = 0; p < n_pairs; ++p) {
-        const int32_t o = pairs[2 * p], t = pairs[2 * p + 1];
-        if (o < 0 || o >= n_seqs || t < 0 || t >= n_seqs)
-            return fail(PRALINE_ERR_ARG, "pair %lld = (%d, %d) out of range", (long long)p, o, t);
+    {
+        int64_t bad = -1;
+        sched_pair_stats(lens, n_seqs, n_pairs, pairs, nullptr, nullptr, &bad);
+        if (bad >= 0) return fail(PRALINE_ERR_ARG, "pair %lld = (%d, %d) out of range", (long long)bad, pairs[2 * bad], pairs[2 * bad + 1]);
     }
     praline_sched *sc = new praline_sched();
     sc->lens.assign(lens, lens + n_seqs);
@@ -1158,13 +1159,17 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     PhaseTimer pt("plan_create");
     const praline_arena &a = *arena;
     bool many_rects = false;   // some pair carries more rectangles than the register-resident mask code holds
-    for (int64_t p = 0; p < n_pairs; ++p) {
-        const int32_t o = pairs[2 * p], t = pairs[2 * p + 1];
-        if (o < 0 || o >= a.n_seqs || t < 0 || t >= a.n_seqs)
-            return fail(PRALINE_ERR_ARG, "pair %lld = (%d, %d) out of range", (long long)p, o, t);
-        if (rect_off && rect_off[p + 1] < rect_off[p]) return fail(PRALINE_ERR_ARG, "rect_off is not ascending at pair %lld", (long long)p);
-        many_rects = many_rects || (rect_off && rect_off[p + 1] - rect_off[p] > PRALINE_MAX_RECTS);
+    int64_t list_cells = 0;
+    {
+        int64_t bad = -1;
+        sched_pair_stats(a.len.data(), a.n_seqs, n_pairs, pairs, &list_cells, nullptr, &bad);
+        if (bad >= 0) return fail(PRALINE_ERR_ARG, "pair %lld = (%d, %d) out of range", (long long)bad, pairs[2 * bad], pairs[2 * bad + 1]);
     }
+    if (rect_off)
+        for (int64_t p = 0; p < n_pairs; ++p) {
+            if (rect_off[p + 1] < rect_off[p]) return fail(PRALINE_ERR_ARG, "rect_off is not ascending at pair %lld", (long long)p);
+            many_rects = many_rects || rect_off[p + 1] - rect_off[p] > PRALINE_MAX_RECTS;
+        }
     praline_plan *pl = new praline_plan();
     pl->arena = arena;
     pl->n_pairs = n_pairs;
@@ -1252,7 +1257,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     if (pl->pipe.ok && !want_paths) {
         // the pipeline schedule is all a scores-only run needs: no task schedule, no per-task boundary scratch
         sch.split = opt.split_layout;
-        for (int64_t p = 0; p < n_pairs; ++p) sch.cells += (int64_t)a.len[pairs[2 * p]] * a.len[pairs[2 * p + 1]];
+        sch.cells = list_cells;
     } else {
         build_schedule(a.len.data(), n_pairs, pairs, opt, sch);
     }

@@ -9,6 +9,7 @@
 #include "sched.h"
 
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -25,13 +26,10 @@ namespace {
 // of the list).  Small lists stay on the calling thread; PRALINE_SCHED_THREADS overrides (1: serial).
 int sched_threads(int64_t n_pairs)
 {
-    static int cached = -1;
-    if (cached < 0) {
-        int hw = (int)std::thread::hardware_concurrency();
-        if (const char *env = getenv("PRALINE_SCHED_THREADS")) hw = atoi(env);
-        cached = std::max(1, std::min(16, hw));
-    }
-    return n_pairs < (1 << 16) ? 1 : cached;
+    if (n_pairs < (1 << 16)) return 1;
+    int hw = (int)std::thread::hardware_concurrency();
+    if (const char *env = getenv("PRALINE_SCHED_THREADS")) hw = atoi(env);
+    return std::max(1, std::min(16, hw));
 }
 
 // A small persistent pool (created on first use, lives as long as the library): a pass over the pair list is a few
@@ -127,13 +125,21 @@ HalfTask empty_half(int32_t two)
 }
 
 // step 1: group by sequence two, sort by len(one) descending, cut into 32-lane half tasks
-std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs)
+std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, std::vector<int32_t> &idx)
 {
     // order = pair indices by (sequence two ascending, length of sequence one descending, index ascending): two stable
     // counting sorts, least significant key first - by length (descending), then by sequence two.  (A comparison sort of
     // the whole list cost 15 of the 19 ms of a 261 632-pair plan, per-group std::stable_sort still 40 of the 98 ms of
     // C3's 1 047 552 pairs; this is linear.)
     const int nt = sched_threads(n_pairs);
+    const bool timing = getenv("PRALINE_SCHED_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sched]   %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     std::vector<int64_t> order((size_t)n_pairs);
     int32_t max_two = -1, max_len = 0;
     {
@@ -176,6 +182,7 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
         counting_sort((int64_t)max_two + 1, [&](int64_t i) { return (int64_t)pairs[2 * i + 1]; },
                       [&](int64_t q) { return (int64_t)by_len[(size_t)q]; }, [&](int64_t at, int64_t i) { order[(size_t)at] = i; });
     }
+    mark("two counting sorts");
     // half tasks: every sequence two's run of `order` in pieces of 32, the columns cut on several threads
     std::vector<int64_t> col_start;      // first position in `order` of every run of equal sequence two, and the end
     {
@@ -212,20 +219,29 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
             }
         }
     });
-    // longest work first; equal-shaped halves end up adjacent (paired into one wave when TP = 2).  Sort indices, not
-    // the 264-byte structs.
-    std::vector<int32_t> idx(halves.size());
-    std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
-        const HalfTask &x = halves[(size_t)a], &y = halves[(size_t)b];
-        const int sx = (lens[x.two] + 31) / 32, sy = (lens[y.two] + 31) / 32;
-        if (sx != sy) return sx > sy;
-        return x.max_l1 > y.max_l1;
-    });
-    std::vector<HalfTask> sorted;
-    sorted.reserve(halves.size());
-    for (int32_t i : idx) sorted.push_back(halves[(size_t)i]);
-    return sorted;
+    mark("halves cut");
+    // longest work first - by strips of the sequence two, then by the longest sequence one, ties in creation order -; equal-
+    // shaped halves end up adjacent (paired into one wave when TP = 2).  Two stable counting sorts of the INDICES (least
+    // significant key first); the 264-byte structs are gathered once, by build_schedule.
+    idx.resize(halves.size());
+    {
+        int max_l = 0, max_s = 0;
+        for (const HalfTask &h : halves) { max_l = std::max(max_l, (int)h.max_l1); max_s = std::max(max_s, (lens[h.two] + 31) / 32); }
+        std::vector<int32_t> tmp(halves.size());
+        std::vector<int64_t> start((size_t)max_l + 2, 0);
+        for (const HalfTask &h : halves) ++start[(size_t)(max_l - h.max_l1) + 1];
+        for (size_t t = 1; t < start.size(); ++t) start[t] += start[t - 1];
+        for (size_t i = 0; i < halves.size(); ++i) tmp[(size_t)start[(size_t)(max_l - halves[i].max_l1)]++] = (int32_t)i;
+        start.assign((size_t)max_s + 2, 0);
+        for (const HalfTask &h : halves) ++start[(size_t)(max_s - (lens[h.two] + 31) / 32) + 1];
+        for (size_t t = 1; t < start.size(); ++t) start[t] += start[t - 1];
+        for (size_t q = 0; q < tmp.size(); ++q) {
+            const HalfTask &h = halves[(size_t)tmp[q]];
+            idx[(size_t)start[(size_t)(max_s - (lens[h.two] + 31) / 32)]++] = tmp[q];
+        }
+    }
+    mark("halves sorted");
+    return halves;
 }
 
 // step 2: XCD-aware placement.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with a
@@ -236,16 +252,17 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
 // only affects speed, never results.  G ~ tasks / 128, i.e. ~16 group rounds per XCD (measured, float profiles,
 // GCUPS: 4 336 tasks: none 1984, G = 4 2115, 16 2393, 32 2384, 64 2314; 33 049 tasks (one rank of C4): none
 // 1674, 16 1817, 64 2242, 256 2634, 1024 2613, 4096 1677; whole length classes per XCD on C2: 30-40 % slower).
-void place_on_xcds(std::vector<HalfTask> &halves, int group)
+// (on the sorted order `idx` of the half tasks: -1 = padding block)
+void place_on_xcds(std::vector<int32_t> &idx, int group)
 {
-    if (halves.empty()) return;
-    int G = group >= 0 ? group : (int)std::min<size_t>(1024, std::max<size_t>(16, halves.size() / 128));
-    if (G <= 1 || halves.size() < (size_t)(16 * G)) return;
-    const std::vector<int64_t> src = xcd_group_order((int64_t)halves.size(), G);
-    std::vector<HalfTask> placed(src.size(), empty_half(halves.back().two));
+    if (idx.empty()) return;
+    int G = group >= 0 ? group : (int)std::min<size_t>(1024, std::max<size_t>(16, idx.size() / 128));
+    if (G <= 1 || idx.size() < (size_t)(16 * G)) return;
+    const std::vector<int64_t> src = xcd_group_order((int64_t)idx.size(), G);
+    std::vector<int32_t> placed(src.size(), -1);
     for (size_t b = 0; b < src.size(); ++b)
-        if (src[b] >= 0) placed[b] = halves[(size_t)src[b]];
-    halves.swap(placed);
+        if (src[b] >= 0) placed[b] = idx[(size_t)src[b]];
+    idx.swap(placed);
 }
 
 // step 3a: shared waves.  Every task gets W = 1, 2 or 4 waves - the smallest W that brings its per-wave cost
@@ -588,10 +605,17 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
         fprintf(stderr, "[sched] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    std::vector<HalfTask> halves = cut_half_tasks(lens, n_pairs, pairs);
+    std::vector<int32_t> order;   // launch position -> half task (-1: padding)
+    const std::vector<HalfTask> half_store = cut_half_tasks(lens, n_pairs, pairs, order);
     mark("half tasks");
-    place_on_xcds(halves, opt.xcd_group);
+    const HalfTask pad_half = empty_half(order.empty() ? -1 : half_store[(size_t)order.back()].two);
+    place_on_xcds(order, opt.xcd_group);
     mark("xcd placement");
+    struct HalfView {
+        const std::vector<HalfTask> &store; const std::vector<int32_t> &order; const HalfTask &pad;
+        size_t size() const { return order.size(); }
+        const HalfTask &operator[](size_t i) const { return order[i] >= 0 ? store[(size_t)order[i]] : pad; }
+    } halves{half_store, order, pad_half};
 
     out.split = opt.split_layout;
     int tp = halves.size() >= 4096 ? 2 : 1;
@@ -688,6 +712,40 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
     out.path_cap = cap;
     out.cells = cells;
     mark("path slots");
+}
+
+// What plan creation needs to know about a pair list before it schedules it, in one pass over slices of the list: the DP
+// cells, the shortest sequence in any pair, and the first pair with an index outside 0 .. n_seqs - 1 (-1: none).
+void sched_pair_stats(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int64_t *cells, int *min_len,
+                      int64_t *first_bad)
+{
+    const int nt = sched_threads(n_pairs);
+    std::vector<int64_t> c((size_t)nt, 0), bad((size_t)nt, -1);
+    std::vector<int> ml((size_t)nt, INT32_MAX);
+    run_threads(nt, [&](int t, int n) {
+        int64_t lo, hi;
+        slice_of(n_pairs, t, n, lo, hi);
+        int64_t cc = 0;
+        int m = INT32_MAX;
+        for (int64_t p = lo; p < hi; ++p) {
+            const int32_t o = pairs[2 * p], w = pairs[2 * p + 1];
+            if (o < 0 || o >= n_seqs || w < 0 || w >= n_seqs) { bad[(size_t)t] = p; break; }
+            const int l1 = lens[o], l2 = lens[w];
+            cc += (int64_t)l1 * l2;
+            m = std::min(m, std::min(l1, l2));
+        }
+        c[(size_t)t] = cc; ml[(size_t)t] = m;
+    });
+    int64_t cells_all = 0, fb = -1;
+    int m_all = INT32_MAX;
+    for (int t = 0; t < nt; ++t) {
+        cells_all += c[(size_t)t];
+        m_all = std::min(m_all, ml[(size_t)t]);
+        if (fb < 0 && bad[(size_t)t] >= 0) fb = bad[(size_t)t];
+    }
+    if (cells) *cells = cells_all;
+    if (min_len) *min_len = n_pairs > 0 ? m_all : 0;
+    if (first_bad) *first_bad = fb;
 }
 
 // ---- pipeline workgroups (k_dp_pipe) ---------------------------------------------------------------------------

@@ -60,3 +60,8 @@ std::vector<int64_t> xcd_group_order(int64_t n, int G);
 // lens: length of every arena sequence; pairs: int32 [n_pairs][2] = (sequence one, sequence two), validated by
 // the caller.
 void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, const SchedOptions &opt, Schedule &out);
+
+// One (threaded) pass over a pair list: DP cells, the shortest sequence of any pair, the first pair with an index outside
+// 0 .. n_seqs - 1 (-1: none; the other results are then meaningless).
+void sched_pair_stats(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int64_t *cells, int *min_len,
+                      int64_t *first_bad);

@@ -18,7 +18,8 @@ LAG = 2   # PRALINE_MW_LAG
 def sched():
     src = os.path.join(CSRC, "sched.cpp")
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", LIB], check=True, cwd=CSRC)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", src,
+                        os.path.join(CSRC, "cluster.cpp"), "-o", LIB], check=True, cwd=CSRC)
     lib = ctypes.CDLL(LIB)
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
     lib.praline_sched_test.argtypes = [vp, i64, vp, ctypes.c_int, ctypes.c_int, i64, i64, i64, vp, vp, vp, vp, vp, vp]
@@ -253,3 +254,30 @@ def test_pipe_schedule_declines_what_does_not_fit(pipe_sched):
     twice = np.concatenate([all_pairs(40), all_pairs(40)[:3]])
     ok, *_ = pipe_sched(lens[:40], twice)
     assert not ok
+
+
+def test_threaded_passes_give_the_one_thread_schedules(sched, pipe_sched, monkeypatch):
+    """Lists of 65 536 pairs and more are scheduled with their passes (counting sorts, set / task / lane assignment, task
+    records, path slots) cut into slices for a small thread pool: every schedule must come out exactly as on one thread,
+    whatever the thread count - task lists, lane assignment, workgroup descriptors, pipeline items."""
+    rng = np.random.default_rng(17)
+    n = 300
+    lens = synth_lengths(rng, n, 120)
+    ordered = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32)     # 89 700 pairs
+    shuffled = ordered.copy()
+    rng.shuffle(shuffled)
+    for pairs in (ordered, shuffled[:70000]):
+        out = {}
+        for threads in ("1", "3", "8"):
+            monkeypatch.setenv("PRALINE_SCHED_THREADS", threads)
+            out[threads] = (sched(lens, pairs, want_paths=True), sched(lens, pairs, want_paths=False), pipe_sched(lens, pairs),
+                            pipe_sched(lens, pairs, block_twos=-32))     # (negative: the one-thread permutation version of step 1)
+        for threads in ("3", "8"):
+            for a, b in zip(out["1"], out[threads]):
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), threads
+        for a, b in zip(out["1"][2], out["1"][3]):
+            assert np.array_equal(a, b)
+    monkeypatch.delenv("PRALINE_SCHED_THREADS")
+    # the same pair twice: not for the pipeline layout, in either version
+    dup = np.concatenate([ordered[:70000], ordered[123:124]])
+    assert not pipe_sched(lens, dup)[0] and not pipe_sched(lens, dup, block_twos=-32)[0]
