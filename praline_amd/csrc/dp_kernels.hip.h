@@ -927,7 +927,7 @@ __global__ __launch_bounds__(64) void k_semiglobal_end(ArenaDev ar, const WaveTa
                                                         float *__restrict__ scores, RunParams rp, int32_t task_lo,
                                                         int32_t task_hi, int layout)
 {
-    const int ls = layout ? 32 : 64;                 // lanes (pairs) per task = lane stride of the scratch
+    const int ls = layout == 2 ? 16 : (layout ? 32 : 64);   // lanes (pairs) per task = lane stride of the scratch
     const int t = task_lo + (int)((blockIdx.x * 64 + threadIdx.x) / ls);
     const int lane = (int)(threadIdx.x % ls);
     if (t >= task_hi) return;
@@ -1034,7 +1034,38 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
     }
     // traceback (praline/util/align.py:155-180)
     emit(y, x);
-    if (layout == 1) {
+    if (layout == 2) {
+        // k_dp_quad_tb planes (dp_quad.hip.h): uint2 [strip][step][64]; lane 16 q + p holds the columns 8 q + 1 .. 8 q + 8 of
+        // pair p; step ((y + 1) >> 1) + q holds the rows y = 2 (t - q) - 1 (.x) and 2 (t - q) (.y); per row: match source
+        // low | high << 8 | U-extend << 16 | L-extend << 24
+        const int64_t nsteps = PRALINE_QUAD_STEPS(tk.max_l1);
+        int guard = L1 + L2 + 2;
+        bool stopped = false;
+        while (y > 0 && x > 0 && guard-- > 0) {
+            bool masked = false;
+            for (int r = 0; r < n_rects; ++r) {
+                const int32_t *q = rl.rects + (int64_t)(r0 + r) * 4;
+                masked = masked || (y >= q[0] && y <= q[1] && x >= q[2] && x <= q[3]);
+            }
+            const int c = (x - 1) & 31, qq = c >> 3, bit = c & 7;
+            const uint2 word = my_tb2[((int64_t)((x - 1) >> 5) * nsteps + ((y + 1) >> 1) + qq) * 64 + 16 * qq];
+            const unsigned w = (y & 1) ? word.x : word.y;
+            const int code = (int)(((w >> bit) & 1u) | (((w >> (8 + bit)) & 1u) << 1));
+            const int ub = (int)((w >> (16 + bit)) & 1u), lb = (int)((w >> (24 + bit)) & 1u);
+            if (masked || (k == 0 && code == 0)) { stopped = true; break; }   // t is 0 there (cext.c:141-149 / clamp)
+            const int nk = k == 0 ? code - 1 : (k == 1 ? ub : 2 * lb);
+            y -= (k != 2);
+            x -= (k != 1);
+            k = nk;
+            emit(y, x);
+        }
+        while (!stopped && guard-- > 0) {
+            if (x == 0 && y >= 1 && k == 1 && !free_one) --y;
+            else if (y == 0 && x >= 1 && k == 2 && !free_two) --x;
+            else break;
+            emit(y, x);
+        }
+    } else if (layout == 1) {
         // k_dp_split16_tb planes: the interior walk as a short loop without a branch per state - the lanes of a wave
         // are at different cells and states, every divergent branch is paid by all of them (and a single alignment
         // pays the instruction count of one lane: ~120 instructions per step before)

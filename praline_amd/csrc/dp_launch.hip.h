@@ -67,6 +67,9 @@ int praline_launch_pipe(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int
 int praline_launch_pipe_keep(const PipeLaunch &pl, const Arena16Dev &a16, int nr, int nterm, void *keep_bnd, float *ckpt,
                              int32_t *end_cells, void *analytic4);
 int praline_pipe_keep_attrs(int nr, int nterm, int *vgprs, int *lds_bytes);
+// k_dp_quad_tb (dp_quad_instance.hip): fill with packed traceback for plain sequences, 16 pairs per task (la.lane_one /
+// lane_pair [task][16], la.bnd float4 [row][16] per task, la.tb uint2 [strip][step][64]); mask: 0, 1 (rectangles), 2 (mask words)
+int praline_launch_quad_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, bool ints, bool local, int mask);
 // two-pass alignments with paths (dp_tb2_instance.hip): flag-free forward fill, then block recompute + traceback
 struct Trace2Args {
     const int64_t *slot_off;

@@ -54,5 +54,9 @@ struct PipeItem {
 #define PRALINE_KEEP_BH 36
 #endif
 
+// k_dp_quad_tb (dp_quad.hip.h): steps per strip - two DP rows per step, quarter q of a pair's 32 strip columns runs q steps
+// behind quarter q - 1, and the loop is unrolled four steps at a time
+#define PRALINE_QUAD_STEPS(max_l1) ((((max_l1) + 1) / 2 + 4 + 3) / 4 * 4 + 4)
+
 #define PRALINE_MAX_RECTS 4   // zero rectangles per pair carried by the batched kernels
 #define PRALINE_MW_LAG 2      // 12-row iterations between consecutive ranks of a shared task

@@ -962,6 +962,7 @@ struct praline_plan {
     int mask_kind = 0;   // 0 none, 1 <= PRALINE_MAX_RECTS rectangles per pair (registers), 2 any number (k_dp_batch MASK = 2)
     int tp = 1;
     bool split = false;  // k_dp_split task layout
+    bool quad = false;   // path plan on a one-hot arena in the 16-pairs-per-task layout of k_dp_quad_tb (dp_quad.hip.h)
     std::vector<WaveTask> tasks;
     std::vector<int64_t> tb_elems;  // per task, uint4 elements
     std::vector<int64_t> aux_elems; // per task, floats
@@ -1189,7 +1190,11 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     // Waterman-Eggert iterations: rare) take the dense-match-score path with per-row column masks (k_build_zmask).
     // (The MFMA-fed k_dp_batch instance with those masks gave wrong LOCAL scores under ROCm 7.2 - codegen-sensitive,
     // not understood - so it is not used.)
-    pl->ref = match_mode() == PRALINE_MATCH_REFERENCE || a.wide || many_rects;
+    // (plain sequences: k_dp_quad_tb reads the per-row mask words itself, any number of rectangles)
+    const bool quad_ok = want_paths && a.nr16 > 0 && a.nterm16 == 1 && a.onehot && match_mode() == PRALINE_MATCH_FAST &&
+                         !(getenv("PRALINE_TB_QUAD") && getenv("PRALINE_TB_QUAD")[0] == '0') &&
+                         !(getenv("PRALINE_KERNEL") && !strcmp(getenv("PRALINE_KERNEL"), "batch"));
+    pl->ref = match_mode() == PRALINE_MATCH_REFERENCE || a.wide || (many_rects && !quad_ok);
     if (many_rects && !a.wide && match_mode() != PRALINE_MATCH_REFERENCE && getenv("PRALINE_EXP_BATCH_MASK2") && want_paths) {
         // experiment (needs a library built with -DPRALINE_EXP_BATCH_MASK2): column masks on the MFMA-fed k_dp_batch
         pl->ref = false;
@@ -1209,6 +1214,15 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         if (a.reft2_state == 1 && worst_tile <= (double)reftile_budget_bytes()) { pl->ref = false; pl->ref_tile = true; }
     }
     if (pl->ref || pl->ppg) { opt.split_layout = false; opt.tp = 1; }
+    // alignments with paths of plain sequences (exact-mode arenas with their symbol stream): k_dp_quad_tb, 16 pairs per
+    // task (PRALINE_TB_QUAD=0: the 32-pair strip kernels, as for every other arena)
+    {
+        const char *tq = getenv("PRALINE_TB_QUAD");
+        const Arena16Dev v16q = a.view16();
+        pl->quad = want_paths && !pl->ref && !pl->ref_tile && !pl->ppg && opt.split_layout && a.nr16 > 0 && a.nterm16 == 1 &&
+                   v16q.sym8 != nullptr && match_mode() == PRALINE_MATCH_FAST && !(tq && tq[0] == '0');
+        opt.quad16 = pl->quad;
+    }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
     if (const char *env = getenv("PRALINE_NO_W2")) opt.shared_waves = env[0] != '1';
     {   // score plans on one-hot arenas run the lookup instances: three waves per SIMD (168 VGPRs, 4.75 KB of LDS per wave)
@@ -1435,15 +1449,15 @@ static int launch_traceback(praline_plan &pl, const LaunchArgs &la, size_t t0, s
     const int threads = 64;
     const int64_t blocks = (pl.n_pairs + threads - 1) / threads;
     if (mode >= PRALINE_MODE_SEMIGLOBAL_BOTH) {   // end cells of the semiglobal modes, scanned per task
-        const int64_t lanes = (int64_t)(t1 - t0) * (pl.split ? 32 : 64);
+        const int64_t lanes = (int64_t)(t1 - t0) * (pl.quad ? 16 : (pl.split ? 32 : 64));
         hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar,
                            pl.d_tasks.p, pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, la.aux,
-                           pl.d_end_cells.p, la.scores, la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
+                           pl.d_end_cells.p, la.scores, la.rp, (int32_t)t0, (int32_t)t1, pl.quad ? 2 : (pl.split ? 1 : 0));
     }
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)blocks), dim3(threads), 0, st, la.ar, pl.d_tasks.p,
                        pl.d_loc.p, pl.d_pairs.p, (const uint4 *)la.tb, la.aux, la.rl, pl.d_end_cells.p,
                        la.scores, pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs,
-                       la.rp, (int32_t)t0, (int32_t)t1, pl.split ? 1 : 0);
+                       la.rp, (int32_t)t0, (int32_t)t1, pl.quad ? 2 : (pl.split ? 1 : 0));
     HIPCHK(hipGetLastError());
     return PRALINE_OK;
 }
@@ -1821,6 +1835,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         const char *lb = local ? "true" : "false";
         if (pl.ref) snprintf(kn, sizeof(kn), "k_dp_batch<2, 1, %s, %d, %d, 1>", lb, pl.want_paths ? 1 : 0, pl.mask_kind);
         else if (!pl.split) snprintf(kn, sizeof(kn), "k_dp_batch<%d, %d, %s, %d, %d, 0>", a.nstep, pl.want_paths ? 1 : pl.tp, lb, pl.want_paths ? 1 : 0, pl.mask_kind);
+        else if (pl.want_paths && pl.quad) snprintf(kn, sizeof(kn), "k_dp_quad_tb<%d, ...>", a.nr16);
         else if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // refined below (nterm, chain)
         else if (la.a16 == nullptr) snprintf(kn, sizeof(kn), "k_dp_split<%d, %s>", a.nstep, lb);
         else {
@@ -1948,7 +1963,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     size_t budget = tb_budget_bytes();
     const bool semiglobal = mode >= 2;
     const size_t tb_elem_bytes = pl.split ? sizeof(uint2) : sizeof(uint4);
-    const int lanes_per_task = pl.split ? 32 : 64;
+    const int lanes_per_task = pl.quad ? 16 : (pl.split ? 32 : 64);
     size_t t0 = 0;
     const size_t nt = pl.tasks.size();
     if (!getenv("PRALINE_TB_BUDGET_MB") && nt > 0) {
@@ -2089,7 +2104,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                 return PRALINE_OK;
             }
         }
-        const bool twopass = pl.split && la.a16 != nullptr && tpv != 0 && (tpv == 2 || (!would_chain && (local || tpv == 1)));
+        const bool twopass = pl.split && !pl.quad && la.a16 != nullptr && tpv != 0 && (tpv == 2 || (!would_chain && (local || tpv == 1)));
         if (twopass) {
             char kn[160];
             snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, %d, %s, %s, false, true>", a.nr16, tb_nterm, local ? "true" : "false",
@@ -2264,7 +2279,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     // chunks of plans whose packed traceback exceeds the scratch budget (long sequences: 32 640 alignments of ~1000 x
     // ~1000 were 96 ms in task mode, three chunks of 380 waves each).  Chain chunks share one set of boundary columns
     // and flags: they all run on the main stream.
-    bool chain_chunks = pl.split && la.a16 != nullptr && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
+    bool chain_chunks = pl.split && !pl.quad && la.a16 != nullptr && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
     {
         int64_t need_bnd = 0;
         size_t need_flags = 0;
@@ -2339,6 +2354,9 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                                    la.lane_pair, pl.d_chain_cand.p, (int)nc, max_strips + 1, pl.d_end_cells.p, la.scores);
             }
             la.bnd = pl.d_bnd.p;
+        } else if (pl.quad) {
+            int rc = praline_launch_quad_tb(la, a16, a.nr16, tb_nterm == 1, local, pl.mask_kind);
+            if (rc != PRALINE_OK) return fail(rc, "no k_dp_quad_tb instance for nr=%d", a.nr16);
         } else if (pl.split) {
             int rc = praline_launch_split16_tb(la, a16, a.nr16, tb_nterm, local, pl.has_rects);
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16_tb instance for nr=%d nterm=%d", a.nr16, tb_nterm);

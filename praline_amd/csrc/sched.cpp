@@ -125,7 +125,7 @@ HalfTask empty_half(int32_t two)
 }
 
 // step 1: group by sequence two, sort by len(one) descending, cut into 32-lane half tasks
-std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, std::vector<int32_t> &idx)
+std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, std::vector<int32_t> &idx, int width = 32)
 {
     // order = pair indices by (sequence two ascending, length of sequence one descending, index ascending): two stable
     // counting sorts, least significant key first - by length (descending), then by sequence two.  (A comparison sort of
@@ -198,7 +198,7 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
     }
     const int64_t n_cols = (int64_t)col_start.size() - 1;
     std::vector<int64_t> half0((size_t)n_cols + 1, 0);
-    for (int64_t c = 0; c < n_cols; ++c) half0[(size_t)c + 1] = half0[(size_t)c] + (col_start[(size_t)c + 1] - col_start[(size_t)c] + 31) / 32;
+    for (int64_t c = 0; c < n_cols; ++c) half0[(size_t)c + 1] = half0[(size_t)c] + (col_start[(size_t)c + 1] - col_start[(size_t)c] + width - 1) / width;
     std::vector<HalfTask> halves((size_t)half0[(size_t)n_cols]);
     run_threads(nt, [&](int t, int n) {
         int64_t lo, hi;
@@ -210,7 +210,7 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
             for (int64_t hix = half0[(size_t)c]; i < end; ++hix) {
                 HalfTask h = empty_half(two);
                 int k = 0;
-                for (; i < end && k < 32; ++i, ++k) {
+                for (; i < end && k < width; ++i, ++k) {
                     h.one[k] = pairs[2 * order[(size_t)i]];
                     h.pair[k] = (int32_t)order[(size_t)i];
                     h.max_l1 = std::max(h.max_l1, lens[h.one[k]]);
@@ -606,7 +606,10 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
         t_prev = now;
     };
     std::vector<int32_t> order;   // launch position -> half task (-1: padding)
-    const std::vector<HalfTask> half_store = cut_half_tasks(lens, n_pairs, pairs, order);
+    // quad16 (path plans of one-hot arenas, k_dp_quad_tb): 16 pairs per task
+    const bool quad = opt.quad16 && opt.split_layout && opt.want_paths;
+    const int width = quad ? 16 : 32;
+    const std::vector<HalfTask> half_store = cut_half_tasks(lens, n_pairs, pairs, order, width);
     mark("half tasks");
     const HalfTask pad_half = empty_half(order.empty() ? -1 : half_store[(size_t)order.back()].two);
     place_on_xcds(order, opt.xcd_group);
@@ -623,7 +626,7 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
     if (opt.tp == 1 || (opt.tp == 2 && !opt.want_paths)) tp = opt.tp;
     if (out.split) tp = 1;       // split-strip kernels: both halves of the wave work on the same 32 pairs
     out.tp = tp;
-    out.lanes_per_task = out.split ? 32 : 64;
+    out.lanes_per_task = quad ? 16 : (out.split ? 32 : 64);
     const int lanes = out.lanes_per_task;
 
     const size_t n_tasks = (halves.size() + tp - 1) / tp;
@@ -649,7 +652,7 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
                 wt.two[hh] = h.two;
                 wt.max_l1 = std::max(wt.max_l1, h.max_l1);
                 wt.nstrips = std::max(wt.nstrips, (lens[h.two] + 31) / 32);
-                for (int q = 0; q < 32; ++q) {
+                for (int q = 0; q < width; ++q) {
                     out.lane_one[t * lanes + hh * 32 + q] = h.one[q];
                     out.lane_pair[t * lanes + hh * 32 + q] = h.pair[q];
                     if (h.pair[q] >= 0) { out.loc[h.pair[q]].task = (int32_t)t; out.loc[h.pair[q]].lane = hh * 32 + q; }
@@ -658,8 +661,10 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
             wt.tb_off = 0;
             wt.aux_off = 0;
             // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]
-            out.tb_elems[t] = out.split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64;
-            out.aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * (out.split ? 32 : 64);
+            // (quad16: uint2 [nstrips][PRALINE_QUAD_STEPS(max_l1)][64] - two rows of 8 columns per lane and step)
+            out.tb_elems[t] = quad ? (int64_t)wt.nstrips * PRALINE_QUAD_STEPS(wt.max_l1) * 64
+                                   : (out.split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64);
+            out.aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * lanes;
         }
     });
     int64_t bnd = 0;
@@ -667,7 +672,7 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
         WaveTask &wt = out.tasks[t];
         wt.bnd_off = bnd;
         // strip-boundary rows: the 12x unrolled loops of the split kernels read ahead
-        bnd += out.split ? (int64_t)(wt.max_l1 + 24) * 32 : (int64_t)(wt.max_l1 + 1) * 64;
+        bnd += quad ? (int64_t)(wt.max_l1 + 24) * 16 : (out.split ? (int64_t)(wt.max_l1 + 24) * 32 : (int64_t)(wt.max_l1 + 1) * 64);
     }
     out.bnd_elems = bnd;
     mark("tasks");
@@ -675,7 +680,7 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
     out.wg.clear();
     out.wg_singles.clear();
     // (path plans too: the forward fill of their two-pass scheme can run on the scores kernel's workgroups)
-    if (out.split && opt.shared_waves) {
+    if (out.split && opt.shared_waves && !quad) {
         out.wg = share_waves(out.tasks, opt);
         if (out.wg.empty()) out.wg_singles = four_singles(out.tasks);
     }

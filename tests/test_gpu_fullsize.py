@@ -392,8 +392,9 @@ def test_chunked_path_plans_on_two_streams(nat, monkeypatch):
     S = nucleotide_matrix()
     arena = nat.Arena(profs, S)
 
-    def run(two, budget):
+    def run(two, budget, quad="0"):
         monkeypatch.setenv("PRALINE_TB_TWOPASS", two)
+        monkeypatch.setenv("PRALINE_TB_QUAD", quad)    # "0": the strip kernels (single pass / two passes); "1": k_dp_quad_tb
         if budget:
             monkeypatch.setenv("PRALINE_TB_BUDGET_MB", budget)
         else:
@@ -407,10 +408,11 @@ def test_chunked_path_plans_on_two_streams(nat, monkeypatch):
         return res
 
     ref = run("0", "160000")                       # one chunk
-    for two, budget in (("0", None), ("2", None), ("2", "3000"), ("0", "3000"), ("2", None)):
-        res = run(two, budget)
-        assert np.array_equal(bits(res[0]), bits(ref[0])), (two, budget)
-        assert np.array_equal(res[3], ref[3]) and np.array_equal(res[2], ref[2]) and np.array_equal(res[1], ref[1]), (two, budget)
+    for two, budget, quad in (("0", None, "0"), ("2", None, "0"), ("2", "3000", "0"), ("0", "3000", "0"), ("2", None, "0"),
+                              ("0", None, "1"), ("0", "3000", "1"), ("0", "160000", "1")):   # ... and the plans' default kernel
+        res = run(two, budget, quad)
+        assert np.array_equal(bits(res[0]), bits(ref[0])), (two, budget, quad)
+        assert np.array_equal(res[3], ref[3]) and np.array_equal(res[2], ref[2]) and np.array_equal(res[1], ref[1]), (two, budget, quad)
     rng = np.random.default_rng(7)
     for k in rng.permutation(len(pairs))[:6]:
         i, j = pairs[k]
@@ -481,6 +483,7 @@ def test_scratch_growth_between_back_to_back_path_runs(nat, monkeypatch):
         return sc, packed_rows(buf, o, r), o.copy(), r.copy()
 
     monkeypatch.setenv("PRALINE_TB_BUDGET_MB", "160000")
+    monkeypatch.setenv("PRALINE_TB_QUAD", "0")     # (the subject is the strip kernels' two scratch layouts)
     ref = []
     for sub in subsets:
         for two in ("0", "2"):

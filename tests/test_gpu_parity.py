@@ -291,10 +291,13 @@ def test_path_plan_execution_forms_agree(nat, bba, kind, monkeypatch):
     pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j], dtype=np.int32)
     rects = [[(2, 20, 3, 30)] if k % 4 == 0 else ([(5, 9, 1, 4), (30, 60, 40, 64)] if k % 4 == 1 else [])
              for k in range(len(pairs))]
-    forms = {"chain": {}, "tasks": {"PRALINE_NO_CHAIN": "1"}, "chunks": {"PRALINE_NO_CHAIN": "1", "PRALINE_TB_BUDGET_MB": "1"}}
+    # (plain sequences: the strip kernels with PRALINE_TB_QUAD=0; "quad" = k_dp_quad_tb, their default, whole and in chunks)
+    forms = {"chain": {"PRALINE_TB_QUAD": "0"}, "tasks": {"PRALINE_TB_QUAD": "0", "PRALINE_NO_CHAIN": "1"},
+             "chunks": {"PRALINE_TB_QUAD": "0", "PRALINE_NO_CHAIN": "1", "PRALINE_TB_BUDGET_MB": "1"},
+             "quad": {}, "quad chunks": {"PRALINE_TB_BUDGET_MB": "1"}}
     out = {}
     for form, env in forms.items():
-        for key in ("PRALINE_NO_CHAIN", "PRALINE_TB_BUDGET_MB"):
+        for key in ("PRALINE_NO_CHAIN", "PRALINE_TB_BUDGET_MB", "PRALINE_TB_QUAD"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
@@ -306,7 +309,7 @@ def test_path_plan_execution_forms_agree(nat, bba, kind, monkeypatch):
             plan.close()
     for mode in MODES:
         ref_sc, ref_paths = out[("chain", mode)]
-        for form in ("tasks", "chunks"):
+        for form in ("tasks", "chunks", "quad", "quad chunks"):
             sc, paths = out[(form, mode)]
             assert np.array_equal(bits(sc), bits(ref_sc)), (form, mode)
             assert all(np.array_equal(a, b) for a, b in zip(paths, ref_paths)), (form, mode)
@@ -361,6 +364,56 @@ def test_pipeline_two_pass_paths_equal_single_pass(nat, bba, monkeypatch):
             s_or, p_or = oracle_dp_on_m("global", arena.match_scores(i, j, pk), GAPS, None)
             assert out["pipeline"][0][k] == np.float32(s_or), (case, i, j)
             assert np.array_equal(out["pipeline"][1][k], p_or), (case, i, j)
+    arena.close()
+
+
+def test_quad_layout_paths_equal_the_strip_kernels(nat, bba, monkeypatch):
+    """Alignments with paths of plain sequences run k_dp_quad_tb (dp_quad.hip.h: 16 pairs per wave, four lanes of 8 columns
+    per pair, two rows per step, its own traceback planes).  Scores, end cells and paths must equal the strip kernels'
+    (PRALINE_TB_QUAD=0) bit for bit and the oracle's: five modes; zero rectangles held in registers (<= 4 per pair) and as
+    per-row mask words (more: the strip kernels hand those plans to k_dp_batch); gap scores on and off the integer grid
+    (tie flags from the predecessor states / from the candidate sums); lengths around the 8-column quarters, the 32-column
+    strips and the two-row steps; sequences of one residue; lanes without a pair."""
+    rng = np.random.default_rng(97)
+    lens = np.array([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 129, 47, 250, 71, 5, 24, 25, 96, 97, 40, 41, 200, 13, 58, 77, 12, 35, 36])
+    profs = [one_hot(rng.integers(0, 20, int(L)), 27) for L in lens]
+    N = len(lens)
+    arena = nat.Arena(profs, bba["S"])
+    allp = np.array([(i, j) for i in range(N) for j in range(N)], dtype=np.int32)
+    pairs = allp[rng.random(len(allp)) < 0.6]
+
+    def rect_lists(nmax):
+        out = []
+        for (i, j) in pairs:
+            rl = []
+            for _ in range(int(rng.integers(0, nmax + 1))):
+                y0, x0 = int(rng.integers(1, lens[i] + 1)), int(rng.integers(1, lens[j] + 1))
+                rl.append((y0, min(int(lens[i]), y0 + int(rng.integers(0, 12))), x0, min(int(lens[j]), x0 + int(rng.integers(0, 30)))))
+            out.append(rl)
+        return out
+    cases = [(mode, gaps, None) for mode in MODES for gaps in (GAPS, (-10.3, -1.7))]
+    cases += [("local", GAPS, rect_lists(3)), ("local", (-7.5, -0.5), rect_lists(9)), ("global", GAPS, rect_lists(6))]
+    for mode, gaps, rects in cases:
+        res = {}
+        for quad in ("0", "1"):
+            monkeypatch.setenv("PRALINE_TB_QUAD", quad)
+            plan = nat.Plan(arena, pairs, want_paths=True, rects=rects)
+            pk = plan.match_kind()
+            plan.run(mode, *gaps)
+            res[quad] = (plan.scores().copy(), [p.copy() for p in plan.paths()], plan.kernel_name())
+            plan.close()
+        assert res["1"][2].startswith("k_dp_quad_tb") and not res["0"][2].startswith("k_dp_quad_tb"), (res["0"][2], res["1"][2])
+        assert np.array_equal(bits(res["0"][0]), bits(res["1"][0])), (mode, gaps, rects is not None)
+        bad = [k for k in range(len(pairs)) if not np.array_equal(res["0"][1][k], res["1"][1][k])]
+        assert not bad, (mode, gaps, rects is not None, pairs[bad[:3]].tolist())
+        for k in range(0, len(pairs), 41):
+            i, j = pairs[k]
+            zero = None
+            if rects is not None and rects[k]:
+                zero = [(y, x) for (y0, y1, x0, x1) in rects[k] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
+            s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(int(i), int(j), pk), gaps, zero)
+            assert res["1"][0][k] == np.float32(s_or), (mode, gaps, i, j)
+            assert np.array_equal(res["1"][1][k], p_or), (mode, gaps, i, j)
     arena.close()
 
 
@@ -704,6 +757,7 @@ def test_two_pass_paths_equal_single_pass(nat, bba, monkeypatch):
     checkpoints + k_trace_recompute, dp_trace2.hip.h) against the single pass and the oracle: identical scores and
     paths in every mode, with Waterman-Eggert rectangles, one-hot (one-hot table operands) and float profiles, lengths
     that straddle the 32-row blocks and the 32-column strips."""
+    monkeypatch.setenv("PRALINE_TB_QUAD", "0")   # (plain sequences would take k_dp_quad_tb: this test is about the strip kernels' two passes)
     rng = np.random.default_rng(41)
     lens = [1, 31, 32, 33, 64, 65, 97, 130, 200, 47]
     sets = {"onehot": [one_hot(rng.integers(0, 20, L), 27) for L in lens],

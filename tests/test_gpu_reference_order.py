@@ -375,7 +375,10 @@ def test_many_rectangles_per_pair(nat, bba):
             plan.close()
             for k, (i, j) in enumerate(pairs):
                 zero = [(y, x) for (y0, y1, x0, x1) in rects[k] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
-                assert kind == 2 or os.environ.get("PRALINE_EXP_BATCH_MASK2")   # such plans evaluate the match scores in the reference's order (experiment builds: scripts/exp_mask2.py)
+                # float profiles: such plans evaluate the match scores in the reference's order (experiment builds:
+                # scripts/exp_mask2.py); plain sequences stay on k_dp_quad_tb, which reads per-row mask words (integer
+                # scoring: the same scores in any order)
+                assert kind == 2 or profs is onehots or os.environ.get("PRALINE_EXP_BATCH_MASK2")
                 s_or, p_or = orc.pairwise_align(mode, [profs[i]], [profs[j]], [bba["S"]], (GO, GE), zero_idxs=zero or None)
                 assert sc[k] == np.float32(s_or), (mode, i, j, len(rects[k]))
                 assert np.array_equal(paths[k], p_or), (mode, i, j, len(rects[k]))
