@@ -305,6 +305,11 @@ int praline_arena_match_scores(praline_arena *arena, int32_t one, int32_t two, i
 int praline_arena_info(const praline_arena *arena, int32_t *n_active, int32_t *mfma_steps_f32,
                        int32_t *f16_ranges, int32_t *f16_terms);
 int praline_plan_match_kind(const praline_plan *plan);
+/* Who writes the match scores of this plan's runs: 0 - the fill itself (matrix pipe / lookup; no match-score matrix in
+ * memory); plans whose fill reads dense tiles: 1 - k_match_tile (reference order, <= 32 symbols, <= 8 nonzeros per row),
+ * 2 - one thread per cell (reference order, any alphabet and row density), 3 - the fp32 MFMA chain (plans made on an
+ * arena with per-position gap scores).  -1: NULL plan. */
+int praline_plan_tile_producer(const praline_plan *plan);
 
 /* Timing of the last praline_plan_run on THIS plan, measured with the plan's own HIP events on the launch
  * stream: kernel_ms = the DP kernel alone (scores-only plans) / fill + end cells + traceback (path plans). */

@@ -96,16 +96,20 @@ int praline_launch_dense(const LaunchArgs &la, const Arena16Dev &a16, bool local
 }
 
 // fill with packed traceback (task mode): the tie flags compare the candidate sums (the NTERM = 3 flavour of the step)
-int praline_launch_dense_tb(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask)
+int praline_launch_dense_tb(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask, bool ppg, bool noflags, int strip_lo,
+                            int strip_cnt)
 {
     if (a16.dense == nullptr || a16.dense_off == nullptr) return PRALINE_ERR_ARG;
+    if (ppg) return praline_launch_dense_tb_ppg(la, a16, local, mask, noflags, strip_lo, strip_cnt);
+    if (noflags && mask) return PRALINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)la.n_tasks), block(64);
-#define PRALINE_DENSE_TB(LOC, MSK)                                                                                       \
-    hipLaunchKernelGGL((k_dp_split16_tb<1, 3, LOC, MSK, false, false, 4>), grid, block, 0, la.stream, a16, la.tasks,       \
+#define PRALINE_DENSE_TB(LOC, MSK, NOF)                                                                                  \
+    hipLaunchKernelGGL((k_dp_split16_tb<1, 3, LOC, MSK, false, false, 4, false, NOF>), grid, block, 0, la.stream, a16, la.tasks, \
                        la.lane_one, la.lane_pair, (float4 *)la.bnd, (uint2 *)la.tb, la.aux, la.rl, la.scores, la.end_cells,  \
-                       la.rp, (int)la.n_tasks)
-    if (local) { if (mask) PRALINE_DENSE_TB(true, true); else PRALINE_DENSE_TB(true, false); }
-    else { if (mask) PRALINE_DENSE_TB(false, true); else PRALINE_DENSE_TB(false, false); }
+                       la.rp, (int)la.n_tasks, nullptr, 0, nullptr, 6, strip_lo, strip_cnt)
+    if (noflags) { if (local) PRALINE_DENSE_TB(true, false, true); else PRALINE_DENSE_TB(false, false, true); }
+    else if (local) { if (mask) PRALINE_DENSE_TB(true, true, false); else PRALINE_DENSE_TB(true, false, false); }
+    else { if (mask) PRALINE_DENSE_TB(false, true, false); else PRALINE_DENSE_TB(false, false, false); }
 #undef PRALINE_DENSE_TB
     return hipGetLastError() == hipSuccess ? PRALINE_OK : PRALINE_ERR_DEVICE;
 }

@@ -6,23 +6,19 @@
 //   * boundary init / end cell / traceback            praline/component/align.py:357-431,
 //                                                     praline/util/align.py:144-185,268-297
 //
-// Batched kernels (k_dp_batch): one wavefront owns up to 64 (TP=2) or 32 (TP=1) pairs.  The
-// pairs of a 32-lane half share their sequence TWO (the all-pairs and master-slave stages align
-// one sequence against many).  The DP matrix of every pair is swept in vertical strips of 32
-// columns of the shared sequence; for each DP row the wave issues NSTEP v_mfma_f32_32x32x2_f32:
-//     D[i][lane] = sum_k Q2[x0+i][k] * P1_lane[y][k]      (Q2 = P2 . S^T, the pre-multiply)
-// i.e. the 32 match scores m[y][x0..x0+31] of EVERY lane's own pair land in that lane's
-// accumulator registers (after a v_permlane32_swap exchange between the two 32-lane halves), so
-// the match-score matrix never exists in LDS or HBM.  The fp32 MFMA is an exact k-ordered fmaf
-// chain, so one-hot x integer scoring is bit-exact and float profiles differ from the
-// reference's summation order by fp32 rounding only.  The recurrence then runs on the VALU with
-// all per-column state in registers; only the strip-boundary column round-trips through HBM/L2.
+// This header holds what every translation unit shares: the device-side views, the boundary-cell formulas, the f16 hi/lo
+// operand split, and - under PRALINE_AUX_KERNELS, for praline_dp.hip alone - the non-template kernels around the fill:
+// profile packing and the S pre-multiply, the fp32-MFMA match-score tiles, the end cells of the semiglobal modes, the
+// traceback walk over the packed flag planes, the mask words of many-rectangle plans, the one-cell-per-thread match scores
+// in the reference's summation order, the merge of aligned profiles.  The batched fills themselves are in dp_split16.hip.h
+// (scores), dp_split16_tb.hip.h (with flags), dp_pipe.hip.h, dp_quad.hip.h and dp_trace2.hip.h.
 //
 // Raw kernels (k_raw_*): the reference's own buffer layout (m, g1, g2, o, t, z), one pair, a
 // single wavefront walking anti-diagonals: lane l owns column x0+l, computes row t-l at step t
 // and receives its left/diagonal neighbours from lane l-1 with __shfl_up.
 #pragma once
 #include "dp_types.h"
+#include "dp_arena16.h"   // PRALINE_DENSE_PAD
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -56,7 +52,7 @@ struct RunParams {
 struct RectList {
     const int32_t *rect_off;  // [n_pairs + 1] or nullptr
     const int32_t *rects;     // [.][4] y0,y1,x0,x1 inclusive DP coordinates
-    // plans in which some pair has more than PRALINE_MAX_RECTS rectangles (k_dp_batch MASK = 2): per pair, strip and
+    // plans in which some pair has more than PRALINE_MAX_RECTS rectangles (dense-tile instances, k_dp_quad_tb): per pair, strip and
     // DP row the 32-bit mask of the strip's zeroed columns, prepared by k_build_zmask
     const unsigned *zmask = nullptr;
     const int64_t *zm_off = nullptr;   // [n_pairs]
@@ -79,6 +75,42 @@ __device__ __forceinline__ float boundary_value_pp(int idx, const float *g, bool
     if (is_free) return 0.0f;
     const int k = idx > 0 ? idx - 1 : 0;
     return (float)((double)(idx - 1) * (double)g[2 * k + 1] + (double)g[0]);
+}
+
+// Where the per-cell match-score kernels (k_match_ref, k_match_reft, k_scores_tile_batch) write: loc == nullptr - pair p's own
+// [L1][L2] matrix at m + m_off[p]; otherwise the dense tile of the task the pair runs in (split-strip layout, dp_split16.hip.h:
+// float [strip - strip_lo][row 1 .. max_l1 (+ PRALINE_DENSE_PAD)][half][lane 0..31][16 columns] at m + dense_off[task]), just the
+// strips [strip_lo, strip_lo + strip_cnt) of it.  The columns between the end of sequence two and the end of its last strip
+// receive zeros (a local alignment must not see stale scores there); rows past a lane's own sequence are never reported.
+struct TileOut {
+    const PairLoc *loc = nullptr;      // [n_pairs]
+    const WaveTask *tasks = nullptr;   // the plan's task list
+    const int64_t *dense_off = nullptr;   // [n_tasks], float offsets
+    int strip_lo = 0, strip_cnt = 0x3fffffff;
+};
+struct TileDst {
+    float *base;    // the task's tile, at this lane's 16-column group of row 0 / strip strip_lo / half 0
+    int64_t strip_floats;
+    int x_lo, x_hi;   // the columns (0-based positions of sequence two) this launch covers: whole strips
+    __device__ __forceinline__ float *at(int y, int x) const   // y, x: 0-based positions
+    {
+        const int xr = x - x_lo;
+        return base + (int64_t)(xr >> 5) * strip_floats + (int64_t)(y + 1) * 1024 + ((xr >> 4) & 1) * 512 + (xr & 15);
+    }
+};
+__device__ __forceinline__ TileDst tile_dst(const TileOut &to, float *m, int p, int L2)
+{
+    const PairLoc pl = to.loc[p];
+    const WaveTask tk = to.tasks[pl.task];
+    TileDst d;
+    d.strip_floats = (int64_t)(tk.max_l1 + PRALINE_DENSE_PAD) * 1024;
+    d.base = m + to.dense_off[pl.task] + (int64_t)pl.lane * 16;
+    const int nstrips = (L2 + 31) >> 5;
+    const int s1 = to.strip_cnt < nstrips - to.strip_lo ? to.strip_lo + to.strip_cnt : nstrips;
+    d.x_lo = to.strip_lo * 32;
+    d.x_hi = s1 * 32;
+    if (d.x_hi < d.x_lo) d.x_hi = d.x_lo;
+    return d;
 }
 
 __device__ __forceinline__ float max3f(float a, float b, float c)
@@ -392,19 +424,31 @@ __global__ __launch_bounds__(64) void k_scores_tile(ArenaDev ar, int one, int tw
 __global__ __launch_bounds__(64) void k_scores_tile_batch(ArenaDev ar, const int32_t *__restrict__ pairs,
                                                            const int32_t *__restrict__ chunk_pairs,
                                                            const int64_t *__restrict__ m_off, int nstep, int tiles_x,
-                                                           float *__restrict__ mref)
+                                                           float *__restrict__ mref, TileOut to)
 {
     const int p = chunk_pairs[blockIdx.x];
     const int one = pairs[2 * p], two = pairs[2 * p + 1];
     const int lane = threadIdx.x;
     const int j = lane & 31, h = lane >> 5;
     const int L1 = ar.len[one], L2 = ar.len[two];
-    const int y0 = (int)(blockIdx.y / tiles_x) * 32, x0 = (int)(blockIdx.y % tiles_x) * 32;
+    const int y0 = (int)(blockIdx.y / tiles_x) * 32, x0 = (int)(blockIdx.y % tiles_x) * 32 + (to.loc ? to.strip_lo * 32 : 0);
     if (y0 >= L1 || x0 >= L2) return;
     const float *pa = ar.P + ((int64_t)ar.row_off[one] + y0 + j) * ar.KP + h * ar.KS;
     const float *qb = ar.Q + ((int64_t)ar.row_off[two] + x0 + j) * ar.KP + h * ar.KS;
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int s = 0; s < nstep; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], acc, 0, 0, 0);
+    if (to.loc != nullptr) {
+        // (x0 is a strip's first column: the block covers the strip's 32 columns, zeros past the sequence)
+        const TileDst d = tile_dst(to, mref, p, L2);
+        if (x0 >= d.x_hi) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int x = x0 + j;
+            if (y < L1) *d.at(y, x) = x < L2 ? acc[r] : 0.0f;
+        }
+        return;
+    }
     float *m = mref + m_off[p];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -416,15 +460,6 @@ __global__ __launch_bounds__(64) void k_scores_tile_batch(ArenaDev ar, const int
 
 #endif  // PRALINE_AUX_KERNELS
 
-// --------------------------------------------------------------------------------------------
-// Fused match-score + DP fill, batched.
-//   OUT = 0: scores only.  Per column: H = max(M,U,L) of the previous row and U of the current
-//            row (computed one row ahead); boundary scratch float2 (H, L-input) per row.
-//   OUT = 1: + packed traceback.  Per column the three states of the previous row; boundary
-//            scratch float4 (M, U, L) per row; four bit planes per 32-cell row segment:
-//            .x/.y = match source (1 MM, 2 MU, 3 ML, 0 stop), .z = U from extend, .w = L from
-//            extend -- the first-set-flag choice get_paths makes (praline/util/align.py:161-174).
-// --------------------------------------------------------------------------------------------
 __device__ __forceinline__ void swap_halves(float &a, float &b)
 {
     // v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b.
@@ -437,453 +472,6 @@ __device__ __forceinline__ void swap_halves(float &a, float &b)
     ub = r[1];
     a = __builtin_bit_cast(float, ua);
     b = __builtin_bit_cast(float, ub);
-}
-
-// v[idx] for a per-lane idx in 0..31: 5-level v_cndmask tree (registers cannot be indexed per lane).
-__device__ __forceinline__ float select32(const float (&v)[32], int idx)
-{
-    float t16[16], t8[8], t4[4], t2[2];
-    const bool b0 = idx & 1, b1 = idx & 2, b2 = idx & 4, b3 = idx & 8, b4 = idx & 16;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t16[k] = b0 ? v[2 * k + 1] : v[2 * k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t8[k] = b1 ? t16[2 * k + 1] : t16[2 * k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t4[k] = b2 ? t8[2 * k + 1] : t8[2 * k];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) t2[k] = b3 ? t4[2 * k + 1] : t4[2 * k];
-    return b4 ? t2[1] : t2[0];
-}
-
-// MSRC = 1 (reference-order audit mode, PRALINE_MATCH_REFERENCE): the match scores are not formed by MFMAs but read
-// from dense per-pair matrices mref + m_off[pair] ([L1][L2] float32) that k_match_ref wrote in the reference's own
-// summation order; TP must be 1.  Everything after the match scores is the same code.
-// MASK: 0 no zero rectangles, 1 up to PRALINE_MAX_RECTS per pair held in registers, 2 any number per pair, walked in
-// memory for every row (plans in which some pair has more than PRALINE_MAX_RECTS: many Waterman-Eggert iterations).
-#ifdef PRALINE_EXP_BATCH_MASK2
-__device__ unsigned praline_dbg[128];
-#endif
-// PPG (with MSRC = 1, TP = 1): per-position gap scores rp.gaps - U[y][x] takes (open, extend) of position y - 1 of the
-// lane's sequence one, L[y][x] those of position x - 1 of the shared sequence two (cext.c:155-158,172-175), the boundary
-// cells follow align.py:371-385.  The shared sequence's scores of a strip are staged in LDS (wave-uniform reads).
-template <int NSTEP, int TP, bool LOCAL, int OUT, int MASK, int MSRC = 0, bool PPG = false>
-__global__ __launch_bounds__(64) void k_dp_batch(ArenaDev ar, const WaveTask *__restrict__ tasks,
-                                                 const int32_t *__restrict__ lane_one,
-                                                 const int32_t *__restrict__ lane_pair,
-                                                 void *__restrict__ bnd_raw, uint4 *__restrict__ tb,
-                                                 float *__restrict__ aux, RectList rl,
-                                                 float *__restrict__ scores,
-                                                 int32_t *__restrict__ end_cells, RunParams rp,
-                                                 const float *__restrict__ mref = nullptr,
-                                                 const int64_t *__restrict__ m_off = nullptr)
-{
-    static_assert(MSRC == 0 || TP == 1, "the dense match-score source is wired for TP = 1");
-    static_assert(!PPG || (MSRC == 1 && TP == 1), "per-position gap scores are wired for the dense match-score source");
-    __shared__ float g2s[PPG ? 2 * 36 : 2];   // PPG: (open, extend) of positions x0 - 1 .. x0 + 32 of sequence two
-    constexpr int NQ = (NSTEP + 3) / 4;  // float4 loads per operand
-    const int lane = threadIdx.x;
-    const int half = lane >> 5;
-    const int j = lane & 31;
-    const int base = blockIdx.x * 64;
-
-    const WaveTask tk = tasks[blockIdx.x];
-    const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
-    const bool semiglobal = rp.mode >= 2;
-    const float go1 = rp.go1, ge1 = rp.ge1, go2 = rp.go2, ge2 = rp.ge2;
-
-    // ---- the pair this lane owns in the DP ----
-    const bool dp_lane = (TP == 2) || (half == 0);
-    const int my_one = dp_lane ? lane_one[base + lane] : -1;
-    const int my_two = tk.two[TP == 2 ? half : 0];
-    const bool have_pair = my_one >= 0 && my_two >= 0;
-    const int L1 = have_pair ? ar.len[my_one] : 0;
-    const int L2 = have_pair ? ar.len[my_two] : 0;
-    const int my_strips = (L2 + 31) >> 5;
-    const int clast = (L2 - 1) & 31;
-    const int my_pair = have_pair ? lane_pair[base + lane] : -1;
-    const float *my_m = (MSRC == 1 && my_pair >= 0) ? mref + m_off[my_pair] : nullptr;
-
-    // ---- MFMA operand sources ----
-    // B operand: lane (j, half) feeds k = 2s + half of the profile row of the pair owned by DP
-    // lane j (tile A) and by DP lane 32 + j (tile B).
-    const int srcA = lane_one[base + j];
-    const float *pA = ar.P + (int64_t)(srcA >= 0 ? ar.row_off[srcA] : 0) * ar.KP + half * ar.KS;
-    const float *pB = pA;
-    if (TP == 2) {
-        const int srcB = lane_one[base + 32 + j];
-        pB = ar.P + (int64_t)(srcB >= 0 ? ar.row_off[srcB] : 0) * ar.KP + half * ar.KS;
-    }
-    // A operand: lane (i = j, half) feeds k = 2s + half of Q2 row x0 + i of the shared sequence.
-    const float *qA = ar.Q + ((int64_t)(tk.two[0] >= 0 ? ar.row_off[tk.two[0]] : 0) + j) * ar.KP + half * ar.KS;
-    const float *qB = qA;
-    if (TP == 2)
-        qB = ar.Q + ((int64_t)(tk.two[1] >= 0 ? ar.row_off[tk.two[1]] : 0) + j) * ar.KP + half * ar.KS;
-
-    // ---- zero rectangles (Waterman-Eggert masks, praline/component/preprofile.py:247-255) ----
-    int rect[PRALINE_MAX_RECTS][4];
-    // MASK == 2: one 32-bit column mask per (strip, row) of this pair, uint32 [nstrips][L1 + 1] at zmask + zm_off[pair]
-    const unsigned *my_zm = nullptr;
-    if constexpr (MASK == 2) {
-        if (my_pair >= 0 && rl.zmask != nullptr) my_zm = rl.zmask + rl.zm_off[my_pair];
-    }
-    if constexpr (MASK == 1) {
-        int n_rects = 0, r0 = 0;
-        if (my_pair >= 0 && rl.rect_off != nullptr) {
-            r0 = rl.rect_off[my_pair];
-            n_rects = rl.rect_off[my_pair + 1] - r0;
-            if (n_rects > PRALINE_MAX_RECTS) n_rects = PRALINE_MAX_RECTS;
-        }
-#pragma unroll
-        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
-            const bool ok = r < n_rects;
-            rect[r][0] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 0] : (1 << 30);
-            rect[r][1] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 1] : -1;
-            rect[r][2] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 2] : (1 << 30);
-            rect[r][3] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 3] : -1;
-        }
-    }
-
-    float2 *bnd2 = reinterpret_cast<float2 *>(bnd_raw) + tk.bnd_off + lane;  // OUT==0: [y][64]
-    float4 *bnd4 = reinterpret_cast<float4 *>(bnd_raw) + tk.bnd_off + lane;  // OUT==1: [y][64]
-    uint4 *my_tb = tb + tk.tb_off + lane;                                     // [strip][y][64]
-    float *lastcol = aux + tk.aux_off + lane;                                 // [y][3][64]
-    float *lastrow = aux + tk.aux_off + (int64_t)(tk.max_l1 + 1) * 3 * 64 + lane;  // [x-1][3][64]
-
-    // PPG: the gap-score rows of this lane's sequence one and of the shared sequence two
-    const float *g1p = PPG ? rp.gaps + (int64_t)(my_one >= 0 ? ar.row_off[my_one] : 0) * 2 : nullptr;
-    const float *g2p = PPG ? rp.gaps + (int64_t)(tk.two[0] >= 0 ? ar.row_off[tk.two[0]] : 0) * 2 : nullptr;
-    const int L2_shared = (PPG && tk.two[0] >= 0) ? ar.len[tk.two[0]] : 0;
-
-    // ---- boundary cells (praline/component/align.py:367-385) ----
-    const float o001 = free_one ? 0.0f : (PPG ? boundary_value_pp(0, g1p, false) : (go1 - ge1));
-    const float o002 = free_two ? 0.0f : (PPG ? boundary_value_pp(0, g2p, false) : (go2 - ge2));
-    const float h00 = max3f(0.0f, o001, o002);
-
-    // ---- end-cell bookkeeping ----
-    // local: first flat argmax over o (align.py:402); among the boundary cells only o[0,0,:] can
-    // be >= 0 for gap scores <= 0 (the host rejects positive gap scores for batched local mode).
-    float best = 0.0f;
-    int best_y = 0, best_x = 0, best_k = 0;
-    if (LOCAL) {
-        if (o001 > best) { best = o001; best_k = 1; }
-        if (o002 > best) { best = o002; best_k = 2; }
-    }
-    float rowmax = have_pair ? (PPG ? boundary_value_pp(L1, g1p, free_one) : boundary_value(L1, go1, ge1, free_one)) : PRALINE_NEG_INF;  // o[L1,0,1]
-    float colmax = have_pair ? (PPG ? boundary_value_pp(L2, g2p, free_two) : boundary_value(L2, go2, ge2, free_two)) : PRALINE_NEG_INF;  // o[0,L2,2]
-    float corner_h = PRALINE_NEG_INF;
-    float corner_m = PRALINE_NEG_INF, corner_u = PRALINE_NEG_INF, corner_l = PRALINE_NEG_INF;
-
-    for (int s = 0; s < tk.nstrips; ++s) {
-        const int x0 = s * 32;  // this strip covers DP columns x0+1 .. x0+32
-        const bool strip_act = have_pair && s < my_strips;
-        const bool is_last = s == my_strips - 1;
-
-        // A operands of this strip (rows x0 + j of the shared sequences' Q2)
-        float aA[NSTEP], aB[NSTEP];
-        {
-            const float4 *sa = reinterpret_cast<const float4 *>(qA + (int64_t)x0 * ar.KP);
-            const float4 *sb = reinterpret_cast<const float4 *>(qB + (int64_t)x0 * ar.KP);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float4 va = sa[q];
-                const float4 vb = (TP == 2) ? sb[q] : va;
-                const float ea[4] = {va.x, va.y, va.z, va.w};
-                const float eb[4] = {vb.x, vb.y, vb.z, vb.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < NSTEP) { aA[4 * q + e] = ea[e]; aB[4 * q + e] = eb[e]; }
-            }
-        }
-
-        // per-column state carried down the strip (only the set of this OUT variant is live)
-        float Hp[32], Uc[32];          // OUT==0
-        float Mp[32], Up[32], Lp[32];  // OUT==1
-        if constexpr (PPG) {
-            // g2s[l] = scores of position x0 - 1 + l (zero outside the sequence: such columns reach no reported cell)
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 36) {
-                const int pos = x0 - 1 + lane;
-                const bool ok = pos >= 0 && pos < L2_shared;
-                g2s[2 * lane] = ok ? g2p[2 * pos] : 0.0f;
-                g2s[2 * lane + 1] = ok ? g2p[2 * pos + 1] : 0.0f;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-        }
-        const float g2_open0 = PPG ? g2p[0] : 0.0f;
-        // o[0,x,2] of DP column x = x0 + c + 1 (c = -1: the cell left of the strip)
-        auto row0 = [&](int c) __attribute__((always_inline)) {
-            if constexpr (PPG) {
-                if (free_two) return 0.0f;
-                return (float)((double)(x0 + c) * (double)g2s[2 * (c + 1) + 1] + (double)g2_open0);   // (x - 1) * extend[x - 1] + open[0]
-            } else {
-                return boundary_value(x0 + c + 1, go2, ge2, free_two);
-            }
-        };
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const float bl = row0(c);  // o[0,x,2]
-            Hp[c] = bl; Uc[c] = PRALINE_NEG_INF;
-            Mp[c] = PRALINE_NEG_INF; Up[c] = PRALINE_NEG_INF; Lp[c] = bl;
-        }
-        // states of the cell (y-1, x0), the diagonal input of column x0+1: row 0 first
-        float dM = (s == 0) ? 0.0f : PRALINE_NEG_INF;
-        float dU = (s == 0) ? o001 : PRALINE_NEG_INF;
-        float dL = (s == 0) ? o002 : row0(-1);
-        float dH = (s == 0) ? h00 : dL;
-        // PPG: (open, extend) of positions y - 1 and y of this lane's sequence one (one row ahead)
-        float2 g1a = make_float2(0.0f, 0.0f), g1b = g1a;
-        if constexpr (PPG) { g1a = make_float2(g1p[0], g1p[1]); g1b = make_float2(g1p[2], g1p[3]); }
-
-        // B operands of row 1
-        float4 nA[NQ], nB[NQ];
-        {
-            const float4 *sa = reinterpret_cast<const float4 *>(pA);
-            const float4 *sb = reinterpret_cast<const float4 *>(pB);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { nA[q] = sa[q]; nB[q] = (TP == 2) ? sb[q] : nA[q]; }
-        }
-
-        for (int y = 1; y <= tk.max_l1; ++y) {
-            // PPG: gy1 = scores of position y - 1 (U[y][x], the boundary cell o[y,0,1]), gy = those of position y (U[y+1][x])
-            const float2 gy1 = g1a, gy = g1b;
-            // (one row ahead, never past row L1 of this lane's own sequence - a row whose values no cell uses: a short lane
-            // of a task with a much longer one does not walk on through other sequences' rows towards the buffer's end)
-            if constexpr (PPG) { const int yn = y + 1 <= L1 ? y + 1 : L1; g1a = g1b; g1b = make_float2(g1p[2 * yn], g1p[2 * yn + 1]); }
-            // MASK == 2: bit c of zrow = cell (y, x0 + c + 1) lies in one of this pair's rectangles; the words were
-            // prepared by k_build_zmask (walking the rectangle list here, in a loop, miscompiled the LOCAL instance with
-            // ROCm 7.2: wrong scores even with empty lists)
-            unsigned zrow = 0;
-            if constexpr (MASK == 2) {
-                if (my_zm != nullptr && y <= L1 && s < my_strips) zrow = my_zm[(int64_t)s * (L1 + 1) + y];
-#ifdef PRALINE_EXP_BATCH_MASK2_DBG
-                // experiment builds (scripts/exp_mask2.py): what does the kernel see where the host put zeros?
-                if constexpr (MSRC == 0 && LOCAL && OUT == 1) {
-                    if (zrow != 0) {
-                        const unsigned again = my_zm ? *reinterpret_cast<const volatile unsigned *>(my_zm + (int64_t)s * (L1 + 1) + y) : 0xdeadbeefu;
-                        const unsigned n = atomicAdd(&praline_dbg[0], 1u);
-                        if (again == 0) atomicAdd(&praline_dbg[1], 1u);
-                        if (n < 12) {
-                            praline_dbg[8 + 6 * n] = (unsigned)my_pair; praline_dbg[9 + 6 * n] = ((unsigned)s << 16) | (unsigned)y;
-                            praline_dbg[10 + 6 * n] = zrow; praline_dbg[11 + 6 * n] = again; praline_dbg[12 + 6 * n] = (unsigned)lane;
-                            praline_dbg[13 + 6 * n] = (unsigned)L1;
-                        }
-                    }
-                }
-#endif
-            }
-            float m[32];
-            if constexpr (MSRC == 1) {
-                // dense reference-order match scores of this lane's own pair
-                const bool row_ok = my_m != nullptr && y <= L1;
-#pragma unroll
-                for (int c = 0; c < 32; ++c)
-                    m[c] = (row_ok && x0 + c < L2) ? my_m[(int64_t)(y - 1) * L2 + x0 + c] : 0.0f;
-            } else {
-            // ---- match scores of row y for all lanes: NSTEP MFMAs per tile ----
-            float bA[NSTEP], bB[NSTEP];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float ea[4] = {nA[q].x, nA[q].y, nA[q].z, nA[q].w};
-                const float eb[4] = {nB[q].x, nB[q].y, nB[q].z, nB[q].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < NSTEP) { bA[4 * q + e] = ea[e]; bB[4 * q + e] = eb[e]; }
-            }
-            // prefetch the next row's B operands (rows past a sequence's end read the arena's
-            // zeroed tail padding or the next sequence: finite values that only reach lanes whose
-            // DP is masked off)
-            {
-                const float4 *sa = reinterpret_cast<const float4 *>(pA + (int64_t)y * ar.KP);
-                const float4 *sb = reinterpret_cast<const float4 *>(pB + (int64_t)y * ar.KP);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) { nA[q] = sa[q]; if (TP == 2) nB[q] = sb[q]; }
-            }
-            f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            f32x16 accB = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < NSTEP; ++k) {
-                accA = __builtin_amdgcn_mfma_f32_32x32x2f32(aA[k], bA[k], accA, 0, 0, 0);
-                if (TP == 2) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aB[k], bB[k], accB, 0, 0, 0);
-            }
-            // D[i][lane]: register r of half h holds i = (r&3) + 8(r>>2) + 4h.  Exchange halves so
-            // every DP lane holds all 32 columns of ITS pair: m[8q+r] = a[4q+r], m[8q+4+r] = b[4q+r].
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float a = accA[r];
-                float b = (TP == 2) ? accB[r] : 0.0f;
-                swap_halves(a, b);
-                m[8 * (r >> 2) + (r & 3)] = a;
-                m[8 * (r >> 2) + 4 + (r & 3)] = b;
-            }
-            }
-
-            if (strip_act && y <= L1) {
-                bool row_in[PRALINE_MAX_RECTS];
-                if constexpr (MASK == 1) {
-#pragma unroll
-                    for (int r = 0; r < PRALINE_MAX_RECTS; ++r) row_in[r] = y >= rect[r][0] && y <= rect[r][1];
-                }
-                if constexpr (OUT == 0) {
-                    float hl, lin;  // H of cell (y, x0) and the L state of cell (y, x0+1)
-                    if (s == 0) {
-                        hl = PPG ? (free_one ? 0.0f : (float)((double)(y - 1) * (double)gy1.y + (double)g1p[0])) : boundary_value(y, go1, ge1, free_one);
-                        lin = PRALINE_NEG_INF;
-                    }
-                    else { const float2 bv = bnd2[(int64_t)y * 64]; hl = bv.x; lin = bv.y; }
-                    float hd = dH, lrun = lin;
-#pragma unroll
-                    for (int c = 0; c < 32; ++c) {
-                        float M = hd + m[c];                       // max_k(o[y-1,x-1,k]) + m  (cext.c:192-222)
-                        if (LOCAL) M = __builtin_fmaxf(M, 0.0f);   // cext.c:208-209
-                        float U = Uc[c];
-                        float Lc = lrun;
-                        if constexpr (MASK == 1) {
-                            bool z = false;
-#pragma unroll
-                            for (int r = 0; r < PRALINE_MAX_RECTS; ++r)
-                                z = z || (row_in[r] && (x0 + c + 1) >= rect[r][2] && (x0 + c + 1) <= rect[r][3]);
-                            if (z) { M = 0.0f; U = 0.0f; Lc = 0.0f; }  // cext.c:141-149
-                        }
-                        if constexpr (MASK == 2) {
-                            if ((zrow >> c) & 1u) { M = 0.0f; U = 0.0f; Lc = 0.0f; }
-                        }
-                        const float H = max3f(M, U, Lc);
-                        if (LOCAL) best = __builtin_fmaxf(best, H);
-                        if constexpr (PPG) {
-                            Uc[c] = __builtin_fmaxf(M + gy.x, U + gy.y);                                   // U[y+1][x]: position y of one
-                            lrun = __builtin_fmaxf(M + g2s[2 * (c + 2)], Lc + g2s[2 * (c + 2) + 1]);       // L[y][x+1]: position x of two
-                        } else {
-                        Uc[c] = __builtin_fmaxf(M + go1, U + ge1);   // U[y+1][x]   (cext.c:152-166,247-254)
-                        lrun = __builtin_fmaxf(M + go2, Lc + ge2);   // L[y][x+1]   (cext.c:169-183,276-283)
-                        }
-                        hd = Hp[c];
-                        Hp[c] = H;
-                    }
-                    dH = hl;
-                    bnd2[(int64_t)y * 64] = make_float2(Hp[31], lrun);
-                    if (semiglobal && is_last) colmax = __builtin_fmaxf(colmax, select32(Hp, clast));
-                } else {
-                    float bm, bu, bl;  // states of the cell (y, x0)
-                    if (s == 0) {
-                        bm = PRALINE_NEG_INF;
-                        bu = PPG ? (free_one ? 0.0f : (float)((double)(y - 1) * (double)gy1.y + (double)g1p[0])) : boundary_value(y, go1, ge1, free_one);
-                        bl = PRALINE_NEG_INF;
-                    }
-                    else { const float4 bv = bnd4[(int64_t)y * 64]; bm = bv.x; bu = bv.y; bl = bv.z; }
-                    float md = dM, ud = dU, ld = dL;   // states of (y-1, x-1)
-                    float mleft = bm, lleft = bl;      // states of (y, x-1)
-                    unsigned w_mlo = 0, w_mhi = 0, w_u = 0, w_l = 0;
-#pragma unroll
-                    for (int c = 0; c < 32; ++c) {
-                        // exact candidate sums; first-match priority MM > MU > ML, UO > UE, LO > LE
-                        // (cext.c:185-295, praline/util/align.py:161-174)
-                        const float sMM = md + m[c], sMU = ud + m[c], sML = ld + m[c];
-                        float M = max3f(sMM, sMU, sML);
-                        if (LOCAL) M = __builtin_fmaxf(M, 0.0f);
-                        // (PPG: U[y][x] takes position y - 1 of one, L[y][x] position x - 1 = x0 + c of two)
-                        const float uo = Mp[c] + (PPG ? gy1.x : go1), ue = Up[c] + (PPG ? gy1.y : ge1);
-                        float U = __builtin_fmaxf(uo, ue);
-                        const float lo = mleft + (PPG ? g2s[2 * (c + 1)] : go2), le = lleft + (PPG ? g2s[2 * (c + 1) + 1] : ge2);
-                        float Lc = __builtin_fmaxf(lo, le);
-                        bool isMM = sMM == M;
-                        bool isMU = !isMM && sMU == M;
-                        bool isML = !isMM && !isMU && sML == M;
-                        if constexpr (MASK == 1) {
-                            bool z = false;
-#pragma unroll
-                            for (int r = 0; r < PRALINE_MAX_RECTS; ++r)
-                                z = z || (row_in[r] && (x0 + c + 1) >= rect[r][2] && (x0 + c + 1) <= rect[r][3]);
-                            if (z) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }
-                        }
-                        if constexpr (MASK == 2) {
-                            if ((zrow >> c) & 1u) { M = 0.0f; U = 0.0f; Lc = 0.0f; isMM = false; isMU = false; isML = false; }
-                        }
-                        w_mlo |= (isMM || isML) ? (1u << c) : 0u;
-                        w_mhi |= (isMU || isML) ? (1u << c) : 0u;
-                        w_u |= (uo >= ue) ? 0u : (1u << c);
-                        w_l |= (lo >= le) ? 0u : (1u << c);
-                        if (LOCAL) {
-                            // first maximum in C order (y, x, k): rows ascend inside a strip and
-                            // later strips have larger x, so only a smaller y wins a tie.
-                            const float H = max3f(M, U, Lc);
-                            if (H > best || (H == best && y < best_y)) {
-                                best = H; best_y = y; best_x = x0 + c + 1;
-                                best_k = (M == H) ? 0 : ((U == H) ? 1 : 2);
-                            }
-                        }
-                        md = Mp[c]; ud = Up[c]; ld = Lp[c];
-                        Mp[c] = M; Up[c] = U; Lp[c] = Lc;
-                        mleft = M; lleft = Lc;
-                    }
-                    dM = bm; dU = bu; dL = bl;
-                    bnd4[(int64_t)y * 64] = make_float4(Mp[31], Up[31], Lp[31], 0.0f);
-                    my_tb[((int64_t)s * (tk.max_l1 + 1) + y) * 64] = make_uint4(w_mlo, w_mhi, w_u, w_l);
-                    if (semiglobal && is_last) {
-                        // o[y, L2, :] for the end-cell scan (align.py:408,418-422)
-                        float *lc = lastcol + (int64_t)y * 3 * 64;
-                        lc[0] = select32(Mp, clast);
-                        lc[64] = select32(Up, clast);
-                        lc[128] = select32(Lp, clast);
-                    }
-                }
-            }
-        }  // rows
-
-        // ---- strip epilogue: every lane's state is frozen at its own last row L1 ----
-        if (strip_act) {
-            if constexpr (OUT == 0) {
-                if (semiglobal) {
-                    const int cmax = is_last ? clast : 31;
-#pragma unroll
-                    for (int c = 0; c < 32; ++c)
-                        rowmax = __builtin_fmaxf(rowmax, (c <= cmax) ? Hp[c] : PRALINE_NEG_INF);
-                }
-                if (is_last) corner_h = select32(Hp, clast);
-            } else {
-                if (is_last) {
-                    corner_m = select32(Mp, clast);
-                    corner_u = select32(Up, clast);
-                    corner_l = select32(Lp, clast);
-                }
-                if (semiglobal) {
-                    // o[L1, x, :] for x = x0+1 .. x0+32 (align.py:407,413-417)
-                    float *lr = lastrow + (int64_t)x0 * 3 * 64;
-#pragma unroll
-                    for (int c = 0; c < 32; ++c) {
-                        lr[(c * 3 + 0) * 64] = Mp[c];
-                        lr[(c * 3 + 1) * 64] = Up[c];
-                        lr[(c * 3 + 2) * 64] = Lp[c];
-                    }
-                }
-            }
-        }
-    }  // strips
-
-    if (have_pair) {
-        if constexpr (OUT == 0) {
-            float score;
-            if (LOCAL) score = best;
-            else if (semiglobal) score = (rowmax > colmax && free_two) ? rowmax : colmax;  // align.py:411-424
-            else score = corner_h;                                                        // align.py:428-430
-            scores[my_pair] = score;
-        } else {
-            int ey = L1, ex = L2, ek = 0;
-            float score = corner_m;
-            if (LOCAL) { ey = best_y; ex = best_x; ek = best_k; score = best; }
-            else {
-                if (corner_u > score) { score = corner_u; ek = 1; }  // np.argmax: first maximum
-                if (corner_l > score) { score = corner_l; ek = 2; }
-            }
-            // semiglobal end cells are resolved by k_traceback from lastrow / lastcol
-            end_cells[(int64_t)my_pair * 4 + 0] = ey;
-            end_cells[(int64_t)my_pair * 4 + 1] = ex;
-            end_cells[(int64_t)my_pair * 4 + 2] = ek;
-            end_cells[(int64_t)my_pair * 4 + 3] = 0;
-            scores[my_pair] = score;
-        }
-    }
 }
 
 #ifdef PRALINE_AUX_KERNELS
@@ -1012,7 +600,7 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
     const int L1 = ar.len[pairs[2 * p]], L2 = ar.len[pairs[2 * p + 1]];
     const bool free_one = mode_free_one(rp.mode), free_two = mode_free_two(rp.mode);
     const bool semiglobal = rp.mode >= 2;
-    // layout 0: k_dp_batch planes (uint4 per 32 cells, rows max_l1 + 1); layout 1: k_dp_split16_tb planes
+    // layout 0: uint4 planes per 32 cells, rows max_l1 + 1 (the retired 64-lane task layout; no caller left); layout 1: k_dp_split16_tb planes
     // (uint2 per 16 cells, lane j = strip columns 1..16, lane j + 32 = columns 17..32, rows max_l1 + 8)
     const uint4 *my_tb = tb + tk.tb_off + pl.lane;
     const uint2 *my_tb2 = reinterpret_cast<const uint2 *>(tb) + tk.tb_off + pl.lane;
@@ -1297,7 +885,7 @@ __global__ void k_fill_i32(int32_t *dst, int64_t n, int32_t value)
     if (i < n) dst[i] = value;
 }
 
-// Column masks of the zero rectangles for k_dp_batch MASK = 2: one block per pair, entry (strip s, row y) = bit c set
+// Column masks of the zero rectangles of plans with more than PRALINE_MAX_RECTS per pair: one block per pair, entry (strip s, row y) = bit c set
 // when cell (y, 32 s + c + 1) lies in one of the pair's rectangles (cext.c:141-149 skips those cells).
 __global__ __launch_bounds__(256) void k_build_zmask(const int32_t *__restrict__ pairs, const int32_t *__restrict__ len,
                                                      const int32_t *__restrict__ rect_off, const int32_t *__restrict__ rects,
@@ -1353,7 +941,7 @@ __global__ __launch_bounds__(256) void k_match_ref(const float *__restrict__ raw
                                                    const unsigned char *__restrict__ nzcnt,
                                                    const int32_t *__restrict__ set_lo, int n_sets,
                                                    const int32_t *__restrict__ pairs, const int32_t *__restrict__ chunk_pairs,
-                                                   const int64_t *__restrict__ m_off, float *__restrict__ mref)
+                                                   const int64_t *__restrict__ m_off, float *__restrict__ mref, TileOut to)
 {
     const int p = chunk_pairs[blockIdx.x];
     const int one = pairs[2 * p], two = pairs[2 * p + 1];
@@ -1362,9 +950,14 @@ __global__ __launch_bounds__(256) void k_match_ref(const float *__restrict__ raw
     if (y0 >= L1) return;
     const int ny = min(PRALINE_REF_ROWS, L1 - y0);
     const int64_t r1 = row_off_raw[one], r2 = row_off_raw[two];
-    float *out = mref + m_off[p];
-    for (int c = threadIdx.x; c < ny * L2; c += blockDim.x) {
-        const int y = y0 + c / L2, x = c % L2;
+    const bool tiled = to.loc != nullptr;
+    TileDst d = {nullptr, 0, 0, L2};
+    if (tiled) d = tile_dst(to, mref, p, L2);
+    float *out = tiled ? nullptr : mref + m_off[p];
+    const int W = d.x_hi - d.x_lo;   // columns per row this launch writes (tiles: whole strips)
+    for (int c = threadIdx.x; c < ny * W; c += blockDim.x) {
+        const int y = y0 + c / W, x = d.x_lo + c % W;
+        if (x >= L2) { *d.at(y, x) = 0.0f; continue; }
         const float *p1 = raw + (r1 + y) * A, *p2 = raw + (r2 + x) * A;
         const unsigned char *i1 = nzidx + (r1 + y) * A, *i2 = nzidx + (r2 + x) * A;
         const int n1 = nzcnt[r1 + y], n2 = nzcnt[r2 + x];
@@ -1389,7 +982,8 @@ __global__ __launch_bounds__(256) void k_match_ref(const float *__restrict__ raw
             }
             score = __fadd_rn(score, acc);
         }
-        out[(int64_t)y * L2 + x] = score;
+        if (tiled) *d.at(y, x) = score;
+        else out[(int64_t)y * L2 + x] = score;
     }
 }
 
@@ -1434,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_match_reft(const float *__restrict__ ra
                                                     const unsigned char *__restrict__ nzcnt,
                                                     const int32_t *__restrict__ set_lo, int n_sets,
                                                     const int32_t *__restrict__ pairs, const int32_t *__restrict__ chunk_pairs,
-                                                    const int64_t *__restrict__ m_off, float *__restrict__ mref)
+                                                    const int64_t *__restrict__ m_off, float *__restrict__ mref, TileOut to)
 {
     const int p = chunk_pairs[blockIdx.x];
     const int one = pairs[2 * p], two = pairs[2 * p + 1];
@@ -1443,7 +1037,11 @@ __global__ __launch_bounds__(256) void k_match_reft(const float *__restrict__ ra
     if (y0 >= L1) return;
     const int ny = min(PRALINE_REF_ROWS, L1 - y0);
     const int64_t r1 = row_off_raw[one], r2 = row_off_raw[two];
-    float *out = mref + m_off[p];
+    const bool tiled = to.loc != nullptr;
+    TileDst d = {nullptr, 0, 0, L2};
+    if (tiled) d = tile_dst(to, mref, p, L2);
+    float *out = tiled ? nullptr : mref + m_off[p];
+    const int W = d.x_hi - d.x_lo;   // columns per row this launch writes (tiles: whole strips)
     // nonzero lists of this block's rows: (symbol, value) pairs, at most 32 per row kept here (longer rows: global)
     __shared__ int s_n[PRALINE_REF_ROWS];
     __shared__ int s_i[PRALINE_REF_ROWS][32];
@@ -1459,8 +1057,9 @@ __global__ __launch_bounds__(256) void k_match_reft(const float *__restrict__ ra
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < ny * L2; c += blockDim.x) {
-        const int yy = c / L2, y = y0 + yy, x = c % L2;
+    for (int c = threadIdx.x; c < ny * W; c += blockDim.x) {
+        const int yy = c / W, y = y0 + yy, x = d.x_lo + c % W;
+        if (x >= L2) { *d.at(y, x) = 0.0f; continue; }
         const float *p1 = raw + (r1 + y) * A;
         const unsigned char *i1 = nzidx + (r1 + y) * A;
         const int n1 = s_n[yy];
@@ -1482,7 +1081,8 @@ __global__ __launch_bounds__(256) void k_match_reft(const float *__restrict__ ra
             }
         }
         for (; s < n_sets; ++s) { score = __fadd_rn(score, acc); acc = 0.0f; }
-        out[(int64_t)y * L2 + x] = score;
+        if (tiled) *d.at(y, x) = score;
+        else out[(int64_t)y * L2 + x] = score;
     }
 }
 

@@ -1,6 +1,5 @@
-// dp_launch.hip.h -- launch glue for k_dp_batch.  The kernel is instantiated once per MFMA step
-// count in its own translation unit (dp_instance.hip, -DPRALINE_NSTEP_INST=N) so the instances
-// compile in parallel.
+// dp_launch.hip.h -- launch glue: what praline_dp.hip calls into the kernel translation units (one per kernel family, so the
+// instances compile in parallel).
 #pragma once
 #include "dp_kernels.hip.h"
 #include "dp_arena16.h"
@@ -25,8 +24,6 @@ struct LaunchArgs {
     const struct WgDesc *wg;  // non-null: four-wave workgroups (k_dp_split16 WPG = 4), n_wg of them
     unsigned n_wg;
     int split;  // 1: k_dp_split task layout (32 lane entries per task, float2 [max_l1+2][32] boundary)
-    const float *mref = nullptr;     // reference-order audit mode: dense match scores, pair p at mref + m_off[p]
-    const int64_t *m_off = nullptr;
 };
 
 // k_dp_split instances (dp_split_instance.hip, built with -mllvm -amdgpu-mfma-vgpr-form)
@@ -96,45 +93,10 @@ int praline_launch_build_reft2(const float *raw, const float *S, int A, const in
 bool praline_match_tile_supported(int A, int TB);
 int praline_launch_match_tile(const RefTileArgs &g, int TB, unsigned n_blocks, hipStream_t stream);
 int praline_launch_dense(const LaunchArgs &la, const Arena16Dev &a16, bool local);
-int praline_launch_dense_tb(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask);
-// k_dp_batch on dense reference-order match scores (dp_ref_instance.hip)
-int praline_launch_dp_ref(const LaunchArgs &la, bool local, int out, int mask);   // (la.rp.gaps set: the per-position instances)
-// k_dp_batch instances (dp_instance.hip)
-int praline_launch_dp_2(const LaunchArgs &la, int tp, bool local, int out, int mask);
-int praline_launch_dp_8(const LaunchArgs &la, int tp, bool local, int out, int mask);
-int praline_launch_dp_10(const LaunchArgs &la, int tp, bool local, int out, int mask);
-int praline_launch_dp_12(const LaunchArgs &la, int tp, bool local, int out, int mask);
-int praline_launch_dp_14(const LaunchArgs &la, int tp, bool local, int out, int mask);
-int praline_launch_dp_16(const LaunchArgs &la, int tp, bool local, int out, int mask);
-
-template <int NSTEP, int TP, bool LOCAL, int OUT, int MASK> static void launch_one(const LaunchArgs &la)
-{
-    hipLaunchKernelGGL((k_dp_batch<NSTEP, TP, LOCAL, OUT, MASK>), dim3(la.n_tasks), dim3(64), 0, la.stream, la.ar,
-                       la.tasks, la.lane_one, la.lane_pair, la.bnd, la.tb, la.aux, la.rl, la.scores, la.end_cells, la.rp);
-}
-
-// Instantiated variants: scores-only (TP 1/2, local or not); traceback (TP 1, local or not, with or
-// without zero rectangles).
-template <int NSTEP> static int launch_nstep(const LaunchArgs &la, int tp, bool local, int out, int mask)
-{
-    if (la.split) return PRALINE_ERR_UNSUPPORTED;  // handled by praline_launch_split_N
-    if (out == 0) {
-        if (mask) return PRALINE_ERR_UNSUPPORTED;
-        if (tp == 2) { if (local) launch_one<NSTEP, 2, true, 0, 0>(la); else launch_one<NSTEP, 2, false, 0, 0>(la); }
-        else if (tp == 1) { if (local) launch_one<NSTEP, 1, true, 0, 0>(la); else launch_one<NSTEP, 1, false, 0, 0>(la); }
-        else return PRALINE_ERR_UNSUPPORTED;
-    } else {
-        if (tp != 1) return PRALINE_ERR_UNSUPPORTED;
-#ifdef PRALINE_EXP_BATCH_MASK2
-        // experiment builds only (scripts/exp_mask2.py): the MFMA-fed column-mask instance, see DESIGN section 3.5
-        if (mask == 2) {
-            if (local) launch_one<NSTEP, 1, true, 1, 2>(la); else launch_one<NSTEP, 1, false, 1, 2>(la);
-            return PRALINE_OK;
-        }
-#endif
-        if (mask == 2) return PRALINE_ERR_UNSUPPORTED;   // column-mask plans run on the dense-match-score instances (dp_ref_instance.hip)
-        if (local) { if (mask) launch_one<NSTEP, 1, true, 1, 1>(la); else launch_one<NSTEP, 1, true, 1, 0>(la); }
-        else { if (mask) launch_one<NSTEP, 1, false, 1, 1>(la); else launch_one<NSTEP, 1, false, 1, 0>(la); }
-    }
-    return PRALINE_OK;
-}
+// fill with packed traceback on dense tiles.  mask: rectangles (la.rl.rects) or - la.rl.zmask set - per-row mask words; ppg:
+// per-position gap scores (la.rp.gaps); noflags: the fill alone (plans without paths: no planes, la.tb unused); strip_lo /
+// strip_cnt: the strips of every task this launch sweeps (the tile holds just those)
+int praline_launch_dense_tb(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask, bool ppg = false, bool noflags = false,
+                            int strip_lo = 0, int strip_cnt = 0x3fffffff);
+int praline_launch_dense_tb_ppg(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask, bool noflags, int strip_lo,
+                                int strip_cnt);   // (dp_dense2_instance.hip)

@@ -90,7 +90,11 @@ struct TbCarry {
 // lanes reading 64 different rows per step cost the CU's L1 one tag cycle per lane, which the flag-free forward fill
 // (150 VALU per step instead of 350) no longer hides - but looked up in the one-hot operand table in LDS
 // (dp_split16.hip.h) by the row's symbol, byte SB of symw.
-template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool DM = false, int SINK = 0, int BSRC = 0, int SB = 0>
+// PPG (dense tiles only): per-position gap scores (GapScoreModel, praline/container/score.py:45-68) - U[y][x] takes (go_row,
+// ge_row) = (open, extend) of position y - 1 of the lane's sequence one, L[y][x] those of position x - 1 of the shared
+// sequence two, g2o[c] / g2e[c] for this lane's 16 columns (cext.c:155-158,172-175).  zm_row (dense tiles, MASK): the per-row
+// column-mask words of plans with more than PRALINE_MAX_RECTS rectangles per pair (k_build_zmask) instead of the rectangles.
+template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool DM = false, int SINK = 0, int BSRC = 0, int SB = 0, bool PPG = false>
 __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, int h, const f32x16 &CUR, f32x16 &PREV,
                                                 float4 (&BOPS)[(NTERM == 1 ? 1 : 2) * NR],
                                                 float4 (&BOLD)[(NTERM == 1 ? 1 : 2) * NR],
@@ -104,8 +108,10 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
                                                 const int (&rect)[PRALINE_MAX_RECTS][4], const int *chain_in = nullptr,
                                                 int *chain_seen = nullptr, int load_row = 0, float *ckpt = nullptr,
                                                 char *lds_flags = nullptr, int lds_row = 0, const char *onehot_lane = nullptr,
-                                                unsigned symw = 0)
+                                                unsigned symw = 0, const unsigned *zm_row = nullptr, int zm_rows = 0, float go_row = 0.0f,
+                                                float ge_row = 0.0f, const float *g2o = nullptr, const float *g2e = nullptr)
 {
+    static_assert(!PPG || BSRC == 4, "per-position gap scores run on the dense-tile instances");
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     // BSRC = 3 (one-hot arenas, integer scoring): the match scores are looked up in the strip's LDS table
     // (dp_split16.hip.h, lookup_stride): CUR holds this lane's 16 scores of its row, PREV receives the next row's (symbol
@@ -142,12 +148,17 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
     // zero mask of this lane's 16 cells in this row: one bit per column, built once per row
     unsigned zmask = 0;
     if constexpr (MASK) {
+        if (BSRC == 4 && zm_row != nullptr) {   // (wave-uniform) mask words: bit c of the strip's word of row yy, this half's 16 bits
+            if (yy >= 1 && yy <= zm_rows) zmask = (zm_row[yy] >> (16 * h)) & 0xffffu;
+        } else {
 #pragma unroll
-        for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
-            // rect[r][2] holds this strip's 16-bit column mask of rectangle r (set by the kernel per strip)
-            zmask |= (yy >= rect[r][0] && yy <= rect[r][1]) ? (unsigned)rect[r][2] : 0u;
+            for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
+                // rect[r][2] holds this strip's 16-bit column mask of rectangle r (set by the kernel per strip)
+                zmask |= (yy >= rect[r][0] && yy <= rect[r][1]) ? (unsigned)rect[r][2] : 0u;
+            }
         }
     }
+    const float go_u = PPG ? go_row : go, ge_u = PPG ? ge_row : ge;
     // "not MM" / "not MU" / (local) "clamp won" bits and the U-extend / L-extend bits of this lane's 16 cells; the
     // shifted-in words hold column c in bit 15 - c (reversed once per row below).
     unsigned w_nm = 0, w_nu = 0, w_stop = 0, w_u = 0, w_l = 0;
@@ -185,9 +196,9 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
                 M = max3f(sMM, sMU, ld + m[c]);
                 Mref = M;
             }
-            const float uo = Mp[c] + go, ue = Up[c] + ge;
+            const float uo = Mp[c] + go_u, ue = Up[c] + ge_u;
             float U = __builtin_fmaxf(uo, ue);
-            const float lo = mleft + go, le = lleft + ge;
+            const float lo = mleft + (PPG ? g2o[c] : go), le = lleft + (PPG ? g2e[c] : ge);
             float Lc = __builtin_fmaxf(lo, le);
             // Match source, first match in the order MM, MU, ML: without the clamp one of the three sums IS the
             // maximum, so "MM is not it" and "MU is not it" (the signs of sMM - max and sMU - max, both <= 0) say
@@ -248,7 +259,7 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
         // the two halves of a pair are resolved when their results are combined.
         // With strictly negative gap scores U and L are always smaller than some earlier M (U = M' + go + k ge), so the
         // maximum of o is attained by M cells only (never tied by a U or L cell): 8 ops per row instead of 31.
-        if (go < 0.0f && ge < 0.0f) {
+        if (!PPG && go < 0.0f && ge < 0.0f) {   // (per-position scores may be zero: the general form)
             const float r0 = max3f(Mp[0], Mp[1], Mp[2]), r1 = max3f(Mp[3], Mp[4], Mp[5]), r2 = max3f(Mp[6], Mp[7], Mp[8]);
             const float r3 = max3f(Mp[9], Mp[10], Mp[11]), r4 = max3f(Mp[12], Mp[13], Mp[14]);
             const float rowH = max3f(max3f(r0, r1, r2), max3f(r3, r4, Mp[15]), PRALINE_NEG_INF);
@@ -354,7 +365,11 @@ __device__ __forceinline__ void split16_tb_step(int yy, int L1, bool have_pair, 
 #ifndef PRALINE_TB_DENSE_WAVES
 #define PRALINE_TB_DENSE_WAVES 1   // waves per SIMD of the dense-tile instances
 #endif
-template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool TWOPASS = false, int BSRC = 0>
+// NOFLAGS (dense tiles): the fill without flags and planes - the scores of plans without paths that run with per-position gap
+// scores or over strip ranges.  strip_lo / strip_cnt (task mode): this launch sweeps the strips [strip_lo, strip_lo + strip_cnt)
+// of every task - the dense tile (ar.dense) then holds just those strips; the boundary column stays in the task's scratch
+// between the launches and a local alignment's running maximum travels through scores / end_cells.
+template <int NR, int NTERM, bool LOCAL, bool MASK, bool CHAIN = false, bool TWOPASS = false, int BSRC = 0, bool PPG = false, bool NOFLAGS = false>
 __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC == 3 ? PRALINE_TB_LOOKUP_WAVES : (BSRC == 4 ? PRALINE_TB_DENSE_WAVES : PRALINE_TB_WAVES_PER_SIMD))) void k_dp_split16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one,
                                                        const int32_t *__restrict__ lane_pair, float4 *bnd,
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
                                                        float *__restrict__ scores, int32_t *__restrict__ end_cells,
                                                        RunParams rp, int n_tasks, int *chain_flags = nullptr,
                                                        int chain_stride = 0, float4 *chain_cand = nullptr,
-                                                       int chain_every = 6)
+                                                       int chain_every = 6, int strip_lo = 0, int strip_cnt = 0x3fffffff)
 {
     constexpr int NP = (NTERM == 1) ? 1 : 2;
     constexpr int NOP = NP * NR;
@@ -372,7 +387,9 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
     // CHAIN && TWOPASS: chain mode WITHOUT flags and checkpoints - the scores-only fill of plans of a few long sequences
     // (one wave per task and strip where the score kernels would put four waves on a task)
     constexpr bool FWD2 = TWOPASS && !CHAIN;   // the forward fill of the two-pass scheme proper
-    constexpr int SINK = TWOPASS ? (CHAIN ? 3 : 1) : 0;
+    constexpr int SINK = TWOPASS ? (CHAIN ? 3 : 1) : (NOFLAGS ? 3 : 0);
+    static_assert(!NOFLAGS || (BSRC == 4 && !CHAIN && !TWOPASS && !MASK), "the flag-free task-mode fill is wired for the dense tiles");
+    static_assert(!PPG || DENSE, "per-position gap scores (rp.gaps) are wired for the dense-tile instances");
     static_assert(BSRC == 0 || (BSRC == 1 && FWD2 && DM) || (LOOKUP && NTERM == 1 && !TWOPASS) || (DENSE && NTERM == 3 && !TWOPASS),
                   "the one-hot table feeds the single-term forward fill; the lookup serves the single-pass integer-scoring fill; "
                   "dense tiles feed the single-pass fill with candidate sums");
@@ -467,16 +484,33 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
 #pragma unroll
         for (int r = 0; r < PRALINE_MAX_RECTS; ++r) { rect[r][0] = 1 << 30; rect[r][1] = -1; rect[r][2] = 1 << 30; rect[r][3] = -1; }
     }
+    // dense tiles, plans with more than PRALINE_MAX_RECTS rectangles per pair: the per-row mask words of k_build_zmask, uint32
+    // [nstrips][L1 + 1] at zmask + zm_off[pair] (lanes without a pair read their own zero: row range 0)
+    const unsigned *my_zm = nullptr;
+    if constexpr (MASK && DENSE) {
+        if (rl.zmask != nullptr) my_zm = (my_pair >= 0) ? rl.zmask + rl.zm_off[my_pair] : rl.zmask;
+    }
+    const int zm_rows = (my_pair >= 0) ? L1 : 0;
+    // PPG: the gap-score rows (open, extend) of this lane's sequence one and of the shared sequence two
+    const float *g1p = PPG ? rp.gaps + (int64_t)(have_pair ? ar.row_off[my_one] : 0) * 2 : nullptr;
+    const float *g2p = PPG ? rp.gaps + (int64_t)ar.row_off[two] * 2 : nullptr;
+    const int g1_last = L1 > 0 ? L1 - 1 : 0;   // the last position a lane reads (the rows past its sequence are not reported)
 
     // boundary cells (praline/component/align.py:367-385)
-    const float o001 = free_one ? 0.0f : (go - ge);
-    const float o002 = free_two ? 0.0f : (go - ge);
+    const float o001 = free_one ? 0.0f : (PPG ? boundary_value_pp(0, g1p, false) : (go - ge));
+    const float o002 = free_two ? 0.0f : (PPG ? boundary_value_pp(0, g2p, false) : (go - ge));
+    // o[0, x, 2]: PPG reads positions of the shared sequence two up to L2 (never past it)
+    auto row0 = [&](int x) __attribute__((always_inline)) {
+        if constexpr (PPG) return boundary_value_pp(x <= L2 ? x : L2, g2p, free_two);
+        else return boundary_value(x, go, ge, free_two);
+    };
 
     // strip 0 reads its boundary column like every other strip: states of (y, 0) = (-inf, o[y,0,1], -inf)
-    if (h == 0 && chain_strip == 0)
+    if (h == 0 && chain_strip == 0 && strip_lo == 0)
         for (int y = 1; y <= max_l1 + 4; ++y)
             *reinterpret_cast<float4 *>(my_bnd + (int64_t)y * BROW) =
-                make_float4(PRALINE_NEG_INF, boundary_value(y, go, ge, free_one), PRALINE_NEG_INF, 0.0f);
+                make_float4(PRALINE_NEG_INF, PPG ? boundary_value_pp(y <= g1_last + 1 ? y : g1_last + 1, g1p, free_one) : boundary_value(y, go, ge, free_one),
+                            PRALINE_NEG_INF, 0.0f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
 
@@ -486,10 +520,15 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
     if (LOCAL) {
         if (o001 > out_best) { out_best = o001; out_k = 1; }
         if (o002 > out_best) { out_best = o002; out_k = 2; }
+        if (!CHAIN && strip_lo > 0 && have_pair) {   // the running maximum of the strips before this launch
+            out_best = scores[my_pair];
+            out_y = end_cells[(int64_t)my_pair * 4 + 0]; out_x = end_cells[(int64_t)my_pair * 4 + 1]; out_k = end_cells[(int64_t)my_pair * 4 + 2];
+        }
     }
     float corner_m = PRALINE_NEG_INF, corner_u = PRALINE_NEG_INF, corner_l = PRALINE_NEG_INF;
 
-    for (int s = CHAIN ? chain_strip : 0; s < (CHAIN ? chain_strip + 1 : nstrips); ++s) {
+    const int strip_end = (strip_cnt < nstrips - strip_lo) ? strip_lo + strip_cnt : nstrips;
+    for (int s = CHAIN ? chain_strip : strip_lo; s < (CHAIN ? chain_strip + 1 : strip_end); ++s) {
         const int x0 = s * 32;
         const int xb = x0 + 16 * h;
         const bool last_owner = (s == nstrips - 1) && own_last;
@@ -528,14 +567,23 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
         for (int c = 0; c < 16; ++c) {
             Mp[c] = PRALINE_NEG_INF;
             Up[c] = PRALINE_NEG_INF;
-            Lp[c] = boundary_value(xb + c + 1, go, ge, free_two);
+            Lp[c] = row0(xb + c + 1);
+        }
+        // PPG: (open, extend) of the positions xb + c of sequence two - the scores of L[y][xb + c + 1]
+        float g2o[PPG ? 16 : 1], g2e[PPG ? 16 : 1];
+        if constexpr (PPG) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int pos = xb + c < L2 ? xb + c : L2 - 1;   // (columns past the sequence reach no reported cell)
+                g2o[c] = g2p[2 * pos]; g2e[c] = g2p[2 * pos + 1];
+            }
         }
         // lower half: states of the cell (0, x0); upper half: states of (0, x0 + 16), which after the first
         // step's generation shift are the diagonal input of its row 1
         float cdM = (s == 0) ? 0.0f : PRALINE_NEG_INF;
         float cdU = (s == 0) ? o001 : PRALINE_NEG_INF;
-        float cdL = (s == 0) ? o002 : boundary_value(x0, go, ge, free_two);
-        float cxm = PRALINE_NEG_INF, cxu = PRALINE_NEG_INF, cxl = boundary_value(x0 + 16, go, ge, free_two);
+        float cdL = (s == 0) ? o002 : row0(x0);
+        float cxm = PRALINE_NEG_INF, cxu = PRALINE_NEG_INF, cxl = row0(x0 + 16);
         float cpxm = PRALINE_NEG_INF, cpxu = PRALINE_NEG_INF, cpxl = PRALINE_NEG_INF;
         float best_run = out_best;
         int best_y = out_y, best_x = out_x, best_k = out_k;
@@ -549,7 +597,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
         if constexpr (DENSE) {
             // rows 1 and 2 of the strip (the upper half takes rows 0 and 1: its first step is undone below); three register
             // sets rotate, the step at T fetches row T + 2
-            dense_lane = dense_task + (int64_t)s * dense_strip;
+            dense_lane = dense_task + (int64_t)(s - strip_lo) * dense_strip;
 #pragma unroll
             for (int r = 1; r <= 2; ++r) {
                 const f4n *q = reinterpret_cast<const f4n *>(dense_lane + (int64_t)r * 4096);
@@ -617,6 +665,13 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
         float4 bnd_prefB = *reinterpret_cast<const float4 *>(col_in + 2 * BROW);  // row 2
         float4 bnd_prefC = *reinterpret_cast<const float4 *>(col_in + 3 * BROW);  // row 3
         uint2 *tb_st = my_tb + (int64_t)s * tb_rows * 64 + (h ? 0 : 64);     // row yy = t - h of step t = 1
+        const unsigned *zm_strip = my_zm ? my_zm + (int64_t)s * (zm_rows + 1) : nullptr;
+        auto g1_at = [&](int pos) __attribute__((always_inline)) {
+            const int q = pos < 0 ? 0 : (pos > g1_last ? g1_last : pos);
+            return *reinterpret_cast<const float2 *>(g1p + 2 * q);
+        };
+        float2 g1rowA = make_float2(0.0f, 0.0f), g1rowB = g1rowA, g1rowC = g1rowA;   // steps 1, 2, 3
+        if constexpr (PPG) { g1rowA = g1_at(0 - h); g1rowB = g1_at(1 - h); g1rowC = g1_at(2 - h); }
 
         // BUSE holds operand row T + 1; BOLD row T (DM; otherwise BUSE again); PREF the boundary states of row T
 #define PRALINE_TB_STEP(T, CUR, PREV, BUSE, BOLD, PREF)                                                              \
@@ -640,12 +695,16 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
                                                 onehot_lane, SYM);                                                          \
         SYM = psym[(T) + 3];
         // dense tile: the step fetches the scores of the row two steps on (lower half: row T + 2)
-#define PRALINE_TB_STEP_DN(T, CUR, PREV, PREF)                                                                        \
-        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, false, SINK, 4>((T) - h, L1, have_pair, h, CUR, PREV, bX, bX, aop, aopH, \
-                                                b_next, b_stride, bnd_ld, bnd_st, PREF, tb_st, Mp, Up, Lp, cxm, cxu, cxl,   \
+        // (SFX: the rotating register set of the boundary prefetch and - PPG - of the row's gap scores: position T - h - 1 of
+        // sequence one at step T, refilled three steps ahead)
+#define PRALINE_TB_STEP_DN(T, CUR, PREV, SFX)                                                                         \
+        split16_tb_step<NR, NTERM, LOCAL, MASK, CHAIN, false, SINK, 4, 0, PPG>((T) - h, L1, have_pair, h, CUR, PREV, bX, bX, aop, aopH, \
+                                                b_next, b_stride, bnd_ld, bnd_st, bnd_pref##SFX, tb_st, Mp, Up, Lp, cxm, cxu, cxl, \
                                                 cpxm, cpxu, cpxl, cdM, cdU, cdL, best_run, best_y, best_x, best_k, go, ge,  \
                                                 xb, srect, chain_in, &chain_seen, (T) + 3, ckpt_strip, nullptr, 0,          \
-                                                dense_lane + (int64_t)((T) + 2) * 4096, 0u);
+                                                dense_lane + (int64_t)((T) + 2) * 4096, 0u, zm_strip, zm_rows, g1row##SFX.x, \
+                                                g1row##SFX.y, g2o, g2e);                                                    \
+        if constexpr (PPG) g1row##SFX = g1_at((T) + 3 - h - 1);
 #define PRALINE_TB_TAILS(T)                                                                                          \
         {                                                                                                            \
             const int yy_ = (T) - h;                                                                                 \
@@ -668,7 +727,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
         {
             const float best_s = best_run;
             const int by = best_y, bx = best_x, bk = best_k;
-            if constexpr (DENSE) { PRALINE_TB_STEP_DN(1, accA, accC, bnd_prefA) }
+            if constexpr (DENSE) { PRALINE_TB_STEP_DN(1, accA, accC, A) }
             else if constexpr (LOOKUP) { PRALINE_TB_STEP_LK(1, accA, accB, bnd_prefA, symA) }
             else if constexpr (BSRC == 1) PRALINE_TB_STEP_OH(1, accA, accB, bX, bZ, bnd_prefA, sw0, 3);
             else if constexpr (DM) PRALINE_TB_STEP(1, accA, accB, bX, bZ, bnd_prefA);
@@ -676,7 +735,7 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
             if (h) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    Mp[c] = PRALINE_NEG_INF; Up[c] = PRALINE_NEG_INF; Lp[c] = boundary_value(xb + c + 1, go, ge, free_two);
+                    Mp[c] = PRALINE_NEG_INF; Up[c] = PRALINE_NEG_INF; Lp[c] = row0(xb + c + 1);
                 }
                 best_run = best_s; best_y = by; best_x = bx; best_k = bk;
             }
@@ -730,17 +789,17 @@ __global__ __launch_bounds__(256, TWOPASS ? PRALINE_TB2_WAVES_PER_SIMD : (BSRC =
                 if (t - 2 >= chain_next) { chain_publish(chain_out, t - 2, lane); chain_next = t - 2 + chain_every; }
             }
             if constexpr (DENSE) {
-                PRALINE_TB_STEP_DN(t, accB, accA, bnd_prefB)
+                PRALINE_TB_STEP_DN(t, accB, accA, B)
                 PRALINE_TB_TAILS(t)
-                PRALINE_TB_STEP_DN(t + 1, accC, accB, bnd_prefC)
+                PRALINE_TB_STEP_DN(t + 1, accC, accB, C)
                 PRALINE_TB_TAILS(t + 1)
-                PRALINE_TB_STEP_DN(t + 2, accA, accC, bnd_prefA)
+                PRALINE_TB_STEP_DN(t + 2, accA, accC, A)
                 PRALINE_TB_TAILS(t + 2)
-                PRALINE_TB_STEP_DN(t + 3, accB, accA, bnd_prefB)
+                PRALINE_TB_STEP_DN(t + 3, accB, accA, B)
                 PRALINE_TB_TAILS(t + 3)
-                PRALINE_TB_STEP_DN(t + 4, accC, accB, bnd_prefC)
+                PRALINE_TB_STEP_DN(t + 4, accC, accB, C)
                 PRALINE_TB_TAILS(t + 4)
-                PRALINE_TB_STEP_DN(t + 5, accA, accC, bnd_prefA)
+                PRALINE_TB_STEP_DN(t + 5, accA, accC, A)
                 PRALINE_TB_TAILS(t + 5)
             } else if constexpr (LOOKUP) {
                 PRALINE_TB_STEP_LK(t, accB, accA, bnd_prefB, symB)

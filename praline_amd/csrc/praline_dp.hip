@@ -410,7 +410,7 @@ struct praline_arena {
     int64_t rp_end = 0;       // padded rows taken by sequences (the zero tail follows)
     bool wide = false;       // more than 32 active symbols: no MFMA operand layouts; every plan runs the reference-order path
     // per-position gap scores (praline_arena_set_gap_scores): (open, extend) per padded row; plans created while they
-    // are set keep the k_dp_batch task layout and can run with them (praline_plan_run_gaps)
+    // are set read their match scores from dense tiles and can run with them (praline_plan_run_gaps)
     DevBuf<float> d_gaps;
     bool has_gaps = false;
     Arena16Dev view16() const
@@ -784,7 +784,7 @@ static int arena_ensure_reft_table(praline_arena *a);
 
 // reference-order match scores of the pairs chunk_pairs[0 .. n_chunk) into mref + m_off[pair]
 static int launch_match_ref(praline_arena *a, const int32_t *d_pairs, const int32_t *d_chunk_pairs, size_t n_chunk, int max_l1,
-                            const int64_t *d_m_off, float *d_mref)
+                            const int64_t *d_m_off, float *d_mref, const TileOut &to = TileOut())
 {
     RC(arena_ensure_ref(a));
     RC(arena_ensure_reft_table(a));
@@ -793,7 +793,7 @@ static int launch_match_ref(praline_arena *a, const int32_t *d_pairs, const int3
     const int n_sets = (int)a->set_lo.size() - 1;
 #define PRALINE_REFT(TB)                                                                                               \
     hipLaunchKernelGGL((k_match_reft<TB>), grid, block, 0, st, a->d_raw.p, a->A, a->d_reft.p, a->rows_raw, a->d_row_off_raw.p, a->d_len.p,  \
-                       a->d_nzidx.p, a->d_nzcnt.p, a->d_set_lo.p, n_sets, d_pairs, d_chunk_pairs, d_m_off, d_mref)
+                       a->d_nzidx.p, a->d_nzcnt.p, a->d_set_lo.p, n_sets, d_pairs, d_chunk_pairs, d_m_off, d_mref, to)
     switch (a->reft_state == 1 ? a->ref_tb : 0) {
         case 4: PRALINE_REFT(4); break;
         case 8: PRALINE_REFT(8); break;
@@ -801,7 +801,7 @@ static int launch_match_ref(praline_arena *a, const int32_t *d_pairs, const int3
         case 32: PRALINE_REFT(32); break;
         default:
             hipLaunchKernelGGL(k_match_ref, grid, block, 0, st, a->d_raw.p, a->d_S.p, a->A, a->d_row_off_raw.p, a->d_len.p, a->d_nzidx.p,
-                               a->d_nzcnt.p, a->d_set_lo.p, n_sets, d_pairs, d_chunk_pairs, d_m_off, d_mref);
+                               a->d_nzcnt.p, a->d_set_lo.p, n_sets, d_pairs, d_chunk_pairs, d_m_off, d_mref, to);
     }
 #undef PRALINE_REFT
     HIPCHK(hipGetLastError());
@@ -853,7 +853,7 @@ static int arena_ensure_reft_table(praline_arena *a)
 }
 
 // the interleaved table of k_match_tile; state -1 when the arena does not qualify (more than 32 symbols, rows with more
-// than 8 nonzeros, table over the limit): such plans keep the k_match_reft / k_dp_batch path
+// than 8 nonzeros, table over the limit): such plans take their tiles from k_match_reft / k_match_ref
 static int arena_ensure_reft2(praline_arena *a)
 {
     if (a->reft2_state != 0) return PRALINE_OK;
@@ -959,7 +959,7 @@ struct praline_plan {
     bool want_paths = false;
     bool has_rects = false;
     int slot_rects = -1;  // >= 0: the rectangles live in fixed slots on the device (praline_plan_mask_path_bounds), this many used
-    int mask_kind = 0;   // 0 none, 1 <= PRALINE_MAX_RECTS rectangles per pair (registers), 2 any number (k_dp_batch MASK = 2)
+    int mask_kind = 0;   // 0 none, 1 <= PRALINE_MAX_RECTS rectangles per pair (registers), 2 any number (per-row mask words, k_build_zmask)
     int tp = 1;
     bool split = false;  // k_dp_split task layout
     bool quad = false;   // path plan on a one-hot arena in the 16-pairs-per-task layout of k_dp_quad_tb (dp_quad.hip.h)
@@ -1010,23 +1010,25 @@ struct praline_plan {
     std::vector<int64_t> slot_off;
     float last_kernel_ms = 0.0f;
     int last_mode = -1;
-    // reference-order audit mode (PRALINE_MATCH_REFERENCE at plan creation): k_dp_batch layout, dense match scores
-    bool ref = false;
+    // plans whose DP reads its match scores from DENSE TILES (the dense-tile instances of k_dp_split16 / k_dp_split16_tb,
+    // plan_run_dense) and who writes the tiles:
+    //   1  k_match_tile - the reference's summation order (PRALINE_MATCH_REFERENCE) on arenas of up to 32 symbols whose rows
+    //      hold at most 8 nonzeros (dp_reftile.hip.h)
+    //   2  k_match_reft / k_match_ref, one cell per thread - the reference's order for every other arena (more than 32 active
+    //      symbols, denser rows) and for plans with more than PRALINE_MAX_RECTS rectangles per pair on float profiles
+    //   3  k_scores_tile_batch, the fp32 MFMA chain - plans created on an arena with per-position gap scores in the default
+    //      match mode (both their constant-gap and their per-position runs)
+    int dense_kind = 0;
     std::vector<int32_t> h_lane_pair, h_pairs;
-    std::vector<int64_t> h_m_off;
-    DevBuf<int64_t> d_m_off;
     DevBuf<int32_t> d_chunk_pairs;
-    DevBuf<float> d_mref;
-    // reference-order match scores on the split-strip kernels (k_match_tile + the dense-tile instances, dp_reftile.hip.h)
-    bool ref_tile = false;
-    bool ppg = false;       // created on an arena with per-position gap scores: k_dp_batch layout, dense match scores
+    bool ppg = false;       // created on an arena with per-position gap scores
     bool run_ppg = false;   // the run in progress uses them (praline_plan_run_gaps)
     DevBuf<float> d_dense;                  // the tiles of one launch chunk
     DevBuf<int64_t> d_dense_off;
     DevBuf<RefTileBlock> d_tile_blocks;
     DevBuf<int32_t> d_tile_grp;
     std::vector<int32_t> h_lane_one;        // [task][32], host copy (groups of tasks with the same sequences one)
-    // mask_kind 2: column masks per (pair, strip, row) for k_dp_batch MASK = 2 (k_build_zmask)
+    // mask_kind 2: column masks per (pair, strip, row) (k_build_zmask)
     DevBuf<unsigned> d_zmask;
     DevBuf<int64_t> d_zm_off;
     std::string last_kernel;        // the DP kernel instance the last run launched (as rocprofv3 names it)
@@ -1181,45 +1183,35 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     // ---- host scheduling (sched.cpp): tasks, launch order, workgroup descriptors ----
     SchedOptions opt;
     opt.want_paths = pl->want_paths;
-    // every plan runs on the split-strip kernels (32 pairs per wave, both halves on the same pairs);
-    // PRALINE_KERNEL=batch selects the older k_dp_batch layout for A/B comparisons
-    opt.split_layout = a.nr16 > 0 || !want_paths;
-    if (const char *env = getenv("PRALINE_KERNEL")) { if (!strcmp(env, "batch")) opt.split_layout = false; }
-    if (const char *env = getenv("PRALINE_TP")) opt.tp = atoi(env);
-    // the split-strip kernels hold PRALINE_MAX_RECTS rectangles per pair in registers; plans with more per pair (many
-    // Waterman-Eggert iterations: rare) take the dense-match-score path with per-row column masks (k_build_zmask).
-    // (The MFMA-fed k_dp_batch instance with those masks gave wrong LOCAL scores under ROCm 7.2 - codegen-sensitive,
-    // not understood - so it is not used.)
-    // (plain sequences: k_dp_quad_tb reads the per-row mask words itself, any number of rectangles)
+    // every plan runs on the split-strip layout (32 pairs per wave, both halves on the same pairs)
+    opt.split_layout = true;
+    // the strip kernels hold PRALINE_MAX_RECTS rectangles per pair in registers; plans with more per pair (many
+    // Waterman-Eggert iterations: rare) read per-row column masks (k_build_zmask): k_dp_quad_tb for plain sequences, the
+    // dense-tile instances for every other arena
     const bool quad_ok = want_paths && a.nr16 > 0 && a.nterm16 == 1 && a.onehot && match_mode() == PRALINE_MATCH_FAST &&
-                         !(getenv("PRALINE_TB_QUAD") && getenv("PRALINE_TB_QUAD")[0] == '0') &&
-                         !(getenv("PRALINE_KERNEL") && !strcmp(getenv("PRALINE_KERNEL"), "batch"));
-    pl->ref = match_mode() == PRALINE_MATCH_REFERENCE || a.wide || (many_rects && !quad_ok);
-    if (many_rects && !a.wide && match_mode() != PRALINE_MATCH_REFERENCE && getenv("PRALINE_EXP_BATCH_MASK2") && want_paths) {
-        // experiment (needs a library built with -DPRALINE_EXP_BATCH_MASK2): column masks on the MFMA-fed k_dp_batch
-        pl->ref = false;
-        opt.split_layout = false;
-        opt.tp = 1;
-    }
+                         !(getenv("PRALINE_TB_QUAD") && getenv("PRALINE_TB_QUAD")[0] == '0');
     pl->ppg = a.has_gaps;
-    // reference order on the split-strip kernels: arenas of up to 32 symbols whose rows hold at most 8 nonzeros
-    // (PRALINE_NO_REFTILE=1: the one-cell-per-thread kernels and k_dp_batch, as for wide arenas and many-rectangle plans)
-    if (pl->ref && !pl->ppg && match_mode() == PRALINE_MATCH_REFERENCE && !a.wide && !many_rects && opt.split_layout && a.nr16 > 0 &&
-        !(getenv("PRALINE_NO_REFTILE") && getenv("PRALINE_NO_REFTILE")[0] == '1')) {
-        int rc = arena_ensure_reft2(arena);
-        if (rc != PRALINE_OK) { delete pl; return rc; }
-        // (a task's tile must fit a launch chunk: strips x rows x 4 KiB - sequences beyond ~16 000 positions keep the
-        // per-pair dense matrices of the per-cell path)
-        const double worst_tile = ((a.max_len + 31) / 32) * (a.max_len + (double)PRALINE_DENSE_PAD) * 4096.0;
-        if (a.reft2_state == 1 && worst_tile <= (double)reftile_budget_bytes()) { pl->ref = false; pl->ref_tile = true; }
+    // who forms the match scores (praline_plan::dense_kind): the reference's order on request, for arenas without packed
+    // operands (more than 32 active symbols) and for many-rectangle plans on float profiles
+    if (match_mode() == PRALINE_MATCH_REFERENCE || a.wide || (many_rects && !quad_ok)) {
+        pl->dense_kind = 2;
+        // arenas of up to 32 symbols whose rows hold at most 8 nonzeros: k_match_tile (PRALINE_NO_REFTILE=1: the
+        // one-cell-per-thread kernels, as for the other arenas - the independent second implementation the tests compare with)
+        if (match_mode() == PRALINE_MATCH_REFERENCE && !a.wide && a.nr16 > 0 &&
+            !(getenv("PRALINE_NO_REFTILE") && getenv("PRALINE_NO_REFTILE")[0] == '1')) {
+            int rc = arena_ensure_reft2(arena);
+            if (rc != PRALINE_OK) { delete pl; return rc; }
+            if (a.reft2_state == 1) pl->dense_kind = 1;
+        }
+    } else if (pl->ppg) {
+        pl->dense_kind = 3;
     }
-    if (pl->ref || pl->ppg) { opt.split_layout = false; opt.tp = 1; }
     // alignments with paths of plain sequences (exact-mode arenas with their symbol stream): k_dp_quad_tb, 16 pairs per
     // task (PRALINE_TB_QUAD=0: the 32-pair strip kernels, as for every other arena)
     {
         const char *tq = getenv("PRALINE_TB_QUAD");
         const Arena16Dev v16q = a.view16();
-        pl->quad = want_paths && !pl->ref && !pl->ref_tile && !pl->ppg && opt.split_layout && a.nr16 > 0 && a.nterm16 == 1 &&
+        pl->quad = want_paths && pl->dense_kind == 0 && a.nr16 > 0 && a.nterm16 == 1 &&
                    v16q.sym8 != nullptr && match_mode() == PRALINE_MATCH_FAST && !(tq && tq[0] == '0');
         opt.quad16 = pl->quad;
     }
@@ -1243,8 +1235,8 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         // path plans without rectangles get the pipeline schedule BESIDE their task schedule: global runs take it as the
         // forward fill of the two-pass scheme (PRALINE_TB_PIPE=0: never), the other modes keep chain / task mode
         const char *tpp = getenv("PRALINE_TB_PIPE");
-        const bool paths_ok = !want_paths || (!pl->has_rects && !pl->ref_tile && !pl->ppg && !(tpp && tpp[0] == '0'));
-        if (paths_ok && !pl->ref && opt.split_layout && a.nr16 > 0 && v16.stage && v16.sym8 == nullptr &&
+        const bool paths_ok = !want_paths || (!pl->has_rects && !(tpp && tpp[0] == '0'));
+        if (paths_ok && pl->dense_kind == 0 && a.nr16 > 0 && v16.stage && v16.sym8 == nullptr &&
             praline_pipe_supported(a.nr16, a.nterm16) && match_mode() == PRALINE_MATCH_FAST && !(np && np[0] == '1') && n_pairs > 0) {
             // (a schedule prepared from the same lengths and pair list while the arena was being created: take it)
             const bool prepared = prep != nullptr && prep->n_pairs == n_pairs && prep->lens == a.len &&
@@ -1289,11 +1281,11 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     pl->cells = sch.cells;
     const std::vector<int32_t> &lane_one = sch.lane_one, &lane_pair = sch.lane_pair;
     const std::vector<PairLoc> &loc = sch.loc;
-    if (pl->ref || pl->ppg) {
+    if (pl->dense_kind != 0) {
         pl->h_lane_pair = sch.lane_pair;
         pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);
     }
-    if (pl->ref_tile) pl->h_lane_one = sch.lane_one;
+    if (pl->dense_kind == 1) pl->h_lane_one = sch.lane_one;
     if (!want_paths && !pl->pipe.ok && pl->h_pairs.empty() && (int64_t)pl->tasks.size() <= chain_max_tasks())
         pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);   // (score plans that may run in chain mode: k_semiglobal_end reads the pairs)
     const int64_t bnd = pl->bnd_elems, cap = pl->path_cap;
@@ -1306,8 +1298,8 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         delete pl;
         return rc;
     }
-    if ((pl->ref || pl->ppg) && !want_paths) {
-        if ((rc = pl->d_pairs.upload(pl->h_pairs, st))) { delete pl; return rc; }
+    if (pl->dense_kind != 0 && !want_paths) {   // (the per-cell match-score kernels and k_semiglobal_end read them)
+        if ((rc = pl->d_pairs.upload(pl->h_pairs, st)) || (rc = pl->d_loc.upload(loc, st))) { delete pl; return rc; }
     }
     if (pl->pipe.ok) {
         if ((rc = pl->d_pipe_items.upload(pl->pipe.items, st)) || (rc = pl->d_pipe_tasks.upload(pl->pipe.tasks, st)) ||
@@ -1406,39 +1398,25 @@ extern "C" int64_t praline_plan_path_capacity(const praline_plan *plan) { return
 extern "C" void *praline_plan_device_scores(praline_plan *plan) { return plan ? (void *)plan->d_scores.p : nullptr; }
 
 // --------------------------------------------------------------------------------------------
-// kernel dispatch: one translation unit per MFMA step count (dp_instance.hip), see dp_launch.hip.h
+// the scores kernels of the split-strip layout: k_dp_split16 on the f16 hi/lo operands, or - PRALINE_MM=f32 - k_dp_split on the
+// fp32 MFMA chain (one translation unit per MFMA step count, dp_split_instance.hip); see dp_launch.hip.h
 // --------------------------------------------------------------------------------------------
-static int launch_dp(int nstep, const LaunchArgs &la, int tp, bool local, int out, int mask)
+static int launch_scores(int nstep, const LaunchArgs &la, bool local)
 {
-    int rc = PRALINE_ERR_UNSUPPORTED;
-    if (la.split) {
-        if (out != 0 || mask) return fail(PRALINE_ERR_UNSUPPORTED, "k_dp_split is scores-only");
-        if (la.a16 != nullptr) {
-            rc = praline_launch_split16(la, *la.a16, la.nr16, la.nterm16, local);
-            if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16 instance for nr=%d nterm=%d", la.nr16, la.nterm16);
-            return PRALINE_OK;
-        }
-        switch (nstep) {
-            case 2: return praline_launch_split_2(la, local);
-            case 8: return praline_launch_split_8(la, local);
-            case 10: return praline_launch_split_10(la, local);
-            case 12: return praline_launch_split_12(la, local);
-            case 14: return praline_launch_split_14(la, local);
-            case 16: return praline_launch_split_16(la, local);
-        }
-        return fail(PRALINE_ERR_UNSUPPORTED, "no k_dp_split instance for nstep=%d", nstep);
+    if (la.a16 != nullptr) {
+        const int rc = praline_launch_split16(la, *la.a16, la.nr16, la.nterm16, local);
+        if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16 instance for nr=%d nterm=%d", la.nr16, la.nterm16);
+        return PRALINE_OK;
     }
     switch (nstep) {
-        case 2: rc = praline_launch_dp_2(la, tp, local, out, mask); break;
-        case 8: rc = praline_launch_dp_8(la, tp, local, out, mask); break;
-        case 10: rc = praline_launch_dp_10(la, tp, local, out, mask); break;
-        case 12: rc = praline_launch_dp_12(la, tp, local, out, mask); break;
-        case 14: rc = praline_launch_dp_14(la, tp, local, out, mask); break;
-        case 16: rc = praline_launch_dp_16(la, tp, local, out, mask); break;
+        case 2: return praline_launch_split_2(la, local);
+        case 8: return praline_launch_split_8(la, local);
+        case 10: return praline_launch_split_10(la, local);
+        case 12: return praline_launch_split_12(la, local);
+        case 14: return praline_launch_split_14(la, local);
+        case 16: return praline_launch_split_16(la, local);
     }
-    if (rc != PRALINE_OK)
-        return fail(rc, "no kernel instance for nstep=%d tp=%d local=%d out=%d mask=%d", nstep, tp, (int)local, out, (int)mask);
-    return PRALINE_OK;
+    return fail(PRALINE_ERR_UNSUPPORTED, "no k_dp_split instance for nstep=%d", nstep);
 }
 
 // end cells of the semiglobal modes + device traceback for the tasks [t0, t1) of a path plan (after their fill)
@@ -1462,94 +1440,6 @@ static int launch_traceback(praline_plan &pl, const LaunchArgs &la, size_t t0, s
     return PRALINE_OK;
 }
 
-// dense reference-order match scores per launch chunk (bytes)
-static size_t ref_budget_bytes()
-{
-    if (const char *env = getenv("PRALINE_REF_BUDGET_MB")) return (size_t)atoll(env) << 20;
-    return (size_t)8 << 30;
-}
-
-// PRALINE_MATCH_REFERENCE: per chunk of tasks, k_match_ref writes the match scores of the chunk's pairs in the
-// reference's summation order, k_dp_batch<MSRC = 1> runs the fill on them (scores-only or with packed traceback).
-static int plan_run_ref(praline_plan &pl, LaunchArgs la, int mode, bool local)
-{
-    praline_arena &a = *pl.arena;
-    if (pl.ref) RC(arena_ensure_ref(&a));
-    hipStream_t st = g_rt.stream;
-    const size_t nt = pl.tasks.size();
-    const size_t m_budget = ref_budget_bytes(), tb_budget = tb_budget_bytes();
-    const bool semiglobal = mode >= 2;
-    if (pl.h_m_off.size() != (size_t)pl.n_pairs) pl.h_m_off.assign((size_t)pl.n_pairs, 0);
-    if (!pl.d_m_off.p) RC(pl.d_m_off.alloc((size_t)pl.n_pairs));
-    if (!pl.d_chunk_pairs.p) RC(pl.d_chunk_pairs.alloc((size_t)pl.n_pairs));
-    if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
-    la.split = 0;
-    size_t t0 = 0;
-    std::vector<int32_t> chunk;
-    while (t0 < nt) {
-        size_t t1 = t0;
-        int64_t tb_e = 0, aux_e = 0, m_e = 0;
-        int max_l1 = 0;
-        chunk.clear();
-        while (t1 < nt) {
-            int64_t m_add = 0;
-            for (int l = 0; l < 64; ++l) {
-                const int32_t p = pl.h_lane_pair[t1 * 64 + l];
-                if (p >= 0) m_add += (int64_t)a.len[pl.h_pairs[2 * p]] * a.len[pl.h_pairs[2 * p + 1]];
-            }
-            const int64_t tb_add = pl.want_paths ? pl.tb_elems[t1] : 0;
-            if (t1 > t0 && ((size_t)(m_e + m_add) * sizeof(float) > m_budget || (size_t)(tb_e + tb_add) * sizeof(uint4) > tb_budget)) break;
-            for (int l = 0; l < 64; ++l) {
-                const int32_t p = pl.h_lane_pair[t1 * 64 + l];
-                if (p < 0) continue;
-                pl.h_m_off[p] = m_e;
-                m_e += (int64_t)a.len[pl.h_pairs[2 * p]] * a.len[pl.h_pairs[2 * p + 1]];
-                max_l1 = std::max(max_l1, (int)a.len[pl.h_pairs[2 * p]]);
-                chunk.push_back(p);
-            }
-            pl.tasks[t1].tb_off = tb_e;
-            pl.tasks[t1].aux_off = aux_e;
-            tb_e += tb_add;
-            aux_e += (pl.want_paths && semiglobal) ? pl.aux_elems[t1] : 0;
-            ++t1;
-        }
-        if (pl.d_mref.n < (size_t)std::max<int64_t>(m_e, 1)) RC(pl.d_mref.alloc((size_t)std::max<int64_t>(m_e, 1)));
-        if (pl.want_paths) {
-            if (pl.d_tb.n < (size_t)tb_e * sizeof(uint4)) RC(pl.d_tb.alloc((size_t)tb_e * sizeof(uint4)));
-            if (pl.d_aux.n < (size_t)std::max<int64_t>(aux_e, 1)) RC(pl.d_aux.alloc((size_t)std::max<int64_t>(aux_e, 1)));
-        }
-        HIPCHK(hipMemcpyAsync(pl.d_tasks.p + t0, pl.tasks.data() + t0, (t1 - t0) * sizeof(WaveTask), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(pl.d_m_off.p, pl.h_m_off.data(), (size_t)pl.n_pairs * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        if (!chunk.empty()) {
-            HIPCHK(hipMemcpyAsync(pl.d_chunk_pairs.p, chunk.data(), chunk.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            if (pl.ref) {
-                RC(launch_match_ref(&a, pl.d_pairs.p, pl.d_chunk_pairs.p, chunk.size(), max_l1, pl.d_m_off.p, pl.d_mref.p));
-            } else {
-                // (a plan running with per-position gap scores in the default match mode: the fp32 MFMA chain of k_scores_tile)
-                const int tiles_x = (a.max_len + 31) / 32, tiles_y = (max_l1 + 31) / 32;
-                hipLaunchKernelGGL(k_scores_tile_batch, dim3((unsigned)chunk.size(), (unsigned)(tiles_x * tiles_y)), dim3(64), 0, st,
-                                   a.view(), pl.d_pairs.p, pl.d_chunk_pairs.p, pl.d_m_off.p, a.nstep, tiles_x, pl.d_mref.p);
-                HIPCHK(hipGetLastError());
-            }
-        }
-        la.tasks = pl.d_tasks.p + t0;
-        la.lane_one = pl.d_lane_one.p + t0 * 64;
-        la.lane_pair = pl.d_lane_pair.p + t0 * 64;
-        la.tb = (uint4 *)pl.d_tb.p;
-        la.aux = pl.d_aux.p;
-        la.n_tasks = (unsigned)(t1 - t0);
-        la.mref = pl.d_mref.p;
-        la.m_off = pl.d_m_off.p;
-        int rc = praline_launch_dp_ref(la, local, pl.want_paths ? 1 : 0, pl.mask_kind);
-        if (rc != PRALINE_OK) return fail(rc, "no reference-order kernel instance (paths=%d mask=%d)", (int)pl.want_paths, (int)pl.has_rects);
-        HIPCHK(hipGetLastError());
-        if (pl.want_paths) RC(launch_traceback(pl, la, t0, t1, mode));
-        HIPCHK(hipStreamSynchronize(st));   // the host lists above are rewritten for the next chunk
-        t0 = t1;
-    }
-    return PRALINE_OK;
-}
-
 // dense match-score tiles per launch chunk (bytes)
 static size_t reftile_budget_bytes()
 {
@@ -1557,26 +1447,41 @@ static size_t reftile_budget_bytes()
     return (size_t)32 << 30;
 }
 
-// PRALINE_MATCH_REFERENCE on the split-strip kernels: per chunk of tasks k_match_tile writes the reference-order match
-// scores as dense tiles (4 bytes per cell and padding), the dense-tile instance of k_dp_split16 (scores) or
-// k_dp_split16_tb (+ k_traceback) consumes them.  One stream, one tile set: a k_match_tile workgroup fills its CU
-// (registers and LDS), so a second stream only time-slices the chip (measured on C2: four chunks alternating between
-// two streams 31 ms, one chunk 19 ms).
-static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int mode, bool local)
+// Plans whose DP reads its match scores from dense tiles (praline_plan::dense_kind: the reference's summation order, arenas
+// without packed operands, many-rectangle plans on float profiles, per-position gap scores).  Per chunk of tasks one of the
+// producers writes the tiles (4 bytes per cell and padding):
+//   1  k_match_tile (dp_reftile.hip.h);  2  k_match_reft / k_match_ref, one cell per thread;  3  k_scores_tile_batch (fp32 MFMA)
+// and a dense-tile DP instance consumes them: k_dp_split16<1, 1, LOCAL, 4> for scores, k_dp_split16_tb<1, 3, LOCAL, MASK, .., 4,
+// PPG, NOFLAGS> (+ k_traceback) for alignments with paths, with per-position gap scores (ppg) and for the scores of tasks that
+// are swept in several launches.  A task whose tile exceeds the chunk budget (sequences beyond ~16 000 positions) runs alone,
+// a range of strips per launch: the tile then holds that range, the boundary column and the local maximum carry over.
+// One stream, one tile set: a k_match_tile workgroup fills its CU (registers and LDS), so a second stream only time-slices the
+// chip (measured on C2: four chunks alternating between two streams 31 ms, one chunk 19 ms).
+static int plan_run_dense(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int mode, bool local)
 {
     praline_arena &a = *pl.arena;
-    if (a.reft2_state == 0) RC(arena_ensure_reft2(&a));   // (the arena changed since the plan was made)
-    if (a.reft2_state != 1) return fail(PRALINE_ERR_UNSUPPORTED, "the arena no longer qualifies for the reference-order tiles");
+    int producer = pl.dense_kind;
+    if (producer == 1) {
+        if (a.reft2_state == 0) RC(arena_ensure_reft2(&a));   // (the arena changed since the plan was made)
+        if (a.reft2_state != 1) producer = 2;                  // (... and no longer qualifies for k_match_tile)
+    }
     hipStream_t st = g_rt.stream;
     const size_t nt = pl.tasks.size();
     const bool semiglobal = mode >= 2;
+    const bool ppg = pl.run_ppg;
     const size_t m_budget = reftile_budget_bytes(), tb_budget = tb_budget_bytes();
-    auto tile_floats = [&](const WaveTask &wt) { return (int64_t)wt.nstrips * (wt.max_l1 + PRALINE_DENSE_PAD) * 1024; };
-    struct Chunk { size_t t0, t1, b0, b1; int64_t m_e, tb_e, aux_e; };
+    auto strip_floats = [&](const WaveTask &wt) { return (int64_t)(wt.max_l1 + PRALINE_DENSE_PAD) * 1024; };
+    // range: the chunk is ONE task and sweeps its strips [strip_lo, strip_lo + strip_cnt); last: the task's end cells are final
+    struct Chunk { size_t t0, t1, b0, b1, c0, c1; int64_t m_e, tb_e, aux_e; int strip_lo, strip_cnt, max_l1, strips; bool range, last; };
     std::vector<Chunk> chunks;
-    std::vector<int64_t> dense_off(nt);
+    std::vector<int64_t> dense_off(nt, 0);
     std::vector<RefTileBlock> blocks;
     std::vector<int32_t> grp;   // group records (dp_reftile.h)
+    std::vector<int32_t> chunk_pairs;   // the pairs of every chunk, chunk after chunk (producers 2 and 3)
+    bool any_range = false;
+    for (size_t t = 0; t < nt; ++t) any_range = any_range || (size_t)(pl.tasks[t].nstrips * strip_floats(pl.tasks[t])) * 4 > m_budget;
+    // plans without paths: the scores kernel, unless a task runs in strip ranges or with per-position gap scores
+    const bool fill_only = !pl.want_paths && (ppg || any_range);
     // k_match_tile's workgroups of a chunk: the tasks are grouped by their 32 sequences one (the schedule gives every
     // sequence two of a set of ones its own task), a group's sequences two are laid end to end and cut into 128 columns
     auto add_blocks = [&](size_t t0, size_t t1) {
@@ -1601,26 +1506,65 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
             for (int32_t c = 0; c * 64 < cum; ++c) blocks.push_back({base, (int32_t)mem.size(), c, 0});
         }
     };
+    auto add_pairs = [&](size_t t0, size_t t1, int &max_l1, int &strips) {
+        for (size_t t = t0; t < t1; ++t) {
+            bool any = false;
+            for (int l = 0; l < 32; ++l) {
+                const int32_t p = pl.h_lane_pair[t * 32 + l];
+                if (p < 0) continue;
+                chunk_pairs.push_back(p);
+                any = true;
+            }
+            if (any) { max_l1 = std::max(max_l1, (int)pl.tasks[t].max_l1); strips = std::max(strips, (int)pl.tasks[t].nstrips); }
+        }
+    };
+    int64_t bnd4_e = 0;   // fill_only: the float4 boundary columns of k_dp_split16_tb (the plan's own are float2)
     for (size_t t0 = 0; t0 < nt;) {
+        const WaveTask &w0 = pl.tasks[t0];
+        const int64_t sf = strip_floats(w0);
+        if ((size_t)(w0.nstrips * sf) * 4 > m_budget) {
+            // one task, strip ranges
+            const int per = (int)std::max<int64_t>(1, (int64_t)(m_budget / 4) / sf);
+            const size_t c0 = chunk_pairs.size();
+            int ml = 0, strips = 0;
+            add_pairs(t0, t0 + 1, ml, strips);
+            dense_off[t0] = 0;
+            pl.tasks[t0].tb_off = 0;
+            pl.tasks[t0].aux_off = 0;
+            if (fill_only) { pl.tasks[t0].bnd_off = bnd4_e; bnd4_e += (int64_t)(w0.max_l1 + 24) * 32; }
+            for (int lo = 0; lo < w0.nstrips; lo += per) {
+                const int cnt = std::min(per, w0.nstrips - lo);
+                chunks.push_back({t0, t0 + 1, blocks.size(), blocks.size(), c0, chunk_pairs.size(), (int64_t)cnt * sf,
+                                  pl.want_paths ? pl.tb_elems[t0] : 0, semiglobal ? pl.aux_elems[t0] : 0, lo, cnt, ml, cnt, true,
+                                  lo + cnt >= w0.nstrips});
+            }
+            ++t0;
+            continue;
+        }
         size_t t1 = t0;
-        const size_t b0 = blocks.size();
+        const size_t b0 = blocks.size(), c0 = chunk_pairs.size();
         int64_t m_e = 0, tb_e = 0, aux_e = 0;
         while (t1 < nt) {
             const WaveTask &wt = pl.tasks[t1];
-            const int64_t m_add = tile_floats(wt), tb_add = pl.want_paths ? pl.tb_elems[t1] : 0;
+            const int64_t m_add = wt.nstrips * strip_floats(wt), tb_add = pl.want_paths ? pl.tb_elems[t1] : 0;
+            if ((size_t)m_add * 4 > m_budget) break;   // (the next task runs alone)
             if (t1 > t0 && ((size_t)(m_e + m_add) * 4 > m_budget || (size_t)(tb_e + tb_add) * 8 > tb_budget)) break;
             dense_off[t1] = m_e;
             pl.tasks[t1].tb_off = tb_e;
             pl.tasks[t1].aux_off = aux_e;
+            if (fill_only) { pl.tasks[t1].bnd_off = bnd4_e; bnd4_e += (int64_t)(wt.max_l1 + 24) * 32; }
             m_e += m_add;
             tb_e += tb_add;
-            aux_e += (pl.want_paths && semiglobal) ? pl.aux_elems[t1] : 0;
+            aux_e += ((pl.want_paths || fill_only) && semiglobal) ? pl.aux_elems[t1] : 0;
             ++t1;
         }
-        add_blocks(t0, t1);
-        chunks.push_back({t0, t1, b0, blocks.size(), m_e, tb_e, aux_e});
+        int ml = 0, strips = 0;
+        if (producer == 1) add_blocks(t0, t1);
+        else add_pairs(t0, t1, ml, strips);
+        chunks.push_back({t0, t1, b0, blocks.size(), c0, chunk_pairs.size(), m_e, tb_e, aux_e, 0, 0x3fffffff, ml, strips, false, true});
         t0 = t1;
     }
+    if (producer != 3 && (producer == 2 || any_range)) { RC(arena_ensure_ref(&a)); }
     {
         size_t need_m = 1, need_tb = 0, need_ax = 1;
         for (const Chunk &ch : chunks) {
@@ -1630,41 +1574,77 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
         }
         // (every buffer is sized once, before the loop: see the chunk loops of praline_plan_run)
         if (pl.d_dense.n < need_m) RC(pl.d_dense.alloc(need_m));
-        if (pl.want_paths) {
-            if (pl.d_tb.n < need_tb) RC(pl.d_tb.alloc(need_tb));
-            if (pl.d_aux.n < need_ax) RC(pl.d_aux.alloc(need_ax));
-        }
+        if (pl.want_paths && pl.d_tb.n < need_tb) RC(pl.d_tb.alloc(need_tb));
+        if ((pl.want_paths || fill_only) && pl.d_aux.n < need_ax) RC(pl.d_aux.alloc(need_ax));
+    }
+    if (fill_only) {
+        if (pl.d_bnd_chain.n < (size_t)bnd4_e * sizeof(float4)) RC(pl.d_bnd_chain.alloc((size_t)bnd4_e * sizeof(float4)));
+        if (pl.d_end_cells.n < (size_t)pl.n_pairs * 4) RC(pl.d_end_cells.alloc((size_t)pl.n_pairs * 4));
     }
     if (!pl.d_tasks.p) RC(pl.d_tasks.alloc(nt));
     if (pl.d_dense_off.n < nt) RC(pl.d_dense_off.alloc(nt));
     if (pl.d_tile_blocks.n < blocks.size()) RC(pl.d_tile_blocks.alloc(std::max<size_t>(blocks.size(), 1)));
     if (pl.d_tile_grp.n < grp.size()) RC(pl.d_tile_grp.alloc(std::max<size_t>(grp.size(), 1)));
+    if (pl.d_chunk_pairs.n < chunk_pairs.size()) RC(pl.d_chunk_pairs.alloc(std::max<size_t>(chunk_pairs.size(), 1)));
     HIPCHK(hipMemcpyAsync(pl.d_tasks.p, pl.tasks.data(), nt * sizeof(WaveTask), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(pl.d_dense_off.p, dense_off.data(), nt * sizeof(int64_t), hipMemcpyHostToDevice, st));
     if (!grp.empty()) HIPCHK(hipMemcpyAsync(pl.d_tile_grp.p, grp.data(), grp.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (!blocks.empty())
         HIPCHK(hipMemcpyAsync(pl.d_tile_blocks.p, blocks.data(), blocks.size() * sizeof(RefTileBlock), hipMemcpyHostToDevice, st));
+    if (!chunk_pairs.empty())
+        HIPCHK(hipMemcpyAsync(pl.d_chunk_pairs.p, chunk_pairs.data(), chunk_pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // (the host lists go out of scope)
+    {
+        char kn[200];
+        const char *lb = local ? "true" : "false";
+        if (pl.want_paths || fill_only)
+            snprintf(kn, sizeof(kn), "k_dp_split16_tb<1, 3, %s, %s, false, false, 4, %s, %s>", lb, pl.has_rects ? "true" : "false",
+                     ppg ? "true" : "false", fill_only ? "true" : "false");
+        else snprintf(kn, sizeof(kn), "k_dp_split16<1, 1, %s, 4, 1, false>", lb);   // (four-wave workgroups: refined below)
+        pl.last_kernel = kn;
+    }
     for (const Chunk &ch : chunks) {
-        RefTileArgs g;
-        g.raw = a.d_raw.p;
-        g.A = a.A;
-        g.T2 = a.d_reft2.p;
-        g.PR = a.pair_rows;
-        g.row_off_raw = a.d_row_off_raw.p;
-        g.len = a.d_len.p;
-        g.pr_off = a.d_pr_off.p;
-        g.set_lo = a.d_set_lo.p;
-        g.n_sets = (int)a.set_lo.size() - 1;
-        g.tasks = pl.d_tasks.p + ch.t0;
-        g.lane_one = pl.d_lane_one.p + ch.t0 * 32;
-        g.dense_off = pl.d_dense_off.p + ch.t0;
-        g.m = pl.d_dense.p;
-        g.blocks = pl.d_tile_blocks.p + ch.b0;
-        g.grp = pl.d_tile_grp.p;
-        g.waves = 0;
-        int rc = praline_launch_match_tile(g, a.ref_tb, (unsigned)(ch.b1 - ch.b0), st);
-        if (rc != PRALINE_OK) return fail(rc, "k_match_tile launch failed (A=%d, tb=%d)", a.A, a.ref_tb);
+        // ---- the tiles ----
+        const int chunk_producer = (producer == 1 && ch.range) ? 2 : producer;
+        if (chunk_producer == 1) {
+            RefTileArgs g;
+            g.raw = a.d_raw.p;
+            g.A = a.A;
+            g.T2 = a.d_reft2.p;
+            g.PR = a.pair_rows;
+            g.row_off_raw = a.d_row_off_raw.p;
+            g.len = a.d_len.p;
+            g.pr_off = a.d_pr_off.p;
+            g.set_lo = a.d_set_lo.p;
+            g.n_sets = (int)a.set_lo.size() - 1;
+            g.tasks = pl.d_tasks.p + ch.t0;
+            g.lane_one = pl.d_lane_one.p + ch.t0 * 32;
+            g.dense_off = pl.d_dense_off.p + ch.t0;
+            g.m = pl.d_dense.p;
+            g.blocks = pl.d_tile_blocks.p + ch.b0;
+            g.grp = pl.d_tile_grp.p;
+            g.waves = 0;
+            int rc = praline_launch_match_tile(g, a.ref_tb, (unsigned)(ch.b1 - ch.b0), st);
+            if (rc != PRALINE_OK) return fail(rc, "k_match_tile launch failed (A=%d, tb=%d)", a.A, a.ref_tb);
+        } else if (ch.c1 > ch.c0) {
+            TileOut to;
+            to.loc = pl.d_loc.p;
+            to.tasks = pl.d_tasks.p;
+            to.dense_off = pl.d_dense_off.p;
+            to.strip_lo = ch.strip_lo;
+            to.strip_cnt = ch.strip_cnt;
+            if (chunk_producer == 2) {
+                RC(launch_match_ref(&a, pl.d_pairs.p, pl.d_chunk_pairs.p + ch.c0, ch.c1 - ch.c0, ch.max_l1, nullptr, pl.d_dense.p, to));
+            } else {
+                const int tiles_x = ch.strips, tiles_y = (ch.max_l1 + 31) / 32;
+                if (tiles_x > 0 && tiles_y > 0) {
+                    hipLaunchKernelGGL(k_scores_tile_batch, dim3((unsigned)(ch.c1 - ch.c0), (unsigned)(tiles_x * tiles_y)), dim3(64), 0, st,
+                                       a.view(), pl.d_pairs.p, pl.d_chunk_pairs.p + ch.c0, nullptr, a.nstep, tiles_x, pl.d_dense.p, to);
+                    HIPCHK(hipGetLastError());
+                }
+            }
+        }
+        // ---- the fill ----
         a16.dense = pl.d_dense.p;
         a16.dense_off = pl.d_dense_off.p + ch.t0;
         la.stream = st;
@@ -1672,8 +1652,9 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
         la.lane_one = pl.d_lane_one.p + ch.t0 * 32;
         la.lane_pair = pl.d_lane_pair.p + ch.t0 * 32;
         la.n_tasks = (unsigned)(ch.t1 - ch.t0);
-        la.bnd = pl.d_bnd.p;
-        if (!pl.want_paths) {
+        la.bnd = fill_only ? (void *)pl.d_bnd_chain.p : (void *)pl.d_bnd.p;
+        int rc;
+        if (!pl.want_paths && !fill_only) {
             la.tb = nullptr;
             la.aux = nullptr;
             la.wg = nullptr;
@@ -1689,12 +1670,21 @@ static int plan_run_reftile(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int
             }
             rc = praline_launch_dense(la, a16, local);
             if (rc != PRALINE_OK) return fail(rc, "dense-tile scores launch failed");
-        } else {
-            la.tb = (uint4 *)pl.d_tb.p;
-            la.aux = pl.d_aux.p;
-            rc = praline_launch_dense_tb(la, a16, local, pl.has_rects);
-            if (rc != PRALINE_OK) return fail(rc, "dense-tile path launch failed");
+            continue;
+        }
+        la.tb = (uint4 *)pl.d_tb.p;
+        la.aux = pl.d_aux.p;
+        la.end_cells = pl.d_end_cells.p;
+        rc = praline_launch_dense_tb(la, a16, local, pl.has_rects, ppg, fill_only, ch.strip_lo, ch.strip_cnt);
+        if (rc != PRALINE_OK) return fail(rc, "dense-tile fill launch failed");
+        if (!ch.last) continue;
+        if (pl.want_paths) {
             RC(launch_traceback(pl, la, ch.t0, ch.t1, mode));
+        } else if (semiglobal) {
+            const int64_t lanes = (int64_t)(ch.t1 - ch.t0) * 32;
+            hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar, pl.d_tasks.p, pl.d_lane_one.p,
+                               pl.d_lane_pair.p, pl.d_pairs.p, la.aux, pl.d_end_cells.p, la.scores, la.rp, (int32_t)ch.t0, (int32_t)ch.t1, 1);
+            HIPCHK(hipGetLastError());
         }
     }
     return PRALINE_OK;
@@ -1833,9 +1823,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     {
         char kn[160];
         const char *lb = local ? "true" : "false";
-        if (pl.ref) snprintf(kn, sizeof(kn), "k_dp_batch<2, 1, %s, %d, %d, 1>", lb, pl.want_paths ? 1 : 0, pl.mask_kind);
-        else if (!pl.split) snprintf(kn, sizeof(kn), "k_dp_batch<%d, %d, %s, %d, %d, 0>", a.nstep, pl.want_paths ? 1 : pl.tp, lb, pl.want_paths ? 1 : 0, pl.mask_kind);
-        else if (pl.want_paths && pl.quad) snprintf(kn, sizeof(kn), "k_dp_quad_tb<%d, ...>", a.nr16);
+        if (pl.want_paths && pl.quad) snprintf(kn, sizeof(kn), "k_dp_quad_tb<%d, ...>", a.nr16);
         else if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // refined below (nterm, chain)
         else if (la.a16 == nullptr) snprintf(kn, sizeof(kn), "k_dp_split<%d, %s>", a.nstep, lb);
         else {
@@ -1850,25 +1838,10 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         }
         pl.last_kernel = kn;
     }
-    if (pl.run_ppg) {
-        la.rp.gaps = a.d_gaps.p;
-        char kn[160];
-        snprintf(kn, sizeof(kn), "k_dp_batch<2, 1, %s, %d, %d, 1, true>", local ? "true" : "false", pl.want_paths ? 1 : 0, pl.mask_kind);
-        pl.last_kernel = kn;
-    }
-    if (pl.ref || pl.run_ppg) {
+    if (pl.run_ppg) la.rp.gaps = a.d_gaps.p;
+    if (pl.dense_kind != 0) {   // (names the kernel it launches)
         HIPCHK(hipEventRecord(pl.ev0, st));
-        RC(plan_run_ref(pl, la, mode, local));
-        HIPCHK(hipEventRecord(pl.ev1, st));
-        return PRALINE_OK;
-    }
-    if (pl.ref_tile) {
-        char kn[160];
-        if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<1, 3, %s, %s, false, false, 4>", local ? "true" : "false", pl.has_rects ? "true" : "false");
-        else snprintf(kn, sizeof(kn), "k_dp_split16<1, 1, %s, 4, 1, false>", local ? "true" : "false");   // (refined by plan_run_reftile)
-        pl.last_kernel = kn;
-        HIPCHK(hipEventRecord(pl.ev0, st));
-        RC(plan_run_reftile(pl, la, a16, mode, local));
+        RC(plan_run_dense(pl, la, a16, mode, local));
         HIPCHK(hipEventRecord(pl.ev1, st));
         return PRALINE_OK;
     }
@@ -1935,7 +1908,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             la.n_wg = (unsigned)pl.wg_singles.size();
         }
         HIPCHK(hipEventRecord(pl.ev0, st));
-        RC(launch_dp(a.nstep, la, pl.tp, local, 0, 0));
+        RC(launch_scores(a.nstep, la, local));
         HIPCHK(hipEventRecord(pl.ev1, st));
         HIPCHK(hipGetLastError());
         return PRALINE_OK;
@@ -2357,12 +2330,9 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         } else if (pl.quad) {
             int rc = praline_launch_quad_tb(la, a16, a.nr16, tb_nterm == 1, local, pl.mask_kind);
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_quad_tb instance for nr=%d", a.nr16);
-        } else if (pl.split) {
+        } else {
             int rc = praline_launch_split16_tb(la, a16, a.nr16, tb_nterm, local, pl.has_rects);
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16_tb instance for nr=%d nterm=%d", a.nr16, tb_nterm);
-        } else {
-            la.split = 0;
-            RC(launch_dp(a.nstep, la, 1, local, 1, pl.mask_kind));
         }
         HIPCHK(hipGetLastError());
         RC(launch_traceback(pl, la, t0, t1, mode));
@@ -2380,7 +2350,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
 // praline_plan_run with the arena's per-position gap scores (praline_arena_set_gap_scores) instead of one (open, extend):
 // U[y][x] takes the scores of position y - 1 of sequence one, L[y][x] those of position x - 1 of sequence two
 // (cext.c:155-158,172-175), the boundary cells follow align.py:371-385.  The plan must have been created while the
-// arena held gap scores (such plans keep the k_dp_batch task layout and take their match scores from dense matrices).
+// arena held gap scores (such plans read their match scores from dense tiles, plan_run_dense).
 extern "C" int praline_plan_run_gaps(praline_plan *plan, int mode, void *d_scores)
 {
     if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
@@ -2614,7 +2584,6 @@ extern "C" int praline_plan_mask_path_bounds(praline_plan *plan)
 {
     if (!plan) return fail(PRALINE_ERR_ARG, "plan is NULL");
     if (!plan->want_paths || plan->last_mode < 0) return fail(PRALINE_ERR_ARG, "the plan has no paths (want_paths + praline_plan_run first)");
-    if (plan->ref) return fail(PRALINE_ERR_UNSUPPORTED, "reference-order plans take their rectangles at creation");
     if (plan->has_rects && plan->slot_rects < 0)
         return fail(PRALINE_ERR_UNSUPPORTED, "the plan was created with its own rectangle lists");
     if (plan->n_pairs == 0) return PRALINE_OK;
@@ -2869,7 +2838,7 @@ extern "C" int praline_raw_align(int mode, const praline_array *m, const praline
 }
 
 // --------------------------------------------------------------------------------------------
-// debug: the per-lane match-score tile exactly as k_dp_batch forms it (NSTEP = arena.nstep via a
+// debug: the per-lane match-score tile exactly as the fp32 MFMA chain forms it (NSTEP = arena.nstep via a
 // runtime loop).  out: [64][32] floats.  Not part of the public header.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_debug_tile(ArenaDev ar, const int32_t *lane_one, int two0, int two1, int x0,
@@ -2962,11 +2931,19 @@ extern "C" int praline_arena_info(const praline_arena *arena, int32_t *n_active,
     return PRALINE_OK;
 }
 
+extern "C" int praline_plan_tile_producer(const praline_plan *plan)
+{
+    if (!plan) return -1;
+    if (plan->dense_kind == 1 && plan->arena->reft2_state != 1) return 2;   // (the arena no longer qualifies for k_match_tile)
+    return plan->dense_kind;
+}
+
 // Which match-score arithmetic praline_plan_run uses for this plan: 0 = fp32 MFMA chain, 1 = f16 split.
 extern "C" int praline_plan_match_kind(const praline_plan *plan)
 {
     if (!plan) return -1;
-    if (plan->ref || plan->ref_tile) return 2;
+    if (plan->dense_kind == 3) return 0;   // (per-position gap plans: the fp32 MFMA chain for both kinds of run)
+    if (plan->dense_kind != 0) return 2;
     if (plan->split && plan->arena->nr16 > 0) {
         if (plan->want_paths) return 1;  // k_dp_split16_tb
         if (match_mode() != PRALINE_MATCH_F32) return 1;

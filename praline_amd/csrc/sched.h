@@ -7,8 +7,8 @@
 
 struct SchedOptions {
     bool want_paths = false;
-    bool split_layout = true;     // split-strip kernels (32 pairs per task); false: k_dp_batch (PRALINE_KERNEL=batch)
-    int tp = 0;                   // k_dp_batch only: sequence-two groups per wave (0 = automatic)
+    bool split_layout = true;     // split-strip kernels (32 pairs per task); false: the retired 64-lane task layout (scheduler unit tests only)
+    int tp = 0;                   // 64-lane layout only: sequence-two groups per wave (0 = automatic)
     int xcd_group = -1;           // XCD placement group size (-1 = automatic: tasks / 128 clamped to 16..1024, 0 = none)
     bool shared_waves = true;     // build the four-wave workgroup lists
     int64_t wave_slots = 2048;    // resident wave slots assumed by the share search (256 CUs x 4 SIMDs x 2)

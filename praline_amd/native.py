@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
 
 MAX_RECTS = 4   # zero rectangles per pair the split-strip kernels hold in registers (PRALINE_MAX_RECTS); plans with more
-                # per pair run on k_dp_batch with the rectangle list walked in memory (no limit)
+                # per pair read per-row mask words (k_build_zmask; no limit)
 
 
 class NativeError(RuntimeError):
@@ -112,6 +112,7 @@ def lib():
     L.praline_arena_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                      ctypes.POINTER(i32)]
     L.praline_plan_match_kind.argtypes = [vp]
+    L.praline_plan_tile_producer.argtypes = [vp]
     L.praline_merge_order.argtypes = [i64, vp, i32, vp]
     L.praline_plan_kernel_name.argtypes = [vp, ctypes.c_char_p, i64]
     if L.praline_abi_version() != 1:
@@ -576,6 +577,11 @@ class Plan(object):
     def match_kind(self):
         """0: this plan's run() evaluates match scores with the fp32 MFMA chain, 1: f16 split, 2: reference order."""
         return int(lib().praline_plan_match_kind(self._h))
+
+    def tile_producer(self):
+        """0: the fill forms its match scores itself; dense-tile plans: 1 k_match_tile, 2 one thread per cell (both in the
+        reference's summation order), 3 the fp32 MFMA chain (praline_plan_tile_producer)."""
+        return int(lib().praline_plan_tile_producer(self._h))
 
     def device_scores_ptr(self):
         return lib().praline_plan_device_scores(self._h)

@@ -1,5 +1,5 @@
 """Reference-order plans on the split-strip kernels (k_match_tile + dense-tile instances) against the one-cell-per-thread
-kernels + k_dp_batch (PRALINE_NO_REFTILE=1): bitwise equality of scores and paths, then the rates on C2."""
+kernels' tiles (PRALINE_NO_REFTILE=1): bitwise equality of scores and paths, then the rates on C2."""
 import sys, os, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -80,7 +80,7 @@ while time.time() < t_end:
             n_cases, kind, ref_mode, N, mu, len(pairs), mode, want_paths, rects is not None, os.environ["PRALINE_TB_TWOPASS"],
             os.environ["PRALINE_TB_KEEP"]), flush=True)
     arena = nat.Arena(profs, S)
-    # one batch in eight with per-position gap scores (praline_plan_run_gaps: k_dp_batch<..., PPG> on dense match scores)
+    # one batch in eight with per-position gap scores (praline_plan_run_gaps: the dense-tile instances with per-position gap scores)
     ppg = None
     if rng.random() < 0.125 and N <= 64:
         exact = kind in ("onehot", "dna")

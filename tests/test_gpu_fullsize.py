@@ -258,14 +258,14 @@ def test_c4_rank_share_full_size(nat, bba, monkeypatch):
     arena.close()
     # the same shard in the reference-order mode (k_match_tile + dense-tile instances; ~700 GB of tiles in 32 GiB launch
     # chunks, groups of several hundred tasks): 16 pairs bit-identical to the oracle's reference-order evaluation, and a
-    # 2 000-pair sample bit for bit against the one-cell-per-thread kernels + k_dp_batch
+    # 2 000-pair sample bit for bit against the tiles of the one-cell-per-thread kernels
     nat.set_match_mode("ref")
     try:
         arena = nat.Arena(profs, S)
         plan = nat.Plan(arena, mine)
         plan.run("global", GO, GE)
         scr = plan.scores().copy()
-        assert plan.match_kind() == 2 and ", 4, " in plan.kernel_name(), plan.kernel_name()
+        assert plan.match_kind() == 2 and plan.tile_producer() == 1 and ", 4, " in plan.kernel_name(), plan.kernel_name()
         plan.close()
         for k in rng.choice(len(mine), 16, replace=False):
             i, j = mine[k]
@@ -276,7 +276,7 @@ def test_c4_rank_share_full_size(nat, bba, monkeypatch):
         sample = np.sort(rng.choice(len(mine), 2000, replace=False))
         plan = nat.Plan(arena, mine[sample])
         plan.run("global", GO, GE)
-        assert "k_dp_batch" in plan.kernel_name()
+        assert plan.tile_producer() == 2 and ", 4, " in plan.kernel_name(), plan.kernel_name()
         assert np.array_equal(bits(plan.scores()), bits(scr[sample]))
         plan.close()
         monkeypatch.delenv("PRALINE_NO_REFTILE")

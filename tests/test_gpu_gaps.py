@@ -37,7 +37,7 @@ def zero_cells(rects, L1, L2):
 
 @pytest.mark.parametrize("kind", ["onehot", "float", "float-ref"])
 def test_per_position_gap_scores_plans(nat, bba, kind):
-    """Plans created on an arena with gap scores run k_dp_batch<..., PPG>: five modes, scores-only and with paths,
+    """Plans created on an arena with gap scores run the dense-tile instances k_dp_split16_tb<..., PPG>: five modes, scores-only and with paths,
     Waterman-Eggert rectangles in local mode, ragged lengths across the strip boundary; scores bit-identical and paths
     identical to the oracle (match scores: exact for sequences, the fp32 MFMA chain / the reference order for float
     profiles).  A constant-gap run of the same plan still equals the constant-gap oracle."""
@@ -70,13 +70,21 @@ def test_per_position_gap_scores_plans(nat, bba, kind):
             plan = nat.Plan(arena, pairs, want_paths=True)
             plan.run_gaps(mode)
             sc, paths = plan.scores(), plan.paths()
-            assert "true>" in plan.kernel_name() and "k_dp_batch" in plan.kernel_name(), plan.kernel_name()
+            # (the dense-tile instance with per-position gap scores; tiles: the fp32 MFMA chain, or the reference order on request)
+            assert "k_dp_split16_tb<1, 3" in plan.kernel_name() and plan.kernel_name().endswith(", 4, true, false>"), plan.kernel_name()
+            assert plan.tile_producer() == (1 if kind == "float-ref" else 3)
             plan.run(mode, -11.0, -1.0)              # the same plan with one constant pair
             sc_c, paths_c = plan.scores(), plan.paths()
+            assert plan.kernel_name().endswith(", 4, false, false>"), plan.kernel_name()
             plan.close()
             plan0 = nat.Plan(arena, pairs, want_paths=False)
             plan0.run_gaps(mode)
             sc0 = plan0.scores()
+            assert plan0.kernel_name().endswith(", 4, true, true>"), plan0.kernel_name()     # (the fill without flags)
+            plan0.run(mode, -11.0, -1.0)
+            sc0_c = plan0.scores()
+            assert "k_dp_split16<1, 1" in plan0.kernel_name(), plan0.kernel_name()
+            assert np.array_equal(bits(sc0_c), bits(sc_c)), mode
             plan0.close()
             for k, (i, j) in enumerate(pairs):
                 s_or, p_or = orc.raw_pairwise_align(mode, ms[(i, j)], gaps[i], gaps[j])
@@ -105,9 +113,9 @@ def test_per_position_gap_scores_plans(nat, bba, kind):
 
 
 def test_per_position_gap_scores_with_many_rectangles(nat, bba):
-    """Per-position gap scores on plans with more rectangles per pair than the register-resident masks hold (column-mask
-    words, MASK = 2): the <LOCAL, traceback, MASK = 2, PPG> instance of k_dp_batch was miscompiled at -O3 (wrong local
-    scores, also for pairs without rectangles; scripts/debug_ppg_mask2.py) - its translation unit is built -O1.  Scores
+    """Per-position gap scores on plans with more rectangles per pair than the register-resident masks hold: the dense-tile
+    instance reads the per-row mask words of k_build_zmask.  (Round 3 ran these plans on k_dp_batch, whose <LOCAL, traceback,
+    MASK = 2, PPG> instance gave wrong local scores at -O3 - also for pairs without rectangles; that kernel is gone.)  Scores
     and paths against the oracle, local and global."""
     rng = np.random.default_rng(5)
     lens = [60, 75, 48, 66, 90, 170, 159]
@@ -130,7 +138,8 @@ def test_per_position_gap_scores_with_many_rectangles(nat, bba):
         mk = plan.match_kind()
         plan.run_gaps(mode)
         sc, paths = plan.scores(), plan.paths()
-        assert ", 2, 1, true>" in plan.kernel_name(), plan.kernel_name()
+        assert "k_dp_split16_tb<1, 3" in plan.kernel_name() and plan.kernel_name().endswith(", true, false, false, 4, true, false>"), plan.kernel_name()
+        assert plan.tile_producer() == 3 and mk == 0
         plan.close()
         for k, (i, j) in enumerate(pairs):
             s_or, p_or = orc.raw_pairwise_align(mode, arena.match_scores(int(i), int(j), mk), gaps[i], gaps[j],
@@ -205,3 +214,84 @@ def test_per_position_gap_scores_c2_sample(nat, bba):
         else:
             os.environ["PRALINE_REF_BUDGET_MB"] = old
         arena.close()
+
+
+@pytest.mark.parametrize("setup", ["float-ref-tile", "float-ref-cell", "float-gaps", "wide-gaps"])
+def test_dense_tiles_in_strip_ranges(nat, bba, monkeypatch, setup):
+    """A task whose dense tile exceeds the launch budget is swept a range of strips per launch (plan_run_dense: the tile
+    holds that range, the boundary column stays in scratch, a local alignment's running maximum travels through scores /
+    end_cells).  With a 1 MiB budget every longer task of this list runs one or two strips per launch: scores-only and with
+    paths, five modes, constant and per-position gap scores, rectangles - bit-identical to the same plans under the default
+    budget, for each producer of the tiles (k_match_tile falls back to one thread per cell for such tasks; the fp32 MFMA
+    chain; a 40-symbol alphabet without packed operands)."""
+    rng = np.random.default_rng({"float-ref-tile": 1, "float-ref-cell": 2, "float-gaps": 3, "wide-gaps": 4}[setup])
+    lens = [150, 33, 97, 64, 201, 31, 1, 130]
+    if setup == "wide-gaps":
+        A = 40
+        S = rng.normal(0, 3, (A, A)).astype(np.float32)
+        profs = []
+        for L in lens:
+            c = np.zeros((L, A), dtype=np.float32)
+            for _ in range(4):
+                c[np.arange(L), rng.integers(0, A, L)] += rng.integers(1, 4, L)
+            profs.append((c / c.sum(axis=1, keepdims=True)).astype(np.float32))
+    else:
+        S = bba["S"]
+        profs = [synth_profile(rng, L)[0] for L in lens]
+    n = len(lens)
+    pairs = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32)
+    rects = [[(3, 9, 30, 41), (60, 70, 20, 90)] if k % 3 == 0 else [] for k in range(len(pairs))]
+    with_gaps = setup.endswith("gaps")
+    gaps = [random_gaps(rng, L, exact=False) for L in lens]
+    if setup.startswith("float-ref"):
+        nat.set_match_mode("ref")
+    if setup == "float-ref-cell":
+        monkeypatch.setenv("PRALINE_NO_REFTILE", "1")
+    want_producer = {"float-ref-tile": 1, "float-ref-cell": 2, "float-gaps": 3, "wide-gaps": 2}[setup]
+    try:
+        arena = nat.Arena(profs, S)
+        if with_gaps:
+            arena.set_gap_scores(gaps)
+
+        def run(mode, want_paths, use_rects, ppg):
+            plan = nat.Plan(arena, pairs, want_paths=want_paths, rects=rects if use_rects else None)
+            assert plan.tile_producer() == want_producer
+            if ppg:
+                plan.run_gaps(mode)
+            else:
+                plan.run(mode, -9.5, -1.25)
+            out = (plan.scores().copy(), [p.copy() for p in plan.paths()] if want_paths else None)
+            plan.close()
+            return out
+
+        cases = [(mode, wp, False, ppg) for mode in MODES for wp in (False, True) for ppg in ((False, True) if with_gaps else (False,))]
+        cases += [("local", True, True, ppg) for ppg in ((False, True) if with_gaps else (False,))]
+        whole = {c: run(*c) for c in cases}
+        monkeypatch.setenv("PRALINE_REFTILE_BUDGET_MB", "1")
+        for c in cases:
+            sc, paths = run(*c)
+            assert np.array_equal(bits(sc), bits(whole[c][0])), (setup, c)
+            if paths is not None:
+                assert all(np.array_equal(x, y) for x, y in zip(paths, whole[c][1])), (setup, c)
+        monkeypatch.delenv("PRALINE_REFTILE_BUDGET_MB")
+        # scores-only and path plans agree, and a sample equals the oracle on the reference-order match scores
+        for mode in MODES:
+            for ppg in ((False, True) if with_gaps else (False,)):
+                assert np.array_equal(bits(whole[(mode, False, False, ppg)][0]), bits(whole[(mode, True, False, ppg)][0])), (setup, mode, ppg)
+        if setup != "float-gaps":
+            for k in rng.choice(len(pairs), 10, replace=False):
+                i, j = pairs[k]
+                m = np.zeros((lens[i], lens[j]), dtype=np.float32)
+                orc.cext_build_scores([profs[i]], [profs[j]], [orc.build_nonzero_matrix(profs[i])], [orc.build_nonzero_matrix(profs[j])], [S], m)
+                for mode in MODES:
+                    g1, g2 = orc.gap_arrays(lens[i], lens[j], (-9.5, -1.25))
+                    s_or, p_or = orc.raw_pairwise_align(mode, m, g1, g2)
+                    assert whole[(mode, True, False, False)][0][k] == np.float32(s_or), (setup, mode, i, j)
+                    assert np.array_equal(whole[(mode, True, False, False)][1][k], p_or), (setup, mode, i, j)
+                    if with_gaps:
+                        s_or, p_or = orc.raw_pairwise_align(mode, m, gaps[i], gaps[j])
+                        assert whole[(mode, True, False, True)][0][k] == np.float32(s_or), (setup, mode, i, j, "gaps")
+                        assert np.array_equal(whole[(mode, True, False, True)][1][k], p_or), (setup, mode, i, j, "gaps")
+        arena.close()
+    finally:
+        nat.set_match_mode(None)

@@ -371,7 +371,7 @@ def test_quad_layout_paths_equal_the_strip_kernels(nat, bba, monkeypatch):
     """Alignments with paths of plain sequences run k_dp_quad_tb (dp_quad.hip.h: 16 pairs per wave, four lanes of 8 columns
     per pair, two rows per step, its own traceback planes).  Scores, end cells and paths must equal the strip kernels'
     (PRALINE_TB_QUAD=0) bit for bit and the oracle's: five modes; zero rectangles held in registers (<= 4 per pair) and as
-    per-row mask words (more: the strip kernels hand those plans to k_dp_batch); gap scores on and off the integer grid
+    per-row mask words (more: on the strip layout those plans run the dense-tile instances); gap scores on and off the integer grid
     (tie flags from the predecessor states / from the candidate sums); lengths around the 8-column quarters, the 32-column
     strips and the two-row steps; sequences of one residue; lanes without a pair."""
     rng = np.random.default_rng(97)
@@ -776,7 +776,7 @@ def test_two_pass_paths_equal_single_pass(nat, bba, monkeypatch):
                     plan.run(mode, *GAPS)
                     res[two] = (plan.scores().copy(), [p.copy() for p in plan.paths()], plan.kernel_name())
                     plan.close()
-                if not res["2"][2].endswith("true>") and (os.environ.get("PRALINE_KERNEL") == "batch" or os.environ.get("PRALINE_MM")):
+                if not res["2"][2].endswith("true>") and os.environ.get("PRALINE_MM"):
                     pytest.skip("the two-pass kernels need the f16 operand layouts (switched off by the environment)")
                 assert res["0"][2] != res["2"][2] and res["2"][2].endswith("true>"), res["2"][2]
                 assert np.array_equal(bits(res["0"][0]), bits(res["2"][0])), (kind, mode, use_rects)

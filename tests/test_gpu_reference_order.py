@@ -112,7 +112,8 @@ def test_reference_order_tiles(nat, bba, monkeypatch):
     in LDS) + the dense-tile instances of the split-strip kernels (dp_reftile.hip.h).  Ragged lengths around the strip /
     chunk / row-group boundaries, two track sets, Waterman-Eggert rectangles, every mode, scores-only and with paths:
     bit-identical to the oracle's reference-order evaluation (cext.c:33-97,389-420) AND to the one-cell-per-thread
-    kernels + k_dp_batch (PRALINE_NO_REFTILE=1); a second run of the same plan reuses stale tile memory."""
+    kernels' tiles (PRALINE_NO_REFTILE=1); a second run of the same plan reuses stale tile memory.  With a tile budget of 2 MiB
+    the longer tasks are swept a range of strips per launch (boundary column and local maximum carried between launches)."""
     rng = np.random.default_rng(41)
     lens = [41, 70, 33, 64, 9, 130, 257, 1, 2, 31, 32, 33, 127, 128, 129, 300, 16, 17, 15]
     p27 = [synth_profile(rng, L)[0] for L in lens]
@@ -139,6 +140,7 @@ def test_reference_order_tiles(nat, bba, monkeypatch):
         if twice:
             plan.run("local" if mode != "local" else "global", GO, GE)       # leaves other scores in the tile memory
             plan.run(mode, GO, GE)
+        assert plan.tile_producer() == (1 if tile else 2)
         out = (plan.scores().copy(), [p.copy() for p in plan.paths()] if want_paths else None, plan.kernel_name(), plan.match_kind())
         plan.close()
         return out
@@ -151,7 +153,7 @@ def test_reference_order_tiles(nat, bba, monkeypatch):
                 t_sc, _, t_kn, t_kind = run(arena, mode, False, True, twice=True)
                 o_sc, _, o_kn, _ = run(arena, mode, False, False)
                 # (dense-tile instance, BSRC = 4: one-task waves or - small one-chunk plans - shared-wave workgroups)
-                assert "k_dp_split16<1, 1" in t_kn and (", 4, 1, false>" in t_kn or ", 4, 4, false>" in t_kn) and "k_dp_batch" in o_kn, (t_kn, o_kn)
+                assert "k_dp_split16<1, 1" in t_kn and (", 4, 1, false>" in t_kn or ", 4, 4, false>" in t_kn) and "k_dp_split16<1, 1" in o_kn, (t_kn, o_kn)
                 assert t_kind == 2
                 assert np.array_equal(bits(t_sc), bits(o_sc)), (name, mode)
                 monkeypatch.setenv("PRALINE_NO_W2", "1")                      # one-task waves instead of shared-wave workgroups
@@ -160,7 +162,7 @@ def test_reference_order_tiles(nat, bba, monkeypatch):
                 assert ", 4, 1, false>" in w_kn and np.array_equal(bits(w_sc), bits(t_sc)), (name, mode, w_kn)
                 t_sc2, t_paths, t_kn, _ = run(arena, mode, True, True)
                 o_sc2, o_paths, _, _ = run(arena, mode, True, False)
-                assert "k_dp_split16_tb<1, 3" in t_kn and t_kn.endswith(", 4>"), t_kn
+                assert "k_dp_split16_tb<1, 3" in t_kn and t_kn.endswith(", 4, false, false>"), t_kn
                 assert np.array_equal(bits(t_sc2), bits(o_sc2)) and np.array_equal(bits(t_sc2), bits(t_sc)), (name, mode)
                 assert all(np.array_equal(x, y) for x, y in zip(t_paths, o_paths)), (name, mode)
                 for k in check:
@@ -180,7 +182,7 @@ def test_reference_order_tiles(nat, bba, monkeypatch):
             # Waterman-Eggert rectangles (local; the register-resident masks of the split-strip path kernels)
             t_sc, t_paths, t_kn, _ = run(arena, "local", True, True, rects=rects)
             o_sc, o_paths, _, _ = run(arena, "local", True, False, rects=rects)
-            assert "true, true, false, false, 4>" in t_kn, t_kn
+            assert "true, true, false, false, 4, false, false>" in t_kn, t_kn
             assert np.array_equal(bits(t_sc), bits(o_sc)) and all(np.array_equal(x, y) for x, y in zip(t_paths, o_paths)), name
             arena.close()
     finally:
@@ -273,7 +275,7 @@ def test_c2_float_profile_alignments_vs_reference_order(nat, bba):
     worst_rel = 0.0
     for q, mode in enumerate(MODES):
         sc, paths, kind = fast[mode]
-        assert kind == (0 if os.environ.get("PRALINE_KERNEL") == "batch" else 1)   # (k_dp_batch has no f16 layouts)
+        assert kind == 1
         rel = np.abs(sc - sc_ref[:, q]) / np.maximum(1.0, np.abs(sc_ref[:, q]))
         assert rel.max() <= 1e-5, (mode, rel.max())
         worst_rel = max(worst_rel, float(rel.max()))
