@@ -495,6 +495,37 @@ def main():
         variants["reference_order_gcups"] = sub_cells / dt_ref / 1e9
         variants["reference_order_with_paths_gcups"] = sub_cells / dt_ref_p / 1e9
         variants["reference_order_sample"] = "%d of %d pairs" % (len(sub), len(my_pairs))
+        # plans whose fill reads dense match-score tiles: per-position gap scores (GapScoreModel arrays, the
+        # fp32 MFMA chain writes the tiles), and an alphabet of 40 active symbols (no packed operands: the reference-order
+        # one-cell-per-thread kernels write them)
+        rng_g = np.random.default_rng(5)
+        arena_g = native.Arena(profs, S)
+        arena_g.set_gap_scores([np.stack([-rng_g.uniform(8.0, 14.0, int(L)), -rng_g.uniform(0.5, 2.0, int(L))], axis=1).astype(np.float32) for L in lens])
+        plan_g = native.Plan(arena_g, my_pairs)
+        variants["per_position_gaps_gcups"] = total_cells / timed(lambda: plan_g.run_gaps(args.mode), reps=3) / 1e9
+        variants["per_position_gaps_kernel"] = plan_g.kernel_name()
+        plan_g.close()
+        plan_g = native.Plan(arena_g, my_pairs, want_paths=True)
+        variants["per_position_gaps_with_paths_gcups"] = total_cells / timed(lambda: plan_g.run_gaps(args.mode), reps=3) / 1e9
+        plan_g.close()
+        arena_g.close()
+        A_w = 40
+        S_w = rng_g.normal(0, 3, (A_w, A_w)).astype(np.float32)
+        profs_w = []
+        for L in lens:
+            c = np.zeros((int(L), A_w), dtype=np.float32)
+            for _ in range(4):
+                c[np.arange(int(L)), rng_g.integers(0, A_w, int(L))] += rng_g.integers(1, 4, int(L))
+            profs_w.append((c / c.sum(axis=1, keepdims=True)).astype(np.float32))
+        arena_w = native.Arena(profs_w, S_w)
+        plan_w = native.Plan(arena_w, my_pairs)
+        variants["wide_alphabet_gcups"] = total_cells / timed(lambda: plan_w.run(args.mode, GAP_OPEN, GAP_EXTEND), reps=2) / 1e9
+        variants["wide_alphabet_kernel"] = plan_w.kernel_name()
+        plan_w.close()
+        plan_w = native.Plan(arena_w, my_pairs, want_paths=True)
+        variants["wide_alphabet_with_paths_gcups"] = total_cells / timed(lambda: plan_w.run(args.mode, GAP_OPEN, GAP_EXTEND), reps=2) / 1e9
+        plan_w.close()
+        arena_w.close()
         rng1 = np.random.default_rng(2)
         profs_1h = [one_hot(rng1.integers(0, 20, int(L)), A) for L in lens]
         arena_1h = native.Arena(profs_1h, S)

@@ -426,35 +426,39 @@ __global__ __launch_bounds__(64) void k_scores_tile_batch(ArenaDev ar, const int
                                                            const int64_t *__restrict__ m_off, int nstep, int tiles_x,
                                                            float *__restrict__ mref, TileOut to)
 {
+    // grid (pairs of the chunk, 32-row blocks): the wave keeps its 32 rows of sequence one and walks the 32-column blocks
+    // of sequence two (one workgroup per 32 x 32 block spent its time being dispatched: 5 M workgroups on C2)
+    // (giving every XCD a contiguous run of the chunk's pairs - the 32 pairs of a task write neighbouring 64-byte pieces of
+    // the same tile rows - was slower: 15.5 against 13.4 ms on C2; the kernel writes 21 GB at 1.6 TB/s either way)
     const int p = chunk_pairs[blockIdx.x];
     const int one = pairs[2 * p], two = pairs[2 * p + 1];
     const int lane = threadIdx.x;
     const int j = lane & 31, h = lane >> 5;
     const int L1 = ar.len[one], L2 = ar.len[two];
-    const int y0 = (int)(blockIdx.y / tiles_x) * 32, x0 = (int)(blockIdx.y % tiles_x) * 32 + (to.loc ? to.strip_lo * 32 : 0);
-    if (y0 >= L1 || x0 >= L2) return;
+    const int y0 = (int)blockIdx.y * 32;
+    if (y0 >= L1) return;
+    const bool tiled = to.loc != nullptr;
+    TileDst d = {nullptr, 0, 0, L2};
+    if (tiled) d = tile_dst(to, mref, p, L2);
+    float *m = tiled ? nullptr : mref + m_off[p];
     const float *pa = ar.P + ((int64_t)ar.row_off[one] + y0 + j) * ar.KP + h * ar.KS;
-    const float *qb = ar.Q + ((int64_t)ar.row_off[two] + x0 + j) * ar.KP + h * ar.KS;
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < nstep; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], acc, 0, 0, 0);
-    if (to.loc != nullptr) {
-        // (x0 is a strip's first column: the block covers the strip's 32 columns, zeros past the sequence)
-        const TileDst d = tile_dst(to, mref, p, L2);
-        if (x0 >= d.x_hi) return;
+    for (int xt = 0; xt < tiles_x; ++xt) {
+        const int x0 = d.x_lo + xt * 32;
+        if (x0 >= L2 || x0 >= d.x_hi) break;
+        const float *qb = ar.Q + ((int64_t)ar.row_off[two] + x0 + j) * ar.KP + h * ar.KS;
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < nstep; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], acc, 0, 0, 0);
+        const int x = x0 + j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int x = x0 + j;
-            if (y < L1) *d.at(y, x) = x < L2 ? acc[r] : 0.0f;
+            if (tiled) {
+                // (x0 is a strip's first column: the strip's 32 columns, zeros past the sequence)
+                if (y < L1) *d.at(y, x) = x < L2 ? acc[r] : 0.0f;
+            } else if (y < L1 && x < L2) {
+                m[(int64_t)y * L2 + x] = acc[r];
+            }
         }
-        return;
-    }
-    float *m = mref + m_off[p];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int x = x0 + j;
-        if (y < L1 && x < L2) m[(int64_t)y * L2 + x] = acc[r];
     }
 }
 

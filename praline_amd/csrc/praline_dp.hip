@@ -1638,7 +1638,7 @@ static int plan_run_dense(praline_plan &pl, LaunchArgs la, Arena16Dev a16, int m
             } else {
                 const int tiles_x = ch.strips, tiles_y = (ch.max_l1 + 31) / 32;
                 if (tiles_x > 0 && tiles_y > 0) {
-                    hipLaunchKernelGGL(k_scores_tile_batch, dim3((unsigned)(ch.c1 - ch.c0), (unsigned)(tiles_x * tiles_y)), dim3(64), 0, st,
+                    hipLaunchKernelGGL(k_scores_tile_batch, dim3((unsigned)(ch.c1 - ch.c0), (unsigned)tiles_y), dim3(64), 0, st,
                                        a.view(), pl.d_pairs.p, pl.d_chunk_pairs.p + ch.c0, nullptr, a.nstep, tiles_x, pl.d_dense.p, to);
                     HIPCHK(hipGetLastError());
                 }
