@@ -657,6 +657,40 @@ __global__ void k_traceback(ArenaDev ar, const WaveTask *__restrict__ tasks,
             else break;
             emit(y, x);
         }
+    } else if (layout == 3) {
+        // k_dp_pk16_tb planes (dp_pk16.hip.h): uint4 [strip][step][64] at tk.tb_off counted in uint2; lane 16 q + (slot & 15)
+        // holds the columns 8 q + 1 .. 8 q + 8 of the task's slots (slot & 15) and (slot & 15) + 16; step ((y + 1) >> 1) + q
+        // holds the rows y = 2 (t - q) - 1 (.x, .y) and 2 (t - q) (.z, .w); per row: first word = match source low bits of slot
+        // A | B << 8 | high bits A << 16 | B << 24, second word = U-extend A | B << 8 | L-extend A << 16 | B << 24
+        const int64_t nsteps = PRALINE_QUAD_STEPS(tk.max_l1);
+        const uint4 *my_tb4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint2 *>(tb) + tk.tb_off) + (pl.lane & 15);
+        const int hsel = 8 * (pl.lane >> 4);
+        int guard = L1 + L2 + 2;
+        bool stopped = false;
+        while (y > 0 && x > 0 && guard-- > 0) {
+            bool masked = false;
+            for (int r = 0; r < n_rects; ++r) {
+                const int32_t *q = rl.rects + (int64_t)(r0 + r) * 4;
+                masked = masked || (y >= q[0] && y <= q[1] && x >= q[2] && x <= q[3]);
+            }
+            const int c = (x - 1) & 31, qq = c >> 3, bit = (c & 7) + hsel;
+            const uint4 word = my_tb4[((int64_t)((x - 1) >> 5) * nsteps + ((y + 1) >> 1) + qq) * 64 + 16 * qq];
+            const unsigned w0 = (y & 1) ? word.x : word.z, w1 = (y & 1) ? word.y : word.w;
+            const int code = (int)(((w0 >> bit) & 1u) | (((w0 >> (16 + bit)) & 1u) << 1));
+            const int ub = (int)((w1 >> bit) & 1u), lb = (int)((w1 >> (16 + bit)) & 1u);
+            if (masked || (k == 0 && code == 0)) { stopped = true; break; }   // t is 0 there (cext.c:141-149 / clamp)
+            const int nk = k == 0 ? code - 1 : (k == 1 ? ub : 2 * lb);
+            y -= (k != 2);
+            x -= (k != 1);
+            k = nk;
+            emit(y, x);
+        }
+        while (!stopped && guard-- > 0) {
+            if (x == 0 && y >= 1 && k == 1 && !free_one) --y;
+            else if (y == 0 && x >= 1 && k == 2 && !free_two) --x;
+            else break;
+            emit(y, x);
+        }
     } else if (layout == 1) {
         // k_dp_split16_tb planes: the interior walk as a short loop without a branch per state - the lanes of a wave
         // are at different cells and states, every divergent branch is paid by all of them (and a single alignment

@@ -67,6 +67,10 @@ int praline_pipe_keep_attrs(int nr, int nterm, int *vgprs, int *lds_bytes);
 // k_dp_quad_tb (dp_quad_instance.hip): fill with packed traceback for plain sequences, 16 pairs per task (la.lane_one /
 // lane_pair [task][16], la.bnd float4 [row][16] per task, la.tb uint2 [strip][step][64]); mask: 0, 1 (rectangles), 2 (mask words)
 int praline_launch_quad_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, bool ints, bool local, int mask);
+// k_dp_pk16_tb (dp_pk16_instance.hip): the same for integer scoring within int16, two pairs per lane - the 32-pair task layout
+// of the strip kernels (la.lane_one / lane_pair [task][32], la.bnd uint4 [row][16] per task, la.tb uint4 [strip][step][64] at
+// tk.tb_off counted in uint2, la.aux as the strip kernels'); mask: rectangles in registers
+int praline_launch_pk16_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, bool local, bool mask, float scale);
 // two-pass alignments with paths (dp_tb2_instance.hip): flag-free forward fill, then block recompute + traceback
 struct Trace2Args {
     const int64_t *slot_off;

@@ -1,0 +1,26 @@
+// dp_pk16_instance.hip -- k_dp_pk16_tb instances (dp_pk16.hip.h): fill with packed traceback for plain sequences under integer
+// scoring, two pairs per lane in packed int16.
+#include "dp_launch.hip.h"
+#include "dp_pk16.hip.h"
+
+template <int NR> static void launch_pk16(const LaunchArgs &la, const Arena16Dev &a16, bool local, bool mask, float scale)
+{
+    const dim3 grid((la.n_tasks + 3) / 4), block(256);
+#define PRALINE_PK16(LOC, MSK)                                                                                           \
+    hipLaunchKernelGGL((k_dp_pk16_tb<NR, LOC, MSK>), grid, block, 0, la.stream, a16, la.tasks, la.lane_one, la.lane_pair,  \
+                       (uint4 *)la.bnd, (uint4 *)la.tb, la.aux, la.rl, la.scores, la.end_cells, la.rp, (int)la.n_tasks, scale)
+    if (local) { if (mask) PRALINE_PK16(true, true); else PRALINE_PK16(true, false); }
+    else { if (mask) PRALINE_PK16(false, true); else PRALINE_PK16(false, false); }
+#undef PRALINE_PK16
+}
+
+// nr: 16-wide symbol ranges of the arena (1 or 2); scale: 2^k, the DP runs on value * scale (integers below 32 000 in
+// magnitude: checked by the caller)
+int praline_launch_pk16_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, bool local, bool mask, float scale)
+{
+    if (a16.sym8 == nullptr) return PRALINE_ERR_UNSUPPORTED;
+    if (nr == 1) launch_pk16<1>(la, a16, local, mask, scale);
+    else if (nr == 2) launch_pk16<2>(la, a16, local, mask, scale);
+    else return PRALINE_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? PRALINE_OK : PRALINE_ERR_DEVICE;
+}

@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256, PRALINE_QUAD_WAVES) void k_dp_quad_tb(Arena16D
         };
         // Scores: the table rows of the rows' symbols (bytes ya - 1 and ya of the sequence: one aligned 16-bit load), read
         // from LDS one step before they are used.
-        auto sym_addr = [&](int ya) { return psym + (ya >= 1 ? ya - 1 : 0); };
+        // (never past the sequence's own rows and padding: a short sequence in a task of long ones may be the arena's last)
+        auto sym_addr = [&](int ya) { return psym + (ya >= 1 ? (ya - 1 < L1 ? ya - 1 : L1) : 0); };
         float mA[8], mB[8];
         auto fetch_scores = [&](unsigned sw, float (&a)[8], float (&b)[8]) {
             if (PRALINE_QUAD_ABLATE & 4) sw &= 0x0f0fu;

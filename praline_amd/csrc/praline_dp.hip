@@ -963,6 +963,10 @@ struct praline_plan {
     int tp = 1;
     bool split = false;  // k_dp_split task layout
     bool quad = false;   // path plan on a one-hot arena in the 16-pairs-per-task layout of k_dp_quad_tb (dp_quad.hip.h)
+    // path plan on a one-hot arena with an integral exchange matrix whose DP values fit int16: the 32-pair layout with planes
+    // sized for k_dp_pk16_tb (dp_pk16.hip.h); a run whose gap scores do not qualify takes the strip kernels on the same tasks
+    bool pk16 = false;
+    bool run_pk16 = false;   // the run in progress / the last run used k_dp_pk16_tb
     std::vector<WaveTask> tasks;
     std::vector<int64_t> tb_elems;  // per task, uint4 elements
     std::vector<int64_t> aux_elems; // per task, floats
@@ -1213,6 +1217,18 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         const Arena16Dev v16q = a.view16();
         pl->quad = want_paths && pl->dense_kind == 0 && a.nr16 > 0 && a.nterm16 == 1 &&
                    v16q.sym8 != nullptr && match_mode() == PRALINE_MATCH_FAST && !(tq && tq[0] == '0');
+        // integer scoring within int16 (the exchange matrix alone is checked here, the gap scores by every run): two pairs per
+        // lane, k_dp_pk16_tb (PRALINE_TB_PK16=0: never).  Plans with more than PRALINE_MAX_RECTS rectangles per pair keep
+        // k_dp_quad_tb, which reads mask words.
+        const char *tk16 = getenv("PRALINE_TB_PK16");
+        // (plans that fill the chip: a task is one wave and holds twice the pairs of a k_dp_quad_tb task - measured on C2,
+        // 32 640 pairs = 1 020 such tasks on 1 024 SIMDs: 0.99 against 1.04 TCUPS; on a C3 slice of 130 944 pairs 1.74 against
+        // 1.41.  PRALINE_TB_PK16=1: every plan that qualifies)
+        const bool big = n_pairs >= 65536 || (tk16 && tk16[0] == '1');
+        pl->pk16 = pl->quad && big && !many_rects && a.all_onehot && a.s_scale_bits >= 0 && a.s_scale_bits <= 8 && !(tk16 && tk16[0] == '0') &&
+                   (2.0 * a.max_len + 4.0) * (double)a.s_absmax * (double)(1 << a.s_scale_bits) < 32000.0;
+        if (pl->pk16) pl->quad = false;
+        opt.pk16 = pl->pk16;
         opt.quad16 = pl->quad;
     }
     if (const char *env = getenv("PRALINE_XCD_GROUP")) opt.xcd_group = atoi(env);
@@ -1427,7 +1443,7 @@ static int launch_traceback(praline_plan &pl, const LaunchArgs &la, size_t t0, s
     const int threads = 64;
     const int64_t blocks = (pl.n_pairs + threads - 1) / threads;
     if (mode >= PRALINE_MODE_SEMIGLOBAL_BOTH) {   // end cells of the semiglobal modes, scanned per task
-        const int64_t lanes = (int64_t)(t1 - t0) * (pl.quad ? 16 : (pl.split ? 32 : 64));
+        const int64_t lanes = (int64_t)(t1 - t0) * (pl.quad ? 16 : (pl.split ? 32 : 64));   // (k_dp_pk16_tb writes the strip kernels' end-cell scratch)
         hipLaunchKernelGGL(k_semiglobal_end, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, la.ar,
                            pl.d_tasks.p, pl.d_lane_one.p, pl.d_lane_pair.p, pl.d_pairs.p, la.aux,
                            pl.d_end_cells.p, la.scores, la.rp, (int32_t)t0, (int32_t)t1, pl.quad ? 2 : (pl.split ? 1 : 0));
@@ -1435,7 +1451,7 @@ static int launch_traceback(praline_plan &pl, const LaunchArgs &la, size_t t0, s
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)blocks), dim3(threads), 0, st, la.ar, pl.d_tasks.p,
                        pl.d_loc.p, pl.d_pairs.p, (const uint4 *)la.tb, la.aux, la.rl, pl.d_end_cells.p,
                        la.scores, pl.d_slot_off.p, pl.d_paths.p, pl.d_path_start.p, pl.d_path_rows.p, pl.n_pairs,
-                       la.rp, (int32_t)t0, (int32_t)t1, pl.quad ? 2 : (pl.split ? 1 : 0));
+                       la.rp, (int32_t)t0, (int32_t)t1, pl.run_pk16 ? 3 : (pl.quad ? 2 : (pl.split ? 1 : 0)));
     HIPCHK(hipGetLastError());
     return PRALINE_OK;
 }
@@ -1824,6 +1840,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         char kn[160];
         const char *lb = local ? "true" : "false";
         if (pl.want_paths && pl.quad) snprintf(kn, sizeof(kn), "k_dp_quad_tb<%d, ...>", a.nr16);
+        else if (pl.want_paths && pl.pk16) snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, ...>", a.nr16);   // (refined below: a run may take the strip kernels)
         else if (pl.want_paths) snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // refined below (nterm, chain)
         else if (la.a16 == nullptr) snprintf(kn, sizeof(kn), "k_dp_split<%d, %s>", a.nstep, lb);
         else {
@@ -1920,7 +1937,11 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     // one-hot profiles, S and gap scores integral after scaling by 2^k, (L1 + L2) * max |score| * 2^k < 2^24.
     // Other exact-mode arenas run the three-term instances (their lo pieces are zero: same match scores).
     int tb_nterm = a.nterm16;
+    pl.run_pk16 = false;
+    float pk16_scale = 1.0f;
     if (a.nterm16 == 1) {
+        double big_scaled = 1e30;
+        int k_bits = 0;
         bool ints = a.all_onehot && a.s_scale_bits >= 0 && !(getenv("PRALINE_NO_INTS") && getenv("PRALINE_NO_INTS")[0] == '1');
         if (ints) {
             int k = a.s_scale_bits;
@@ -1930,8 +1951,19 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             }
             const double big = std::max((double)a.s_absmax, std::max(std::fabs((double)gap_open), std::fabs((double)gap_extend)));
             ints = k <= 8 && (2.0 * a.max_len + 4.0) * big * (double)(1 << std::min(k, 8)) < 16777216.0;
+            k_bits = k;
+            big_scaled = big * (double)(1 << std::min(k, 8));
         }
         tb_nterm = ints ? 1 : 3;
+        // two pairs per lane in int16 when every DP value of this run fits (dp_pk16.hip.h)
+        pl.run_pk16 = pl.want_paths && pl.pk16 && ints && (2.0 * a.max_len + 4.0) * big_scaled < 32000.0;
+        pk16_scale = (float)(1 << std::min(std::max(k_bits, 0), 8));
+    }
+    if (pl.want_paths && pl.pk16) {
+        char kn[160];
+        if (pl.run_pk16) snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, %s, %s>", a.nr16, local ? "true" : "false", pl.has_rects ? "true" : "false");
+        else snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // (gap scores off the int16 grid: the strip kernels)
+        pl.last_kernel = kn;
     }
     size_t budget = tb_budget_bytes();
     const bool semiglobal = mode >= 2;
@@ -2077,7 +2109,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                 return PRALINE_OK;
             }
         }
-        const bool twopass = pl.split && !pl.quad && la.a16 != nullptr && tpv != 0 && (tpv == 2 || (!would_chain && (local || tpv == 1)));
+        const bool twopass = pl.split && !pl.quad && !pl.run_pk16 && la.a16 != nullptr && tpv != 0 && (tpv == 2 || (!would_chain && (local || tpv == 1)));
         if (twopass) {
             char kn[160];
             snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, %d, %s, %s, false, true>", a.nr16, tb_nterm, local ? "true" : "false",
@@ -2252,7 +2284,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     // chunks of plans whose packed traceback exceeds the scratch budget (long sequences: 32 640 alignments of ~1000 x
     // ~1000 were 96 ms in task mode, three chunks of 380 waves each).  Chain chunks share one set of boundary columns
     // and flags: they all run on the main stream.
-    bool chain_chunks = pl.split && !pl.quad && la.a16 != nullptr && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
+    bool chain_chunks = pl.split && !pl.quad && !pl.run_pk16 && la.a16 != nullptr && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
     {
         int64_t need_bnd = 0;
         size_t need_flags = 0;
@@ -2330,6 +2362,9 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         } else if (pl.quad) {
             int rc = praline_launch_quad_tb(la, a16, a.nr16, tb_nterm == 1, local, pl.mask_kind);
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_quad_tb instance for nr=%d", a.nr16);
+        } else if (pl.run_pk16) {
+            int rc = praline_launch_pk16_tb(la, a16, a.nr16, local, pl.has_rects, pk16_scale);
+            if (rc != PRALINE_OK) return fail(rc, "no k_dp_pk16_tb instance for nr=%d", a.nr16);
         } else {
             int rc = praline_launch_split16_tb(la, a16, a.nr16, tb_nterm, local, pl.has_rects);
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_split16_tb instance for nr=%d nterm=%d", a.nr16, tb_nterm);

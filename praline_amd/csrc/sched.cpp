@@ -662,7 +662,9 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
             wt.aux_off = 0;
             // traceback planes: split layout uint2 [nstrips][max_l1 + 8][64], batch layout uint4 [nstrips][max_l1 + 1][64]
             // (quad16: uint2 [nstrips][PRALINE_QUAD_STEPS(max_l1)][64] - two rows of 8 columns per lane and step)
-            out.tb_elems[t] = quad ? (int64_t)wt.nstrips * PRALINE_QUAD_STEPS(wt.max_l1) * 64
+            // (pk16: uint4 [nstrips][PRALINE_QUAD_STEPS(max_l1)][64] counted in uint2 - never less than the strip kernels' planes)
+            out.tb_elems[t] = (opt.pk16 && out.split && !quad) ? (int64_t)wt.nstrips * std::max(2 * PRALINE_QUAD_STEPS(wt.max_l1), wt.max_l1 + 8) * 64 :
+                              quad ? (int64_t)wt.nstrips * PRALINE_QUAD_STEPS(wt.max_l1) * 64
                                    : (out.split ? (int64_t)wt.nstrips * (wt.max_l1 + 8) * 64 : (int64_t)wt.nstrips * (wt.max_l1 + 1) * 64);
             out.aux_elems[t] = ((int64_t)(wt.max_l1 + 1) * 3 + (int64_t)wt.nstrips * 32 * 3) * lanes;
         }

@@ -14,6 +14,7 @@ struct SchedOptions {
     int64_t wave_slots = 2048;    // resident wave slots assumed by the share search (256 CUs x 4 SIMDs x 2)
     bool snake = true;            // launch order: longest workgroups share a CU with the shortest
     bool wg_xcd = true;           // shared-wave workgroups: sequences two in eight contiguous runs, one per XCD
+    bool pk16 = false;            // path plans that may run k_dp_pk16_tb (32 pairs per task; larger traceback planes)
     bool quad16 = false;          // path plans on one-hot arenas: 16 pairs per task (k_dp_quad_tb, dp_quad.hip.h)
     bool balance = false;         // experiment: choose the wave counts by the modelled busiest SIMD, not by the longest wave (no measured gain)
 };
