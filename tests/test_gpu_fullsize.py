@@ -392,9 +392,10 @@ def test_chunked_path_plans_on_two_streams(nat, monkeypatch):
     S = nucleotide_matrix()
     arena = nat.Arena(profs, S)
 
-    def run(two, budget, quad="0"):
+    def run(two, budget, quad="0", pk16="0"):
         monkeypatch.setenv("PRALINE_TB_TWOPASS", two)
         monkeypatch.setenv("PRALINE_TB_QUAD", quad)    # "0": the strip kernels (single pass / two passes); "1": k_dp_quad_tb
+        monkeypatch.setenv("PRALINE_TB_PK16", pk16)    # "1" (with quad "1"): k_dp_pk16_tb - (2 302 + 2) * 11 = 25 344 < 32 000
         if budget:
             monkeypatch.setenv("PRALINE_TB_BUDGET_MB", budget)
         else:
@@ -403,16 +404,18 @@ def test_chunked_path_plans_on_two_streams(nat, monkeypatch):
         plan.run("global", *GAPS)
         sc = plan.scores().copy()
         buf, o, r = plan.paths_packed()
+        assert plan.kernel_name().startswith("k_dp_pk16_tb") == (quad == "1" and pk16 == "1"), plan.kernel_name()
         res = (sc, packed_rows(buf, o, r), o.copy(), r.copy(), plan.match_kind(), buf)
         plan.close()
         return res
 
     ref = run("0", "160000")                       # one chunk
-    for two, budget, quad in (("0", None, "0"), ("2", None, "0"), ("2", "3000", "0"), ("0", "3000", "0"), ("2", None, "0"),
-                              ("0", None, "1"), ("0", "3000", "1"), ("0", "160000", "1")):   # ... and the plans' default kernel
-        res = run(two, budget, quad)
-        assert np.array_equal(bits(res[0]), bits(ref[0])), (two, budget, quad)
-        assert np.array_equal(res[3], ref[3]) and np.array_equal(res[2], ref[2]) and np.array_equal(res[1], ref[1]), (two, budget, quad)
+    for two, budget, quad, pk16 in (("0", None, "0", "0"), ("2", None, "0", "0"), ("2", "3000", "0", "0"), ("0", "3000", "0", "0"), ("2", None, "0", "0"),
+                                    ("0", None, "1", "0"), ("0", "3000", "1", "0"), ("0", "160000", "1", "0"),   # ... and the plans' default kernel
+                                    ("0", None, "1", "1"), ("0", "3000", "1", "1")):                            # ... and packed int16
+        res = run(two, budget, quad, pk16)
+        assert np.array_equal(bits(res[0]), bits(ref[0])), (two, budget, quad, pk16)
+        assert np.array_equal(res[3], ref[3]) and np.array_equal(res[2], ref[2]) and np.array_equal(res[1], ref[1]), (two, budget, quad, pk16)
     rng = np.random.default_rng(7)
     for k in rng.permutation(len(pairs))[:6]:
         i, j = pairs[k]

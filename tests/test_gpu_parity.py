@@ -417,6 +417,67 @@ def test_quad_layout_paths_equal_the_strip_kernels(nat, bba, monkeypatch):
     arena.close()
 
 
+def test_packed_int16_paths_equal_the_float_kernels(nat, bba, monkeypatch):
+    """Integer scoring within int16 runs k_dp_pk16_tb (dp_pk16.hip.h: two pairs per lane, v_pk_*_i16 with saturation, sign bytes
+    gathered with v_perm_b32, traceback layout 3).  Scores, end cells and paths must equal k_dp_quad_tb's (PRALINE_TB_PK16=0) bit
+    for bit and the oracle's: five modes, integer / half-integer gap scores (scale 1 / 2) and open == extend, rectangles in
+    registers, lengths around the quarters / strips / two-row steps, lanes and half lanes without a pair, sequence 0 in the
+    upper half of a lane.  Gap scores off the grid (-10.3, -1.7) and scores beyond int16 fall back to the float kernels on the
+    same plan."""
+    rng = np.random.default_rng(131)
+    lens = np.array([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 129, 47, 250, 71, 5, 24, 25, 96, 97, 40, 41, 200, 13, 58, 77, 12, 35, 36,
+                     300, 18, 19, 20, 21, 22, 23, 110, 111, 112, 45, 46, 66, 67, 68, 69])
+    profs = [one_hot(rng.integers(0, 20, int(L)), 27) for L in lens]
+    N = len(lens)
+    arena = nat.Arena(profs, bba["S"])
+    allp = np.array([(i, j) for i in range(N) for j in range(N)], dtype=np.int32)
+    pairs = allp[rng.random(len(allp)) < 0.7]
+
+    def rect_lists(nmax):
+        out = []
+        for (i, j) in pairs:
+            rl = []
+            for _ in range(int(rng.integers(0, nmax + 1))):
+                y0, x0 = int(rng.integers(1, lens[i] + 1)), int(rng.integers(1, lens[j] + 1))
+                rl.append((y0, min(int(lens[i]), y0 + int(rng.integers(0, 12))), x0, min(int(lens[j]), x0 + int(rng.integers(0, 30)))))
+            out.append(rl)
+        return out
+    cases = [(mode, gaps, None) for mode in MODES for gaps in (GAPS, (-7.5, -0.5), (-4.0, -4.0))]
+    cases += [("local", GAPS, rect_lists(3)), ("local", (-7.5, -0.5), rect_lists(4)), ("global", GAPS, rect_lists(4)), ("semiglobal_both", GAPS, rect_lists(2))]
+    cases += [("global", (-10.3, -1.7), None), ("local", (-60.0, -1.0), None)]     # off the grid; (L1 + L2 + 2) * 60 > 32 000
+    for mode, gaps, rects in cases:
+        res = {}
+        for pk16 in ("0", "1"):
+            monkeypatch.setenv("PRALINE_TB_PK16", pk16)
+            plan = nat.Plan(arena, pairs, want_paths=True, rects=rects)
+            pk = plan.match_kind()
+            plan.run(mode, *gaps)
+            res[pk16] = (plan.scores().copy(), [p.copy() for p in plan.paths()], plan.kernel_name())
+            plan.close()
+        fits = gaps not in ((-10.3, -1.7), (-60.0, -1.0))
+        assert res["1"][2].startswith("k_dp_pk16_tb") == fits and res["0"][2].startswith("k_dp_quad_tb"), (gaps, res["0"][2], res["1"][2])
+        assert np.array_equal(bits(res["0"][0]), bits(res["1"][0])), (mode, gaps, rects is not None)
+        bad = [k for k in range(len(pairs)) if not np.array_equal(res["0"][1][k], res["1"][1][k])]
+        assert not bad, (mode, gaps, rects is not None, pairs[bad[:3]].tolist())
+        for k in range(0, len(pairs), 97):
+            i, j = pairs[k]
+            zero = None
+            if rects is not None and rects[k]:
+                zero = [(y, x) for (y0, y1, x0, x1) in rects[k] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
+            s_or, p_or = oracle_dp_on_m(mode, arena.match_scores(int(i), int(j), pk), gaps, zero)
+            assert res["1"][0][k] == np.float32(s_or), (mode, gaps, i, j)
+            assert np.array_equal(res["1"][1][k], p_or), (mode, gaps, i, j)
+    arena.close()
+    monkeypatch.delenv("PRALINE_TB_PK16")
+    # plans below 65 536 pairs keep k_dp_quad_tb unless asked
+    arena = nat.Arena(profs[:8], bba["S"])
+    plan = nat.Plan(arena, allp[:40][allp[:40].max(axis=1) < 8], want_paths=True)
+    plan.run("global", *GAPS)
+    assert plan.kernel_name().startswith("k_dp_quad_tb"), plan.kernel_name()
+    plan.close()
+    arena.close()
+
+
 def test_batch_waterman_eggert_masks(nat, bba):
     """LocalMasterSlaveAligner's inner calls (praline/component/preprofile.py:227-267)."""
     d = load_golden("preprofile.npz")
