@@ -129,16 +129,24 @@ __device__ __forceinline__ uint2 pk16_row(const s16x2 (&m)[8], const PkIn &in, s
 
 // NR: 16-wide symbol ranges of the lookup table (1: <= 16 active symbols, 2: <= 32).  MASK: zero rectangles in registers
 // (<= PRALINE_MAX_RECTS per pair).  scale = 2^k: DP values are stored as value * scale.
-template <int NR, bool LOCAL, bool MASK>
-__global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+// CHAIN (plans of few tasks: one alignment, the merge steps of the progressive MSA, C2-sized batches): one wave per task AND
+// strip, 64-thread blocks in strip-major order, the strips of a task pipelined across workgroups as in k_dp_split16_tb's
+// chain mode (dp_split16_tb.hip.h): every strip boundary has its own column (uint4 [strip][row][16] at tk.bnd_off), quarter 3
+// stores its rows with agent-scope write-through stores and publishes the finished row count every `chain_every` rows;
+// the wave of the next strip polls that count before it issues the loads of rows it has not seen published.  Local
+// alignments report one first-argmax candidate per strip (chain_cand, k_chain_local_end picks per pair).
+template <int NR, bool LOCAL, bool MASK, bool CHAIN = false>
+__global__ __launch_bounds__(CHAIN ? 64 : 256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one, const int32_t *__restrict__ lane_pair,
                                                        uint4 *bnd, uint4 *__restrict__ tb, float *__restrict__ aux, RectList rl,
                                                        float *__restrict__ scores, int32_t *__restrict__ end_cells, RunParams rp,
-                                                       int n_tasks, float scale)
+                                                       int n_tasks, float scale, int *chain_flags = nullptr, int chain_stride = 0,
+                                                       float4 *chain_cand = nullptr, int chain_every = 6)
 {
-    __shared__ __attribute__((aligned(16))) char lookup_all[4 * pk16_table_bytes(NR)];   // one table per wave of the block
-    const int wv = (int)(threadIdx.x >> 6);
-    const int task = (int)blockIdx.x * 4 + wv;
+    __shared__ __attribute__((aligned(16))) char lookup_all[(CHAIN ? 1 : 4) * pk16_table_bytes(NR)];   // one table per wave of the block
+    const int wv = CHAIN ? 0 : (int)(threadIdx.x >> 6);
+    const int task = CHAIN ? (int)(blockIdx.x % n_tasks) : (int)blockIdx.x * 4 + wv;
+    const int chain_strip = CHAIN ? (int)(blockIdx.x / n_tasks) : 0;
     if (task >= n_tasks) return;          // (the waves of a block are independent: no block-level barrier below)
     const int lane = threadIdx.x & 63;
     const int p = lane & 15, q = lane >> 4;
@@ -176,7 +184,14 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
     char *lookup_tab = lookup_all + wv * pk16_table_bytes(NR);
     const char *tab_lane = lookup_tab + q * 16;              // this lane's 8 columns of a table row
     const unsigned char *psymA = ar.sym8 + (haveA ? ar.row_off[oneA] : 0), *psymB = ar.sym8 + (haveB ? ar.row_off[oneB] : 0);
-    uint4 *my_bnd = bnd + tk.bnd_off + p;                    // (M, U, L) of the strip's left boundary column, [row][16]
+    if (CHAIN && chain_strip >= nstrips) return;
+    // (M, U, L) of the strip's left boundary column, [row][16]; chain mode: one column per strip boundary, read / written
+    const int64_t chain_col = CHAIN ? (int64_t)(max_l1 + 24) * 16 : 0;
+    uint4 *my_bnd = bnd + tk.bnd_off + chain_col * chain_strip + p;
+    uint4 *my_bnd_out = bnd + tk.bnd_off + chain_col * (chain_strip + 1) + p;
+    const int *chain_in = (CHAIN && chain_strip > 0) ? chain_flags + (int64_t)task * chain_stride + chain_strip - 1 : nullptr;
+    int *chain_out = CHAIN ? chain_flags + (int64_t)task * chain_stride + chain_strip : nullptr;
+    int chain_seen = 0, chain_next = chain_every;
     uint4 *my_tb = reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(tb) + tk.tb_off) + lane;   // [strip][step][64] (tb_off counts uint2, even)
     float *lastcol = aux + tk.aux_off;                                       // [y][3][32]
     float *lastrow = aux + tk.aux_off + (int64_t)(max_l1 + 1) * 3 * 32;      // [x - 1][3][32]
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
     int out_yA = 0, out_xA = 0, out_kA = init_k, out_yB = 0, out_xB = 0, out_kB = init_k;
     s16x2 corner_m = pk_dup(PRALINE_PK_NEG), corner_u = corner_m, corner_l = corner_m;
 
-    for (int s = 0; s < nstrips; ++s) {
+    for (int s = CHAIN ? chain_strip : 0; s < (CHAIN ? chain_strip + 1 : nstrips); ++s) {
         const int x0 = s * 32;
         const int xb = x0 + 8 * q;
         const bool last_owner = (s == nstrips - 1) && own_last;
@@ -295,6 +310,7 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
         // (With the loads one step ahead, as in k_dp_quad_tb, every step exposed a memory latency that two waves per SIMD do
         // not cover: 59 % of the VALU issue slots used on a C3 slice.)
         // prologue: set 1 = rows 1, 2 and the symbols of step 1; set 0 = rows 3, 4 and the symbols of step 2
+        if constexpr (CHAIN) { if (chain_in != nullptr) chain_seen = chain_wait(chain_in, 4, chain_seen); }
         f4n ld1A = quad_load_f4(my_bnd + 16), ld1B = quad_load_f4(my_bnd + 32);
         unsigned sym1A = quad_load_u16(sym_addr_cap(psymA, L1A, 1 - 2 * q)), sym1B = quad_load_u16(sym_addr_cap(psymB, L1B, 1 - 2 * q));
         f4n ld0A = quad_load_f4(my_bnd + 48), ld0B = quad_load_f4(my_bnd + 64);
@@ -304,16 +320,20 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
         // with copies of registers whose loads were still in flight)
         {
             const f4n z = {0.0f, 0.0f, 0.0f, 0.0f};
-            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off" : : "v"(my_bnd), "v"(z) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off" : : "v"(CHAIN ? my_bnd_out : my_bnd), "v"(z) : "memory");
+            if constexpr (CHAIN)   // (chain mode: five stores per step)
+                asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off" : : "v"(my_bnd_out), "v"(z) : "memory");
         }
-        PRALINE_QUAD_WAIT(7, ld1A, ld1B, sym1A);
+        if constexpr (CHAIN) { PRALINE_QUAD_WAIT(9, ld1A, ld1B, sym1A); }
+        else { PRALINE_QUAD_WAIT(7, ld1A, ld1B, sym1A); }
         asm volatile("" : "+v"(sym1B));
         uint4 *tb_st = my_tb + (int64_t)s * nsteps * 64 + 64;     // step 1
 
         auto step = [&](const int t, f4n &ldA, f4n &ldB, unsigned &symA_ld, unsigned &symB_ld) __attribute__((always_inline)) {
             const int ya = 2 * (t - q) - 1;          // this quarter's rows ya, ya + 1 (<= 0: it has not started yet)
             // this step's set has landed (step 1: waited for in the prologue)
-            PRALINE_QUAD_WAIT(10, ldA, ldB, symA_ld);
+            if constexpr (CHAIN) { PRALINE_QUAD_WAIT(14, ldA, ldB, symA_ld); }    // (five stores per step: two per boundary row)
+            else { PRALINE_QUAD_WAIT(10, ldA, ldB, symA_ld); }
             asm volatile("" : "+v"(symB_ld));
             s16x2 mA[8], mB[8];   // packed match scores of the step's two rows
             fetch_scores(symA_ld, symB_ld, mA, mB);
@@ -451,6 +471,7 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
             row_tails(ya + 1);
             // ---- end of the step: what the next steps consume, then this step's stores (see the strip prologue) ----
             if (q != 0) { nxA = {rAm, rAu, rAl}; nxB = {rBm, rBu, rBl}; }
+            if constexpr (CHAIN) { if (chain_in != nullptr) chain_seen = chain_wait(chain_in, 2 * t + 4, chain_seen); }
             ldA = quad_load_f4(my_bnd + (int64_t)(2 * t + 3) * 16);      // boundary rows of quarter 0's step t + 2
             ldB = quad_load_f4(my_bnd + (int64_t)(2 * t + 4) * 16);
             symA_ld = quad_load_u16(sym_addr_cap(psymA, L1A, (PRALINE_PK16_ABLATE & 4) ? 1 : ya + 4));    // symbols of step t + 2
@@ -458,7 +479,11 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
             // quarter 3: this strip's last column is the next strip's boundary column (rows <= 0: the unused row 0)
             if (q == 3) {
                 const int ra = ya >= 1 ? ya : 0, rb = ya >= 1 ? ya + 1 : 0;
-                if (!(PRALINE_PK16_ABLATE & 2) || pk_u(sAm) == 0x12345678u) {
+                if constexpr (CHAIN) {
+                    // (two store instructions per row: the steps' hand-counted wait below counts five stores in chain mode)
+                    chain_store_row(reinterpret_cast<char *>(my_bnd_out + (int64_t)ra * 16), __uint_as_float(pk_u(sAm)), __uint_as_float(pk_u(sAu)), __uint_as_float(pk_u(sAl)));
+                    chain_store_row(reinterpret_cast<char *>(my_bnd_out + (int64_t)rb * 16), __uint_as_float(pk_u(sBm)), __uint_as_float(pk_u(sBu)), __uint_as_float(pk_u(sBl)));
+                } else if (!(PRALINE_PK16_ABLATE & 2) || pk_u(sAm) == 0x12345678u) {
                 my_bnd[(int64_t)ra * 16] = make_uint4(pk_u(sAm), pk_u(sAu), pk_u(sAl), 0u);
                 my_bnd[(int64_t)rb * 16] = make_uint4(pk_u(sBm), pk_u(sBu), pk_u(sBl), 0u);
                 }
@@ -475,6 +500,11 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
                 }
             }
             tb_st += 64;
+            if constexpr (CHAIN) {
+                // quarter 3 has stored the rows up to 2 (t - 3); every publish drains the wave's memory operations
+                const int done = 2 * (t - 3);
+                if (done >= chain_next) { chain_publish(chain_out, done, lane); chain_next = done + chain_every; }
+            }
         };
         // (an odd run_steps runs one step more: rows past max_l1 that nobody reports; the planes and the boundary column
         // have room for it, PRALINE_QUAD_STEPS)
@@ -482,11 +512,13 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
             step(t, ld1A, ld1B, sym1A, sym1B);
             step(t + 1, ld0A, ld0B, sym0A, sym0B);
         }
+        if constexpr (CHAIN) chain_publish(chain_out, PRALINE_CHAIN_DONE, lane);
         // (the next strip's quarter 0 reads rows that quarter 3 stored a few steps ago - same wave, in program order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
     }
 
+    if (CHAIN && !LOCAL && chain_strip != nstrips - 1) return;   // the last strip's wave reports the end cell
     // ---- combine the four quarters: end cell (y, x, k) and score (align.py:401-431) ----
     int bestA = out_best.x, bestB = out_best.y;
     if (LOCAL) {
@@ -509,6 +541,15 @@ __global__ __launch_bounds__(256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_
         cm = pk_maxs(cm, pk_of((unsigned)__shfl_xor((int)pk_u(cm), mk)));
         cu = pk_maxs(cu, pk_of((unsigned)__shfl_xor((int)pk_u(cu), mk)));
         cl = pk_maxs(cl, pk_of((unsigned)__shfl_xor((int)pk_u(cl), mk)));
+    }
+    if (CHAIN && LOCAL) {
+        // every strip reports its own first-argmax candidate (value, y, x, k) per pair; k_chain_local_end picks
+        if (q == 0) {
+            float4 *cd = chain_cand + ((int64_t)task * chain_stride + chain_strip) * 32;
+            cd[p] = make_float4((float)bestA * inv, __builtin_bit_cast(float, out_yA), __builtin_bit_cast(float, out_xA), __builtin_bit_cast(float, out_kA));
+            cd[16 + p] = make_float4((float)bestB * inv, __builtin_bit_cast(float, out_yB), __builtin_bit_cast(float, out_xB), __builtin_bit_cast(float, out_kB));
+        }
+        return;
     }
     if (q == 0) {
         auto report = [&](bool have, int pair, int L1, int vm, int vu, int vl, int best, int by, int bx, int bk) {

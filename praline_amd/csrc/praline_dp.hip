@@ -1215,8 +1215,9 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     {
         const char *tq = getenv("PRALINE_TB_QUAD");
         const Arena16Dev v16q = a.view16();
-        pl->quad = want_paths && pl->dense_kind == 0 && a.nr16 > 0 && a.nterm16 == 1 &&
-                   v16q.sym8 != nullptr && match_mode() == PRALINE_MATCH_FAST && !(tq && tq[0] == '0');
+        const bool quad_kind = want_paths && pl->dense_kind == 0 && a.nr16 > 0 && a.nterm16 == 1 &&
+                               v16q.sym8 != nullptr && match_mode() == PRALINE_MATCH_FAST && !(tq && tq[0] == '0');
+        pl->quad = quad_kind;
         // integer scoring within int16 (the exchange matrix alone is checked here, the gap scores by every run): two pairs per
         // lane, k_dp_pk16_tb (PRALINE_TB_PK16=0: never).  Plans with more than PRALINE_MAX_RECTS rectangles per pair keep
         // k_dp_quad_tb, which reads mask words.
@@ -1224,10 +1225,15 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         // (plans that fill the chip: a task is one wave and holds twice the pairs of a k_dp_quad_tb task - measured on C2,
         // 32 640 pairs = 1 020 such tasks on 1 024 SIMDs: 0.99 against 1.04 TCUPS; on a C3 slice of 130 944 pairs 1.74 against
         // 1.41.  PRALINE_TB_PK16=1: every plan that qualifies)
-        const bool big = n_pairs >= 65536 || (tk16 && tk16[0] == '1');
-        pl->pk16 = pl->quad && big && !many_rects && a.all_onehot && a.s_scale_bits >= 0 && a.s_scale_bits <= 8 && !(tk16 && tk16[0] == '0') &&
+        // (smaller plans run it in chain mode, one wave per task and strip)
+        pl->pk16 = pl->quad && !many_rects && a.all_onehot && a.s_scale_bits >= 0 && a.s_scale_bits <= 8 && !(tk16 && tk16[0] == '0') &&
                    (2.0 * a.max_len + 4.0) * (double)a.s_absmax * (double)(1 << a.s_scale_bits) < 32000.0;
         if (pl->pk16) pl->quad = false;
+        // k_dp_quad_tb has no chain mode: a task is one wave from the first strip to the last.  Plans that do not fill the chip
+        // with such waves (measured: one alignment of 1 400 x 1 400 26 ms against 2 ms in chain mode; 2 016 pairs of ~400 3.8
+        // against 1.1 ms; C2-sized plans level) keep the 32-pair strip kernels and their chain mode - unless the plan needs the
+        // mask words only k_dp_quad_tb reads (PRALINE_TB_QUAD=1: always)
+        if (pl->quad && n_pairs < 32768 && !many_rects && !(tq && tq[0] == '1')) pl->quad = false;
         opt.pk16 = pl->pk16;
         opt.quad16 = pl->quad;
     }
@@ -1961,7 +1967,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     }
     if (pl.want_paths && pl.pk16) {
         char kn[160];
-        if (pl.run_pk16) snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, %s, %s>", a.nr16, local ? "true" : "false", pl.has_rects ? "true" : "false");
+        if (pl.run_pk16) snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, %s, %s, false>", a.nr16, local ? "true" : "false", pl.has_rects ? "true" : "false");   // (chain mode: below)
         else snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // (gap scores off the int16 grid: the strip kernels)
         pl.last_kernel = kn;
     }
@@ -2284,7 +2290,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     // chunks of plans whose packed traceback exceeds the scratch budget (long sequences: 32 640 alignments of ~1000 x
     // ~1000 were 96 ms in task mode, three chunks of 380 waves each).  Chain chunks share one set of boundary columns
     // and flags: they all run on the main stream.
-    bool chain_chunks = pl.split && !pl.quad && !pl.run_pk16 && la.a16 != nullptr && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
+    bool chain_chunks = pl.split && !pl.quad && la.a16 != nullptr && !(getenv("PRALINE_NO_CHAIN") && getenv("PRALINE_NO_CHAIN")[0] == '1');
     {
         int64_t need_bnd = 0;
         size_t need_flags = 0;
@@ -2349,10 +2355,20 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
                 for (const WaveTask &wt : ct) rows = std::max(rows, (int)wt.max_l1);
                 every = std::min(every, std::max(6, rows / 4));
             }
+            // (k_dp_pk16_tb: two rows per step and shorter steps - measured on C2 one-hot 96 rows 1.55, 24 rows 1.60 TCUPS;
+            // 2 016 pairs 12 rows; one alignment 6 rows: scripts/exp_pk16_chain.py)
+            if (pl.run_pk16) every = std::min(every, nc >= 512 ? 24 : (nc >= 64 ? 12 : 6));
             if (const char *env = getenv("PRALINE_CHAIN_EVERY")) every = std::max(6, atoi(env));
-            int rc = praline_launch_split16_tb_chain(la, a16, a.nr16, tb_nterm, local, pl.has_rects, max_strips,
-                                                     pl.d_chain_flags.p, pl.d_chain_cand.p, every);
-            if (rc != PRALINE_OK) return fail(rc, "no chain instance of k_dp_split16_tb for nr=%d nterm=%d", a.nr16, tb_nterm);
+            if (pl.run_pk16) {
+                char kn[160];
+                snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, %s, %s, true>", a.nr16, local ? "true" : "false", pl.has_rects ? "true" : "false");
+                pl.last_kernel = kn;
+            }
+            int rc = pl.run_pk16 ? praline_launch_pk16_tb_chain(la, a16, a.nr16, local, pl.has_rects, pk16_scale, max_strips, pl.d_chain_flags.p,
+                                                                pl.d_chain_cand.p, every)
+                                 : praline_launch_split16_tb_chain(la, a16, a.nr16, tb_nterm, local, pl.has_rects, max_strips,
+                                                                   pl.d_chain_flags.p, pl.d_chain_cand.p, every);
+            if (rc != PRALINE_OK) return fail(rc, "no chain instance of the path kernel for nr=%d nterm=%d", a.nr16, tb_nterm);
             if (local) {
                 const int64_t lanes = (int64_t)nc * 32;
                 hipLaunchKernelGGL(k_chain_local_end, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, la.tasks,

@@ -292,12 +292,15 @@ def test_path_plan_execution_forms_agree(nat, bba, kind, monkeypatch):
     rects = [[(2, 20, 3, 30)] if k % 4 == 0 else ([(5, 9, 1, 4), (30, 60, 40, 64)] if k % 4 == 1 else [])
              for k in range(len(pairs))]
     # (plain sequences: the strip kernels with PRALINE_TB_QUAD=0; "quad" = k_dp_quad_tb, their default, whole and in chunks)
+    # (... and k_dp_pk16_tb, the default of integer scoring: chain mode, one wave per task, chunks)
     forms = {"chain": {"PRALINE_TB_QUAD": "0"}, "tasks": {"PRALINE_TB_QUAD": "0", "PRALINE_NO_CHAIN": "1"},
              "chunks": {"PRALINE_TB_QUAD": "0", "PRALINE_NO_CHAIN": "1", "PRALINE_TB_BUDGET_MB": "1"},
-             "quad": {}, "quad chunks": {"PRALINE_TB_BUDGET_MB": "1"}}
+             "quad": {"PRALINE_TB_QUAD": "1", "PRALINE_TB_PK16": "0"}, "quad chunks": {"PRALINE_TB_QUAD": "1", "PRALINE_TB_PK16": "0", "PRALINE_TB_BUDGET_MB": "1"},
+             "pk16 chain": {}, "pk16 tasks": {"PRALINE_NO_CHAIN": "1"}, "pk16 chunks": {"PRALINE_NO_CHAIN": "1", "PRALINE_TB_BUDGET_MB": "1"},
+             "pk16 chain chunks": {"PRALINE_TB_BUDGET_MB": "1"}}
     out = {}
     for form, env in forms.items():
-        for key in ("PRALINE_NO_CHAIN", "PRALINE_TB_BUDGET_MB", "PRALINE_TB_QUAD"):
+        for key in ("PRALINE_NO_CHAIN", "PRALINE_TB_BUDGET_MB", "PRALINE_TB_QUAD", "PRALINE_TB_PK16"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
@@ -306,10 +309,17 @@ def test_path_plan_execution_forms_agree(nat, bba, kind, monkeypatch):
             pk = plan.match_kind()
             plan.run(mode, *GAPS)
             out[(form, mode)] = (plan.scores().copy(), [p.copy() for p in plan.paths()])
+            if kind == "onehot":
+                want = "k_dp_quad_tb" if form.startswith("quad") else ("k_dp_pk16_tb" if form.startswith("pk16") else "k_dp_split16_tb")
+                assert plan.kernel_name().startswith(want), (form, plan.kernel_name())
+                if form.startswith("pk16"):
+                    assert plan.kernel_name().endswith(", true>") == ("chain" in form), (form, plan.kernel_name())
             plan.close()
+    for key in ("PRALINE_NO_CHAIN", "PRALINE_TB_BUDGET_MB", "PRALINE_TB_QUAD", "PRALINE_TB_PK16"):
+        monkeypatch.delenv(key, raising=False)
     for mode in MODES:
         ref_sc, ref_paths = out[("chain", mode)]
-        for form in ("tasks", "chunks", "quad", "quad chunks"):
+        for form in ("tasks", "chunks", "quad", "quad chunks", "pk16 chain", "pk16 tasks", "pk16 chunks", "pk16 chain chunks"):
             sc, paths = out[(form, mode)]
             assert np.array_equal(bits(sc), bits(ref_sc)), (form, mode)
             assert all(np.array_equal(a, b) for a, b in zip(paths, ref_paths)), (form, mode)
@@ -393,6 +403,7 @@ def test_quad_layout_paths_equal_the_strip_kernels(nat, bba, monkeypatch):
         return out
     cases = [(mode, gaps, None) for mode in MODES for gaps in (GAPS, (-10.3, -1.7))]
     cases += [("local", GAPS, rect_lists(3)), ("local", (-7.5, -0.5), rect_lists(9)), ("global", GAPS, rect_lists(6))]
+    monkeypatch.setenv("PRALINE_TB_PK16", "0")     # (integer scoring would take k_dp_pk16_tb)
     for mode, gaps, rects in cases:
         res = {}
         for quad in ("0", "1"):
@@ -447,8 +458,10 @@ def test_packed_int16_paths_equal_the_float_kernels(nat, bba, monkeypatch):
     cases += [("global", (-10.3, -1.7), None), ("local", (-60.0, -1.0), None)]     # off the grid; (L1 + L2 + 2) * 60 > 32 000
     for mode, gaps, rects in cases:
         res = {}
+        monkeypatch.setenv("PRALINE_TB_QUAD", "1")      # (the comparison: k_dp_quad_tb also for a plan of this size)
         for pk16 in ("0", "1"):
             monkeypatch.setenv("PRALINE_TB_PK16", pk16)
+            monkeypatch.setenv("PRALINE_NO_CHAIN", "1" if mode in ("global", "semiglobal_two") and rects is None else "0")   # one wave per task / chain mode
             plan = nat.Plan(arena, pairs, want_paths=True, rects=rects)
             pk = plan.match_kind()
             plan.run(mode, *gaps)
@@ -456,6 +469,7 @@ def test_packed_int16_paths_equal_the_float_kernels(nat, bba, monkeypatch):
             plan.close()
         fits = gaps not in ((-10.3, -1.7), (-60.0, -1.0))
         assert res["1"][2].startswith("k_dp_pk16_tb") == fits and res["0"][2].startswith("k_dp_quad_tb"), (gaps, res["0"][2], res["1"][2])
+        assert not fits or res["1"][2].endswith(", true>") == (not (mode in ("global", "semiglobal_two") and rects is None)), res["1"][2]
         assert np.array_equal(bits(res["0"][0]), bits(res["1"][0])), (mode, gaps, rects is not None)
         bad = [k for k in range(len(pairs)) if not np.array_equal(res["0"][1][k], res["1"][1][k])]
         assert not bad, (mode, gaps, rects is not None, pairs[bad[:3]].tolist())
@@ -468,14 +482,8 @@ def test_packed_int16_paths_equal_the_float_kernels(nat, bba, monkeypatch):
             assert res["1"][0][k] == np.float32(s_or), (mode, gaps, i, j)
             assert np.array_equal(res["1"][1][k], p_or), (mode, gaps, i, j)
     arena.close()
-    monkeypatch.delenv("PRALINE_TB_PK16")
-    # plans below 65 536 pairs keep k_dp_quad_tb unless asked
-    arena = nat.Arena(profs[:8], bba["S"])
-    plan = nat.Plan(arena, allp[:40][allp[:40].max(axis=1) < 8], want_paths=True)
-    plan.run("global", *GAPS)
-    assert plan.kernel_name().startswith("k_dp_quad_tb"), plan.kernel_name()
-    plan.close()
-    arena.close()
+    for key in ("PRALINE_TB_PK16", "PRALINE_TB_QUAD", "PRALINE_NO_CHAIN"):
+        monkeypatch.delenv(key)
 
 
 def test_batch_waterman_eggert_masks(nat, bba):
