@@ -70,10 +70,10 @@ int praline_launch_quad_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, 
 // k_dp_pk16_tb (dp_pk16_instance.hip): the same for integer scoring within int16, two pairs per lane - the 32-pair task layout
 // of the strip kernels (la.lane_one / lane_pair [task][32], la.bnd uint4 [row][16] per task, la.tb uint4 [strip][step][64] at
 // tk.tb_off counted in uint2, la.aux as the strip kernels'); mask: rectangles in registers
-int praline_launch_pk16_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, bool local, bool mask, float scale);
+int praline_launch_pk16_tb(const LaunchArgs &la, const Arena16Dev &a16, int nr, bool local, int mask, float scale);   // mask: rectangle slots per pair (0, 1, 2, <= PRALINE_MAX_RECTS)
 // ... in chain mode (one wave per task and strip; la.bnd: one uint4 [row][16] column per strip boundary; flags, cand as
 // praline_launch_split16_tb_chain's)
-int praline_launch_pk16_tb_chain(const LaunchArgs &la, const Arena16Dev &a16, int nr, bool local, bool mask, float scale, int max_strips,
+int praline_launch_pk16_tb_chain(const LaunchArgs &la, const Arena16Dev &a16, int nr, bool local, int mask, float scale, int max_strips,
                                  int *flags, void *cand, int every);
 // two-pass alignments with paths (dp_tb2_instance.hip): flag-free forward fill, then block recompute + traceback
 struct Trace2Args {

@@ -128,15 +128,17 @@ __device__ __forceinline__ uint2 pk16_row(const s16x2 (&m)[8], const PkIn &in, s
 }
 
 // NR: 16-wide symbol ranges of the lookup table (1: <= 16 active symbols, 2: <= 32).  MASK: zero rectangles in registers
-// (<= PRALINE_MAX_RECTS per pair).  scale = 2^k: DP values are stored as value * scale.
+// (MASK = 1, 2 or PRALINE_MAX_RECTS of them per pair: the first MASK slots of a pair's list - a Waterman-Eggert pass k holds
+// k - 1; two pairs' rectangles cost 8 registers each, and with one per pair the kernel keeps three waves per SIMD).
+// scale = 2^k: DP values are stored as value * scale.
 // CHAIN (plans of few tasks: one alignment, the merge steps of the progressive MSA, C2-sized batches): one wave per task AND
 // strip, 64-thread blocks in strip-major order, the strips of a task pipelined across workgroups as in k_dp_split16_tb's
 // chain mode (dp_split16_tb.hip.h): every strip boundary has its own column (uint4 [strip][row][16] at tk.bnd_off), quarter 3
 // stores its rows with agent-scope write-through stores and publishes the finished row count every `chain_every` rows;
 // the wave of the next strip polls that count before it issues the loads of rows it has not seen published.  Local
 // alignments report one first-argmax candidate per strip (chain_cand, k_chain_local_end picks per pair).
-template <int NR, bool LOCAL, bool MASK, bool CHAIN = false>
-__global__ __launch_bounds__(CHAIN ? 64 : 256, MASK ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+template <int NR, bool LOCAL, int MASK, bool CHAIN = false>
+__global__ __launch_bounds__(CHAIN ? 64 : 256, MASK > 1 ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one, const int32_t *__restrict__ lane_pair,
                                                        uint4 *bnd, uint4 *__restrict__ tb, float *__restrict__ aux, RectList rl,
                                                        float *__restrict__ scores, int32_t *__restrict__ end_cells, RunParams rp,
@@ -196,17 +198,19 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, MASK ? 2 : PRALINE_PK16_WAVES) vo
     float *lastcol = aux + tk.aux_off;                                       // [y][3][32]
     float *lastrow = aux + tk.aux_off + (int64_t)(max_l1 + 1) * 3 * 32;      // [x - 1][3][32]
 
-    int rectA[PRALINE_MAX_RECTS][4], rectB[PRALINE_MAX_RECTS][4];
-    if constexpr (MASK) {
-        auto load_rects = [&](int pair, int (&rect)[PRALINE_MAX_RECTS][4]) {
+    constexpr int NRECT = MASK > 0 ? MASK : 1;
+    static_assert(MASK >= 0 && MASK <= PRALINE_MAX_RECTS, "rectangle slots held in registers");
+    int rectA[NRECT][4], rectB[NRECT][4];
+    if constexpr (MASK != 0) {
+        auto load_rects = [&](int pair, int (&rect)[NRECT][4]) {
             int n_rects = 0, r0 = 0;
             if (pair >= 0 && rl.rect_off != nullptr) {
                 r0 = rl.rect_off[pair];
                 n_rects = rl.rect_off[pair + 1] - r0;
-                if (n_rects > PRALINE_MAX_RECTS) n_rects = PRALINE_MAX_RECTS;
+                if (n_rects > NRECT) n_rects = NRECT;
             }
 #pragma unroll
-            for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
+            for (int r = 0; r < NRECT; ++r) {
                 const bool ok = r < n_rects;
                 rect[r][0] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 0] : (1 << 30);
                 rect[r][1] = ok ? rl.rects[(int64_t)(r0 + r) * 4 + 1] : -1;
@@ -238,10 +242,10 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, MASK ? 2 : PRALINE_PK16_WAVES) vo
         const int xb = x0 + 8 * q;
         const bool last_owner = (s == nstrips - 1) && own_last;
 
-        int smA[PRALINE_MAX_RECTS], smB[PRALINE_MAX_RECTS];   // column masks of the rectangles inside this lane's 8 columns
-        if constexpr (MASK) {
+        int smA[NRECT], smB[NRECT];   // column masks of the rectangles inside this lane's 8 columns
+        if constexpr (MASK != 0) {
 #pragma unroll
-            for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
+            for (int r = 0; r < NRECT; ++r) {
                 const int loA = max(rectA[r][2] - (xb + 1), 0), hiA = min(rectA[r][3] - (xb + 1), 7);
                 const int loB = max(rectB[r][2] - (xb + 1), 0), hiB = min(rectB[r][3] - (xb + 1), 7);
                 smA[r] = (loA <= hiA) ? (int)((0xffu >> (7 - hiA)) & (0xffu << loA)) : 0;
@@ -338,6 +342,8 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, MASK ? 2 : PRALINE_PK16_WAVES) vo
             s16x2 mA[8], mB[8];   // packed match scores of the step's two rows
             fetch_scores(symA_ld, symB_ld, mA, mB);
             if (q == 0) boundary_of(2 * t - 1, ldA, ldB, nxA, nxB);
+            if (t <= 4) {   // (wave-uniform: the later steps skip the 27 conditional moves; the empty asm keeps it a branch)
+                asm volatile("");
             if (t == q + 1) {
                 // the quarter starts: row 0 of its columns, and the states of the cell left of them (0, xb)
 #pragma unroll
@@ -346,10 +352,11 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, MASK ? 2 : PRALINE_PK16_WAVES) vo
                 dU = (xb == 0) ? pk_dup(pk_scaled(o001, scale)) : neg;
                 dL = (xb == 0) ? pk_dup(pk_scaled(o002, scale)) : pk_dup(pk_scaled(boundary_value(xb, go, ge, free_two), scale));
             }
+            }
             unsigned zAa = 0, zAb = 0, zBa = 0, zBb = 0;   // row ya: pairs A, B; row ya + 1: pairs A, B
-            if constexpr (MASK) {
+            if constexpr (MASK != 0) {
 #pragma unroll
-                for (int r = 0; r < PRALINE_MAX_RECTS; ++r) {
+                for (int r = 0; r < NRECT; ++r) {
                     zAa |= (ya >= rectA[r][0] && ya <= rectA[r][1]) ? (unsigned)smA[r] : 0u;
                     zAb |= (ya >= rectB[r][0] && ya <= rectB[r][1]) ? (unsigned)smB[r] : 0u;
                     zBa |= (ya + 1 >= rectA[r][0] && ya + 1 <= rectA[r][1]) ? (unsigned)smA[r] : 0u;
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, MASK ? 2 : PRALINE_PK16_WAVES) vo
                 }
             };
             auto one_row = [&](const s16x2 (&m)[8], const PkIn &in, unsigned za, unsigned zb) {
-                if constexpr (MASK) {
+                if constexpr (MASK != 0) {
                     if (__ballot((za | zb) != 0u) != 0ull) return pk16_row<LOCAL, true>(m, in, Mp, Up, Lp, dM, dU, dL, go2, ge2, za, zb);
                 }
                 return pk16_row<LOCAL, false>(m, in, Mp, Up, Lp, dM, dU, dL, go2, ge2, 0u, 0u);

@@ -299,6 +299,8 @@ __global__ __launch_bounds__(256, PRALINE_QUAD_WAVES) void k_dp_quad_tb(Arena16D
             if (t > 1) PRALINE_QUAD_WAIT(3, ldA, ldB, sym_ld);
             if (q == 0) boundary_of(2 * t - 1, ldA, ldB, nxA, nxB);
             const unsigned sym_now = sym_ld;         // the symbols of step t + 1
+            if (t <= 4) {   // (wave-uniform: the later steps skip the 27 conditional moves; the empty asm keeps it a branch)
+                asm volatile("");
             if (t == q + 1) {
                 // the quarter starts: row 0 of its columns, and the states of the cell left of them (0, xb)
 #pragma unroll
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(256, PRALINE_QUAD_WAVES) void k_dp_quad_tb(Arena16D
                 dM = (xb == 0) ? 0.0f : PRALINE_NEG_INF;
                 dU = (xb == 0) ? o001 : PRALINE_NEG_INF;
                 dL = (xb == 0) ? o002 : boundary_value(xb, go, ge, free_two);
+            }
             }
             unsigned zA = 0, zB = 0;
             if constexpr (MASK == 1) {

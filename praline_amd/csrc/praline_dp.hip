@@ -246,9 +246,14 @@ static void *pool_alloc(size_t bytes, size_t *got)
     // takes ANY block that fits (a first hipMalloc of a 24 GiB scratch block costs the better part of a second - more
     // than the C3 stage it serves) and would rather wait for a block in flight than go to the driver; smaller ones
     // only take blocks of up to twice their size
+    if (bytes < ((size_t)1 << 20)) {   // small requests: power-of-two size classes from 4 KiB, so that released blocks fit again
+        size_t cls = 4096;
+        while (cls < bytes) cls <<= 1;
+        bytes = cls;
+    }
     size_t best = (size_t)-1, best_busy = (size_t)-1;
     for (size_t i = 0; i < g_pool.size(); ++i) {
-        if (!(g_pool[i].bytes >= bytes && (bytes >= ((size_t)1 << 30) || g_pool[i].bytes <= 2 * bytes + (1 << 20)))) continue;
+        if (!(g_pool[i].bytes >= bytes && (bytes >= ((size_t)1 << 30) || g_pool[i].bytes <= 2 * bytes + (bytes >= ((size_t)1 << 20) ? (1 << 20) : 0)))) continue;
         size_t &slot = pool_block_ready(g_pool[i]) ? best : best_busy;
         if (slot == (size_t)-1 || g_pool[i].bytes < g_pool[slot].bytes) slot = i;
     }
@@ -276,8 +281,10 @@ static void *pool_alloc(size_t bytes, size_t *got)
 static void pool_release(void *p, size_t bytes)
 {
     if (!p) return;
-    // (hipFree waits for the device: a small block that is freed outright cannot be in use afterwards either)
-    if (bytes < ((size_t)1 << 20) || g_pool_bytes + bytes > pool_keep_bytes() || !g_rt.ready) { (void)hipFree(p); return; }
+    // (small blocks are cached too: a plan holds a dozen buffers below a MiB, and a hipFree - which waits for the device -
+    // of each made praline_plan_destroy of a C3-sized plan 18-20 ms of host time; they come in power-of-two sizes,
+    // pool_alloc)
+    if (g_pool_bytes + bytes > pool_keep_bytes() || !g_rt.ready) { (void)hipFree(p); return; }
     PoolBlock b{p, bytes, {pool_event(), pool_event()}};
     const hipStream_t streams[2] = {g_rt.stream, g_rt.stream2};
     for (int k = 0; k < 2; ++k)
@@ -958,6 +965,7 @@ struct praline_plan {
     int64_t path_cap = 0;
     bool want_paths = false;
     bool has_rects = false;
+    int max_rects = 0;    // rectangles of the pair with the most (lists given at creation)
     int slot_rects = -1;  // >= 0: the rectangles live in fixed slots on the device (praline_plan_mask_path_bounds), this many used
     int mask_kind = 0;   // 0 none, 1 <= PRALINE_MAX_RECTS rectangles per pair (registers), 2 any number (per-row mask words, k_build_zmask)
     int tp = 1;
@@ -1166,6 +1174,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     PhaseTimer pt("plan_create");
     const praline_arena &a = *arena;
     bool many_rects = false;   // some pair carries more rectangles than the register-resident mask code holds
+    int max_rects = 0;         // the longest rectangle list of a pair
     int64_t list_cells = 0;
     {
         int64_t bad = -1;
@@ -1176,12 +1185,14 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         for (int64_t p = 0; p < n_pairs; ++p) {
             if (rect_off[p + 1] < rect_off[p]) return fail(PRALINE_ERR_ARG, "rect_off is not ascending at pair %lld", (long long)p);
             many_rects = many_rects || rect_off[p + 1] - rect_off[p] > PRALINE_MAX_RECTS;
+            max_rects = std::max(max_rects, (int)(rect_off[p + 1] - rect_off[p]));
         }
     praline_plan *pl = new praline_plan();
     pl->arena = arena;
     pl->n_pairs = n_pairs;
     pl->want_paths = want_paths != 0;
     pl->has_rects = rect_off && rect_off[n_pairs] > 0;
+    pl->max_rects = max_rects;
     pl->mask_kind = !pl->has_rects ? 0 : (many_rects ? 2 : 1);
 
     // ---- host scheduling (sched.cpp): tasks, launch order, workgroup descriptors ----
@@ -1227,7 +1238,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
         // 1.41.  PRALINE_TB_PK16=1: every plan that qualifies)
         // (smaller plans run it in chain mode, one wave per task and strip)
         pl->pk16 = pl->quad && !many_rects && a.all_onehot && a.s_scale_bits >= 0 && a.s_scale_bits <= 8 && !(tk16 && tk16[0] == '0') &&
-                   (2.0 * a.max_len + 4.0) * (double)a.s_absmax * (double)(1 << a.s_scale_bits) < 32000.0;
+                   (2.0 * a.max_len + 36.0) * (double)a.s_absmax * (double)(1 << a.s_scale_bits) < 32000.0;   // (+ 36: the boundary cells of a last strip's padding columns)
         if (pl->pk16) pl->quad = false;
         // k_dp_quad_tb has no chain mode: a task is one wave from the first strip to the last.  Plans that do not fill the chip
         // with such waves (measured: one alignment of 1 400 x 1 400 26 ms against 2 ms in chain mode; 2 016 pairs of ~400 3.8
@@ -1391,10 +1402,13 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
 extern "C" int praline_plan_destroy(praline_plan *plan)
 {
     if (!plan) return PRALINE_OK;
-    // (blocks of a MiB and more go back to the stream-ordered pool; smaller ones are freed, which waits for the device -
-    // the explicit waits keep the plan's host-side state from outliving work that still reads it)
+    // (the device blocks go back to the stream-ordered pool; the explicit waits keep the plan's host-side state from
+    // outliving work that still reads it)
+    PhaseTimer pt("plan_destroy");
     if (g_rt.ready) { (void)hipStreamSynchronize(g_rt.stream); (void)hipStreamSynchronize(g_rt.stream2); }
+    pt.mark("wait for both streams");
     delete plan;
+    pt.mark("release");
     return PRALINE_OK;
 }
 
@@ -1962,12 +1976,16 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
         }
         tb_nterm = ints ? 1 : 3;
         // two pairs per lane in int16 when every DP value of this run fits (dp_pk16.hip.h)
-        pl.run_pk16 = pl.want_paths && pl.pk16 && ints && (2.0 * a.max_len + 4.0) * big_scaled < 32000.0;
+        pl.run_pk16 = pl.want_paths && pl.pk16 && ints && (2.0 * a.max_len + 36.0) * big_scaled < 32000.0;
         pk16_scale = (float)(1 << std::min(std::max(k_bits, 0), 8));
     }
+    // rectangle slots per pair the packed kernel holds in registers: the lists' longest, or the slots filled so far
+    // (praline_plan_mask_path_bounds), rounded up to an instance (1, 2, PRALINE_MAX_RECTS)
+    int pk16_slots = !pl.has_rects ? 0 : (pl.slot_rects >= 0 ? pl.slot_rects : pl.max_rects);
+    pk16_slots = pk16_slots <= 0 ? (pl.has_rects ? 1 : 0) : (pk16_slots <= 2 ? pk16_slots : PRALINE_MAX_RECTS);
     if (pl.want_paths && pl.pk16) {
         char kn[160];
-        if (pl.run_pk16) snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, %s, %s, false>", a.nr16, local ? "true" : "false", pl.has_rects ? "true" : "false");   // (chain mode: below)
+        if (pl.run_pk16) snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, %s, %d, false>", a.nr16, local ? "true" : "false", pk16_slots);   // (chain mode: below)
         else snprintf(kn, sizeof(kn), "k_dp_split16_tb<%d, ...>", a.nr16);   // (gap scores off the int16 grid: the strip kernels)
         pl.last_kernel = kn;
     }
@@ -2361,10 +2379,10 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             if (const char *env = getenv("PRALINE_CHAIN_EVERY")) every = std::max(6, atoi(env));
             if (pl.run_pk16) {
                 char kn[160];
-                snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, %s, %s, true>", a.nr16, local ? "true" : "false", pl.has_rects ? "true" : "false");
+                snprintf(kn, sizeof(kn), "k_dp_pk16_tb<%d, %s, %d, true>", a.nr16, local ? "true" : "false", pk16_slots);
                 pl.last_kernel = kn;
             }
-            int rc = pl.run_pk16 ? praline_launch_pk16_tb_chain(la, a16, a.nr16, local, pl.has_rects, pk16_scale, max_strips, pl.d_chain_flags.p,
+            int rc = pl.run_pk16 ? praline_launch_pk16_tb_chain(la, a16, a.nr16, local, pk16_slots, pk16_scale, max_strips, pl.d_chain_flags.p,
                                                                 pl.d_chain_cand.p, every)
                                  : praline_launch_split16_tb_chain(la, a16, a.nr16, tb_nterm, local, pl.has_rects, max_strips,
                                                                    pl.d_chain_flags.p, pl.d_chain_cand.p, every);
@@ -2379,7 +2397,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
             int rc = praline_launch_quad_tb(la, a16, a.nr16, tb_nterm == 1, local, pl.mask_kind);
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_quad_tb instance for nr=%d", a.nr16);
         } else if (pl.run_pk16) {
-            int rc = praline_launch_pk16_tb(la, a16, a.nr16, local, pl.has_rects, pk16_scale);
+            int rc = praline_launch_pk16_tb(la, a16, a.nr16, local, pk16_slots, pk16_scale);
             if (rc != PRALINE_OK) return fail(rc, "no k_dp_pk16_tb instance for nr=%d", a.nr16);
         } else {
             int rc = praline_launch_split16_tb(la, a16, a.nr16, tb_nterm, local, pl.has_rects);

@@ -132,8 +132,27 @@ def device_count():
     return n.value if rc == OK else 0
 
 
+def keep_host_memory_mapped(enable=True):
+    """Stage-sized host buffers (pair lists, count arenas, the plans' schedules: 4-30 MB each) come and go with every
+    submission; glibc serves blocks of that size with mmap and hands them back with munmap, so every one of them is
+    page-faulted in again - about 1 ms per MB on the MI355X hosts, 30-40 ms of a 75 ms preprofile stage on C3.  This
+    raises glibc's mmap and trim thresholds (mallopt: blocks up to 32 MB from the heap, the heap not trimmed) so that
+    such buffers are recycled by malloc.  Process-wide, which is why it is a switch: init() applies it unless
+    PRALINE_KEEP_HOST_MEMORY=0."""
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        M_TRIM_THRESHOLD, M_MMAP_THRESHOLD = -1, -3
+        if enable:
+            return bool(libc.mallopt(M_MMAP_THRESHOLD, 32 << 20)) and bool(libc.mallopt(M_TRIM_THRESHOLD, (1 << 31) - 1))
+        return bool(libc.mallopt(M_MMAP_THRESHOLD, 128 << 10)) and bool(libc.mallopt(M_TRIM_THRESHOLD, 128 << 10))
+    except (OSError, AttributeError):
+        return False
+
+
 def init(device=0):
     _check(lib().praline_init(int(device)))
+    if os.environ.get("PRALINE_KEEP_HOST_MEMORY", "1") != "0":
+        keep_host_memory_mapped(True)
 
 
 def synchronize():
@@ -315,6 +334,21 @@ def _result_view(n_floats):
     return v[:n_floats]
 
 
+_counts_stage = {"view": None}
+
+
+def _counts_view(n_ints):
+    """A reused int32 host buffer for count read-backs (grown on demand, at most 1 GB): its pages are touched once, where a
+    fresh 27 MB array per call costs ~20 ms of page faults.  Ordinary memory on purpose - numpy reads the counts back out
+    of it, and CPU reads of page-locked (fine-grained, uncached) memory ran at 1 GB/s."""
+    if n_ints * 4 > (1 << 30):
+        return None
+    v = _counts_stage["view"]
+    if v is None or v.size < n_ints:
+        v = _counts_stage["view"] = np.empty(max(1 << 16, 1 << int(n_ints - 1).bit_length()), dtype=np.int32)
+    return v[:n_ints]
+
+
 def _stage_profiles(profiles, A):
     """The float32 [sum L, A] concatenation of `profiles`, in page-locked memory when they are float32 already."""
     first = profiles[0]
@@ -446,9 +480,17 @@ class Arena(object):
         """Zero the preprofile count buffer int32 [sum L, A] (praline_arena_counts_reset)."""
         _check(lib().praline_arena_counts_reset(self._h))
 
-    def counts(self):
-        """The preprofile counts accumulated by Plan.add_counts, int32 [sum L, A] on the host."""
-        out = np.empty((int(self.lens.sum()), self.A), dtype=np.int32)
+    def counts(self, staged=False):
+        """The preprofile counts accumulated by Plan.add_counts, int32 [sum L, A] on the host.  staged: a view of the
+        process's reused read-back buffer (no page faults of a fresh 27 MB array on C3) - valid until the next staged
+        read-back; the caller copies what it keeps."""
+        rows = int(self.lens.sum())
+        if staged:
+            v = _counts_view(rows * self.A)
+            if v is not None:
+                _check(lib().praline_arena_counts_read(self._h, v.ctypes.data))
+                return v.reshape(rows, self.A)
+        out = np.empty((rows, self.A), dtype=np.int32)
         _check(lib().praline_arena_counts_read(self._h, out.ctypes.data))
         return out
 
