@@ -38,6 +38,9 @@
 #ifndef PRALINE_PK16_STORE_NT
 #define PRALINE_PK16_STORE_NT 1   // flag words: streaming stores
 #endif
+#ifndef PRALINE_PK16_MASK1_WAVES
+#define PRALINE_PK16_MASK1_WAVES 3   // ... the instances with one rectangle slot per pair
+#endif
 #ifndef PRALINE_PK16_WAVES
 #define PRALINE_PK16_WAVES 3   // waves per SIMD the instances without rectangles are compiled for (those with: 2)
 #endif
@@ -138,7 +141,7 @@ __device__ __forceinline__ uint2 pk16_row(const s16x2 (&m)[8], const PkIn &in, s
 // the wave of the next strip polls that count before it issues the loads of rows it has not seen published.  Local
 // alignments report one first-argmax candidate per strip (chain_cand, k_chain_local_end picks per pair).
 template <int NR, bool LOCAL, int MASK, bool CHAIN = false>
-__global__ __launch_bounds__(CHAIN ? 64 : 256, MASK > 1 ? 2 : PRALINE_PK16_WAVES) void k_dp_pk16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
+__global__ __launch_bounds__(CHAIN ? 64 : 256, MASK > 1 ? 2 : (MASK == 1 ? PRALINE_PK16_MASK1_WAVES : PRALINE_PK16_WAVES)) void k_dp_pk16_tb(Arena16Dev ar, const WaveTask *__restrict__ tasks,
                                                        const int32_t *__restrict__ lane_one, const int32_t *__restrict__ lane_pair,
                                                        uint4 *bnd, uint4 *__restrict__ tb, float *__restrict__ aux, RectList rl,
                                                        float *__restrict__ scores, int32_t *__restrict__ end_cells, RunParams rp,

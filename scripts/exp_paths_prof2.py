@@ -1,7 +1,8 @@
-"""The alignments-with-paths kernels under a profiler: C2 (256 float profiles ~400 aa, all 32 640 pairs, global: chain
-mode, MFMA-fed flagged fill + k_traceback) and a C3 slice (N one-hot sequences ~250 aa, all ordered pairs: task mode with
-the match-score lookup, global; LOCAL in two passes: forward fill + k_trace_recompute).  scripts/profile_paths.sh runs it
-under rocprofv3 --kernel-trace --stats and, in separate passes, --pmc."""
+"""The alignments-with-paths kernels under a profiler: C2 float profiles (256 x ~400 aa, all 32 640 pairs, global: the pipeline
+two-pass, k_dp_pipe<KEEP> + k_trace_recompute<36>; local: chain mode of k_dp_split16_tb), C2 one-hot (k_dp_pk16_tb in chain
+mode) and a C3 slice (N one-hot sequences ~250 aa, all ordered pairs: k_dp_pk16_tb, one wave per task; k_dp_quad_tb beside it
+with PRALINE_TB_PK16=0).  scripts/profile_paths.sh runs it under rocprofv3 --kernel-trace --stats and, in separate passes,
+--pmc."""
 import sys, os, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,11 +23,18 @@ def run(tag, ar, pairs, lens, modes, reps=3):
         pl.close()
 rng = np.random.default_rng(2); lens = synth_lengths(rng, 256, 400)
 ar = nat.Arena([synth_profile(rng, int(L)) for L in lens], S)
-run("C2-float", ar, allpairs.enumerate_pairs(256), lens, ("global",))
+run("C2-float", ar, allpairs.enumerate_pairs(256), lens, ("global", "local"))
+ar.close()
+rng1 = np.random.default_rng(2)
+ar = nat.Arena([np.eye(27, dtype=np.float32)[rng1.integers(0, 20, int(L))] for L in lens], S)
+run("C2-onehot", ar, allpairs.enumerate_pairs(256), lens, ("global", "local"))
 ar.close()
 N = int(os.environ.get("N", "512"))
 rng = np.random.default_rng(3); lens = synth_lengths(rng, N, 250)
 ar = nat.Arena([np.eye(27, dtype=np.float32)[rng.integers(0, 20, int(L))] for L in lens], S)
 pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j], dtype=np.int32)
 run("C3-slice-N%d" % N, ar, pairs, lens, ("global", "local"))
+os.environ["PRALINE_TB_PK16"] = "0"
+run("C3-slice-N%d-quad" % N, ar, pairs, lens, ("global",))
+os.environ.pop("PRALINE_TB_PK16")
 ar.close()
