@@ -1884,7 +1884,7 @@ extern "C" int praline_plan_run(praline_plan *plan, int mode, float gap_open, fl
     }
     if (!pl.want_paths && pl.pipe.ok) {   // (the match-score mode was read when the plan was created)
         char kn[160];
-        snprintf(kn, sizeof(kn), "k_dp_pipe<%d, %d, %s, %s>", a.nr16, a.nterm16, local ? "true" : "false", mode >= 2 ? "true" : "false");
+        snprintf(kn, sizeof(kn), "k_dp_pipe<%d, %d, %s, %s, false>", a.nr16, a.nterm16, local ? "true" : "false", mode >= 2 ? "true" : "false");
         pl.last_kernel = kn;
         PipeLaunch pp;
         pp.items = pl.d_pipe_items.p;
