@@ -851,6 +851,53 @@ __global__ void k_path_counts(const int32_t *__restrict__ pairs, const float *__
     }
 }
 
+// The same for pair lists in which the pairs of a master are contiguous (the preprofile stage's own order: master outer,
+// slaves ascending): one workgroup per RUN of pairs with the same master keeps the master's count block [len][A] in LDS -
+// the N - 1 slave paths of a master all hit those few thousand counters (262 M global atomics on C3, 7.5 ms) - and adds
+// its nonzero entries to the arena once.  runs: int64 [n_runs][2] = first pair, one past the last.
+__global__ __launch_bounds__(256) void k_path_counts_runs(const int32_t *__restrict__ pairs, const float *__restrict__ scores,
+                                                          const int32_t *__restrict__ paths, const int64_t *__restrict__ path_start,
+                                                          const int32_t *__restrict__ path_rows, const int64_t *__restrict__ runs,
+                                                          int use_threshold, float threshold, int local,
+                                                          const int32_t *__restrict__ row_off_raw, const int32_t *__restrict__ len,
+                                                          const unsigned char *__restrict__ sym_raw, int A, int32_t *__restrict__ counts)
+{
+    extern __shared__ int hist[];   // [len[master]][A]
+    const int64_t p0 = runs[2 * (int64_t)blockIdx.x], p1 = runs[2 * (int64_t)blockIdx.x + 1];
+    const int master = pairs[2 * p0];
+    const int n = len[master] * A;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        if (use_threshold && !(scores[p] >= threshold)) continue;   // preprofile.py:145,258
+        const int rows = path_rows[p];
+        if (rows <= 0) continue;
+        const int slave = pairs[2 * p + 1];
+        const int32_t *path = paths + path_start[p] * 2;
+        const unsigned char *ss = sym_raw + row_off_raw[slave];
+        const int ls = len[slave];
+        int y = path[0], xk = path[1];   // last kept row: (master index, slave index)
+        if (local && y > 0) {
+            const int sx = xk >= 1 ? xk - 1 : ls - 1;
+            atomicAdd(&hist[(y - 1) * A + ss[sx]], 1);
+        }
+        for (int r = 1; r < rows; ++r) {
+            const int y1 = path[2 * r], x1 = path[2 * r + 1];
+            if (y1 > y) {   // the master advances: a kept row
+                if (x1 > xk) atomicAdd(&hist[(y1 - 1) * A + ss[x1 - 1]], 1);
+                xk = x1;
+                y = y1;
+            }
+        }
+    }
+    __syncthreads();
+    int32_t *mc = counts + (int64_t)row_off_raw[master] * A;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int v = hist[i];
+        if (v != 0) atomicAdd(mc + i, v);
+    }
+}
+
 // first and last row of every path = its bounding box (paths are monotone): (y0, y1, x0, x1), the rectangle the
 // next Waterman-Eggert iteration masks (praline/component/preprofile.py:247-255)
 __global__ void k_path_bounds(const int32_t *__restrict__ paths, const int64_t *__restrict__ path_start,

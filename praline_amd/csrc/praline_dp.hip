@@ -966,6 +966,8 @@ struct praline_plan {
     bool want_paths = false;
     bool has_rects = false;
     int max_rects = 0;    // rectangles of the pair with the most (lists given at creation)
+    int64_t count_runs = -1;            // praline_plan_add_counts: runs of pairs with one master (-1: not looked for yet, 0: none)
+    DevBuf<int64_t> d_count_runs;
     int slot_rects = -1;  // >= 0: the rectangles live in fixed slots on the device (praline_plan_mask_path_bounds), this many used
     int mask_kind = 0;   // 0 none, 1 <= PRALINE_MAX_RECTS rectangles per pair (registers), 2 any number (per-row mask words, k_build_zmask)
     int tp = 1;
@@ -2524,6 +2526,41 @@ extern "C" int praline_plan_add_counts(praline_plan *plan, int use_threshold, fl
         return fail(PRALINE_ERR_UNSUPPORTED, "preprofile counting needs one-hot profiles (plain sequences), as "
                     "ProfileBuilder needs plain tracks (praline/util/align.py:187-213)");
     if (plan->n_pairs == 0) return PRALINE_OK;
+    // pair lists whose masters come in runs (the preprofile stage's order): a workgroup per run with the master's count
+    // block in LDS (k_path_counts_runs).  The runs are found once per plan, from the device copy of the pair list.
+    if (plan->count_runs < 0) {
+        plan->count_runs = 0;
+        const size_t lds_need = (size_t)a.max_len * a.A * sizeof(int32_t);
+        const char *cr = getenv("PRALINE_COUNT_RUNS");   // 0: never; 1: whenever the count block fits LDS (tests); default: runs of 64 pairs and more on average
+        const bool forced = cr && cr[0] == '1';
+        const int64_t max_runs = forced ? plan->n_pairs : plan->n_pairs / 64;
+        if (lds_need <= (size_t)64 << 10 && (plan->n_pairs >= 4096 || forced) && !(cr && cr[0] == '0')) {
+            std::vector<int32_t> hp((size_t)plan->n_pairs * 2);
+            HIPCHK(hipMemcpyAsync(hp.data(), plan->d_pairs.p, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, g_rt.stream));
+            HIPCHK(hipStreamSynchronize(g_rt.stream));
+            std::vector<int64_t> runs;
+            for (int64_t p = 0; p < plan->n_pairs;) {
+                int64_t q = p + 1;
+                while (q < plan->n_pairs && hp[(size_t)(2 * q)] == hp[(size_t)(2 * p)]) ++q;
+                runs.push_back(p); runs.push_back(q);
+                p = q;
+                if ((int64_t)runs.size() / 2 > max_runs) break;   // (short runs: one lane per pair and global atomics)
+            }
+            if ((int64_t)runs.size() / 2 <= max_runs) {
+                RC(plan->d_count_runs.upload(runs, g_rt.stream));
+                HIPCHK(hipStreamSynchronize(g_rt.stream));   // (runs goes out of scope)
+                plan->count_runs = (int64_t)runs.size() / 2;
+            }
+        }
+    }
+    if (plan->count_runs > 0) {
+        hipLaunchKernelGGL(k_path_counts_runs, dim3((unsigned)plan->count_runs), dim3(256), (size_t)a.max_len * a.A * sizeof(int32_t),
+                           g_rt.stream, plan->d_pairs.p, plan->last_scores, plan->d_paths.p, plan->d_path_start.p, plan->d_path_rows.p,
+                           plan->d_count_runs.p, use_threshold, threshold, local, a.d_row_off_raw.p, a.d_len.p, a.d_sym_raw.p, a.A,
+                           a.counts_ptr());
+        HIPCHK(hipGetLastError());
+        return PRALINE_OK;
+    }
     const int threads = 64;
     const int64_t blocks = (plan->n_pairs + threads - 1) / threads;
     hipLaunchKernelGGL(k_path_counts, dim3((unsigned)blocks), dim3(threads), 0, g_rt.stream, plan->d_pairs.p,

@@ -85,10 +85,12 @@ def test_master_slave_aligners_and_profile_builder(env, seqs):
         assert np.array_equal(prof['profile_track'].profile, d[key + "profile_f32"]), key
 
 
-def test_device_preprofile_stage(env, seqs):
+def test_device_preprofile_stage(env, seqs, monkeypatch):
     """build_preprofiles: the counting over the master-slave merge runs on the device paths.  Pinned to the
     reference's own ProfileBuilder counts (goldens) and, on a synthetic set with short and empty-ish local
-    alignments, to the mirrored component chain."""
+    alignments, to the mirrored component chain.  Both counting kernels: one lane per pair with global atomics (small
+    lists) and one workgroup per master with its count block in LDS (PRALINE_COUNT_RUNS=1 forces it; the default from
+    4 096 pairs on)."""
     d = load_golden("preprofile.npz")
     blosum = env["blosum"]
     for key, mode, master, kw in (("global_m0_", "global", 0, {}), ("global_m2_", "global", 2, {}),
@@ -115,6 +117,10 @@ def test_device_preprofile_stage(env, seqs):
                                 ("local", comp.LocalMasterSlaveAligner, {"score_threshold": 20.0}),
                                 ("global", comp.GlobalMasterSlaveAligner, {"score_threshold": 0.0})):
         tracks = comp.build_preprofiles(syn, ct.TRACK_ID_INPUT, blosum, mode=mode, **kw)
+        monkeypatch.setenv("PRALINE_COUNT_RUNS", "1")
+        tracks_runs = comp.build_preprofiles(syn, ct.TRACK_ID_INPUT, blosum, mode=mode, **kw)
+        monkeypatch.delenv("PRALINE_COUNT_RUNS")
+        assert all(np.array_equal(a.counts, b.counts) for a, b in zip(tracks, tracks_runs)), (mode, kw)
         for master in range(len(syn)):
             slaves = [s for k, s in enumerate(syn) if k != master]
             out = run_one(env["serial"], component, kw, master_sequence=syn[master], slave_sequences=slaves,
