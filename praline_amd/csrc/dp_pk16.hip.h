@@ -325,22 +325,24 @@ __global__ __launch_bounds__(CHAIN ? 64 : 256, MASK > 1 ? 2 : (MASK == 1 ? PRALI
         // (three stores to the unused row 0, so that step 2 finds the same ten operations behind its set as every later step:
         // ONE wait instruction for all steps - two of them in two branches made the compiler merge their register operands
         // with copies of registers whose loads were still in flight)
+        // stores a step issues: two boundary rows (chain mode: two instructions each) and the flag words - the ablation builds
+        // that leave some out count accordingly (a wait that assumes stores which are not there lets a step read registers
+        // whose loads are still in flight: garbage end cells, a traceback out of bounds)
+        constexpr int NST = (CHAIN ? 5 : 3) - ((PRALINE_PK16_ABLATE & 1) ? 1 : 0) - ((PRALINE_PK16_ABLATE & 2) ? (CHAIN ? 4 : 2) : 0);
         {
             const f4n z = {0.0f, 0.0f, 0.0f, 0.0f};
-            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off" : : "v"(CHAIN ? my_bnd_out : my_bnd), "v"(z) : "memory");
-            if constexpr (CHAIN)   // (chain mode: five stores per step)
-                asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off" : : "v"(my_bnd_out), "v"(z) : "memory");
+#pragma unroll
+            for (int k = 0; k < NST; ++k)
+                asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(CHAIN ? my_bnd_out : my_bnd), "v"(z) : "memory");
         }
-        if constexpr (CHAIN) { PRALINE_QUAD_WAIT(9, ld1A, ld1B, sym1A); }
-        else { PRALINE_QUAD_WAIT(7, ld1A, ld1B, sym1A); }
+        PRALINE_QUAD_WAIT(4 + NST, ld1A, ld1B, sym1A);
         asm volatile("" : "+v"(sym1B));
         uint4 *tb_st = my_tb + (int64_t)s * nsteps * 64 + 64;     // step 1
 
         auto step = [&](const int t, f4n &ldA, f4n &ldB, unsigned &symA_ld, unsigned &symB_ld) __attribute__((always_inline)) {
             const int ya = 2 * (t - q) - 1;          // this quarter's rows ya, ya + 1 (<= 0: it has not started yet)
             // this step's set has landed (step 1: waited for in the prologue)
-            if constexpr (CHAIN) { PRALINE_QUAD_WAIT(14, ldA, ldB, symA_ld); }    // (five stores per step: two per boundary row)
-            else { PRALINE_QUAD_WAIT(10, ldA, ldB, symA_ld); }
+            PRALINE_QUAD_WAIT(4 + 2 * NST, ldA, ldB, symA_ld);   // (10; chain mode 14: five stores per step)
             asm volatile("" : "+v"(symB_ld));
             s16x2 mA[8], mB[8];   // packed match scores of the step's two rows
             fetch_scores(symA_ld, symB_ld, mA, mB);
