@@ -109,8 +109,13 @@ __device__ __forceinline__ uint2 pk16_row(const s16x2 (&m)[8], const PkIn &in, s
         }
         if constexpr (MK) {
             // cext.c:141-149: masked cells hold zeros (stop code: row end)
-            const unsigned keep = ((zA >> c) & 1u ? 0u : 0x0000ffffu) | ((zB >> c) & 1u ? 0u : 0xffff0000u);
-            M = pk_of(pk_u(M) & keep); U = pk_of(pk_u(U) & keep); Lc = pk_of(pk_u(Lc) & keep);
+            // (v_bfe_i32 spreads each pair's bit over a word, v_bfi_b32 joins the halves and clears the states: six operations)
+            // (opaque to the optimiser, which turns the bit tests into compare / select pairs with their wait states)
+            unsigned kA, kB, kill;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(kA) : "v"(zA), "n"(c));
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(kB) : "v"(zB), "n"(c));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(kill) : "s"(0x0000ffffu), "v"(kA), "v"(kB));
+            M = pk_of(pk_u(M) & ~kill); U = pk_of(pk_u(U) & ~kill); Lc = pk_of(pk_u(Lc) & ~kill);
         }
         md = Mp[c]; ud = Up[c]; ld = Lp[c];
         Mp[c] = M; Up[c] = U; Lp[c] = Lc;
