@@ -594,13 +594,15 @@ def build_preprofiles(sequences, track_id, score_matrix, mode="global", gap_seri
         pairs[:, 1] = slave + (slave >= pairs[:, 0])          # skip j == i
     counts = _preprofile_counts_exchange(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations,
                                          world, group)
-    out = []
-    for i, t in enumerate(tracks):
-        # (converted per track: one int64 copy of the whole arena - 54 MB on C3 - cost 25 ms of page faults)
-        c = counts[row_off[i]:row_off[i] + lens[i]].astype(int)
-        c[np.arange(lens[i]), np.asarray(t.values)] += 1      # the master advances in every column
-        out.append(ProfileTrack(c, alphabet))
-    return out
+    # the master advances in every column: its own symbol once per position, for all sequences in one indexed add on the
+    # int32 arena (a view of the read-back buffer; ProfileTrack makes its own int copy per track - one int64 copy of the
+    # whole arena, 54 MB on C3, cost 25 ms of page faults)
+    counts = np.asarray(counts)
+    if not counts.flags.writeable:
+        counts = counts.copy()
+    if n:
+        counts[np.arange(int(lens.sum())), np.concatenate([np.asarray(t.values, dtype=np.int64) for t in tracks])] += 1
+    return [ProfileTrack(counts[row_off[i]:row_off[i] + lens[i]], alphabet) for i in range(n)]
 
 
 def _preprofile_counts_exchange(profiles, S, pairs, mode, gap_open, gap_extend, score_threshold, iterations, world, group):
