@@ -471,8 +471,12 @@ def main():
         variants = {}
         plan_p = native.Plan(arena, my_pairs, want_paths=True)
         dt_paths = timed(lambda: plan_p.run(args.mode, GAP_OPEN, GAP_EXTEND))
+        variants["float_profiles_with_paths_kernel"] = plan_p.kernel_name()
+        # (local alignments of float profiles keep the strip kernels' chain mode: the pipeline two-pass serves global runs)
+        dt_paths_l = timed(lambda: plan_p.run("local", GAP_OPEN, GAP_EXTEND), reps=3)
         plan_p.close()
         variants["float_profiles_with_paths_gcups"] = total_cells / dt_paths / 1e9
+        variants["float_profiles_with_paths_local_gcups"] = total_cells / dt_paths_l / 1e9
         # fp32 MFMA chain instead of the f16 split (PRALINE_MATCH_F32)
         native.set_match_mode("f32")
         plan_f = native.Plan(arena, my_pairs)
@@ -536,6 +540,8 @@ def main():
         plan_1h.close()
         plan_1hp = native.Plan(arena_1h, my_pairs, want_paths=True)
         dt_1hp = timed(lambda: plan_1hp.run(args.mode, GAP_OPEN, GAP_EXTEND))
+        variants["onehot_with_paths_kernel"] = plan_1hp.kernel_name()
+        variants["onehot_with_paths_local_gcups"] = total_cells / timed(lambda: plan_1hp.run("local", GAP_OPEN, GAP_EXTEND), reps=3) / 1e9
         plan_1hp.close()
         arena_1h.close()
         variants["onehot_with_paths_gcups"] = total_cells / dt_1hp / 1e9
