@@ -333,7 +333,7 @@ template <typename T> struct DevBuf {
         HIPCHK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
         return PRALINE_OK;
     }
-    int upload(const std::vector<T> &v, hipStream_t st)
+    template <class A> int upload(const std::vector<T, A> &v, hipStream_t st)
     {
         int rc = alloc(v.size());
         if (rc) return rc;

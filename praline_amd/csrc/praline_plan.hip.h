@@ -65,7 +65,7 @@ struct praline_plan {
     DevBuf<float> d_aux_b;
     DevBuf<float4> d_bnd2_b;
     DevBuf<int64_t> d_slot_off, d_path_start;
-    std::vector<int64_t> slot_off;
+    RawVec<int64_t> slot_off;
     float last_kernel_ms = 0.0f;
     int last_mode = -1;
     // plans whose DP reads its match scores from DENSE TILES (the dense-tile instances of k_dp_split16 / k_dp_split16_tb,
@@ -358,13 +358,13 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     pl->slot_off.swap(sch.slot_off);
     pl->path_cap = sch.path_cap;
     pl->cells = sch.cells;
-    const std::vector<int32_t> &lane_one = sch.lane_one, &lane_pair = sch.lane_pair;
-    const std::vector<PairLoc> &loc = sch.loc;
+    const RawVec<int32_t> &lane_one = sch.lane_one, &lane_pair = sch.lane_pair;
+    const RawVec<PairLoc> &loc = sch.loc;
     if (pl->dense_kind != 0) {
-        pl->h_lane_pair = sch.lane_pair;
+        pl->h_lane_pair.assign(sch.lane_pair.begin(), sch.lane_pair.end());
         pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);
     }
-    if (pl->dense_kind == 1) pl->h_lane_one = sch.lane_one;
+    if (pl->dense_kind == 1) pl->h_lane_one.assign(sch.lane_one.begin(), sch.lane_one.end());
     if (!want_paths && !pl->pipe.ok && pl->h_pairs.empty() && (int64_t)pl->tasks.size() <= chain_max_tasks())
         pl->h_pairs.assign(pairs, pairs + 2 * n_pairs);   // (score plans that may run in chain mode: k_semiglobal_end reads the pairs)
     const int64_t bnd = pl->bnd_elems, cap = pl->path_cap;

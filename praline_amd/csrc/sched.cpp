@@ -631,9 +631,15 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
 
     const size_t n_tasks = (halves.size() + tp - 1) / tp;
     out.tasks.assign(n_tasks, WaveTask());
-    out.lane_one.assign(n_tasks * lanes, -1);
-    out.lane_pair.assign(n_tasks * lanes, -1);
-    out.loc.assign((size_t)n_pairs, PairLoc());
+    if (tp == 1 && width == lanes) {   // (every lane of every task and every pair is written below: no initial pass)
+        out.lane_one.resize(n_tasks * lanes);
+        out.lane_pair.resize(n_tasks * lanes);
+        out.loc.resize((size_t)n_pairs);
+    } else {
+        out.lane_one.assign(n_tasks * lanes, -1);
+        out.lane_pair.assign(n_tasks * lanes, -1);
+        out.loc.assign((size_t)n_pairs, PairLoc());
+    }
     out.tb_elems.assign(n_tasks, 0);
     out.aux_elems.assign(n_tasks, 0);
     const int nt = sched_threads(n_pairs);
@@ -689,7 +695,7 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
 
     mark("workgroup lists");
     // path slots (capacity l1 + l2 + 2 rows per pair) and the cell count: a prefix sum in two passes over slices
-    out.slot_off.assign((size_t)n_pairs, 0);
+    out.slot_off.resize((size_t)n_pairs);   // (written by the slices below)
     int64_t cap = 0, cells = 0;
     {
         std::vector<int64_t> pcap((size_t)nt, 0), pcells((size_t)nt, 0);

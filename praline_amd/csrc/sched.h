@@ -1,9 +1,26 @@
 // sched.h -- host-side scheduling of a pair list onto wavefront tasks (no HIP in here: sched.cpp also builds with
 // g++ for the CPU unit tests, tests/test_scheduler_cpu.py).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
+#include <new>
 #include <vector>
 #include "dp_types.h"
+
+// Schedule arrays of millions of entries that the scheduler's threads fill completely: a vector whose resize() leaves new
+// elements uninitialised (value-initialising them first was a single-threaded pass over 25 MB for a C3-sized path plan).
+template <class T> struct NoInitAlloc {
+    using value_type = T;
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { ::operator delete(p); }
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }   // default-initialise: trivial types stay as they are
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(static_cast<A0 &&>(a0), static_cast<A &&>(a)...); }
+    bool operator==(const NoInitAlloc &) const { return true; }
+    bool operator!=(const NoInitAlloc &) const { return false; }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
 
 struct SchedOptions {
     bool want_paths = false;
@@ -24,13 +41,13 @@ struct Schedule {
     int tp = 1;
     int lanes_per_task = 32;
     std::vector<WaveTask> tasks;          // launch order (XCD placement applied; max_l1 == 0: padding)
-    std::vector<int32_t> lane_one, lane_pair;   // [tasks][lanes_per_task], -1 = empty lane
-    std::vector<PairLoc> loc;             // per pair
+    RawVec<int32_t> lane_one, lane_pair;  // [tasks][lanes_per_task], -1 = empty lane
+    RawVec<PairLoc> loc;                  // per pair
     std::vector<int64_t> tb_elems, aux_elems;   // per task scratch sizes (path plans)
     int64_t bnd_elems = 0;
     std::vector<WgDesc> wg;               // small batches: shared waves (empty when not applicable)
     std::vector<WgDesc> wg_singles;       // large batches: four independent tasks per workgroup
-    std::vector<int64_t> slot_off;        // per pair: row offset of its path slot (capacity l1 + l2 + 2)
+    RawVec<int64_t> slot_off;             // per pair: row offset of its path slot (capacity l1 + l2 + 2)
     int64_t path_cap = 0, cells = 0;
 };
 
@@ -39,9 +56,9 @@ struct Schedule {
 struct PipeSchedule {
     bool ok = false;                      // false: the pair list does not suit the layout (the caller keeps the task schedule)
     std::vector<PipeItem> items;          // launch order
-    std::vector<WaveTask> tasks;          // two[0], max_l1 (of the set), nstrips; the tasks of an item are consecutive
+    RawVec<WaveTask> tasks;               // two[0], max_l1 (of the set), nstrips; the tasks of an item are consecutive
     std::vector<int32_t> set_one;         // [n_sets][32] arena index of each lane's sequence one (-1: no sequence)
-    std::vector<int32_t> lane_pair;       // [n_tasks][32] pair index, -1 = no pair in this lane
+    RawVec<int32_t> lane_pair;            // [n_tasks][32] pair index, -1 = no pair in this lane
     int64_t bnd_elems = 0;                // float2 elements of the wrap-around boundary columns
     int64_t lanes_used = 0, steps = 0;    // pairs placed; wave steps of the launch (4 x nrounds x rsteps summed over the items)
 };
