@@ -143,8 +143,11 @@ static void pipe_schedule_for(const int32_t *lens, int64_t n_seqs, int64_t n_pai
 {
     int min_len = max_len;
     (void)max_len;
+    PhaseTimer pt("pipe_schedule_for");
     sched_pair_stats(lens, n_seqs, n_pairs, pairs, nullptr, &min_len, nullptr);
+    pt.mark("shortest sequence of the list");
     if (min_len >= 1) build_pipe_schedule(lens, n_seqs, n_pairs, pairs, pipe_options_for(n_pairs), pipe);
+    pt.mark("build_pipe_schedule");
     int64_t min_tasks = 200;
     if (const char *env = getenv("PRALINE_PIPE_MIN_TASKS")) min_tasks = atoll(env);
     if (pipe.ok && (int64_t)pipe.tasks.size() < min_tasks) pipe = PipeSchedule();
@@ -163,6 +166,7 @@ extern "C" int praline_sched_prepare(int64_t n_seqs, const int32_t *lens, int64_
     if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (n_seqs <= 0 || !lens || n_pairs < 0 || (n_pairs > 0 && !pairs)) return fail(PRALINE_ERR_ARG, "bad schedule arguments");
+    if (n_pairs > (int64_t)INT32_MAX) return fail(PRALINE_ERR_ARG, "a schedule holds at most 2^31 - 1 pairs (split the list)");
     int max_len = 0;
     for (int64_t s = 0; s < n_seqs; ++s) {
         if (lens[s] <= 0) return fail(PRALINE_ERR_ARG, "sequence %lld has length %d (must be >= 1)", (long long)s, lens[s]);
@@ -211,6 +215,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
     if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!arena || n_pairs < 0 || (n_pairs > 0 && !pairs)) return fail(PRALINE_ERR_ARG, "bad plan arguments");
+    if (n_pairs > (int64_t)INT32_MAX) return fail(PRALINE_ERR_ARG, "a plan holds at most 2^31 - 1 pairs (split the list)");
     RC(arena_ready(arena));
     if ((rect_off != nullptr) != (rects != nullptr) && rect_off && rect_off[n_pairs] > 0)
         return fail(PRALINE_ERR_ARG, "rect_off given without rects");
@@ -233,6 +238,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
             many_rects = many_rects || rect_off[p + 1] - rect_off[p] > PRALINE_MAX_RECTS;
             max_rects = std::max(max_rects, (int)(rect_off[p + 1] - rect_off[p]));
         }
+    pt.mark("pair list checked");
     praline_plan *pl = new praline_plan();
     pl->arena = arena;
     pl->n_pairs = n_pairs;
@@ -325,6 +331,7 @@ static int plan_create_impl(praline_arena *arena, int64_t n_pairs, const int32_t
             if (prepared) { prep->pipe = PipeSchedule(); prep->n_pairs = -1; }   // (consumed)
         }
     }
+    pt.mark("pipeline schedule");
     if (pl->pipe.ok && want_paths) {
         // scratch of the KEEP forward fill: per task (nstrips + 1) kept columns of max_l1 + PRALINE_TB2_PAD rows and
         // nstrips x pipe_keep_blocks row checkpoints; plans beyond the scratch budget keep chain / task mode

@@ -20,6 +20,77 @@
 #include <functional>
 #include <memory>
 
+// ---- large scratch and schedule blocks, kept between calls (sched.h: NoInitAlloc) ----
+namespace {
+struct BigBlocks {
+    struct Block { void *p; size_t cap; };
+    std::mutex m;
+    std::vector<Block> kept, lent;   // kept: oldest first
+    size_t kept_bytes = 0, limit = (size_t)256 << 20;
+    BigBlocks()
+    {
+        if (const char *env = getenv("PRALINE_SCHED_CACHE_MB")) limit = (size_t)std::max(0ll, atoll(env)) << 20;
+        if (const char *env = getenv("PRALINE_KEEP_HOST_MEMORY"))
+            if (env[0] == '0') limit = 0;
+    }
+    static BigBlocks &get() { static BigBlocks *g = new BigBlocks(); return *g; }   // (never destroyed: blocks may outlive main)
+};
+}  // namespace
+
+void *sched_big_alloc(size_t bytes)
+{
+    BigBlocks &g = BigBlocks::get();
+    {
+        std::lock_guard<std::mutex> lk(g.m);
+        // the smallest kept block that holds the request without being half as large again
+        int best = -1;
+        for (size_t i = 0; i < g.kept.size(); ++i)
+            if (g.kept[i].cap >= bytes && g.kept[i].cap <= bytes + bytes / 2 && (best < 0 || g.kept[i].cap < g.kept[(size_t)best].cap)) best = (int)i;
+        if (best >= 0) {
+            const BigBlocks::Block b = g.kept[(size_t)best];
+            g.kept.erase(g.kept.begin() + best);
+            g.kept_bytes -= b.cap;
+            g.lent.push_back(b);
+            return b.p;
+        }
+    }
+    const size_t unit = (size_t)2 << 20;
+    const size_t cap = (bytes + unit - 1) / unit * unit;
+    void *p = ::operator new(cap);
+    std::lock_guard<std::mutex> lk(g.m);
+    g.lent.push_back(BigBlocks::Block{p, cap});
+    return p;
+}
+
+void sched_big_free(void *p)
+{
+    if (!p) return;
+    BigBlocks &g = BigBlocks::get();
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g.m);
+        size_t i = 0;
+        while (i < g.lent.size() && g.lent[i].p != p) ++i;
+        if (i == g.lent.size()) { drop.push_back(p); }   // (not one of ours: cannot happen through NoInitAlloc)
+        else {
+            const BigBlocks::Block b = g.lent[i];
+            g.lent.erase(g.lent.begin() + (long)i);
+            if (b.cap > g.limit) drop.push_back(b.p);
+            else {
+                // make room: the oldest kept blocks go first
+                while (g.kept_bytes + b.cap > g.limit && !g.kept.empty()) {
+                    drop.push_back(g.kept.front().p);
+                    g.kept_bytes -= g.kept.front().cap;
+                    g.kept.erase(g.kept.begin());
+                }
+                g.kept.push_back(b);
+                g.kept_bytes += b.cap;
+            }
+        }
+    }
+    for (void *q : drop) ::operator delete(q);
+}
+
 namespace {
 
 // Host threads of the scheduler's passes over a large pair list (the counting and scatter loops are independent per slice
@@ -125,7 +196,7 @@ HalfTask empty_half(int32_t two)
 }
 
 // step 1: group by sequence two, sort by len(one) descending, cut into 32-lane half tasks
-std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, std::vector<int32_t> &idx, int width = 32)
+RawVec<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, std::vector<int32_t> &idx, int width = 32)
 {
     // order = pair indices by (sequence two ascending, length of sequence one descending, index ascending): two stable
     // counting sorts, least significant key first - by length (descending), then by sequence two.  (A comparison sort of
@@ -140,7 +211,7 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
         fprintf(stderr, "[sched]   %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    std::vector<int64_t> order((size_t)n_pairs);
+    RawVec<int32_t> order((size_t)n_pairs);   // (pair indices: a pair list holds fewer than 2^31 pairs)
     int32_t max_two = -1, max_len = 0;
     {
         std::vector<int32_t> mt((size_t)nt, -1), ml((size_t)nt, 0);
@@ -175,12 +246,12 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
         });
     };
     {
-        std::vector<int32_t> by_len((size_t)n_pairs);
+        RawVec<int32_t> by_len((size_t)n_pairs);
         // bucket b = max_len - len: longer first
         counting_sort((int64_t)max_len + 1, [&](int64_t i) { return (int64_t)(max_len - lens[pairs[2 * i]]); },
                       [&](int64_t q) { return q; }, [&](int64_t at, int64_t i) { by_len[(size_t)at] = (int32_t)i; });
         counting_sort((int64_t)max_two + 1, [&](int64_t i) { return (int64_t)pairs[2 * i + 1]; },
-                      [&](int64_t q) { return (int64_t)by_len[(size_t)q]; }, [&](int64_t at, int64_t i) { order[(size_t)at] = i; });
+                      [&](int64_t q) { return (int64_t)by_len[(size_t)q]; }, [&](int64_t at, int64_t i) { order[(size_t)at] = (int32_t)i; });
     }
     mark("two counting sorts");
     // half tasks: every sequence two's run of `order` in pieces of 32, the columns cut on several threads
@@ -199,7 +270,7 @@ std::vector<HalfTask> cut_half_tasks(const int32_t *lens, int64_t n_pairs, const
     const int64_t n_cols = (int64_t)col_start.size() - 1;
     std::vector<int64_t> half0((size_t)n_cols + 1, 0);
     for (int64_t c = 0; c < n_cols; ++c) half0[(size_t)c + 1] = half0[(size_t)c] + (col_start[(size_t)c + 1] - col_start[(size_t)c] + width - 1) / width;
-    std::vector<HalfTask> halves((size_t)half0[(size_t)n_cols]);
+    RawVec<HalfTask> halves((size_t)half0[(size_t)n_cols]);   // (every entry is written below)
     run_threads(nt, [&](int t, int n) {
         int64_t lo, hi;
         slice_of(n_cols, t, n, lo, hi);
@@ -609,13 +680,13 @@ void build_schedule(const int32_t *lens, int64_t n_pairs, const int32_t *pairs, 
     // quad16 (path plans of one-hot arenas, k_dp_quad_tb): 16 pairs per task
     const bool quad = opt.quad16 && opt.split_layout && opt.want_paths;
     const int width = quad ? 16 : 32;
-    const std::vector<HalfTask> half_store = cut_half_tasks(lens, n_pairs, pairs, order, width);
+    const RawVec<HalfTask> half_store = cut_half_tasks(lens, n_pairs, pairs, order, width);
     mark("half tasks");
     const HalfTask pad_half = empty_half(order.empty() ? -1 : half_store[(size_t)order.back()].two);
     place_on_xcds(order, opt.xcd_group);
     mark("xcd placement");
     struct HalfView {
-        const std::vector<HalfTask> &store; const std::vector<int32_t> &order; const HalfTask &pad;
+        const RawVec<HalfTask> &store; const std::vector<int32_t> &order; const HalfTask &pad;
         size_t size() const { return order.size(); }
         const HalfTask &operator[](size_t i) const { return order[i] >= 0 ? store[(size_t)order[i]] : pad; }
     } halves{half_store, order, pad_half};
@@ -795,7 +866,7 @@ struct ScratchTask { int32_t two, set, nstrips; int32_t pair[32]; };
 // The lists (one per set: its tasks by ascending sequence two) and set_one come out exactly as the serial version's.
 // Returns false when the byte table would be too large (the caller takes the serial version); dup: the same pair twice.
 bool pipe_front_sliced(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int B, int nt,
-                       std::vector<ScratchTask> &st, std::vector<PipeList> &lists, std::vector<int32_t> &set_one,
+                       RawVec<ScratchTask> &st, std::vector<PipeList> &lists, std::vector<int32_t> &set_one,
                        int64_t &old_tasks, bool &dup)
 {
     dup = false;
@@ -888,8 +959,8 @@ bool pipe_front_sliced(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, con
     // d.  every pair into its word
     // (uninitialised: the threads that fill it touch its pages first)
     const int64_t n_tmp = tbase[(size_t)n_blocks];
-    std::unique_ptr<int32_t[]> tmp_mem(new int32_t[(size_t)std::max<int64_t>(n_tmp, 1)]);
-    int32_t *tmp = tmp_mem.get();
+    RawVec<int32_t> tmp_mem((size_t)std::max<int64_t>(n_tmp, 1));
+    int32_t *tmp = tmp_mem.data();
     run_threads(nt, [&](int t, int n) {
         int64_t lo, hi;
         slice_of(n_tmp, t, n, lo, hi);
@@ -909,39 +980,48 @@ bool pipe_front_sliced(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, con
     // e.  tasks: the (set, sequence two) columns that hold a pair, numbered block by block, set by set, by sequence two
     std::vector<int64_t> task0((size_t)n_blocks + 1, 0);
     std::vector<int64_t> filled((size_t)n_blocks, 0);
+    // (blocks dealt round-robin: in an all-pairs list block b holds b + 1 sets, contiguous slices would leave the last
+    // thread with twice the average)
     run_threads(nt, [&](int t, int n) {
-        int64_t lo, hi;
-        slice_of(n_blocks, t, n, lo, hi);
-        for (int64_t b = lo; b < hi; ++b) {
+        for (int64_t b = t; b < n_blocks; b += n) {
             const int64_t nsets = set0[(size_t)b + 1] - set0[(size_t)b];
             const int64_t n_twos = std::min<int64_t>(B, (int64_t)twos.size() - b * B);
+            // (lane by lane, the sequences two of a lane are consecutive words: the column-wise walk was a stride of n_twos
+            // words over 37 MB for all of C4)
             int64_t nt_b = 0;
-            for (int64_t g = 0; g < nsets; ++g)
-                for (int64_t q = 0; q < n_twos; ++q) {
-                    const int32_t *w = tmp + tbase[(size_t)b] + g * 32 * n_twos + q;
-                    bool any = false;
-                    for (int l = 0; l < 32 && !any; ++l) any = w[l * n_twos] >= 0;
-                    nt_b += any;
-                }
+            std::vector<uint8_t> any((size_t)n_twos);
+            for (int64_t g = 0; g < nsets; ++g) {
+                std::fill(any.begin(), any.end(), (uint8_t)0);
+                const int32_t *w = tmp + tbase[(size_t)b] + g * 32 * n_twos;
+                for (int l = 0; l < 32; ++l)
+                    for (int64_t q = 0; q < n_twos; ++q) any[q] |= (uint8_t)(w[l * n_twos + q] >= 0);
+                for (int64_t q = 0; q < n_twos; ++q) nt_b += any[q];
+            }
             task0[(size_t)b + 1] = nt_b;
         }
     });
     for (int64_t b = 0; b < n_blocks; ++b) task0[(size_t)b + 1] += task0[(size_t)b];
     st.resize((size_t)task0[(size_t)n_blocks]);
     run_threads(nt, [&](int t, int n) {
-        int64_t lo, hi;
-        slice_of(n_blocks, t, n, lo, hi);
-        for (int64_t b = lo; b < hi; ++b) {
+        for (int64_t b = t; b < n_blocks; b += n) {
             const int64_t nsets = set0[(size_t)b + 1] - set0[(size_t)b];
             const int64_t n_twos = std::min<int64_t>(B, (int64_t)twos.size() - b * B);
             int64_t tk = task0[(size_t)b], got = 0;
-            for (int64_t g = 0; g < nsets; ++g)
+            std::vector<ScratchTask> row((size_t)n_twos);
+            std::vector<int> cnt((size_t)n_twos);
+            for (int64_t g = 0; g < nsets; ++g) {
+                const int32_t *w = tmp + tbase[(size_t)b] + g * 32 * n_twos;
+                std::fill(cnt.begin(), cnt.end(), 0);
+                for (int l = 0; l < 32; ++l)
+                    for (int64_t q = 0; q < n_twos; ++q) {
+                        const int32_t v = w[l * n_twos + q];
+                        row[(size_t)q].pair[l] = v;
+                        cnt[(size_t)q] += v >= 0;
+                    }
                 for (int64_t q = 0; q < n_twos; ++q) {
-                    const int32_t *w = tmp + tbase[(size_t)b] + g * 32 * n_twos + q;
-                    int cnt_l = 0;
-                    ScratchTask x;
-                    for (int l = 0; l < 32; ++l) { x.pair[l] = w[l * n_twos]; cnt_l += x.pair[l] >= 0; }
+                    const int cnt_l = cnt[(size_t)q];
                     if (!cnt_l) continue;
+                    ScratchTask &x = row[(size_t)q];
                     x.two = twos[(size_t)(b * B + q)];
                     x.set = (int32_t)(set0[(size_t)b] + g);
                     x.nstrips = (lens[x.two] + 31) / 32;
@@ -950,6 +1030,7 @@ bool pipe_front_sliced(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, con
                     ++tk;
                     got += cnt_l;
                 }
+            }
             filled[(size_t)b] = got;
         }
     });
@@ -963,7 +1044,7 @@ bool pipe_front_sliced(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, con
 
 // the same step with one permutation of the pair list by sequence two (any list size, any number of sequences)
 void pipe_front_serial(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, const int32_t *pairs, int B,
-                       std::vector<ScratchTask> &st, std::vector<PipeList> &lists, std::vector<int32_t> &set_one,
+                       RawVec<ScratchTask> &st, std::vector<PipeList> &lists, std::vector<int32_t> &set_one,
                        int64_t &old_tasks, bool &dup)
 {
     dup = false;
@@ -1034,17 +1115,13 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
 {
     out = PipeSchedule();
     if (n_pairs <= 0 || n_seqs <= 0) return;
-    std::vector<ScratchTask> st;
+    RawVec<ScratchTask> st;
     std::vector<PipeList> lists;
     std::vector<int32_t> set_one;
     const int B = std::max(1, opt.block_twos);
     int64_t old_tasks = 0;   // what the per-column schedule would need
     bool dup = false;
     const int nt = sched_threads(n_pairs);
-    if (opt.serial_front || !pipe_front_sliced(lens, n_seqs, n_pairs, pairs, B, nt, st, lists, set_one, old_tasks, dup)) {
-        st.clear(); lists.clear(); set_one.clear();
-        pipe_front_serial(lens, n_seqs, n_pairs, pairs, B, st, lists, set_one, old_tasks, dup);
-    }
     const bool timing = getenv("PRALINE_SCHED_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {
@@ -1053,6 +1130,11 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
         fprintf(stderr, "[sched] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
+    if (opt.serial_front || !pipe_front_sliced(lens, n_seqs, n_pairs, pairs, B, nt, st, lists, set_one, old_tasks, dup)) {
+        st.clear(); lists.clear(); set_one.clear();
+        pipe_front_serial(lens, n_seqs, n_pairs, pairs, B, st, lists, set_one, old_tasks, dup);
+    }
+    mark("a-e with their scratch released");
     if (dup) return;
     if (st.empty() || lens == nullptr) return;
     for (const ScratchTask &t : st)
@@ -1068,21 +1150,30 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
     // items of one list under the bound c*: bin packing of its tasks (<= PRALINE_PIPE_MAX_TASKS per item) into bins of
     // floor(c* / rsteps) rounds = 4 x that many strips, first fit decreasing - long and short sequences two end up
     // together, so the strip totals come out near the multiples of four that the rounds are made of
-    struct Cut { int32_t list; std::vector<int32_t> task; };
+    struct Cut { int32_t list; int64_t nstrips; std::vector<int32_t> task; };   // nstrips: the strip total of its tasks
     // max_tasks: tasks per item; n_single: per list, this share (in 1/1024) of its tasks - the shortest - become items
     // of their own (large batches: the short items the dispatcher fills the tail of the launch with)
     // (every list's tasks by descending strip count, once: the bisection below packs them a dozen times)
     std::vector<std::vector<int32_t>> sorted_tasks(lists.size());
-    for (size_t li = 0; li < lists.size(); ++li) {
-        sorted_tasks[li] = lists[li].task;
-        std::stable_sort(sorted_tasks[li].begin(), sorted_tasks[li].end(), [&](int32_t x, int32_t y) { return st[(size_t)x].nstrips > st[(size_t)y].nstrips; });
-    }
-    auto cut_count = [&](int64_t cstar, int max_tasks, int single_share, std::vector<Cut> *cuts) {
+    std::vector<int64_t> list_total(lists.size(), 0), list_longest(lists.size(), 0);   // cost of the whole list, of its longest task
+    const int nt_lists = sched_threads((int64_t)st.size());
+    run_threads(nt_lists, [&](int th, int n) {   // (the lists are independent of each other)
+        int64_t lo, hi;
+        slice_of((int64_t)lists.size(), th, n, lo, hi);
+        for (size_t li = (size_t)lo; li < (size_t)hi; ++li) {
+            sorted_tasks[li] = lists[li].task;
+            std::stable_sort(sorted_tasks[li].begin(), sorted_tasks[li].end(), [&](int32_t x, int32_t y) { return st[(size_t)x].nstrips > st[(size_t)y].nstrips; });
+            list_total[li] = list_cost(lists[li], 0, lists[li].task.size());
+            if (!sorted_tasks[li].empty()) list_longest[li] = (st[(size_t)sorted_tasks[li][0]].nstrips + 3) / 4 * (int64_t)lists[li].rsteps;
+        }
+    });
+    // first-fit packing of the lists li0 .. li1 - 1 (each list on its own): items of at most max_tasks tasks and cstar cost
+    auto cut_range = [&](size_t li0, size_t li1, int64_t cstar, int max_tasks, int single_share, std::vector<Cut> *cuts) {
         int64_t n = 0;
         std::vector<int64_t> load;
         std::vector<int32_t> count;
         std::vector<std::vector<int32_t>> member;
-        for (size_t li = 0; li < lists.size(); ++li) {
+        for (size_t li = li0; li < li1; ++li) {
             const PipeList &l = lists[li];
             const int64_t cap = std::max<int64_t>(1, cstar / l.rsteps) * 4;   // strips per item
             const std::vector<int32_t> &order = sorted_tasks[li];
@@ -1104,21 +1195,17 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
             }
             n += (int64_t)load.size();
             if (cuts)
-                for (auto &m : member) cuts->push_back(Cut{(int32_t)li, m});
+                for (size_t b = 0; b < member.size(); ++b) cuts->push_back(Cut{(int32_t)li, load[b], std::move(member[b])});
         }
         return n;
     };
-    mark("f. lists sorted");
-    auto item_cost = [&](const Cut &c) {
-        int64_t q = 0;
-        for (int32_t t : c.task) q += st[(size_t)t].nstrips;
-        return (q + 3) / 4 * (int64_t)lists[(size_t)c.list].rsteps;
+    auto cut_count = [&](int64_t cstar, int max_tasks, int single_share, std::vector<Cut> *cuts) {
+        return cut_range(0, lists.size(), cstar, max_tasks, single_share, cuts);
     };
+    mark("f. lists sorted");
+    auto item_cost = [&](const Cut &c) { return (c.nstrips + 3) / 4 * (int64_t)lists[(size_t)c.list].rsteps; };
     int64_t total = 0, one_max = 0;
-    for (const PipeList &l : lists) {
-        total += list_cost(l, 0, l.task.size());
-        for (size_t k = 0; k < l.task.size(); ++k) one_max = std::max(one_max, list_cost(l, k, k + 1));
-    }
+    for (size_t li = 0; li < lists.size(); ++li) { total += list_total[li]; one_max = std::max(one_max, list_longest[li]); }
     // Small batches (up to 2.5 tasks per workgroup slot): everything resident at once - the smallest bound c* whose
     // items fit the slots.  Larger batches: items of up to k tasks, k a third of a slot's share (at most
     // PRALINE_PIPE_MAX_TASKS: the strip total of a long list wastes less of its last round), and two slots' worth of
@@ -1140,18 +1227,47 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
         } else {
             const int k = (int)std::min<int64_t>(PRALINE_PIPE_MAX_TASKS, std::max<int64_t>(1, n_tasks / (3 * slots)));
             const int share = k == 1 ? 0 : (int)std::min<int64_t>(1024, 2 * slots * 1024 / n_tasks);
-            cut_count(INT64_MAX / 8, k, share, &cuts);
+            // (one pass; slices of the lists on several threads, their items joined in list order)
+            std::vector<std::vector<Cut>> part((size_t)nt_lists);
+            run_threads(nt_lists, [&](int th, int n) {
+                int64_t lo, hi;
+                slice_of((int64_t)lists.size(), th, n, lo, hi);
+                cut_range((size_t)lo, (size_t)hi, INT64_MAX / 8, k, share, &part[(size_t)th]);
+            });
+            size_t total_cuts = 0;
+            for (const auto &pc : part) total_cuts += pc.size();
+            cuts.reserve(total_cuts);
+            for (auto &pc : part)
+                for (auto &c : pc) cuts.push_back(std::move(c));
         }
     }
     mark("g. items cut");
     // launch order: longest first; when everything is resident at once (two workgroups per CU: launch positions b and
     // b + 256 share a CU), the longest share their CUs with the shortest.  (Measured and dropped: keeping the items of one
     // list on one XCD - positions of equal b % 8 - so that its L2 serves their common operand rows: C2 1.90 -> 2.06 ms.)
+    // (by descending cost, equal costs in item order: one key per item, the cost's complement above the item's index)
     std::vector<int64_t> cost(cuts.size());
-    for (size_t c = 0; c < cuts.size(); ++c) cost[c] = item_cost(cuts[c]);
+    int64_t cost_max = 0;
+    for (size_t c = 0; c < cuts.size(); ++c) { cost[c] = item_cost(cuts[c]); cost_max = std::max(cost_max, cost[c]); }
     std::vector<int32_t> order(cuts.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
+    if (cost_max < ((int64_t)1 << 32)) {
+        // two stable counting passes over the halves of the complemented cost
+        std::vector<int32_t> pass(cuts.size());
+        std::vector<uint32_t> start(65537);
+        for (int half = 0; half < 2; ++half) {
+            auto digit = [&](int32_t c) { return ((0xffffffffu - (uint32_t)cost[(size_t)c]) >> (16 * half)) & 0xffffu; };
+            std::fill(start.begin(), start.end(), 0u);
+            for (size_t c = 0; c < cuts.size(); ++c) ++start[digit(half == 0 ? (int32_t)c : pass[c]) + 1];
+            for (size_t d = 1; d < start.size(); ++d) start[d] += start[d - 1];
+            for (size_t c = 0; c < cuts.size(); ++c) {
+                const int32_t it = half == 0 ? (int32_t)c : pass[c];
+                (half == 0 ? pass : order)[start[digit(it)]++] = it;
+            }
+        }
+    } else {
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
+    }
     if ((int64_t)order.size() > 256 && (int64_t)order.size() <= opt.wg_slots) {
         std::vector<int32_t> snake(order.begin(), order.begin() + 256);
         for (size_t k = order.size(); k > 256; --k) snake.push_back(order[k - 1]);
@@ -1171,9 +1287,8 @@ void build_pipe_schedule(const int32_t *lens, int64_t n_seqs, int64_t n_pairs, c
             it.set = l.set;
             it.task0 = (int32_t)t0;
             it.ntasks = (int32_t)cut.task.size();
-            it.nstrips = 0;
+            it.nstrips = (int32_t)cut.nstrips;
             it.rsteps = l.rsteps;
-            for (int32_t tsk : cut.task) it.nstrips += st[(size_t)tsk].nstrips;
             it.nrounds = (it.nstrips + 3) / 4;
             it.bnd_off = bnd;
             bnd += (int64_t)(it.rsteps + 16) * 32;

@@ -9,12 +9,19 @@
 
 // Schedule arrays of millions of entries that the scheduler's threads fill completely: a vector whose resize() leaves new
 // elements uninitialised (value-initialising them first was a single-threaded pass over 25 MB for a C3-sized path plan).
+// Blocks of SCHED_BIG_BYTES and more - which malloc would map afresh and unmap again, however its thresholds are set:
+// the pages of the 37 + 42 + 34 MB an all-of-C4 plan passes through cost more than the passes that fill them - are kept
+// by the scheduler between calls (sched_big_alloc / sched_big_free, sched.cpp: up to PRALINE_SCHED_CACHE_MB, default 256;
+// 0 or PRALINE_KEEP_HOST_MEMORY=0: nothing is kept).
+constexpr size_t SCHED_BIG_BYTES = (size_t)32 << 20;
+void *sched_big_alloc(size_t bytes);
+void sched_big_free(void *p);
 template <class T> struct NoInitAlloc {
     using value_type = T;
     NoInitAlloc() = default;
     template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
-    T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
-    void deallocate(T *p, size_t) { ::operator delete(p); }
+    T *allocate(size_t n) { return static_cast<T *>(n * sizeof(T) >= SCHED_BIG_BYTES ? sched_big_alloc(n * sizeof(T)) : ::operator new(n * sizeof(T))); }
+    void deallocate(T *p, size_t n) { if (n * sizeof(T) >= SCHED_BIG_BYTES) sched_big_free(p); else ::operator delete(p); }
     template <class U> void construct(U *p) { ::new ((void *)p) U; }   // default-initialise: trivial types stay as they are
     template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(static_cast<A0 &&>(a0), static_cast<A &&>(a)...); }
     bool operator==(const NoInitAlloc &) const { return true; }

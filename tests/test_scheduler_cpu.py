@@ -239,6 +239,11 @@ def test_pipe_schedule_fits_the_slots_for_small_batches(pipe_sched):
     assert ok
     counts = np.bincount(items[:, 2], minlength=PIPE_MAX_TASKS + 1)
     assert counts[PIPE_MAX_TASKS] > counts[1] >= 512
+    # launch order of a large batch: by descending cost (rounds x steps), equal costs in list (= set) order
+    cost = items[:, 5].astype(np.int64) * items[:, 4]
+    assert np.all(np.diff(cost) <= 0)
+    same = np.diff(cost) == 0
+    assert np.all(np.diff(items[:, 0])[same] >= 0)
 
 
 def test_pipe_schedule_declines_what_does_not_fit(pipe_sched):
