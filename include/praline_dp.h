@@ -285,6 +285,29 @@ int praline_plan_mask_path_bounds(praline_plan *plan);
 int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float gap_extend,
                          int64_t n_pairs, const int32_t *pairs, float *scores);
 
+/* A batch of RawPairwiseAligner requests (praline/component/align.py:254-447) in one submission - the operator the
+ * reference runs once per caller-supplied MatchScoreModel / GapScoreModel pair (align.py:302-447 on cext_align_*,
+ * praline/util/cext.c:99-306).  Request r aligns its own match scores m_r (float32 [l1[r]][l2[r]], row-major) under its own
+ * gap scores g1_r (float32 [l1[r]][2]) and g2_r (float32 [l2[r]][2]: open, extend per position, align.py:346-348) with its
+ * own zero cells (zero_idxs: (y, x) cells of the DP matrix fixed to zero, align.py:362-367).  m, g1, g2: the requests'
+ * arrays one after the other, host or device memory; zero_off [n + 1] delimits request r's (y, x) pairs in zero_idx (both
+ * NULL: no zero cells).  The inputs are copied once; praline_raw_batch_run may be called any number of times (per-request
+ * modes, or one mode for all with modes = NULL), asynchronously on the library stream; praline_raw_batch_results waits and
+ * returns the scores and path lengths, praline_raw_batch_paths the paths (int32 (y, x) rows as get_paths +
+ * extend_path_semiglobal produce them, praline/util/align.py:144-185, 268-297) one after the other in request order.
+ * Scores, end cells and paths are those of the reference's RawPairwiseAligner bit for bit (same fp32 operations in the same
+ * order, same tie rules). */
+typedef struct praline_raw_batch praline_raw_batch;
+int praline_raw_batch_create(int64_t n, const int32_t *l1, const int32_t *l2, const float *m, const float *g1, const float *g2,
+                             const int64_t *zero_off, const int32_t *zero_idx, praline_raw_batch **out);
+int praline_raw_batch_run(praline_raw_batch *batch, const int32_t *modes, int mode);
+int praline_raw_batch_results(praline_raw_batch *batch, float *scores, int64_t *path_rows);
+int praline_raw_batch_paths(praline_raw_batch *batch, int32_t *paths, int64_t cap_rows);
+int64_t praline_raw_batch_cells(const praline_raw_batch *batch);
+/* Device time of the last run (boundary rows + fill + end cells and paths), valid after praline_raw_batch_results. */
+int praline_raw_batch_last_timing(const praline_raw_batch *batch, float *kernel_ms);
+void praline_raw_batch_destroy(praline_raw_batch *batch);
+
 /* Guide-tree clustering (host code, no device needed): the merge order of the agglomerative clustering of
  * praline/util/cluster.py:27-114 on an n x n float64 distance matrix (row-major; (i, j) and (j, i) are read separately
  * as in the reference) - repeatedly the first minimum of the cluster linkage table in cluster-id order, the merged

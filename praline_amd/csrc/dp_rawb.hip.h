@@ -1,0 +1,377 @@
+// dp_rawb.hip.h -- a batch of RawPairwiseAligner requests (praline/component/align.py:302-447 on cext_align_*,
+// praline/util/cext.c:99-306): every request has its own m, g1, g2 and zero cells, so there is nothing for the lanes of a
+// wave to share ACROSS requests - the parallelism is inside one request.
+//
+// k_rawb_fill: one workgroup per request, one wave per strip of 64 ROWS.  Lane l owns row y0 + l and walks along it; at step
+// s it computes column x = s - l, the cells of one step form an anti-diagonal:
+//   - left neighbour (y, x - 1): the lane's own previous step;
+//   - up neighbour (y - 1, x): lane l - 1's previous step, one `v_mov_b32_dpp wave_shr:1`; the diagonal neighbour is the up
+//     neighbour of the step before;
+//   - m[y][x]: a lane reads along its own row, 16 floats per 16 steps into registers, the load of the next 16 in flight
+//     (addresses skewed by the lane: all lanes use element i of their 16 at the same step - no LDS staging, no transposition);
+//   - g1[y] is a lane constant, g2[x] enters at lane 0 and moves down one lane per step (wave_shr:1 again);
+//   - the seven tie flags of a cell are one byte; a lane stores 16 of them per 16 steps into its flag row, rows skewed by
+//     (y - 1) % 64 bytes so that the stores are 16-byte aligned;
+//   - zero cells: one bit per cell in the same skewed row layout (k_rawb_zero).
+// Lane 0 takes its up neighbour - the last row of the strip above - from an LDS ring written by lane 63 of the wave that owns
+// that strip and runs >= 64 columns ahead; the waves signal progress through two LDS counters per ring, checked every 16
+// steps (no barrier: a wave whose strips are done leaves).  Wave 0 is fed from memory instead, sixteen columns at a time
+// through a small LDS buffer: strip 0 reads the boundary row o[0][x] (k_rawb_init), its later strips (requests of more than
+// 64 x PRALINE_RAWB_WAVES rows) the row that the last wave wrote to `wrap` - a whole row, so that no ring bounds how far the
+// last wave of a round may run ahead of the first wave of the next (a cycle of full rings otherwise, from ~2 600 columns on).
+// Nothing but the flags, the last row and column (end cell of the global and semiglobal modes) and every lane's first maximum
+// (local mode) leaves the kernel: o is never stored.  k_rawb_trace finds the end cell and walks the flags.
+#pragma once
+#include "dp_rawb.h"
+
+#define RAWB_NEG_INF (-__builtin_inff())
+
+__device__ __forceinline__ bool rawb_free_one(int mode) { return mode == 2 || mode == 3; }
+__device__ __forceinline__ bool rawb_free_two(int mode) { return mode == 2 || mode == 4; }
+// o[y,0,1] / o[0,x,2] for idx >= 1 (align.py:375,383): float64 arithmetic, one rounding
+__device__ __forceinline__ float rawb_boundary(int idx, float go, float ge, bool is_free)
+{
+    return is_free ? 0.0f : (float)((double)(idx - 1) * (double)ge + (double)go);
+}
+
+__device__ __forceinline__ float rawb_shr1(float old, float src)   // lane l <- src of lane l - 1; lane 0 <- old
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
+struct __attribute__((packed, aligned(4))) RawbF4 { float v[4]; };   // 16 bytes at any float address
+
+struct RawbRow16 { float v[16]; };
+
+__device__ __forceinline__ void rawb_load16(RawbRow16 &r, const float *p)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const RawbF4 f = *reinterpret_cast<const RawbF4 *>(p + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r.v[4 * q + e] = f.v[e];
+    }
+}
+
+// wait until *flag >= need (the neighbour wave is resident: same workgroup).  A wave that has waited ~0.1 s gives up, reports
+// and stops waiting for the rest of the kernel (`dead`): a broken hand-off ends in an error code, not in a hung device.
+__device__ __forceinline__ void rawb_wait(volatile int *flag, int need, int32_t *error, bool &dead)
+{
+    if (!dead) {
+        int spins = 0;
+        while (__builtin_amdgcn_readfirstlane(*flag) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 20)) { *error = 1; dead = true; break; }
+        }
+    }
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// a row entry another wave of the workgroup stored: past the vector L1 (the same addresses held the previous round's row)
+__device__ __forceinline__ float4 rawb_load_fresh(const float4 *p)
+{
+    const unsigned *q = reinterpret_cast<const unsigned *>(p);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = __hip_atomic_load(q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__builtin_bit_cast(float, w[0]), __builtin_bit_cast(float, w[1]), __builtin_bit_cast(float, w[2]), __builtin_bit_cast(float, w[3]));
+}
+
+// Boundary row o[0][x] of every request (align.py:357-385), x = 0 .. L2 (+ padding the fill kernel may read)
+__global__ __launch_bounds__(256) void k_rawb_init(RawBatchDev d)
+{
+    const RawReq rq = d.reqs[blockIdx.x];
+    const float2 *g1 = d.g1 + rq.g1_off, *g2 = d.g2 + rq.g2_off;
+    const bool free_one = rawb_free_one(rq.mode), free_two = rawb_free_two(rq.mode);
+    float4 *top = d.top + rq.top_off;
+    const float g2_00 = g2[0].x;
+    for (int x = threadIdx.x; x < rq.L2 + PRALINE_RAWB_ROW_PAD; x += blockDim.x) {
+        float4 v = make_float4(RAWB_NEG_INF, RAWB_NEG_INF, RAWB_NEG_INF, 0.0f);
+        if (x == 0) {
+            v.x = 0.0f;
+            v.y = free_one ? 0.0f : g1[0].x - g1[0].y;
+            v.z = free_two ? 0.0f : g2[0].x - g2[0].y;
+        } else if (x <= rq.L2) {
+            v.z = rawb_boundary(x, g2_00, g2[x - 1].y, free_two);
+        }
+        top[x] = v;
+    }
+}
+
+// zero cells -> bits of the skewed mask rows (cells on the boundary row / column have no effect: cext.c:141-149 starts at 1)
+__global__ __launch_bounds__(256) void k_rawb_zero(RawBatchDev d, const int32_t *__restrict__ zero_req, const int32_t *__restrict__ zero_idx, int64_t n_zero)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_zero) return;
+    const RawReq rq = d.reqs[zero_req[i]];
+    const int y = zero_idx[2 * i], x = zero_idx[2 * i + 1];
+    if (y < 1 || y > rq.L1 || x < 1 || x > rq.L2) return;
+    const int p = x - 1 + ((y - 1) & 63);
+    const int64_t word = rq.z_off + (int64_t)y * rq.zs + (p >> 4);
+    unsigned int *w32 = reinterpret_cast<unsigned int *>(d.z) + (word >> 1);
+    atomicOr(w32, 1u << ((p & 15) + ((word & 1) ? 16 : 0)));
+}
+
+// sixteen steps of one strip.  EDGE: some lane is before its first or at / beyond its last column in these steps.
+template <bool MASK, bool EDGE, bool LOCAL>
+__device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits, const float2 g2c, int c, int lane, int L2, int y, bool row_ok,
+                                           bool last_strip, bool feeds, int L1, float base, float go1, float ge1, float bndU, const float4 *hand /* LDS, entry of step 0 */,
+                                           int hand_mask, int hand_pos, float4 *out_ring, int out_pos, float4 *out_row /* or NULL */, float4 *edge_row, float4 *edge_col,
+                                           float &curM, float &curU, float &curL, float &upM, float &upU, float &upL, float &go2, float &ge2,
+                                           float &sbest, int &scode, float &sM, float &sU, uint4 &flags)
+{
+    unsigned pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int s = 16 * c + 1 + i;
+        const int x = s - lane;
+        // lane 0's up neighbour: the row above the strip
+        __asm__ volatile("" ::: "memory");   // (one step's LDS read and stores at a time: hoisted, the sixteen reads alone hold 64 registers)
+        const float4 h = hand[(hand_pos + i) & hand_mask];
+        const float nuM = rawb_shr1(h.x, curM), nuU = rawb_shr1(h.y, curU), nuL = rawb_shr1(h.z, curL);
+        const float sgo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g2c.x), i));
+        const float sge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g2c.y), i));
+        go2 = rawb_shr1(sgo, go2);
+        ge2 = rawb_shr1(sge, ge2);
+        const float ms = mrow.v[i];
+        // cext.c:141-183
+        const float mm = upM + ms, mu = upU + ms, ml = upL + ms;   // (upM/U/L still hold the step before: the diagonal)
+        float mmax = __builtin_fmaxf(__builtin_fmaxf(mm, mu), __builtin_fmaxf(ml, base));
+        const float up_open = nuM + go1, up_ext = nuU + ge1;
+        float umax = __builtin_fmaxf(up_open, up_ext);
+        const float lf_open = curM + go2, lf_ext = curL + ge2;
+        float lmax = __builtin_fmaxf(lf_open, lf_ext);
+        unsigned f = (mm == mmax ? 2u : 0u) | (mu == mmax ? 4u : 0u) | (ml == mmax ? 8u : 0u) | (up_open == umax ? 16u : 0u) |
+                     (up_ext == umax ? 32u : 0u) | (lf_open == lmax ? 64u : 0u) | (lf_ext == lmax ? 128u : 0u);
+        if (MASK) {
+            const bool zc = (zbits >> i) & 1u;   // a zero cell keeps what the caller initialised: zeros (align.py:362-367, cext.c:147-149)
+            mmax = zc ? 0.0f : mmax; umax = zc ? 0.0f : umax; lmax = zc ? 0.0f : lmax;
+            f = zc ? 0u : f;
+        }
+        if (EDGE && x < 1) { mmax = RAWB_NEG_INF; umax = bndU; lmax = RAWB_NEG_INF; }   // not started: the lane shows its boundary cell (y, 0)
+        pk[i >> 2] |= f << (8 * (i & 3));
+        __asm__ volatile("" : "+v"(pk[i >> 2]));   // (the flags of a step are formed in that step: deferred to the end of the chunk, their inputs spill)
+        const bool in_row = !EDGE || (x >= 1 && x <= L2);
+        if (LOCAL) {
+            const float v3 = __builtin_fmaxf(__builtin_fmaxf(mmax, umax), lmax);
+            const bool gt = in_row && v3 > sbest;
+            sbest = gt ? v3 : sbest; scode = gt ? s : scode; sM = gt ? mmax : sM; sU = gt ? umax : sU;
+        } else {
+            if (last_strip && y == L1 && in_row) edge_row[x] = make_float4(mmax, umax, lmax, 0.0f);
+            if (EDGE && x == L2 && row_ok) edge_col[y] = make_float4(mmax, umax, lmax, 0.0f);
+        }
+        if (feeds && lane == 63 && in_row) {
+            if (out_row) out_row[x] = make_float4(mmax, umax, lmax, 0.0f);
+            else out_ring[(out_pos + x - 1) & (PRALINE_RAWB_RING - 1)] = make_float4(mmax, umax, lmax, 0.0f);
+        }
+        upM = nuM; upU = nuU; upL = nuL;
+        curM = mmax; curU = umax; curL = lmax;
+    }
+    flags = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void k_rawb_fill(RawBatchDev d)
+{
+    __shared__ float4 ring[PRALINE_RAWB_WAVES][PRALINE_RAWB_RING];
+    __shared__ float4 topbuf[32];                         // strip 0: the boundary row, two halves of 16 columns
+    __shared__ int produced[PRALINE_RAWB_WAVES], consumed[PRALINE_RAWB_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const RawReq rq = d.reqs[blockIdx.x];
+    if (lane == 0) { produced[wave] = 0; consumed[wave] = 0; }
+    __syncthreads();
+    const int L1 = rq.L1, L2 = rq.L2, R = rq.nstrips;
+    const bool local = rq.mode == 1, free_one = rawb_free_one(rq.mode);
+    const float base = local ? 0.0f : RAWB_NEG_INF;
+    const float2 *g1 = d.g1 + rq.g1_off, *g2 = d.g2 + rq.g2_off;
+    const float4 *top = d.top + rq.top_off;
+    float4 *wrap = d.wrap + rq.top_off;                   // (same shape as the boundary row)
+    float4 *edge_row = d.edge + rq.edge_off, *edge_col = edge_row + (L2 + 1);
+    const float g1_00 = g1[0].x;
+    const int prod = (wave + W - 1) % W;
+    const int NC = (L2 + 63 + 15) / 16;
+    bool dead = false;
+    float bestv = RAWB_NEG_INF;
+    int best_y = 0, best_x = 0, best_k = 0;
+    for (int k = wave; k < R; k += W) {
+        const int j = k / W, jp = k > 0 ? (k - 1) / W : 0;
+        const bool feeds = k + 1 < R, fed = k > 0, last_strip = k == R - 1;
+        const bool from_row = wave == 0;                  // the row above comes from memory: boundary row or `wrap`
+        float4 *out_row = feeds && wave == W - 1 ? wrap : nullptr;
+        const float4 *feed = k == 0 ? top : wrap;
+        const int y = 64 * k + 1 + lane;
+        const bool row_ok = y <= L1;
+        const int yc = row_ok ? y : L1;
+        const float2 gv = g1[yc - 1];
+        const float go1 = gv.x, ge1 = gv.y;
+        const float bndU = rawb_boundary(yc, g1_00, ge1, free_one);
+        float curM = RAWB_NEG_INF, curU = bndU, curL = RAWB_NEG_INF;
+        // lane 0's first diagonal neighbour: the boundary cell of the row above the strip
+        float upM = RAWB_NEG_INF, upU = RAWB_NEG_INF, upL = RAWB_NEG_INF;
+        if (k == 0) { const float4 t0 = top[0]; upM = t0.x; upU = t0.y; upL = t0.z; }
+        else upU = rawb_boundary(64 * k, g1_00, g1[64 * k - 1].y, free_one);
+        float go2 = 0.0f, ge2 = 0.0f;
+        const float *mrow = d.m + rq.m_off + (int64_t)(yc - 1) * L2 - lane;
+        uint8_t *trow = d.t + rq.t_off + (int64_t)y * rq.ts;
+        const uint16_t *zrow = d.z + rq.z_off + (int64_t)yc * rq.zs;
+        float sbest = RAWB_NEG_INF, sM = 0.0f, sU = 0.0f;
+        int scode = 0;
+        RawbRow16 mA, mB;
+        unsigned zA = 0, zB = 0;
+        float2 gA, gB;
+        float4 treg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rawb_load16(mA, mrow);
+        if (MASK) zA = zrow[0];
+        gA = g2[lane & 15];
+        if (from_row) {
+            if (fed) rawb_wait(&produced[prod], jp * L2 + min(32, L2), d.error, dead);
+            if (lane < 16) topbuf[lane] = rawb_load_fresh(feed + 1 + lane);
+            treg = rawb_load_fresh(feed + 17 + (lane & 15));
+        }
+        const float4 *hand = from_row ? topbuf : ring[prod];
+        const int hand_mask = from_row ? 31 : PRALINE_RAWB_RING - 1;
+        const int hand_base = from_row ? 0 : jp * L2;     // position of column 1 in the hand-off stream
+        const int out_base = j * L2;
+        for (int c = 0; c < NC; ++c) {
+            // the neighbours: the strip above has produced this chunk's columns (wave 0 reads the row two chunks ahead); the strip
+            // below has read what this chunk overwrites
+            if (fed) rawb_wait(&produced[prod], jp * L2 + min(16 * c + (from_row ? 48 : 16), L2), d.error, dead);
+            if (feeds && !out_row) rawb_wait(&consumed[wave], out_base + min(max(16 * c + 16 - 63, 0), L2) - PRALINE_RAWB_RING, d.error, dead);
+            // the next chunk's inputs
+            rawb_load16(mB, mrow + 16 * (c + 1));
+            if (MASK) zB = zrow[c + 1];
+            gB = g2[16 * (c + 1) + (lane & 15)];
+            if (from_row) {
+                if (lane < 16) topbuf[16 * ((c + 1) & 1) + lane] = treg;
+                treg = rawb_load_fresh(feed + 16 * (c + 2) + 1 + (lane & 15));
+            }
+            uint4 fl;
+            const bool edge = 16 * c < 63 || 16 * c + 16 >= L2;
+#define RAWB_CHUNK(E, L)                                                                                                                        \
+    rawb_chunk<MASK, E, L>(mA, zA, gA, c, lane, L2, y, row_ok, last_strip, feeds, L1, base, go1, ge1, bndU, hand, hand_mask, hand_base + 16 * c,  \
+                           ring[wave], out_base, out_row, edge_row, edge_col, curM, curU, curL, upM, upU, upL, go2, ge2, sbest, scode, sM, sU, fl)
+            if (local) { if (edge) RAWB_CHUNK(true, true); else RAWB_CHUNK(false, true); }
+            else { if (edge) RAWB_CHUNK(true, false); else RAWB_CHUNK(false, false); }
+#undef RAWB_CHUNK
+            *reinterpret_cast<uint4 *>(trow + 16 * c) = fl;
+            // progress: this strip's last row up to column 16 c + 16 - 63, the row above read up to column 16 c + 16
+            if (out_row) __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the row entries have reached the L2)
+            else __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                if (feeds) *(volatile int *)&produced[wave] = out_base + min(max(16 * c + 16 - 63, 0), L2);
+                if (fed) *(volatile int *)&consumed[prod] = jp * L2 + min(16 * c + 16, L2);
+            }
+            mA = mB; zA = zB; gA = gB;
+        }
+        if (local && row_ok && sbest > bestv) {   // rows ascend with the strips: the first maximum of the lane stays
+            bestv = sbest; best_y = y; best_x = scode - lane;
+            best_k = sM == sbest ? 0 : (sU == sbest ? 1 : 2);
+        }
+    }
+    if (local && wave < R)
+        d.best[rq.best_off + wave * 64 + lane] = make_float4(bestv, __builtin_bit_cast(float, best_y), __builtin_bit_cast(float, best_x), __builtin_bit_cast(float, best_k));
+}
+
+// End cell (align.py:401-431), score and path (praline/util/align.py:144-185, 268-297) of every request: one thread each.
+__global__ __launch_bounds__(64) void k_rawb_trace(RawBatchDev d)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.n) return;
+    const RawReq rq = d.reqs[r];
+    const int L1 = rq.L1, L2 = rq.L2, mode = rq.mode;
+    const bool free_one = rawb_free_one(mode), free_two = rawb_free_two(mode);
+    const bool semiglobal = mode >= 2;
+    const float2 *g1 = d.g1 + rq.g1_off;
+    const float4 *top = d.top + rq.top_off;
+    const float4 *edge_row = d.edge + rq.edge_off, *edge_col = edge_row + (L2 + 1);
+    auto row_at = [&](int x) {   // o[L1][x]
+        return x == 0 ? make_float4(RAWB_NEG_INF, rawb_boundary(L1, g1[0].x, g1[L1 - 1].y, free_one), RAWB_NEG_INF, 0.0f) : edge_row[x];
+    };
+    auto col_at = [&](int y) { return y == 0 ? top[L2] : edge_col[y]; };   // o[y][L2]
+    auto pick = [](const float4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
+    int cy = L1, cx = L2, ck = 0;
+    float score;
+    if (mode == 1) {
+        // first flat argmax of o (align.py:402): the boundary row, then per row the boundary cell and the lanes' first maxima
+        float bv = RAWB_NEG_INF;
+        int by = 0, bx = 0, bk = 0;
+        bool have = false;
+        auto offer = [&](float v, int y, int x, int k) {   // in any order: larger value, or equal and earlier in flat order
+            const bool earlier = y < by || (y == by && (x < bx || (x == bx && k < bk)));
+            if (!have || v > bv || (v == bv && earlier)) { bv = v; by = y; bx = x; bk = k; have = true; }
+        };
+        for (int x = 0; x <= L2; ++x) { const float4 v = top[x]; offer(v.x, 0, x, 0); offer(v.y, 0, x, 1); offer(v.z, 0, x, 2); }
+        for (int y = 1; y <= L1; ++y) {
+            offer(RAWB_NEG_INF, y, 0, 0);
+            offer(rawb_boundary(y, g1[0].x, g1[y - 1].y, free_one), y, 0, 1);
+        }
+        const int nrec = min(rq.nstrips, PRALINE_RAWB_WAVES) * 64;
+        for (int q = 0; q < nrec; ++q) {
+            const float4 b = d.best[rq.best_off + q];
+            const int y = __builtin_bit_cast(int, b.y);
+            if (y >= 1) offer(b.x, y, __builtin_bit_cast(int, b.z), __builtin_bit_cast(int, b.w));
+        }
+        cy = by; cx = bx; ck = bk; score = bv;
+    } else if (mode == 0) {
+        const float4 q = row_at(L2);
+        ck = 0;
+        if (q.y > pick(q, ck)) ck = 1;
+        if (q.z > pick(q, ck)) ck = 2;
+        score = pick(q, ck);
+    } else {
+        float rmax = RAWB_NEG_INF, cmax = RAWB_NEG_INF;
+        for (int x = 0; x <= L2; ++x) { const float4 v = row_at(x); rmax = __builtin_fmaxf(rmax, __builtin_fmaxf(v.x, __builtin_fmaxf(v.y, v.z))); }
+        for (int y = 0; y <= L1; ++y) { const float4 v = col_at(y); cmax = __builtin_fmaxf(cmax, __builtin_fmaxf(v.x, __builtin_fmaxf(v.y, v.z))); }
+        bool found = false;
+        if (rmax > cmax && free_two) {
+            for (int x = L2; x >= 0 && !found; --x) {
+                const float4 v = row_at(x);
+                for (int k = 0; k < 3; ++k)
+                    if (pick(v, k) == rmax) { cy = L1; cx = x; ck = k; found = true; break; }
+            }
+            score = rmax;
+        } else {
+            for (int y = L1; y >= 0 && !found; --y) {
+                const float4 v = col_at(y);
+                for (int k = 0; k < 3; ++k)
+                    if (pick(v, k) == cmax) { cy = y; cx = L2; ck = k; found = true; break; }
+            }
+            score = cmax;
+        }
+    }
+    d.scores[rq.index] = score;
+    const int cap = L1 + L2 + 2;
+    int32_t *path = d.paths + 2 * rq.path_off;
+    int w = cap;
+    auto emit = [&](int yy, int xx) { --w; path[2 * w] = yy; path[2 * w + 1] = xx; };
+    int y = cy, x = cx, k = ck;
+    if (semiglobal) {
+        if (y != L1) { for (int yy = L1; yy > y; --yy) emit(yy, x); }
+        else if (x != L2) { for (int xx = L2; xx > x; --xx) emit(y, xx); }
+    }
+    emit(y, x);
+    const uint8_t *t = d.t + rq.t_off;
+    for (int guard = 0; guard < cap; ++guard) {
+        unsigned f;
+        if (y == 0 && x == 0) f = 0;
+        else if (x == 0) f = (k == 1 && !free_one) ? 32u : 0u;      // t[1:,0,1] = insert-up-extend (align.py:377)
+        else if (y == 0) f = (k == 2 && !free_two) ? 128u : 0u;     // t[0,1:,2] = insert-left-extend (align.py:385)
+        else f = t[(int64_t)y * rq.ts + (x - 1) + ((y - 1) & 63)];
+        f &= k == 0 ? 0x0eu : (k == 1 ? 0x30u : 0xc0u);
+        if (f & 2) { --y; --x; k = 0; }
+        else if (f & 4) { --y; --x; k = 1; }
+        else if (f & 8) { --y; --x; k = 2; }
+        else if (f & 16) { --y; k = 0; }
+        else if (f & 32) { --y; k = 1; }
+        else if (f & 64) { --x; k = 0; }
+        else if (f & 128) { --x; k = 2; }
+        else break;
+        emit(y, x);
+    }
+    if (semiglobal) {
+        if (y != 0) { for (int yy = y - 1; yy >= 0; --yy) emit(yy, 0); }
+        else if (x != 0) { for (int xx = x - 1; xx >= 0; --xx) emit(0, xx); }
+    }
+    d.path_info[2 * (int64_t)rq.index] = w;
+    d.path_info[2 * (int64_t)rq.index + 1] = cap - w;
+}

@@ -365,3 +365,4 @@ struct PhaseTimer {
 #include "praline_plan_run.hip.h"
 #include "praline_stage.hip.h"
 #include "praline_raw.hip.h"
+#include "praline_rawb.hip.h"

@@ -115,6 +115,15 @@ def lib():
     L.praline_plan_tile_producer.argtypes = [vp]
     L.praline_merge_order.argtypes = [i64, vp, i32, vp]
     L.praline_plan_kernel_name.argtypes = [vp, ctypes.c_char_p, i64]
+    L.praline_raw_batch_create.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.praline_raw_batch_run.argtypes = [vp, vp, i32]
+    L.praline_raw_batch_results.argtypes = [vp, vp, vp]
+    L.praline_raw_batch_paths.argtypes = [vp, vp, i64]
+    L.praline_raw_batch_cells.argtypes = [vp]
+    L.praline_raw_batch_cells.restype = i64
+    L.praline_raw_batch_last_timing.argtypes = [vp, ctypes.POINTER(f32)]
+    L.praline_raw_batch_destroy.argtypes = [vp]
+    L.praline_raw_batch_destroy.restype = None
     if L.praline_abi_version() != 1:
         raise NativeError(ERR_ARG, "ABI version mismatch")
     _lib = L
@@ -283,6 +292,89 @@ def raw_align(mode, m, g1, g2, z=None):
                                    ctypes.byref(ag2), ctypes.byref(az) if az is not None else None,
                                    ctypes.byref(score), path.ctypes.data, ctypes.byref(rows)))
     return float(score.value), path[:rows.value].copy()
+
+
+class RawBatch(object):
+    """A list of RawPairwiseAligner requests on the device (praline_raw_batch_*; praline/component/align.py:254-447):
+    `requests` = (m, g1, g2, zero_idxs or None) per request - the reference operator's `match_score_model.scores`,
+    `gap_score_model_one / two.scores` and `zero_idxs` inputs.  run(modes) aligns all of them in one launch; results()
+    returns (scores float32 [n], [path int32 [rows, 2] per request])."""
+
+    def __init__(self, requests):
+        n = len(requests)
+        if n == 0:
+            raise ValueError("empty request list")
+        ms, g1s, g2s, zs = [], [], [], []
+        l1 = np.zeros(n, np.int32)
+        l2 = np.zeros(n, np.int32)
+        zoff = np.zeros(n + 1, np.int64)
+        for r, (m, g1, g2, zero_idxs) in enumerate(requests):
+            m = np.ascontiguousarray(m, dtype=np.float32)
+            g1 = np.ascontiguousarray(g1, dtype=np.float32)
+            g2 = np.ascontiguousarray(g2, dtype=np.float32)
+            if m.ndim != 2 or g1.shape != (m.shape[0], 2) or g2.shape != (m.shape[1], 2):
+                raise ValueError("request %d: m %s, g1 %s, g2 %s do not fit" % (r, m.shape, g1.shape, g2.shape))
+            l1[r], l2[r] = m.shape
+            ms.append(m.reshape(-1)); g1s.append(g1.reshape(-1)); g2s.append(g2.reshape(-1))
+            if zero_idxs is not None and len(zero_idxs):
+                z = np.asarray(zero_idxs, dtype=np.int64).reshape(-1, 2)
+                # (the reference indexes a numpy array with these tuples: negative indices count from the end)
+                z = np.where(z < 0, z + np.array([m.shape[0] + 1, m.shape[1] + 1]), z)
+                zs.append(z.astype(np.int32))
+                zoff[r + 1] = zoff[r] + len(z)
+            else:
+                zoff[r + 1] = zoff[r]
+        self.n, self.l1, self.l2 = n, l1, l2
+        m_all, g1_all, g2_all = np.concatenate(ms), np.concatenate(g1s), np.concatenate(g2s)
+        z_all = np.ascontiguousarray(np.concatenate(zs)) if zs else None
+        h = ctypes.c_void_p()
+        _check(lib().praline_raw_batch_create(n, l1.ctypes.data, l2.ctypes.data, m_all.ctypes.data, g1_all.ctypes.data,
+                                              g2_all.ctypes.data, zoff.ctypes.data if z_all is not None else None,
+                                              z_all.ctypes.data if z_all is not None else None, ctypes.byref(h)))
+        self._h = h
+
+    @property
+    def cells(self):
+        return int(lib().praline_raw_batch_cells(self._h))
+
+    def run(self, modes):
+        """modes: one mode name for every request, or a list of n names.  Asynchronous."""
+        if isinstance(modes, str):
+            _check(lib().praline_raw_batch_run(self._h, None, MODES[modes]))
+        else:
+            arr = np.array([MODES[mo] for mo in modes], dtype=np.int32)
+            if len(arr) != self.n:
+                raise ValueError("%d modes for %d requests" % (len(arr), self.n))
+            _check(lib().praline_raw_batch_run(self._h, arr.ctypes.data, 0))
+        return self
+
+    def results(self, paths=True):
+        scores = np.zeros(self.n, np.float32)
+        rows = np.zeros(self.n, np.int64)
+        _check(lib().praline_raw_batch_results(self._h, scores.ctypes.data, rows.ctypes.data))
+        if not paths:
+            return scores, None
+        total = int(rows.sum())
+        flat = np.zeros((max(total, 1), 2), np.int32)
+        _check(lib().praline_raw_batch_paths(self._h, flat.ctypes.data, total))
+        ends = np.cumsum(rows)
+        return scores, [flat[e - k:e] for e, k in zip(ends, rows)]
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float(0.0)
+        _check(lib().praline_raw_batch_last_timing(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self._h:
+            lib().praline_raw_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- batched path --------------------------------------------------------------------------------
