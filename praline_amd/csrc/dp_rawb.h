@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #define PRALINE_RAWB_WAVES 8      // waves of a workgroup = row strips of one request in flight
+#define PRALINE_RAWB_GROUPS 512   // workgroups of a fill launch (each takes every 512th request of the list)
 #define PRALINE_RAWB_RING 256     // columns of a wave's hand-off ring (a power of two)
 #define PRALINE_RAWB_ROW_PAD 160  // entries behind a request's g2 and boundary rows that the prefetches may read
 #define PRALINE_RAWB_M_PAD 128    // floats in front of and behind every request's m (the skewed 16-float loads of the first and last rows)
@@ -40,5 +41,5 @@ struct RawBatchDev {
 
 void praline_launch_rawb_init(const RawBatchDev &d, hipStream_t st);
 void praline_launch_rawb_zero(const RawBatchDev &d, const int32_t *zero_req, const int32_t *zero_idx, int64_t n_zero, hipStream_t st);
-void praline_launch_rawb_fill(const RawBatchDev &d, int waves, bool mask, hipStream_t st);
+void praline_launch_rawb_fill(const RawBatchDev &d, int waves, bool mask, bool global_like, bool local, hipStream_t st);
 void praline_launch_rawb_trace(const RawBatchDev &d, hipStream_t st);

@@ -121,13 +121,15 @@ __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits
                                            float &sbest, int &scode, float &sM, float &sU, uint4 &flags)
 {
     unsigned pk[4] = {0u, 0u, 0u, 0u};
+    float4 hn = hand[hand_pos & hand_mask];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int s = 16 * c + 1 + i;
         const int x = s - lane;
-        // lane 0's up neighbour: the row above the strip
+        // lane 0's up neighbour: the row above the strip, read one step ahead
         __asm__ volatile("" ::: "memory");   // (one step's LDS read and stores at a time: hoisted, the sixteen reads alone hold 64 registers)
-        const float4 h = hand[(hand_pos + i) & hand_mask];
+        const float4 h = hn;
+        if (i < 15) hn = hand[(hand_pos + i + 1) & hand_mask];
         const float nuM = rawb_shr1(h.x, curM), nuU = rawb_shr1(h.y, curU), nuL = rawb_shr1(h.z, curL);
         const float sgo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g2c.x), i));
         const float sge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g2c.y), i));
@@ -149,6 +151,7 @@ __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits
             f = zc ? 0u : f;
         }
         if (EDGE && x < 1) { mmax = RAWB_NEG_INF; umax = bndU; lmax = RAWB_NEG_INF; }   // not started: the lane shows its boundary cell (y, 0)
+        __asm__ volatile("" : "+v"(f));          // (the byte first, then its place in the word: folded into the selects, the shifted flag constants hold 20 registers)
         pk[i >> 2] |= f << (8 * (i & 3));
         __asm__ volatile("" : "+v"(pk[i >> 2]));   // (the flags of a step are formed in that step: deferred to the end of the chunk, their inputs spill)
         const bool in_row = !EDGE || (x >= 1 && x <= L2);
@@ -156,45 +159,51 @@ __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits
             const float v3 = __builtin_fmaxf(__builtin_fmaxf(mmax, umax), lmax);
             const bool gt = in_row && v3 > sbest;
             sbest = gt ? v3 : sbest; scode = gt ? s : scode; sM = gt ? mmax : sM; sU = gt ? umax : sU;
+            __asm__ volatile("" : "+v"(sbest), "+v"(scode), "+v"(sM), "+v"(sU));   // (decided in this step: deferred, the values of sixteen steps stay live)
         } else {
             if (last_strip && y == L1 && in_row) edge_row[x] = make_float4(mmax, umax, lmax, 0.0f);
             if (EDGE && x == L2 && row_ok) edge_col[y] = make_float4(mmax, umax, lmax, 0.0f);
         }
-        if (feeds && lane == 63 && in_row) {
-            if (out_row) out_row[x] = make_float4(mmax, umax, lmax, 0.0f);
-            else out_ring[(out_pos + x - 1) & (PRALINE_RAWB_RING - 1)] = make_float4(mmax, umax, lmax, 0.0f);
-        }
+        if (feeds && !out_row && lane == 63 && in_row) out_ring[(out_pos + x - 1) & (PRALINE_RAWB_RING - 1)] = make_float4(mmax, umax, lmax, 0.0f);
+        __asm__ volatile("" ::: "memory");   // (two stores: merged into one through a generic pointer, the LDS write becomes a flat store)
+        if (out_row && lane == 63 && in_row) out_row[x] = make_float4(mmax, umax, lmax, 0.0f);
         upM = nuM; upU = nuU; upL = nuL;
         curM = mmax; curU = umax; curL = lmax;
     }
     flags = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
 
-template <bool MASK>
+template <bool MASK, bool LOCAL>
 __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void k_rawb_fill(RawBatchDev d)
 {
     __shared__ float4 ring[PRALINE_RAWB_WAVES][PRALINE_RAWB_RING];
     __shared__ float4 topbuf[32];                         // strip 0: the boundary row, two halves of 16 columns
     __shared__ int produced[PRALINE_RAWB_WAVES], consumed[PRALINE_RAWB_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
-    const RawReq rq = d.reqs[blockIdx.x];
     if (lane == 0) { produced[wave] = 0; consumed[wave] = 0; }
     __syncthreads();
+    // A workgroup takes every gridDim.x-th request of the (size-sorted) list, one after the other: wave w goes from strip w of
+    // one request straight to strip w of the next, so the start-up skew of the waves (64 + 16 columns each) is paid once per
+    // workgroup, not once per request.  The hand-off streams simply continue: out_pos / in_pos count the columns a wave has
+    // handed down / taken over since the kernel started, in the order both sides visit the strips.
+    const int prod = (wave + W - 1) % W;
+    bool dead = false;
+    int out_pos = 0, in_pos = 0;
+    for (int q = blockIdx.x; q < d.n; q += gridDim.x) {
+    const RawReq rq = d.reqs[q];
+    if ((rq.mode == 1) != LOCAL) continue;                // (the other instance's request)
     const int L1 = rq.L1, L2 = rq.L2, R = rq.nstrips;
-    const bool local = rq.mode == 1, free_one = rawb_free_one(rq.mode);
+    const bool local = LOCAL, free_one = rawb_free_one(rq.mode);
     const float base = local ? 0.0f : RAWB_NEG_INF;
     const float2 *g1 = d.g1 + rq.g1_off, *g2 = d.g2 + rq.g2_off;
     const float4 *top = d.top + rq.top_off;
     float4 *wrap = d.wrap + rq.top_off;                   // (same shape as the boundary row)
     float4 *edge_row = d.edge + rq.edge_off, *edge_col = edge_row + (L2 + 1);
     const float g1_00 = g1[0].x;
-    const int prod = (wave + W - 1) % W;
     const int NC = (L2 + 63 + 15) / 16;
-    bool dead = false;
     float bestv = RAWB_NEG_INF;
     int best_y = 0, best_x = 0, best_k = 0;
     for (int k = wave; k < R; k += W) {
-        const int j = k / W, jp = k > 0 ? (k - 1) / W : 0;
         const bool feeds = k + 1 < R, fed = k > 0, last_strip = k == R - 1;
         const bool from_row = wave == 0;                  // the row above comes from memory: boundary row or `wrap`
         float4 *out_row = feeds && wave == W - 1 ? wrap : nullptr;
@@ -224,18 +233,18 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
         if (MASK) zA = zrow[0];
         gA = g2[lane & 15];
         if (from_row) {
-            if (fed) rawb_wait(&produced[prod], jp * L2 + min(32, L2), d.error, dead);
+            if (fed) rawb_wait(&produced[prod], in_pos + min(32, L2), d.error, dead);
             if (lane < 16) topbuf[lane] = rawb_load_fresh(feed + 1 + lane);
             treg = rawb_load_fresh(feed + 17 + (lane & 15));
         }
         const float4 *hand = from_row ? topbuf : ring[prod];
         const int hand_mask = from_row ? 31 : PRALINE_RAWB_RING - 1;
-        const int hand_base = from_row ? 0 : jp * L2;     // position of column 1 in the hand-off stream
-        const int out_base = j * L2;
+        const int hand_base = from_row ? 0 : in_pos;      // position of column 1 in the hand-off stream
+        const int out_base = out_pos;
         for (int c = 0; c < NC; ++c) {
             // the neighbours: the strip above has produced this chunk's columns (wave 0 reads the row two chunks ahead); the strip
             // below has read what this chunk overwrites
-            if (fed) rawb_wait(&produced[prod], jp * L2 + min(16 * c + (from_row ? 48 : 16), L2), d.error, dead);
+            if (fed) rawb_wait(&produced[prod], in_pos + min(16 * c + (from_row ? 48 : 16), L2), d.error, dead);
             if (feeds && !out_row) rawb_wait(&consumed[wave], out_base + min(max(16 * c + 16 - 63, 0), L2) - PRALINE_RAWB_RING, d.error, dead);
             // the next chunk's inputs
             rawb_load16(mB, mrow + 16 * (c + 1));
@@ -250,8 +259,7 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
 #define RAWB_CHUNK(E, L)                                                                                                                        \
     rawb_chunk<MASK, E, L>(mA, zA, gA, c, lane, L2, y, row_ok, last_strip, feeds, L1, base, go1, ge1, bndU, hand, hand_mask, hand_base + 16 * c,  \
                            ring[wave], out_base, out_row, edge_row, edge_col, curM, curU, curL, upM, upU, upL, go2, ge2, sbest, scode, sM, sU, fl)
-            if (local) { if (edge) RAWB_CHUNK(true, true); else RAWB_CHUNK(false, true); }
-            else { if (edge) RAWB_CHUNK(true, false); else RAWB_CHUNK(false, false); }
+            if (edge) RAWB_CHUNK(true, LOCAL); else RAWB_CHUNK(false, LOCAL);
 #undef RAWB_CHUNK
             *reinterpret_cast<uint4 *>(trow + 16 * c) = fl;
             // progress: this strip's last row up to column 16 c + 16 - 63, the row above read up to column 16 c + 16
@@ -259,10 +267,12 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
             else __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) {
                 if (feeds) *(volatile int *)&produced[wave] = out_base + min(max(16 * c + 16 - 63, 0), L2);
-                if (fed) *(volatile int *)&consumed[prod] = jp * L2 + min(16 * c + 16, L2);
+                if (fed) *(volatile int *)&consumed[prod] = in_pos + min(16 * c + 16, L2);
             }
             mA = mB; zA = zB; gA = gB;
         }
+        if (feeds) out_pos += L2;
+        if (fed) in_pos += L2;
         if (local && row_ok && sbest > bestv) {   // rows ascend with the strips: the first maximum of the lane stays
             bestv = sbest; best_y = y; best_x = scode - lane;
             best_k = sM == sbest ? 0 : (sU == sbest ? 1 : 2);
@@ -270,12 +280,43 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
     }
     if (local && wave < R)
         d.best[rq.best_off + wave * 64 + lane] = make_float4(bestv, __builtin_bit_cast(float, best_y), __builtin_bit_cast(float, best_x), __builtin_bit_cast(float, best_k));
+    }
 }
 
-// End cell (align.py:401-431), score and path (praline/util/align.py:144-185, 268-297) of every request: one thread each.
-__global__ __launch_bounds__(64) void k_rawb_trace(RawBatchDev d)
+// wave-wide reductions of the end-cell search (all lanes receive the result)
+__device__ __forceinline__ float rawb_wave_max(float v)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int rawb_wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned long long rawb_wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+// End cell (align.py:401-431), score and path (praline/util/align.py:144-185, 268-297) of every request: one wave each.  The
+// lanes search the last row / column (or the lanes' first maxima and the boundary cells, local mode) together; the walk
+// itself is serial, so the wave fetches the flags it is about to need as a tile - 16 rows x 64 bytes ending at the current
+// cell, one 16-byte piece per lane - into LDS and walks inside it until the path leaves it (a step is an LDS read instead of
+// a dependent read of memory: ~50 tile fetches instead of ~800 memory round trips for a 400 x 400 alignment).
+__global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
+{
+    __shared__ uint4 tiles[4][16][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
     if (r >= d.n) return;
     const RawReq rq = d.reqs[r];
     const int L1 = rq.L1, L2 = rq.L2, mode = rq.mode;
@@ -284,34 +325,35 @@ __global__ __launch_bounds__(64) void k_rawb_trace(RawBatchDev d)
     const float2 *g1 = d.g1 + rq.g1_off;
     const float4 *top = d.top + rq.top_off;
     const float4 *edge_row = d.edge + rq.edge_off, *edge_col = edge_row + (L2 + 1);
+    const float g1_00 = g1[0].x;
     auto row_at = [&](int x) {   // o[L1][x]
-        return x == 0 ? make_float4(RAWB_NEG_INF, rawb_boundary(L1, g1[0].x, g1[L1 - 1].y, free_one), RAWB_NEG_INF, 0.0f) : edge_row[x];
+        return x == 0 ? make_float4(RAWB_NEG_INF, rawb_boundary(L1, g1_00, g1[L1 - 1].y, free_one), RAWB_NEG_INF, 0.0f) : edge_row[x];
     };
     auto col_at = [&](int y) { return y == 0 ? top[L2] : edge_col[y]; };   // o[y][L2]
     auto pick = [](const float4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
+    auto max3 = [](const float4 &v) { return __builtin_fmaxf(v.x, __builtin_fmaxf(v.y, v.z)); };
     int cy = L1, cx = L2, ck = 0;
     float score;
     if (mode == 1) {
-        // first flat argmax of o (align.py:402): the boundary row, then per row the boundary cell and the lanes' first maxima
+        // first flat argmax of o (align.py:402): the largest value, among equals the smallest (y, x, k) - over the boundary row,
+        // the boundary column and the lanes' first maxima of their rows
         float bv = RAWB_NEG_INF;
-        int by = 0, bx = 0, bk = 0;
-        bool have = false;
-        auto offer = [&](float v, int y, int x, int k) {   // in any order: larger value, or equal and earlier in flat order
-            const bool earlier = y < by || (y == by && (x < bx || (x == bx && k < bk)));
-            if (!have || v > bv || (v == bv && earlier)) { bv = v; by = y; bx = x; bk = k; have = true; }
+        unsigned long long bkey = ~0ull;
+        auto offer = [&](float v, int y, int x, int k) {
+            const unsigned long long key = ((unsigned long long)(unsigned)y << 34) | ((unsigned long long)(unsigned)x << 2) | (unsigned)k;
+            if (v > bv || (v == bv && key < bkey)) { bv = v; bkey = key; }
         };
-        for (int x = 0; x <= L2; ++x) { const float4 v = top[x]; offer(v.x, 0, x, 0); offer(v.y, 0, x, 1); offer(v.z, 0, x, 2); }
-        for (int y = 1; y <= L1; ++y) {
-            offer(RAWB_NEG_INF, y, 0, 0);
-            offer(rawb_boundary(y, g1[0].x, g1[y - 1].y, free_one), y, 0, 1);
-        }
+        for (int x = lane; x <= L2; x += 64) { const float4 v = top[x]; offer(v.x, 0, x, 0); offer(v.y, 0, x, 1); offer(v.z, 0, x, 2); }
+        for (int y = 1 + lane; y <= L1; y += 64) offer(rawb_boundary(y, g1_00, g1[y - 1].y, free_one), y, 0, 1);
         const int nrec = min(rq.nstrips, PRALINE_RAWB_WAVES) * 64;
-        for (int q = 0; q < nrec; ++q) {
+        for (int q = lane; q < nrec; q += 64) {
             const float4 b = d.best[rq.best_off + q];
             const int y = __builtin_bit_cast(int, b.y);
             if (y >= 1) offer(b.x, y, __builtin_bit_cast(int, b.z), __builtin_bit_cast(int, b.w));
         }
-        cy = by; cx = bx; ck = bk; score = bv;
+        score = rawb_wave_max(bv);
+        const unsigned long long key = rawb_wave_min_u64(bv == score ? bkey : ~0ull);
+        cy = (int)(key >> 34); cx = (int)((key >> 2) & 0xffffffffull); ck = (int)(key & 3);
     } else if (mode == 0) {
         const float4 q = row_at(L2);
         ck = 0;
@@ -320,30 +362,32 @@ __global__ __launch_bounds__(64) void k_rawb_trace(RawBatchDev d)
         score = pick(q, ck);
     } else {
         float rmax = RAWB_NEG_INF, cmax = RAWB_NEG_INF;
-        for (int x = 0; x <= L2; ++x) { const float4 v = row_at(x); rmax = __builtin_fmaxf(rmax, __builtin_fmaxf(v.x, __builtin_fmaxf(v.y, v.z))); }
-        for (int y = 0; y <= L1; ++y) { const float4 v = col_at(y); cmax = __builtin_fmaxf(cmax, __builtin_fmaxf(v.x, __builtin_fmaxf(v.y, v.z))); }
-        bool found = false;
+        for (int x = lane; x <= L2; x += 64) rmax = __builtin_fmaxf(rmax, max3(row_at(x)));
+        for (int y = lane; y <= L1; y += 64) cmax = __builtin_fmaxf(cmax, max3(col_at(y)));
+        rmax = rawb_wave_max(rmax); cmax = rawb_wave_max(cmax);
+        // the LARGEST coordinate that holds the maximum, there the smallest k (align.py:414-423)
         if (rmax > cmax && free_two) {
-            for (int x = L2; x >= 0 && !found; --x) {
-                const float4 v = row_at(x);
-                for (int k = 0; k < 3; ++k)
-                    if (pick(v, k) == rmax) { cy = L1; cx = x; ck = k; found = true; break; }
-            }
+            int bx = -1;
+            for (int x = lane; x <= L2; x += 64) { const float4 v = row_at(x); if (v.x == rmax || v.y == rmax || v.z == rmax) bx = x; }
+            cx = rawb_wave_max_i(bx); cy = L1;
+            const float4 v = row_at(cx);
+            ck = v.x == rmax ? 0 : (v.y == rmax ? 1 : 2);
             score = rmax;
         } else {
-            for (int y = L1; y >= 0 && !found; --y) {
-                const float4 v = col_at(y);
-                for (int k = 0; k < 3; ++k)
-                    if (pick(v, k) == cmax) { cy = y; cx = L2; ck = k; found = true; break; }
-            }
+            int by = -1;
+            for (int y = lane; y <= L1; y += 64) { const float4 v = col_at(y); if (v.x == cmax || v.y == cmax || v.z == cmax) by = y; }
+            cy = rawb_wave_max_i(by); cx = L2;
+            const float4 v = col_at(cy);
+            ck = v.x == cmax ? 0 : (v.y == cmax ? 1 : 2);
             score = cmax;
         }
     }
-    d.scores[rq.index] = score;
+    cy = __builtin_amdgcn_readfirstlane(cy); cx = __builtin_amdgcn_readfirstlane(cx); ck = __builtin_amdgcn_readfirstlane(ck);
+    if (lane == 0) d.scores[rq.index] = score;
     const int cap = L1 + L2 + 2;
     int32_t *path = d.paths + 2 * rq.path_off;
     int w = cap;
-    auto emit = [&](int yy, int xx) { --w; path[2 * w] = yy; path[2 * w + 1] = xx; };
+    auto emit = [&](int yy, int xx) { --w; if (lane == 0) { path[2 * w] = yy; path[2 * w + 1] = xx; } };
     int y = cy, x = cx, k = ck;
     if (semiglobal) {
         if (y != L1) { for (int yy = L1; yy > y; --yy) emit(yy, x); }
@@ -351,12 +395,29 @@ __global__ __launch_bounds__(64) void k_rawb_trace(RawBatchDev d)
     }
     emit(y, x);
     const uint8_t *t = d.t + rq.t_off;
+    const uint8_t *tile = reinterpret_cast<const uint8_t *>(&tiles[wv][0][0]);
+    int ty = -1, tx = 0;   // the cell the tile was fetched at (ty < 0: none yet)
+    // window of row yy in a tile fetched at (ty, tx): 64 bytes from a 16-byte boundary, at least 32 of them to the left of the cell
+    auto window = [&](int yy) { return max(0, (tx - 1) + ((yy - 1) & 63) - 47) & ~15; };
     for (int guard = 0; guard < cap; ++guard) {
         unsigned f;
         if (y == 0 && x == 0) f = 0;
         else if (x == 0) f = (k == 1 && !free_one) ? 32u : 0u;      // t[1:,0,1] = insert-up-extend (align.py:377)
         else if (y == 0) f = (k == 2 && !free_two) ? 128u : 0u;     // t[0,1:,2] = insert-left-extend (align.py:385)
-        else f = t[(int64_t)y * rq.ts + (x - 1) + ((y - 1) & 63)];
+        else {
+            const int p = (x - 1) + ((y - 1) & 63);
+            if (ty < 0 || ty - y > 15 || p < window(y)) {
+                // fetch: lane = (row ty - i, piece j)
+                ty = y; tx = x;
+                const int i = lane >> 2, j = lane & 3, yy = ty - i;
+                uint4 piece = make_uint4(0u, 0u, 0u, 0u);
+                if (yy >= 1) piece = *reinterpret_cast<const uint4 *>(t + (int64_t)yy * rq.ts + window(yy) + 16 * j);
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads of the tile this one replaces)
+                tiles[wv][i][j] = piece;
+                __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            f = tile[(ty - y) * 64 + (p - window(y))];
+        }
         f &= k == 0 ? 0x0eu : (k == 1 ? 0x30u : 0xc0u);
         if (f & 2) { --y; --x; k = 0; }
         else if (f & 4) { --y; --x; k = 1; }
@@ -366,12 +427,15 @@ __global__ __launch_bounds__(64) void k_rawb_trace(RawBatchDev d)
         else if (f & 64) { --x; k = 0; }
         else if (f & 128) { --x; k = 2; }
         else break;
+        y = __builtin_amdgcn_readfirstlane(y); x = __builtin_amdgcn_readfirstlane(x); k = __builtin_amdgcn_readfirstlane(k);
         emit(y, x);
     }
     if (semiglobal) {
         if (y != 0) { for (int yy = y - 1; yy >= 0; --yy) emit(yy, 0); }
         else if (x != 0) { for (int xx = x - 1; xx >= 0; --xx) emit(0, xx); }
     }
-    d.path_info[2 * (int64_t)rq.index] = w;
-    d.path_info[2 * (int64_t)rq.index + 1] = cap - w;
+    if (lane == 0) {
+        d.path_info[2 * (int64_t)rq.index] = w;
+        d.path_info[2 * (int64_t)rq.index + 1] = cap - w;
+    }
 }

@@ -1,5 +1,6 @@
 // dp_rawb_instance.hip -- the kernels of a batch of RawPairwiseAligner requests (dp_rawb.hip.h) and their launches.
 #include "dp_rawb.hip.h"
+#include <algorithm>
 
 void praline_launch_rawb_init(const RawBatchDev &d, hipStream_t st)
 {
@@ -12,14 +13,22 @@ void praline_launch_rawb_zero(const RawBatchDev &d, const int32_t *zero_req, con
     hipLaunchKernelGGL(k_rawb_zero, dim3((unsigned)((n_zero + 255) / 256)), dim3(256), 0, st, d, zero_req, zero_idx, n_zero);
 }
 
-void praline_launch_rawb_fill(const RawBatchDev &d, int waves, bool mask, hipStream_t st)
+// global_like / local: whether the batch holds requests of that kind (each instance skips the other's)
+void praline_launch_rawb_fill(const RawBatchDev &d, int waves, bool mask, bool global_like, bool local, hipStream_t st)
 {
-    const dim3 grid((unsigned)d.n), block(64u * (unsigned)waves);
-    if (mask) hipLaunchKernelGGL(k_rawb_fill<true>, grid, block, 0, st, d);
-    else hipLaunchKernelGGL(k_rawb_fill<false>, grid, block, 0, st, d);
+    // two workgroups of up to eight waves per CU (128 registers per lane): no more workgroups than are resident at once
+    const dim3 grid((unsigned)std::min(d.n, PRALINE_RAWB_GROUPS)), block(64u * (unsigned)waves);
+    if (global_like) {
+        if (mask) hipLaunchKernelGGL((k_rawb_fill<true, false>), grid, block, 0, st, d);
+        else hipLaunchKernelGGL((k_rawb_fill<false, false>), grid, block, 0, st, d);
+    }
+    if (local) {
+        if (mask) hipLaunchKernelGGL((k_rawb_fill<true, true>), grid, block, 0, st, d);
+        else hipLaunchKernelGGL((k_rawb_fill<false, true>), grid, block, 0, st, d);
+    }
 }
 
 void praline_launch_rawb_trace(const RawBatchDev &d, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rawb_trace, dim3((unsigned)((d.n + 63) / 64)), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_rawb_trace, dim3((unsigned)((d.n + 3) / 4)), dim3(256), 0, st, d);
 }

@@ -157,7 +157,9 @@ extern "C" int praline_raw_batch_run(praline_raw_batch *b, const int32_t *modes,
     const RawBatchDev d = b->view();
     HIPCHK(hipEventRecord(b->ev0, st));
     praline_launch_rawb_init(d, st);
-    praline_launch_rawb_fill(d, b->waves, b->mask, st);
+    bool any_local = false, any_other = false;
+    for (const RawReq &rq : b->reqs) { any_local = any_local || rq.mode == 1; any_other = any_other || rq.mode != 1; }
+    praline_launch_rawb_fill(d, b->waves, b->mask, any_other, any_local, st);
     praline_launch_rawb_trace(d, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1, st));
