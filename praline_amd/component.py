@@ -1166,7 +1166,9 @@ class BatchManager(Manager):
       * Global / LocalMasterSlaveAligner lists - the workflow's preprofile stage, ONE Execution with a task per master
         (praline/component/workflow.py:139-161): one plan over every (master, slave) pair, one run per Waterman-Eggert
         iteration with the path bounding boxes turned into the next iteration's masks on the device;
-      * ProfileBuilder lists (workflow.py:211-224): counted on the host, one scatter-add per alignment.
+      * ProfileBuilder lists (workflow.py:211-224): counted on the host, one scatter-add per alignment;
+      * RawPairwiseAligner lists (praline/component/align.py:254-447; caller-supplied score models): one submission, one
+        launch for all requests and modes (native.RawBatch).
     Anything else falls back to the serial loop.
 
     rank / world / group: this process's place in a torch.distributed process group, one process per GPU - the
@@ -1250,12 +1252,40 @@ class BatchManager(Manager):
                 lo = hi
         return results
 
+    def _raw_batch(self, requests):
+        """Outputs of a list of RawPairwiseAligner requests (praline/component/align.py:254-447): every request brings its own
+        match scores, gap scores and zero cells; all of them go to the device in one submission (native.RawBatch) and
+        are aligned by one launch, each in its own mode."""
+        raw = []
+        for tid, inputs, tag, env in requests:
+            component = RawPairwiseAligner(self, env, tag)
+            self._check_request(component, inputs, env)
+            if inputs['mode'] not in MODES:
+                raise ComponentError("unknown alignment mode: '{0}'".format(inputs['mode']))
+            raw.append((inputs['match_score_model'].scores, inputs['gap_score_model_one'].scores,
+                        inputs['gap_score_model_two'].scores, inputs.get('zero_idxs')))
+        batch = native.RawBatch(raw)
+        try:
+            batch.run([inputs['mode'] for _, inputs, _, _ in requests])
+            scores, paths = batch.results()
+        finally:
+            batch.close()
+        results = []
+        for (tid, inputs, tag, env), sc, pt in zip(requests, scores, paths):
+            alignment = Alignment([inputs['sequence_one'], inputs['sequence_two']], _path_for_output(inputs['mode'], pt))
+            results.append({'alignment': alignment, 'score': float(sc)})
+        return results
+
     def execute_many(self, requests, parent_tag):
         self._require_open()
         requests = list(requests)
         tids = set(tid for tid, _, _, _ in requests)
         if len(requests) >= 2 and tids <= {GlobalMasterSlaveAligner.tid, LocalMasterSlaveAligner.tid}:
             for message in self._emit(requests, self._master_slave_batch(requests), parent_tag):
+                yield message
+            return
+        if len(requests) >= 2 and tids == {RawPairwiseAligner.tid}:
+            for message in self._emit(requests, self._raw_batch(requests), parent_tag):
                 yield message
             return
         if len(requests) >= 2 and tids == {ProfileBuilder.tid}:

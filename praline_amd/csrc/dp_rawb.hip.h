@@ -179,7 +179,9 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
     __shared__ float4 ring[PRALINE_RAWB_WAVES][PRALINE_RAWB_RING];
     __shared__ float4 topbuf[32];                         // strip 0: the boundary row, two halves of 16 columns
     __shared__ int produced[PRALINE_RAWB_WAVES], consumed[PRALINE_RAWB_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    // (the wave index as a scalar: everything derived from it - strips, neighbours, hand-off conditions - is uniform, and the
+    // compiler can only branch on it with scalar instructions if it knows)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
     if (lane == 0) { produced[wave] = 0; consumed[wave] = 0; }
     __syncthreads();
     // A workgroup takes every gridDim.x-th request of the (size-sorted) list, one after the other: wave w goes from strip w of
@@ -309,13 +311,14 @@ __device__ __forceinline__ unsigned long long rawb_wave_min_u64(unsigned long lo
 
 // End cell (align.py:401-431), score and path (praline/util/align.py:144-185, 268-297) of every request: one wave each.  The
 // lanes search the last row / column (or the lanes' first maxima and the boundary cells, local mode) together; the walk
-// itself is serial, so the wave fetches the flags it is about to need as a tile - 16 rows x 64 bytes ending at the current
-// cell, one 16-byte piece per lane - into LDS and walks inside it until the path leaves it (a step is an LDS read instead of
-// a dependent read of memory: ~50 tile fetches instead of ~800 memory round trips for a 400 x 400 alignment).
+// itself is serial, so the wave fetches the flags it is about to need as a tile - 64 rows x 128 bytes ending at the current
+// cell, one row per lane - into LDS and walks inside it until the path leaves it (a step is an LDS read instead of a dependent
+// read of memory: ~15 tile fetches instead of ~800 memory round trips for a 400 x 400 alignment).
+#define RAWB_TILE_W 128
 __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
 {
-    __shared__ uint4 tiles[4][16][4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ uint4 tiles[4][64][RAWB_TILE_W / 16 + 1];   // (+ 16 bytes per row: the lanes' row writes spread over the banks)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the walk is uniform)
     const int r = blockIdx.x * 4 + wv;
     if (r >= d.n) return;
     const RawReq rq = d.reqs[r];
@@ -386,8 +389,18 @@ __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
     if (lane == 0) d.scores[rq.index] = score;
     const int cap = L1 + L2 + 2;
     int32_t *path = d.paths + 2 * rq.path_off;
-    int w = cap;
-    auto emit = [&](int yy, int xx) { --w; if (lane == 0) { path[2 * w] = yy; path[2 * w + 1] = xx; } };
+    // path rows are written back to front; they are collected in two registers (row j since the last flush in lane j) and
+    // stored 64 at a time
+    int w = cap, w_flushed = cap, held = 0, hy = 0, hx = 0;
+    auto flush = [&]() {
+        if (lane < held) { const int at = w_flushed - 1 - lane; path[2 * at] = hy; path[2 * at + 1] = hx; }
+        w_flushed = w; held = 0;
+    };
+    auto emit = [&](int yy, int xx) {
+        hy = lane == held ? yy : hy; hx = lane == held ? xx : hx;
+        --w; ++held;
+        if (held == 64) flush();
+    };
     int y = cy, x = cx, k = ck;
     if (semiglobal) {
         if (y != L1) { for (int yy = L1; yy > y; --yy) emit(yy, x); }
@@ -397,8 +410,9 @@ __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
     const uint8_t *t = d.t + rq.t_off;
     const uint8_t *tile = reinterpret_cast<const uint8_t *>(&tiles[wv][0][0]);
     int ty = -1, tx = 0;   // the cell the tile was fetched at (ty < 0: none yet)
-    // window of row yy in a tile fetched at (ty, tx): 64 bytes from a 16-byte boundary, at least 32 of them to the left of the cell
-    auto window = [&](int yy) { return max(0, (tx - 1) + ((yy - 1) & 63) - 47) & ~15; };
+    // window of row yy in a tile fetched at (ty, tx): RAWB_TILE_W bytes from a 16-byte boundary, at least RAWB_TILE_W - 32 of
+    // them to the left of the cell
+    auto window = [&](int yy) { return max(0, (tx - 1) + ((yy - 1) & 63) - (RAWB_TILE_W - 17)) & ~15; };
     for (int guard = 0; guard < cap; ++guard) {
         unsigned f;
         if (y == 0 && x == 0) f = 0;
@@ -406,34 +420,41 @@ __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
         else if (y == 0) f = (k == 2 && !free_two) ? 128u : 0u;     // t[0,1:,2] = insert-left-extend (align.py:385)
         else {
             const int p = (x - 1) + ((y - 1) & 63);
-            if (ty < 0 || ty - y > 15 || p < window(y)) {
-                // fetch: lane = (row ty - i, piece j)
+            if (ty < 0 || ty - y > 63 || p < window(y)) {
+                // fetch: lane i = row ty - i
                 ty = y; tx = x;
-                const int i = lane >> 2, j = lane & 3, yy = ty - i;
-                uint4 piece = make_uint4(0u, 0u, 0u, 0u);
-                if (yy >= 1) piece = *reinterpret_cast<const uint4 *>(t + (int64_t)yy * rq.ts + window(yy) + 16 * j);
+                const int yy = ty - lane;
+                uint4 piece[RAWB_TILE_W / 16];
+#pragma unroll
+                for (int j = 0; j < RAWB_TILE_W / 16; ++j) piece[j] = make_uint4(0u, 0u, 0u, 0u);
+                if (yy >= 1) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(t + (int64_t)yy * rq.ts + window(yy));
+#pragma unroll
+                    for (int j = 0; j < RAWB_TILE_W / 16; ++j) piece[j] = src[j];
+                }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads of the tile this one replaces)
-                tiles[wv][i][j] = piece;
+#pragma unroll
+                for (int j = 0; j < RAWB_TILE_W / 16; ++j) tiles[wv][lane][j] = piece[j];
                 __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
-            f = tile[(ty - y) * 64 + (p - window(y))];
+            f = tile[(ty - y) * (RAWB_TILE_W + 16) + (p - window(y))];
+            f = __builtin_amdgcn_readfirstlane(f);
         }
         f &= k == 0 ? 0x0eu : (k == 1 ? 0x30u : 0xc0u);
-        if (f & 2) { --y; --x; k = 0; }
-        else if (f & 4) { --y; --x; k = 1; }
-        else if (f & 8) { --y; --x; k = 2; }
-        else if (f & 16) { --y; k = 0; }
-        else if (f & 32) { --y; k = 1; }
-        else if (f & 64) { --x; k = 0; }
-        else if (f & 128) { --x; k = 2; }
-        else break;
-        y = __builtin_amdgcn_readfirstlane(y); x = __builtin_amdgcn_readfirstlane(x); k = __builtin_amdgcn_readfirstlane(k);
+        if (f == 0) break;
+        // the lowest set flag decides (praline/util/align.py:155-183): match from M / U / L (bits 1-3: up-left, next state 0 / 1 / 2),
+        // insert-up open / extend (bits 4, 5: up, state 0 / 1), insert-left open / extend (bits 6, 7: left, state 0 / 2)
+        const int bit = __builtin_ctz(f) - 1;
+        y -= (0x1f >> bit) & 1;
+        x -= (0x67 >> bit) & 1;
+        k = (0x2124 >> (2 * bit)) & 3;
         emit(y, x);
     }
     if (semiglobal) {
         if (y != 0) { for (int yy = y - 1; yy >= 0; --yy) emit(yy, 0); }
         else if (x != 0) { for (int xx = x - 1; xx >= 0; --xx) emit(0, xx); }
     }
+    flush();
     if (lane == 0) {
         d.path_info[2 * (int64_t)rq.index] = w;
         d.path_info[2 * (int64_t)rq.index + 1] = cap - w;

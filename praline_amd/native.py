@@ -320,6 +320,8 @@ class RawBatch(object):
                 z = np.asarray(zero_idxs, dtype=np.int64).reshape(-1, 2)
                 # (the reference indexes a numpy array with these tuples: negative indices count from the end)
                 z = np.where(z < 0, z + np.array([m.shape[0] + 1, m.shape[1] + 1]), z)
+                if (z < 0).any() or (z[:, 0] > m.shape[0]).any() or (z[:, 1] > m.shape[1]).any():
+                    raise IndexError("request %d: zero_idxs outside the %d x %d matrix" % (r, m.shape[0] + 1, m.shape[1] + 1))
                 zs.append(z.astype(np.int32))
                 zoff[r + 1] = zoff[r] + len(z)
             else:
