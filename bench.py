@@ -635,11 +635,28 @@ def main():
             variants["c3_build_preprofiles_%s_ms" % m3] = (time.perf_counter() - t_a) * 1e3
         del seqs3
         native.pool_trim()
+        # batched RawPairwiseAligner (praline_raw_batch_*): requests of 400 x 400 with their own m, g1, g2, inputs resident in
+        # HBM; one step = boundary rows + fill (k_rawb_fill) + end cells and paths (k_rawb_trace) of every request
+        rng_r = np.random.default_rng(9)
+        base_r = []
+        for _ in range(8):
+            m_r = (rng_r.standard_normal((400, 400)) * 3 - 0.5).astype(np.float32)
+            g_r = [np.stack([-rng_r.uniform(5, 12, 400), -rng_r.uniform(0.5, 2, 400)], axis=1).astype(np.float32) for _ in range(2)]
+            base_r.append((m_r, g_r[0], g_r[1], None))
+        for n_r in (500, 2048):
+            rb = native.RawBatch([base_r[k % 8] for k in range(n_r)])
+            for mode_r in ("global", "local"):
+                dt_r = timed(lambda: rb.run(mode_r), reps=5, sync=lambda: rb.results(paths=False))
+                variants["raw_batch_%d_%s_gcups" % (n_r, mode_r)] = rb.cells / dt_r / 1e9
+            rb.close()
+        variants["raw_batch_kernel"] = "k_rawb_fill<false, false> + k_rawb_trace"
+        native.pool_trim()
         variants["note"] = ("driver-timed like `value` (inputs / results in HBM).  with_paths = fill with packed traceback + "
                             "end cells + device traceback; onehot = integer scoring (bit-exact mode); f32_chain = fp32 MFMA "
                             "match scores; reference_order = PRALINE_MATCH_REFERENCE (bit-identical alignments for float "
                             "profiles); c3 = all 1 047 552 ordered pairs with paths (build_preprofiles: sequences in, profile tracks "
-                            "out, local = two Waterman-Eggert passes); c4 = shard 3 of 8; c5 = shard 5 of 14")
+                            "out, local = two Waterman-Eggert passes); c4 = shard 3 of 8; c5 = shard 5 of 14; raw_batch_<n> = n RawPairwiseAligner "
+                            "requests of 400 x 400 (own m, g1, g2 each) in one submission, scores and paths")
         out["variants"] = variants
 
     # ---- CPU baseline: the oracle (C restatement of the reference path) on the host cores ----

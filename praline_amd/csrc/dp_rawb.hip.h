@@ -112,8 +112,19 @@ __global__ __launch_bounds__(256) void k_rawb_zero(RawBatchDev d, const int32_t 
     atomicOr(w32, 1u << ((p & 15) + ((word & 1) ? 16 : 0)));
 }
 
-// sixteen steps of one strip.  EDGE: some lane is before its first or at / beyond its last column in these steps.
-template <bool MASK, bool EDGE, bool LOCAL>
+// f = 2 f + (a == b): a tie flag shifted in with two instructions (compare into vcc, add with carry) instead of compare,
+// select and an OR per three flags
+__device__ __forceinline__ unsigned rawb_flag_in(unsigned f, float a, float b)
+{
+    unsigned r;
+    __asm__("v_cmp_eq_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %3, %3, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(f) : "vcc");
+    return r;
+}
+
+// sixteen steps of one strip.  EDGE: some lane is before its first or at / beyond its last column in these steps.  OUT: where
+// the strip's last row goes - 0 nowhere, 1 the LDS ring of the wave below, 2 the `wrap` row in memory (the wave below is wave 0
+// of the next round), 3 the request's last row (end cell of the global and semiglobal modes).
+template <bool MASK, bool EDGE, bool LOCAL, int OUT>
 __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits, const float2 g2c, int c, int lane, int L2, int y, bool row_ok,
                                            bool last_strip, bool feeds, int L1, float base, float go1, float ge1, float bndU, const float4 *hand /* LDS, entry of step 0 */,
                                            int hand_mask, int hand_pos, float4 *out_ring, int out_pos, float4 *out_row /* or NULL */, float4 *edge_row, float4 *edge_col,
@@ -138,13 +149,19 @@ __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits
         const float ms = mrow.v[i];
         // cext.c:141-183
         const float mm = upM + ms, mu = upU + ms, ml = upL + ms;   // (upM/U/L still hold the step before: the diagonal)
-        float mmax = __builtin_fmaxf(__builtin_fmaxf(mm, mu), __builtin_fmaxf(ml, base));
+        float mmax = LOCAL ? __builtin_fmaxf(__builtin_fmaxf(mm, mu), __builtin_fmaxf(ml, base)) : __builtin_fmaxf(__builtin_fmaxf(mm, mu), ml);
         const float up_open = nuM + go1, up_ext = nuU + ge1;
         float umax = __builtin_fmaxf(up_open, up_ext);
         const float lf_open = curM + go2, lf_ext = curL + ge2;
         float lmax = __builtin_fmaxf(lf_open, lf_ext);
-        unsigned f = (mm == mmax ? 2u : 0u) | (mu == mmax ? 4u : 0u) | (ml == mmax ? 8u : 0u) | (up_open == umax ? 16u : 0u) |
-                     (up_ext == umax ? 32u : 0u) | (lf_open == lmax ? 64u : 0u) | (lf_ext == lmax ? 128u : 0u);
+        // bits 6 .. 0 = lf_ext, lf_open, up_ext, up_open, ml, mu, mm: the reference's flag byte (cext.c:155-183) shifted right by one
+        unsigned f = lf_ext == lmax ? 1u : 0u;
+        f = rawb_flag_in(f, lf_open, lmax);
+        f = rawb_flag_in(f, up_ext, umax);
+        f = rawb_flag_in(f, up_open, umax);
+        f = rawb_flag_in(f, ml, mmax);
+        f = rawb_flag_in(f, mu, mmax);
+        f = rawb_flag_in(f, mm, mmax);
         if (MASK) {
             const bool zc = (zbits >> i) & 1u;   // a zero cell keeps what the caller initialised: zeros (align.py:362-367, cext.c:147-149)
             mmax = zc ? 0.0f : mmax; umax = zc ? 0.0f : umax; lmax = zc ? 0.0f : lmax;
@@ -152,7 +169,7 @@ __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits
         }
         if (EDGE && x < 1) { mmax = RAWB_NEG_INF; umax = bndU; lmax = RAWB_NEG_INF; }   // not started: the lane shows its boundary cell (y, 0)
         __asm__ volatile("" : "+v"(f));          // (the byte first, then its place in the word: folded into the selects, the shifted flag constants hold 20 registers)
-        pk[i >> 2] |= f << (8 * (i & 3));
+        pk[i >> 2] |= f << (8 * (i & 3) + 1);
         __asm__ volatile("" : "+v"(pk[i >> 2]));   // (the flags of a step are formed in that step: deferred to the end of the chunk, their inputs spill)
         const bool in_row = !EDGE || (x >= 1 && x <= L2);
         if (LOCAL) {
@@ -161,12 +178,11 @@ __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits
             sbest = gt ? v3 : sbest; scode = gt ? s : scode; sM = gt ? mmax : sM; sU = gt ? umax : sU;
             __asm__ volatile("" : "+v"(sbest), "+v"(scode), "+v"(sM), "+v"(sU));   // (decided in this step: deferred, the values of sixteen steps stay live)
         } else {
-            if (last_strip && y == L1 && in_row) edge_row[x] = make_float4(mmax, umax, lmax, 0.0f);
+            if (OUT == 3 && y == L1 && in_row) edge_row[x] = make_float4(mmax, umax, lmax, 0.0f);
             if (EDGE && x == L2 && row_ok) edge_col[y] = make_float4(mmax, umax, lmax, 0.0f);
         }
-        if (feeds && !out_row && lane == 63 && in_row) out_ring[(out_pos + x - 1) & (PRALINE_RAWB_RING - 1)] = make_float4(mmax, umax, lmax, 0.0f);
-        __asm__ volatile("" ::: "memory");   // (two stores: merged into one through a generic pointer, the LDS write becomes a flat store)
-        if (out_row && lane == 63 && in_row) out_row[x] = make_float4(mmax, umax, lmax, 0.0f);
+        if (OUT == 1 && lane == 63 && in_row) out_ring[(out_pos + x - 1) & (PRALINE_RAWB_RING - 1)] = make_float4(mmax, umax, lmax, 0.0f);
+        if (OUT == 2 && lane == 63 && in_row) out_row[x] = make_float4(mmax, umax, lmax, 0.0f);
         upM = nuM; upU = nuU; upL = nuL;
         curM = mmax; curU = umax; curL = lmax;
     }
@@ -209,6 +225,7 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
         const bool feeds = k + 1 < R, fed = k > 0, last_strip = k == R - 1;
         const bool from_row = wave == 0;                  // the row above comes from memory: boundary row or `wrap`
         float4 *out_row = feeds && wave == W - 1 ? wrap : nullptr;
+        const int out_kind = feeds ? (out_row ? 2 : 1) : (LOCAL ? 0 : 3);
         const float4 *feed = k == 0 ? top : wrap;
         const int y = 64 * k + 1 + lane;
         const bool row_ok = y <= L1;
@@ -258,10 +275,13 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
             }
             uint4 fl;
             const bool edge = 16 * c < 63 || 16 * c + 16 >= L2;
-#define RAWB_CHUNK(E, L)                                                                                                                        \
-    rawb_chunk<MASK, E, L>(mA, zA, gA, c, lane, L2, y, row_ok, last_strip, feeds, L1, base, go1, ge1, bndU, hand, hand_mask, hand_base + 16 * c,  \
+#define RAWB_CHUNK(E, O)                                                                                                                        \
+    rawb_chunk<MASK, E, LOCAL, O>(mA, zA, gA, c, lane, L2, y, row_ok, last_strip, feeds, L1, base, go1, ge1, bndU, hand, hand_mask, hand_base + 16 * c,  \
                            ring[wave], out_base, out_row, edge_row, edge_col, curM, curU, curL, upM, upU, upL, go2, ge2, sbest, scode, sM, sU, fl)
-            if (edge) RAWB_CHUNK(true, LOCAL); else RAWB_CHUNK(false, LOCAL);
+            if (out_kind == 1) { if (edge) RAWB_CHUNK(true, 1); else RAWB_CHUNK(false, 1); }
+            else if (out_kind == 2) { if (edge) RAWB_CHUNK(true, 2); else RAWB_CHUNK(false, 2); }
+            else if (out_kind == 3) { if (edge) RAWB_CHUNK(true, 3); else RAWB_CHUNK(false, 3); }
+            else { if (edge) RAWB_CHUNK(true, 0); else RAWB_CHUNK(false, 0); }
 #undef RAWB_CHUNK
             *reinterpret_cast<uint4 *>(trow + 16 * c) = fl;
             // progress: this strip's last row up to column 16 c + 16 - 63, the row above read up to column 16 c + 16

@@ -53,7 +53,10 @@ if __name__ == "__main__":
         total_bad += check([rand_requests(rng, 1, 1300, 1400)[0], rand_requests(rng, 1, 600, 3000)[0]], ["local", "global"], "long")
         print("mismatches:", total_bad, flush=True)
     if total_bad == 0 and "--no-bench" not in sys.argv:
-        for n, L in ((500, 400), (2048, 400), (256, 1000)):
+        sizes = ((500, 400), (2048, 400), (256, 1000))
+        if "--sizes" in sys.argv:
+            sizes = [tuple(int(v) for v in t.split("x")) for t in sys.argv[sys.argv.index("--sizes") + 1].split(",")]
+        for n, L in sizes:
             reqs = rand_requests(rng, 8, L, L, zero_share=0.0)
             reqs = [reqs[i % 8] for i in range(n)]
             rb = nat.RawBatch(reqs)
