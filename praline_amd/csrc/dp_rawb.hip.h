@@ -25,6 +25,11 @@
 #include "dp_rawb.h"
 
 #define RAWB_NEG_INF (-__builtin_inff())
+// measurement builds only (scripts/build_variant.sh, VARIANT_RAWB=1): bit 0 no tie flags, bit 1 no waiting for the neighbour
+// strips, bit 2 no zero-cell / boundary selects - wrong results, never in the product library
+#ifndef PRALINE_RAWB_ABLATE
+#define PRALINE_RAWB_ABLATE 0
+#endif
 
 __device__ __forceinline__ bool rawb_free_one(int mode) { return mode == 2 || mode == 3; }
 __device__ __forceinline__ bool rawb_free_two(int mode) { return mode == 2 || mode == 4; }
@@ -39,17 +44,15 @@ __device__ __forceinline__ float rawb_shr1(float old, float src)   // lane l <- 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
-struct __attribute__((packed, aligned(4))) RawbF4 { float v[4]; };   // 16 bytes at any float address
-
 struct RawbRow16 { float v[16]; };
 
-__device__ __forceinline__ void rawb_load16(RawbRow16 &r, const float *p)
+// a lane's 16 match scores of one chunk: four float4, 64 apart (one contiguous KB per wave and piece)
+__device__ __forceinline__ void rawb_load16(RawbRow16 &r, const float4 *p)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const RawbF4 f = *reinterpret_cast<const RawbF4 *>(p + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r.v[4 * q + e] = f.v[e];
+        const float4 f = p[64 * q];
+        r.v[4 * q] = f.x; r.v[4 * q + 1] = f.y; r.v[4 * q + 2] = f.z; r.v[4 * q + 3] = f.w;
     }
 }
 
@@ -57,7 +60,7 @@ __device__ __forceinline__ void rawb_load16(RawbRow16 &r, const float *p)
 // and stops waiting for the rest of the kernel (`dead`): a broken hand-off ends in an error code, not in a hung device.
 __device__ __forceinline__ void rawb_wait(volatile int *flag, int need, int32_t *error, bool &dead)
 {
-    if (!dead) {
+    if (!dead && !(PRALINE_RAWB_ABLATE & 2)) {
         int spins = 0;
         while (__builtin_amdgcn_readfirstlane(*flag) < need) {
             __builtin_amdgcn_s_sleep(2);
@@ -98,6 +101,29 @@ __global__ __launch_bounds__(256) void k_rawb_init(RawBatchDev d)
     }
 }
 
+// the caller's m (row-major, requests one after the other) -> the arena layout (dp_rawb.h): one workgroup per (strip, chunk)
+// block, thread = (piece q, lane l): the four floats of row 64 k + l + 1 at columns 16 c + 4 q - l ... (zero outside the matrix)
+__global__ __launch_bounds__(256) void k_rawb_stage(RawBatchDev d, const float *__restrict__ src, float4 *__restrict__ dst, const int64_t *__restrict__ block0)
+{
+    // block0[r]: the first workgroup of request r (requests in launch order); found by bisection
+    int lo = 0, hi = d.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (block0[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const RawReq rq = d.reqs[lo];
+    const int b = (int)((int64_t)blockIdx.x - block0[lo]);     // k * ncs + c
+    const int k = b / rq.ncs, c = b % rq.ncs;
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int y = 64 * k + lane;                               // 0-based row
+    const int x0 = 16 * c + 4 * q - lane;                      // 0-based column of the piece's first float
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (y < rq.L1) {
+        const float *sr = src + rq.src_off + (int64_t)y * rq.L2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e >= 0 && x0 + e < rq.L2) v[e] = sr[x0 + e];
+    }
+    dst[rq.m_off + (int64_t)b * 256 + q * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // zero cells -> bits of the skewed mask rows (cells on the boundary row / column have no effect: cext.c:141-149 starts at 1)
 __global__ __launch_bounds__(256) void k_rawb_zero(RawBatchDev d, const int32_t *__restrict__ zero_req, const int32_t *__restrict__ zero_idx, int64_t n_zero)
 {
@@ -106,8 +132,8 @@ __global__ __launch_bounds__(256) void k_rawb_zero(RawBatchDev d, const int32_t 
     const RawReq rq = d.reqs[zero_req[i]];
     const int y = zero_idx[2 * i], x = zero_idx[2 * i + 1];
     if (y < 1 || y > rq.L1 || x < 1 || x > rq.L2) return;
-    const int p = x - 1 + ((y - 1) & 63);
-    const int64_t word = rq.z_off + (int64_t)y * rq.zs + (p >> 4);
+    const int p = x - 1 + ((y - 1) & 63);                      // step - 1 of the cell in its strip
+    const int64_t word = rq.z_off + ((int64_t)((y - 1) >> 6) * rq.ncs + (p >> 4)) * 64 + ((y - 1) & 63);
     unsigned int *w32 = reinterpret_cast<unsigned int *>(d.z) + (word >> 1);
     atomicOr(w32, 1u << ((p & 15) + ((word & 1) ? 16 : 0)));
 }
@@ -156,12 +182,14 @@ __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits
         float lmax = __builtin_fmaxf(lf_open, lf_ext);
         // bits 6 .. 0 = lf_ext, lf_open, up_ext, up_open, ml, mu, mm: the reference's flag byte (cext.c:155-183) shifted right by one
         unsigned f = lf_ext == lmax ? 1u : 0u;
-        f = rawb_flag_in(f, lf_open, lmax);
-        f = rawb_flag_in(f, up_ext, umax);
-        f = rawb_flag_in(f, up_open, umax);
-        f = rawb_flag_in(f, ml, mmax);
-        f = rawb_flag_in(f, mu, mmax);
-        f = rawb_flag_in(f, mm, mmax);
+        if (!(PRALINE_RAWB_ABLATE & 1)) {
+            f = rawb_flag_in(f, lf_open, lmax);
+            f = rawb_flag_in(f, up_ext, umax);
+            f = rawb_flag_in(f, up_open, umax);
+            f = rawb_flag_in(f, ml, mmax);
+            f = rawb_flag_in(f, mu, mmax);
+            f = rawb_flag_in(f, mm, mmax);
+        }
         if (MASK) {
             const bool zc = (zbits >> i) & 1u;   // a zero cell keeps what the caller initialised: zeros (align.py:362-367, cext.c:147-149)
             mmax = zc ? 0.0f : mmax; umax = zc ? 0.0f : umax; lmax = zc ? 0.0f : lmax;
@@ -239,9 +267,10 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
         if (k == 0) { const float4 t0 = top[0]; upM = t0.x; upU = t0.y; upL = t0.z; }
         else upU = rawb_boundary(64 * k, g1_00, g1[64 * k - 1].y, free_one);
         float go2 = 0.0f, ge2 = 0.0f;
-        const float *mrow = d.m + rq.m_off + (int64_t)(yc - 1) * L2 - lane;
-        uint8_t *trow = d.t + rq.t_off + (int64_t)y * rq.ts;
-        const uint16_t *zrow = d.z + rq.z_off + (int64_t)yc * rq.zs;
+        // the strip's blocks in the three chunk-ordered arenas (dp_rawb.h)
+        const float4 *mrow = reinterpret_cast<const float4 *>(d.m) + rq.m_off + (int64_t)k * rq.ncs * 256 + lane;
+        uint4 *trow = reinterpret_cast<uint4 *>(d.t) + rq.t_off + (int64_t)k * rq.ncs * 64 + lane;
+        const uint16_t *zrow = d.z + rq.z_off + (int64_t)k * rq.ncs * 64 + lane;
         float sbest = RAWB_NEG_INF, sM = 0.0f, sU = 0.0f;
         int scode = 0;
         RawbRow16 mA, mB;
@@ -266,8 +295,8 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
             if (fed) rawb_wait(&produced[prod], in_pos + min(16 * c + (from_row ? 48 : 16), L2), d.error, dead);
             if (feeds && !out_row) rawb_wait(&consumed[wave], out_base + min(max(16 * c + 16 - 63, 0), L2) - PRALINE_RAWB_RING, d.error, dead);
             // the next chunk's inputs
-            rawb_load16(mB, mrow + 16 * (c + 1));
-            if (MASK) zB = zrow[c + 1];
+            rawb_load16(mB, mrow + 256 * (c + 1));
+            if (MASK) zB = zrow[64 * (c + 1)];
             gB = g2[16 * (c + 1) + (lane & 15)];
             if (from_row) {
                 if (lane < 16) topbuf[16 * ((c + 1) & 1) + lane] = treg;
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(64 * PRALINE_RAWB_WAVES) __attribute__((amdgpu_wave
             else if (out_kind == 3) { if (edge) RAWB_CHUNK(true, 3); else RAWB_CHUNK(false, 3); }
             else { if (edge) RAWB_CHUNK(true, 0); else RAWB_CHUNK(false, 0); }
 #undef RAWB_CHUNK
-            *reinterpret_cast<uint4 *>(trow + 16 * c) = fl;
+            trow[64 * c] = fl;
             // progress: this strip's last row up to column 16 c + 16 - 63, the row above read up to column 16 c + 16
             if (out_row) __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the row entries have reached the L2)
             else __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -427,7 +456,7 @@ __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
         else if (x != L2) { for (int xx = L2; xx > x; --xx) emit(y, xx); }
     }
     emit(y, x);
-    const uint8_t *t = d.t + rq.t_off;
+    const uint4 *t = reinterpret_cast<const uint4 *>(d.t) + rq.t_off;
     const uint8_t *tile = reinterpret_cast<const uint8_t *>(&tiles[wv][0][0]);
     int ty = -1, tx = 0;   // the cell the tile was fetched at (ty < 0: none yet)
     // window of row yy in a tile fetched at (ty, tx): RAWB_TILE_W bytes from a 16-byte boundary, at least RAWB_TILE_W - 32 of
@@ -448,9 +477,10 @@ __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
 #pragma unroll
                 for (int j = 0; j < RAWB_TILE_W / 16; ++j) piece[j] = make_uint4(0u, 0u, 0u, 0u);
                 if (yy >= 1) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(t + (int64_t)yy * rq.ts + window(yy));
+                    // (consecutive chunks of a row are 64 uint4 apart: dp_rawb.h)
+                    const uint4 *src = t + ((int64_t)((yy - 1) >> 6) * rq.ncs + (window(yy) >> 4)) * 64 + ((yy - 1) & 63);
 #pragma unroll
-                    for (int j = 0; j < RAWB_TILE_W / 16; ++j) piece[j] = src[j];
+                    for (int j = 0; j < RAWB_TILE_W / 16; ++j) piece[j] = src[64 * j];
                 }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads of the tile this one replaces)
 #pragma unroll

@@ -7,6 +7,11 @@ void praline_launch_rawb_init(const RawBatchDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_rawb_init, dim3((unsigned)d.n), dim3(256), 0, st, d);
 }
 
+void praline_launch_rawb_stage(const RawBatchDev &d, const float *src, float *dst, const int64_t *block0, int64_t n_blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rawb_stage, dim3((unsigned)n_blocks), dim3(256), 0, st, d, src, reinterpret_cast<float4 *>(dst), block0);
+}
+
 void praline_launch_rawb_zero(const RawBatchDev &d, const int32_t *zero_req, const int32_t *zero_idx, int64_t n_zero, hipStream_t st)
 {
     if (n_zero <= 0) return;

@@ -68,20 +68,24 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
     b->cells = m_off[(size_t)n];
     b->reqs.resize((size_t)n);
     b->place.resize((size_t)n);
-    int64_t t_bytes = 0, z_words = 0, rows4 = 0, edge4 = 0, path_rows = 0;
+    int64_t n_blocks = 0, rows4 = 0, edge4 = 0, path_rows = 0;
+    std::vector<int64_t> block0((size_t)n);
     int max_strips = 1;
     for (int64_t q = 0; q < n; ++q) {
         const int32_t r = order[(size_t)q];
         RawReq &rq = b->reqs[(size_t)q];
         b->place[(size_t)r] = (int32_t)q;
         rq.L1 = l1[r]; rq.L2 = l2[r]; rq.mode = 0; rq.nstrips = (l1[r] + 63) / 64;
-        const int nc = (l2[r] + 63 + 15) / 16;
-        rq.ts = 16 * (nc + 1); rq.zs = nc + 1;
-        rq.index = r; rq.pad = 0;
-        rq.m_off = PRALINE_RAWB_M_PAD + m_off[(size_t)r];
+        rq.ncs = (l2[r] + 63 + 15) / 16 + 1; rq.pad0 = 0;
+        rq.index = r; rq.pad1 = 0;
+        const int64_t blocks = (int64_t)rq.nstrips * rq.ncs;     // (strip, chunk) blocks of the request
+        block0[(size_t)q] = n_blocks;
+        rq.m_off = n_blocks * 256;
+        rq.src_off = m_off[(size_t)r];
         rq.g1_off = g1_off[(size_t)r]; rq.g2_off = g2_off[(size_t)r];
-        rq.t_off = t_bytes; t_bytes += (int64_t)(64 * rq.nstrips + 1) * rq.ts;
-        rq.z_off = z_words; z_words += ((int64_t)(l1[r] + 1) * rq.zs + 1) / 2 * 2;
+        rq.t_off = n_blocks * 64;
+        rq.z_off = n_blocks * 64;
+        n_blocks += blocks;
         rq.top_off = rows4; rows4 += l2[r] + PRALINE_RAWB_ROW_PAD;
         rq.edge_off = edge4; edge4 += l1[r] + l2[r] + 2;
         rq.best_off = q * (PRALINE_RAWB_WAVES * 64);
@@ -93,31 +97,38 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
     b->n_zero = zero_off ? zero_off[n] - zero_off[0] : 0;
     b->mask = b->n_zero > 0;
     hipStream_t st = g_rt.stream;
-    RC(b->d_m.alloc((size_t)(b->cells + 2 * PRALINE_RAWB_M_PAD)));
+    if (n_blocks > (int64_t)1 << 31) return fail(PRALINE_ERR_UNSUPPORTED, "raw batch of %lld chunk blocks (split the list)", (long long)n_blocks);
+    RC(b->d_m.alloc((size_t)n_blocks * 1024));
     RC(b->d_g1.alloc((size_t)(g1_off[(size_t)n] + PRALINE_RAWB_ROW_PAD)));
     RC(b->d_g2.alloc((size_t)(g2_off[(size_t)n] + PRALINE_RAWB_ROW_PAD)));
-    RC(b->d_z.alloc((size_t)std::max<int64_t>(b->mask ? z_words : 0, 2)));
+    RC(b->d_z.alloc((size_t)std::max<int64_t>(b->mask ? n_blocks * 64 : 0, 2)));
     RC(b->d_top.alloc((size_t)rows4));
     RC(b->d_wrap.alloc(max_strips > PRALINE_RAWB_WAVES ? (size_t)rows4 : 1));
     RC(b->d_edge.alloc((size_t)edge4));
     RC(b->d_best.alloc((size_t)n * PRALINE_RAWB_WAVES * 64));
-    RC(b->d_t.alloc((size_t)t_bytes));
+    RC(b->d_t.alloc((size_t)n_blocks * 1024));
     RC(b->d_paths.alloc((size_t)path_rows * 2));
     RC(b->d_info.alloc((size_t)n * 2));
     RC(b->d_scores.alloc((size_t)n));
     RC(b->d_error.alloc(1));
     RC(b->d_reqs.alloc((size_t)n));
-    // the inputs: one copy each (host or device pointers).  The padding in front of and behind m, and behind g1 / g2, is read
-    // by the skewed prefetches and never used: it only has to exist - it is cleared once so that no run reads uninitialised memory.
-    HIPCHK(hipMemsetAsync(b->d_m.p, 0, PRALINE_RAWB_M_PAD * sizeof(float), st));
-    HIPCHK(hipMemsetAsync(b->d_m.p + PRALINE_RAWB_M_PAD + b->cells, 0, PRALINE_RAWB_M_PAD * sizeof(float), st));
+    // the inputs: one copy each (host or device pointers).  The padding behind g1 / g2 is read by the prefetches and never
+    // used: it only has to exist - it is cleared once so that no run reads uninitialised memory.
     HIPCHK(hipMemsetAsync(b->d_g1.p + g1_off[(size_t)n], 0, PRALINE_RAWB_ROW_PAD * sizeof(float2), st));
     HIPCHK(hipMemsetAsync(b->d_g2.p + g2_off[(size_t)n], 0, PRALINE_RAWB_ROW_PAD * sizeof(float2), st));
-    HIPCHK(hipMemcpyAsync(b->d_m.p + PRALINE_RAWB_M_PAD, m, (size_t)b->cells * sizeof(float), hipMemcpyDefault, st));
     HIPCHK(hipMemcpyAsync(b->d_g1.p, g1, (size_t)g1_off[(size_t)n] * sizeof(float2), hipMemcpyDefault, st));
     HIPCHK(hipMemcpyAsync(b->d_g2.p, g2, (size_t)g2_off[(size_t)n] * sizeof(float2), hipMemcpyDefault, st));
     HIPCHK(hipMemsetAsync(b->d_error.p, 0, sizeof(int32_t), st));
     HIPCHK(hipMemcpyAsync(b->d_reqs.p, b->reqs.data(), (size_t)n * sizeof(RawReq), hipMemcpyHostToDevice, st));
+    {   // m: the caller's rows into the arena's aligned rows (dp_rawb.h)
+        DevBuf<float> tmp;
+        DevBuf<int64_t> d_block0;
+        RC(tmp.alloc((size_t)b->cells));
+        RC(d_block0.upload(block0, st));
+        HIPCHK(hipMemcpyAsync(tmp.p, m, (size_t)b->cells * sizeof(float), hipMemcpyDefault, st));
+        praline_launch_rawb_stage(b->view(), tmp.p, b->d_m.p, d_block0.p, n_blocks, st);
+        HIPCHK(hipGetLastError());
+    }
     if (b->mask) {
         // zero cells -> mask bits, on the device
         std::vector<int32_t> zreq((size_t)b->n_zero);
@@ -126,7 +137,7 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
         RC(b->d_zero_req.upload(zreq, st));
         RC(b->d_zero_idx.alloc((size_t)b->n_zero * 2));
         HIPCHK(hipMemcpyAsync(b->d_zero_idx.p, zero_idx + 2 * zero_off[0], (size_t)b->n_zero * 2 * sizeof(int32_t), hipMemcpyDefault, st));
-        HIPCHK(hipMemsetAsync(b->d_z.p, 0, (size_t)z_words * sizeof(uint16_t), st));
+        HIPCHK(hipMemsetAsync(b->d_z.p, 0, (size_t)n_blocks * 64 * sizeof(uint16_t), st));
         praline_launch_rawb_zero(b->view(), b->d_zero_req.p, b->d_zero_idx.p, b->n_zero, st);
         HIPCHK(hipGetLastError());
     }

@@ -15,6 +15,7 @@ if [ -n "$VARIANT_PIPE_ONLY" ]; then cp $C/build/dp_split16.o $OUT/obj_$NAME/dp_
 if [ -n "$VARIANT_TB" ]; then /opt/rocm/bin/hipcc $FLAGS "$@" -c $C/dp_tb2_instance.hip -o $OUT/obj_$NAME/dp_tb2.o & else cp $C/build/dp_tb2.o $OUT/obj_$NAME/dp_tb2.o; fi
 if [ -n "$VARIANT_QUAD" ]; then /opt/rocm/bin/hipcc ${FLAGS% -mllvm -amdgpu-mfma-vgpr-form} "$@" -c $C/dp_quad_instance.hip -o $OUT/obj_$NAME/dp_quad.o & fi
 if [ -n "$VARIANT_PK16" ]; then /opt/rocm/bin/hipcc ${FLAGS% -mllvm -amdgpu-mfma-vgpr-form} "$@" -c $C/dp_pk16_instance.hip -o $OUT/obj_$NAME/dp_pk16.o & fi
+if [ -n "$VARIANT_RAWB" ]; then /opt/rocm/bin/hipcc ${FLAGS% -mllvm -amdgpu-mfma-vgpr-form} "$@" -c $C/dp_rawb_instance.hip -o $OUT/obj_$NAME/dp_rawb.o & fi
 if [ -n "$VARIANT_HOST" ]; then /opt/rocm/bin/hipcc ${FLAGS% -mllvm -amdgpu-mfma-vgpr-form} "$@" -c $C/praline_dp.hip -o $OUT/obj_$NAME/praline_dp.o & fi
 if [ -n "$VARIANT_BATCH" ]; then for n in 2 8 10 12 14 16; do /opt/rocm/bin/hipcc ${FLAGS% -mllvm -amdgpu-mfma-vgpr-form} $VARIANT_BATCH_FLAGS "$@" -DPRALINE_NSTEP_INST=$n -c $C/dp_instance.hip -o $OUT/obj_$NAME/dp_instance_$n.o & done; fi
 wait
@@ -23,5 +24,6 @@ if [ -n "$VARIANT_BATCH" ]; then OBJS="$(echo "$OBJS" | grep -v "dp_instance_") 
 if [ -n "$VARIANT_HOST" ]; then OBJS="$(echo "$OBJS" | grep -v "praline_dp.o") $OUT/obj_$NAME/praline_dp.o"; fi
 if [ -n "$VARIANT_QUAD" ]; then OBJS="$(echo "$OBJS" | grep -v "dp_quad.o") $OUT/obj_$NAME/dp_quad.o"; fi
 if [ -n "$VARIANT_PK16" ]; then OBJS="$(echo "$OBJS" | grep -v "dp_pk16.o") $OUT/obj_$NAME/dp_pk16.o"; fi
+if [ -n "$VARIANT_RAWB" ]; then OBJS="$(echo "$OBJS" | grep -v "dp_rawb.o") $OUT/obj_$NAME/dp_rawb.o"; fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $OUT/obj_$NAME/dp_split16.o $OUT/obj_$NAME/dp_pipe.o $OUT/obj_$NAME/dp_tb2.o -o $OUT/libpraline_dp_$NAME.so
 echo built $OUT/libpraline_dp_$NAME.so
