@@ -8,11 +8,12 @@
 //   - up neighbour (y - 1, x): lane l - 1's previous step, one `v_mov_b32_dpp wave_shr:1`; the diagonal neighbour is the up
 //     neighbour of the step before;
 //   - m[y][x]: a lane reads along its own row, 16 floats per 16 steps into registers, the load of the next 16 in flight
-//     (addresses skewed by the lane: all lanes use element i of their 16 at the same step - no LDS staging, no transposition);
+//     (columns skewed by the lane: all lanes use element i of their 16 at the same step - no LDS staging);
 //   - g1[y] is a lane constant, g2[x] enters at lane 0 and moves down one lane per step (wave_shr:1 again);
-//   - the seven tie flags of a cell are one byte; a lane stores 16 of them per 16 steps into its flag row, rows skewed by
-//     (y - 1) % 64 bytes so that the stores are 16-byte aligned;
-//   - zero cells: one bit per cell in the same skewed row layout (k_rawb_zero).
+//   - the tie flags of a cell are one byte (as far as the traceback reads them: see rawb_chunk); a lane stores 16 of them per
+//     16 steps;
+//   - zero cells: one bit per cell (k_rawb_zero);
+//   - m, flags and zero bits lie in [strip][chunk][lane] order (dp_rawb.h): every wave-level access is one contiguous block.
 // Lane 0 takes its up neighbour - the last row of the strip above - from an LDS ring written by lane 63 of the wave that owns
 // that strip and runs >= 64 columns ahead; the waves signal progress through two LDS counters per ring, checked every 16
 // steps (no barrier: a wave whose strips are done leaves).  Wave 0 is fed from memory instead, sixteen columns at a time
@@ -138,15 +139,6 @@ __global__ __launch_bounds__(256) void k_rawb_zero(RawBatchDev d, const int32_t 
     atomicOr(w32, 1u << ((p & 15) + ((word & 1) ? 16 : 0)));
 }
 
-// f = 2 f + (a == b): a tie flag shifted in with two instructions (compare into vcc, add with carry) instead of compare,
-// select and an OR per three flags
-__device__ __forceinline__ unsigned rawb_flag_in(unsigned f, float a, float b)
-{
-    unsigned r;
-    __asm__("v_cmp_eq_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %3, %3, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(f) : "vcc");
-    return r;
-}
-
 // sixteen steps of one strip.  EDGE: some lane is before its first or at / beyond its last column in these steps.  OUT: where
 // the strip's last row goes - 0 nowhere, 1 the LDS ring of the wave below, 2 the `wrap` row in memory (the wave below is wave 0
 // of the next round), 3 the request's last row (end cell of the global and semiglobal modes).
@@ -180,15 +172,15 @@ __device__ __forceinline__ void rawb_chunk(const RawbRow16 &mrow, unsigned zbits
         float umax = __builtin_fmaxf(up_open, up_ext);
         const float lf_open = curM + go2, lf_ext = curL + ge2;
         float lmax = __builtin_fmaxf(lf_open, lf_ext);
-        // bits 6 .. 0 = lf_ext, lf_open, up_ext, up_open, ml, mu, mm: the reference's flag byte (cext.c:155-183) shifted right by one
-        unsigned f = lf_ext == lmax ? 1u : 0u;
+        // The reference's flag byte (cext.c:155-183; here shifted right by one: bits 6 .. 0 = lf_ext, lf_open, up_ext, up_open, ml,
+        // mu, mm) - as far as the traceback reads it: it takes the FIRST set flag of a state's group (praline/util/align.py:155-183),
+        // so the last flag of every group may be set unconditionally (one of up_open / up_ext equals their maximum: if not the
+        // first, then the second; the same for lf_* and - without the local mode's zero - for mm / mu / ml).  Four compares instead
+        // of seven (five in local mode), the same paths.
+        unsigned f = LOCAL ? 0x50u : 0x54u;
         if (!(PRALINE_RAWB_ABLATE & 1)) {
-            f = rawb_flag_in(f, lf_open, lmax);
-            f = rawb_flag_in(f, up_ext, umax);
-            f = rawb_flag_in(f, up_open, umax);
-            f = rawb_flag_in(f, ml, mmax);
-            f = rawb_flag_in(f, mu, mmax);
-            f = rawb_flag_in(f, mm, mmax);
+            f |= (mm == mmax ? 1u : 0u) | (mu == mmax ? 2u : 0u) | (up_open >= up_ext ? 8u : 0u) | (lf_open >= lf_ext ? 32u : 0u);
+            if (LOCAL) f |= ml == mmax ? 4u : 0u;
         }
         if (MASK) {
             const bool zc = (zbits >> i) & 1u;   // a zero cell keeps what the caller initialised: zeros (align.py:362-367, cext.c:147-149)
