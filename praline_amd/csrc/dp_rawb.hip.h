@@ -470,9 +470,13 @@ __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
                 for (int j = 0; j < RAWB_TILE_W / 16; ++j) piece[j] = make_uint4(0u, 0u, 0u, 0u);
                 if (yy >= 1) {
                     // (consecutive chunks of a row are 64 uint4 apart: dp_rawb.h)
-                    const uint4 *src = t + ((int64_t)((yy - 1) >> 6) * rq.ncs + (window(yy) >> 4)) * 64 + ((yy - 1) & 63);
+                    // (a strip of a narrow request has fewer chunk blocks than a tile is wide: never beyond them - behind the last
+                    // strip of the last request the arena ends)
+                    const int c0 = window(yy) >> 4;
+                    const uint4 *src = t + ((int64_t)((yy - 1) >> 6) * rq.ncs + c0) * 64 + ((yy - 1) & 63);
 #pragma unroll
-                    for (int j = 0; j < RAWB_TILE_W / 16; ++j) piece[j] = src[64 * j];
+                    for (int j = 0; j < RAWB_TILE_W / 16; ++j)
+                        if (c0 + j < rq.ncs) piece[j] = src[64 * j];
                 }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads of the tile this one replaces)
 #pragma unroll

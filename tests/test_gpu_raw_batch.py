@@ -105,7 +105,7 @@ def test_every_request_in_every_mode_and_shape_corner(nat):
     and chunk sizes of the kernel (64 rows per wave, 16 columns per register block), single rows and columns."""
     rng = np.random.default_rng(7)
     shapes = [(1, 1), (1, 70), (70, 1), (2, 2), (63, 15), (64, 16), (65, 17), (64, 64), (128, 33), (129, 48), (17, 300),
-              (300, 17), (191, 193), (512, 40), (513, 40)]
+              (300, 17), (191, 193), (512, 40), (513, 40), (200, 3), (150, 2)]   # (narrow ones: fewer chunk blocks per strip than a traceback tile is wide)
     reqs = []
     for L1, L2 in shapes:
         m, g1, g2, z = rand_request(rng, 1, 1, zero_share=0.0)
