@@ -352,13 +352,13 @@ __device__ __forceinline__ unsigned long long rawb_wave_min_u64(unsigned long lo
 
 // End cell (align.py:401-431), score and path (praline/util/align.py:144-185, 268-297) of every request: one wave each.  The
 // lanes search the last row / column (or the lanes' first maxima and the boundary cells, local mode) together; the walk
-// itself is serial, so the wave fetches the flags it is about to need as a tile - 64 rows x 128 bytes ending at the current
+// itself is serial, so the wave fetches the flags it is about to need as a tile - 64 rows x 128 columns ending at the current
 // cell, one row per lane - into LDS and walks inside it until the path leaves it (a step is an LDS read instead of a dependent
 // read of memory: ~15 tile fetches instead of ~800 memory round trips for a 400 x 400 alignment).
-#define RAWB_TILE_W 128
+#define RAWB_TILE_RS 176   // bytes per tile row in LDS: 16 of headroom for the dword shift, 36 dwords, 16 spare (and rows 44 banks apart)
 __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
 {
-    __shared__ uint4 tiles[4][64][RAWB_TILE_W / 16 + 1];   // (+ 16 bytes per row: the lanes' row writes spread over the banks)
+    __shared__ uint4 tiles[4][64 * RAWB_TILE_RS / 16];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the walk is uniform)
     const int r = blockIdx.x * 4 + wv;
     if (r >= d.n) return;
@@ -449,52 +449,69 @@ __global__ __launch_bounds__(256) void k_rawb_trace(RawBatchDev d)
     }
     emit(y, x);
     const uint4 *t = reinterpret_cast<const uint4 *>(d.t) + rq.t_off;
-    const uint8_t *tile = reinterpret_cast<const uint8_t *>(&tiles[wv][0][0]);
-    int ty = -1, tx = 0;   // the cell the tile was fetched at (ty < 0: none yet)
-    // window of row yy in a tile fetched at (ty, tx): RAWB_TILE_W bytes from a 16-byte boundary, at least RAWB_TILE_W - 32 of
-    // them to the left of the cell
-    auto window = [&](int yy) { return max(0, (tx - 1) + ((yy - 1) & 63) - (RAWB_TILE_W - 17)) & ~15; };
-    for (int guard = 0; guard < cap; ++guard) {
-        unsigned f;
-        if (y == 0 && x == 0) f = 0;
-        else if (x == 0) f = (k == 1 && !free_one) ? 32u : 0u;      // t[1:,0,1] = insert-up-extend (align.py:377)
-        else if (y == 0) f = (k == 2 && !free_two) ? 128u : 0u;     // t[0,1:,2] = insert-left-extend (align.py:385)
-        else {
-            const int p = (x - 1) + ((y - 1) & 63);
-            if (ty < 0 || ty - y > 63 || p < window(y)) {
-                // fetch: lane i = row ty - i
-                ty = y; tx = x;
-                const int yy = ty - lane;
-                uint4 piece[RAWB_TILE_W / 16];
-#pragma unroll
-                for (int j = 0; j < RAWB_TILE_W / 16; ++j) piece[j] = make_uint4(0u, 0u, 0u, 0u);
-                if (yy >= 1) {
-                    // (consecutive chunks of a row are 64 uint4 apart: dp_rawb.h)
-                    // (a strip of a narrow request has fewer chunk blocks than a tile is wide: never beyond them - behind the last
-                    // strip of the last request the arena ends)
-                    const int c0 = window(yy) >> 4;
-                    const uint4 *src = t + ((int64_t)((yy - 1) >> 6) * rq.ncs + c0) * 64 + ((yy - 1) & 63);
-#pragma unroll
-                    for (int j = 0; j < RAWB_TILE_W / 16; ++j)
-                        if (c0 + j < rq.ncs) piece[j] = src[64 * j];
-                }
-                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads of the tile this one replaces)
-#pragma unroll
-                for (int j = 0; j < RAWB_TILE_W / 16; ++j) tiles[wv][lane][j] = piece[j];
-                __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
-            f = tile[(ty - y) * (RAWB_TILE_W + 16) + (p - window(y))];
-            f = __builtin_amdgcn_readfirstlane(f);
+    // A tile: rows ty - 63 .. ty, columns xw .. xw + 127 with xw = max(1, tx - 111), fetched at the cell (ty, tx).  Lane i
+    // loads the nine 16-byte pieces of row ty - i that hold those columns (a row's pieces start at step boundaries, i.e. at
+    // x - 1 + lane of the row: a different byte offset per row), shifts them so that column xw comes first - the bytes with
+    // v_alignbyte, the dwords through the LDS address - and the walk's address is (rows up) * RAWB_TILE_RS + (x - xw):
+    // + RAWB_TILE_RS for a step up, - 1 for a step left.
+    uint8_t *tile = reinterpret_cast<uint8_t *>(&tiles[wv][0]);
+    int ty = -1, tx = 0, xw = 0;
+    int guard = 0;
+    bool done = false;
+    while (!done && guard < cap) {
+        if (y == 0 || x == 0) {
+            // on the boundary row / column: t[1:,0,1] = insert-up-extend (align.py:377), t[0,1:,2] = insert-left-extend (align.py:385)
+            unsigned f = 0;
+            if (y == 0 && x == 0) f = 0;
+            else if (x == 0) f = (k == 1 && !free_one) ? 32u : 0u;
+            else f = (k == 2 && !free_two) ? 128u : 0u;
+            if (f == 0) break;
+            if (f == 32u) --y; else --x;
+            emit(y, x);
+            ++guard;
+            continue;
         }
-        f &= k == 0 ? 0x0eu : (k == 1 ? 0x30u : 0xc0u);
-        if (f == 0) break;
-        // the lowest set flag decides (praline/util/align.py:155-183): match from M / U / L (bits 1-3: up-left, next state 0 / 1 / 2),
-        // insert-up open / extend (bits 4, 5: up, state 0 / 1), insert-left open / extend (bits 6, 7: left, state 0 / 2)
-        const int bit = __builtin_ctz(f) - 1;
-        y -= (0x1f >> bit) & 1;
-        x -= (0x67 >> bit) & 1;
-        k = (0x2124 >> (2 * bit)) & 3;
-        emit(y, x);
+        if (ty < 0 || ty - y > 63 || x < xw) {
+            ty = y; tx = x; xw = max(1, tx - 111);
+            const int yy = ty - lane;
+            unsigned wd[37];
+#pragma unroll
+            for (int e = 0; e < 37; ++e) wd[e] = 0u;
+            int a = 0;
+            if (yy >= 1) {
+                const int p0 = (xw - 1) + ((yy - 1) & 63), c0 = p0 >> 4;
+                a = p0 & 15;
+                // (a strip of a narrow request has fewer chunk blocks than a tile is wide: never beyond them - behind the last
+                // strip of the last request the arena ends)
+                const uint4 *src = t + ((int64_t)((yy - 1) >> 6) * rq.ncs + c0) * 64 + ((yy - 1) & 63);
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+                    if (c0 + q < rq.ncs) { const uint4 v = src[64 * q]; wd[4 * q] = v.x; wd[4 * q + 1] = v.y; wd[4 * q + 2] = v.z; wd[4 * q + 3] = v.w; }
+            }
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads of the tile this one replaces)
+            // bytes a & 3 out with v_alignbyte, dwords a >> 2 out through the address: byte (x - xw) of the row lands at offset x - xw
+            unsigned *row = reinterpret_cast<unsigned *>(tile + lane * RAWB_TILE_RS + 16) - (a >> 2);
+#pragma unroll
+            for (int e = 0; e < 36; ++e) row[e] = __builtin_amdgcn_alignbyte(wd[e + 1], wd[e], (unsigned)(a & 3));
+            __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        // inside the tile
+        int up = ty - y;
+        int addr = up * RAWB_TILE_RS + 16 + (x - xw);
+        while (true) {
+            unsigned f = __builtin_amdgcn_readfirstlane((unsigned)tile[addr]);
+            f &= (0xc0300eu >> (8 * k)) & 0xffu;
+            if (f == 0) { done = true; break; }
+            // the lowest set flag decides (praline/util/align.py:155-183): match from M / U / L (bits 1-3: up-left, next state
+            // 0 / 1 / 2), insert-up open / extend (bits 4, 5: up, state 0 / 1), insert-left open / extend (bits 6, 7: left, state 0 / 2)
+            const int bit = __builtin_ctz(f) - 1;
+            const int dy = (0x1f >> bit) & 1, dx = (0x67 >> bit) & 1;
+            k = (0x2124 >> (2 * bit)) & 3;
+            y -= dy; x -= dx; up += dy;
+            addr += dy * RAWB_TILE_RS - dx;
+            emit(y, x);
+            if (++guard >= cap || y == 0 || x < xw || up > 63) break;   // (x < xw covers x == 0: xw >= 1)
+        }
     }
     if (semiglobal) {
         if (y != 0) { for (int yy = y - 1; yy >= 0; --yy) emit(yy, 0); }
