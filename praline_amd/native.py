@@ -335,6 +335,21 @@ class RawBatch(object):
                                               z_all.ctypes.data if z_all is not None else None, ctypes.byref(h)))
         self._h = h
 
+    @classmethod
+    def from_pointers(cls, l1, l2, m_ptr, g1_ptr, g2_ptr):
+        """Requests whose arrays already lie one after the other in host or DEVICE memory (m: the l1[r] x l2[r] float32
+        matrices, g1 / g2: float32 [l1[r]][2] / [l2[r]][2]); no zero cells.  The arrays are copied into the batch's own
+        layout by the call and may be released afterwards."""
+        self = cls.__new__(cls)
+        self.l1 = np.ascontiguousarray(l1, dtype=np.int32)
+        self.l2 = np.ascontiguousarray(l2, dtype=np.int32)
+        self.n = len(self.l1)
+        h = ctypes.c_void_p()
+        _check(lib().praline_raw_batch_create(self.n, self.l1.ctypes.data, self.l2.ctypes.data, int(m_ptr), int(g1_ptr),
+                                              int(g2_ptr), None, None, ctypes.byref(h)))
+        self._h = h
+        return self
+
     @property
     def cells(self):
         return int(lib().praline_raw_batch_cells(self._h))

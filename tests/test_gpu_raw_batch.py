@@ -167,6 +167,31 @@ def test_batch_equals_the_single_request_entry_point(nat):
         assert np.float32(s) == scores[r] and np.array_equal(p, paths[r]), (r, modes[r], m.shape)
 
 
+def test_requests_resident_in_device_memory(nat):
+    """m, g1, g2 of the whole list in DEVICE memory (torch tensors): praline_raw_batch_create takes the pointers as they are."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    rng = np.random.default_rng(21)
+    reqs = [rand_request(rng, 30, 200, zero_share=0.0) for _ in range(24)]
+    dev = torch.device("cuda", 0)
+    m = torch.from_numpy(np.concatenate([r[0].reshape(-1) for r in reqs])).to(dev)
+    g1 = torch.from_numpy(np.concatenate([r[1].reshape(-1) for r in reqs])).to(dev)
+    g2 = torch.from_numpy(np.concatenate([r[2].reshape(-1) for r in reqs])).to(dev)
+    torch.cuda.synchronize()
+    rb = nat.RawBatch.from_pointers([r[0].shape[0] for r in reqs], [r[0].shape[1] for r in reqs], m.data_ptr(), g1.data_ptr(),
+                                    g2.data_ptr())
+    del m, g1, g2
+    try:
+        for mode in ("global", "local", "semiglobal_one"):
+            scores, paths = rb.run(mode).results()
+            for r, (mm, a, b, _) in enumerate(reqs):
+                s, p = orc.raw_pairwise_align(mode, mm, a, b, None)
+                assert scores[r] == np.float32(s) and np.array_equal(paths[r], np.asarray(p)), (mode, r)
+    finally:
+        rb.close()
+
+
 def test_raw_batch_rejects_misuse(nat):
     L = nat.lib()
     h = ctypes.c_void_p()
