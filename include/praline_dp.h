@@ -290,8 +290,9 @@ int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float g
  * praline/util/cext.c:99-306).  Request r aligns its own match scores m_r (float32 [l1[r]][l2[r]], row-major) under its own
  * gap scores g1_r (float32 [l1[r]][2]) and g2_r (float32 [l2[r]][2]: open, extend per position, align.py:346-348) with its
  * own zero cells (zero_idxs: (y, x) cells of the DP matrix fixed to zero, align.py:362-367).  m, g1, g2: the requests'
- * arrays one after the other, host or device memory; zero_off [n + 1] delimits request r's (y, x) pairs in zero_idx (both
- * NULL: no zero cells).  The inputs are copied once; praline_raw_batch_run may be called any number of times (per-request
+ * arrays one after the other, host or device memory; zero_off [n + 1] (host memory) delimits request r's (y, x) pairs in
+ * zero_idx (host or device memory; both NULL: no zero cells; cells outside 1 .. l1[r] x 1 .. l2[r] have no effect, as in
+ * cext.c:141-149, whose loops start at 1).  l1, l2: host memory.  The inputs are copied once; praline_raw_batch_run may be called any number of times (per-request
  * modes, or one mode for all with modes = NULL), asynchronously on the library stream; praline_raw_batch_results waits and
  * returns the scores and path lengths, praline_raw_batch_paths the paths (int32 (y, x) rows as get_paths +
  * extend_path_semiglobal produce them, praline/util/align.py:144-185, 268-297) one after the other in request order.
