@@ -16,6 +16,7 @@
 #include <thread>
 #include <chrono>
 #include <mutex>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -106,6 +107,11 @@ int sched_threads(int64_t n_pairs)
 // A small persistent pool (created on first use, lives as long as the library): a pass over the pair list is a few
 // hundred microseconds of work per thread, which spawning threads per pass would eat.  One caller at a time (the library is
 // for one host thread per device; praline_sched_prepare may run beside it on another thread: the mutex serialises them).
+// A schedule is fifteen to twenty such passes back to back, and waking fifteen sleepers through one condition variable cost
+// 100-250 us per pass - as much as the passes themselves for a million pairs: a worker therefore spins on the generation
+// counter for a short while after a pass (the next one usually follows within microseconds) before it goes to sleep, and
+// the caller spins as briefly for the last worker.  EVERY pool thread acknowledges every generation (those beyond the
+// pass's thread count without doing work), so the job description is never replaced while a worker may still read it.
 class SchedPool {
 public:
     static SchedPool &get() { static SchedPool p; return p; }
@@ -113,20 +119,32 @@ public:
     {
         std::lock_guard<std::mutex> whole(one_caller_);
         ensure(nt - 1);
+        job_ = &fn; job_nt_ = nt;
+        pending_.store((int)th_.size(), std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn; job_nt_ = nt; pending_ = nt - 1; ++gen_;
+            std::lock_guard<std::mutex> lk(m_);   // (under the mutex: a worker between its predicate and its wait cannot miss it)
+            gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         fn(0, nt);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&] { return pending_ == 0; });
+        for (int spins = 0; pending_.load(std::memory_order_acquire) != 0;) {
+            if (++spins < kSpins) { cpu_relax(); continue; }
+            std::unique_lock<std::mutex> lk(m_);
+            done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
         job_ = nullptr;
     }
 private:
+    static constexpr int kSpins = 20000;   // ~100-200 us of polling
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
     ~SchedPool()
     {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        { std::lock_guard<std::mutex> lk(m_); stop_.store(true, std::memory_order_relaxed); gen_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
         for (std::thread &t : th_) t.join();
     }
@@ -134,23 +152,26 @@ private:
     {
         while ((int)th_.size() < n) {
             const int id = (int)th_.size() + 1;
-            uint64_t seen;
-            { std::lock_guard<std::mutex> lk(m_); seen = gen_; }
-            th_.emplace_back([this, id, seen]() mutable {
+            const uint64_t seen0 = gen_.load(std::memory_order_acquire);
+            th_.emplace_back([this, id, seen0]() {
+                uint64_t seen = seen0;
                 for (;;) {
-                    const std::function<void(int, int)> *job = nullptr;
-                    int nt = 0;
-                    {
+                    uint64_t g = seen;
+                    for (int spins = 0; (g = gen_.load(std::memory_order_acquire)) == seen && spins < kSpins; ++spins) cpu_relax();
+                    if (g == seen) {
                         std::unique_lock<std::mutex> lk(m_);
-                        cv_.wait(lk, [&] { return gen_ != seen; });
-                        seen = gen_;
-                        if (stop_) return;
-                        job = job_; nt = job_nt_;
+                        cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                        g = gen_.load(std::memory_order_acquire);
                     }
-                    if (job && id < nt) {
-                        (*job)(id, nt);
+                    seen = g;
+                    if (stop_.load(std::memory_order_relaxed)) return;
+                    // (job_ / job_nt_ were written before the generation was published and stay until every thread has acknowledged)
+                    const std::function<void(int, int)> *job = job_;
+                    const int nt = job_nt_;
+                    if (job && id < nt) (*job)(id, nt);
+                    if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                         std::lock_guard<std::mutex> lk(m_);
-                        if (--pending_ == 0) done_.notify_one();
+                        done_.notify_one();
                     }
                 }
             });
@@ -160,9 +181,10 @@ private:
     std::condition_variable cv_, done_;
     std::vector<std::thread> th_;
     const std::function<void(int, int)> *job_ = nullptr;
-    int job_nt_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
+    int job_nt_ = 0;
+    std::atomic<int> pending_{0};
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<bool> stop_{false};
 };
 
 template <class F> void run_threads(int nt, F &&fn)   // fn(thread, n_threads)
