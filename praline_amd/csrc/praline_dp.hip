@@ -110,7 +110,12 @@ extern "C" int praline_device_count(int *count)
     return PRALINE_OK;
 }
 
-extern "C" int praline_init(int device) { return ensure_runtime(device); }
+extern "C" int praline_init(int device)
+{
+    const int rc = ensure_runtime(device);
+    if (rc == PRALINE_OK) sched_warm_threads();
+    return rc;
+}
 
 extern "C" int praline_shutdown(void)
 {

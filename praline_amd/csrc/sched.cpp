@@ -115,6 +115,11 @@ int sched_threads(int64_t n_pairs)
 class SchedPool {
 public:
     static SchedPool &get() { static SchedPool p; return p; }
+    void warm(int nt)
+    {
+        std::lock_guard<std::mutex> whole(one_caller_);
+        ensure(nt - 1);
+    }
     void run(int nt, const std::function<void(int, int)> &fn)
     {
         std::lock_guard<std::mutex> whole(one_caller_);
@@ -186,6 +191,12 @@ private:
     std::atomic<uint64_t> gen_{0};
     std::atomic<bool> stop_{false};
 };
+
+}  // namespace
+
+void sched_warm_threads() { SchedPool::get().warm(sched_threads((int64_t)1 << 20)); }
+
+namespace {
 
 template <class F> void run_threads(int nt, F &&fn)   // fn(thread, n_threads)
 {

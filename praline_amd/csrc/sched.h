@@ -29,6 +29,9 @@ template <class T> struct NoInitAlloc {
 };
 template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
 
+// starts the scheduler's host threads (otherwise the first plan of a million pairs pays for them: ~1 ms)
+void sched_warm_threads();
+
 struct SchedOptions {
     bool want_paths = false;
     bool split_layout = true;     // split-strip kernels (32 pairs per task); false: the retired 64-lane task layout (scheduler unit tests only)
