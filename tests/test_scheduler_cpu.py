@@ -286,3 +286,24 @@ def test_threaded_passes_give_the_one_thread_schedules(sched, pipe_sched, monkey
     # the same pair twice: not for the pipeline layout, in either version
     dup = np.concatenate([ordered[:70000], ordered[123:124]])
     assert not pipe_sched(lens, dup)[0] and not pipe_sched(lens, dup, block_twos=-32)[0]
+
+
+def test_thread_pool_back_to_back_with_changing_thread_counts(pipe_sched, monkeypatch):
+    """The scheduler's pool threads poll for the next pass before they sleep and every pool thread acknowledges every pass,
+    also those beyond the pass's thread count: many schedules back to back with the thread count changing from call to
+    call (and pauses long enough for the workers to fall asleep) give the one-thread schedule every time."""
+    import time
+    rng = np.random.default_rng(23)
+    n = 380
+    lens = synth_lengths(rng, n, 100)
+    pairs = all_pairs(n)                                                   # 72 010 pairs: above the threading threshold
+    monkeypatch.setenv("PRALINE_SCHED_THREADS", "1")
+    want = pipe_sched(lens, pairs)
+    assert want[0]
+    for k in range(60):
+        monkeypatch.setenv("PRALINE_SCHED_THREADS", str(int(rng.integers(2, 9))))
+        got = pipe_sched(lens, pairs)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), k
+        if k % 20 == 19:
+            time.sleep(0.02)
+    monkeypatch.delenv("PRALINE_SCHED_THREADS")
