@@ -26,7 +26,7 @@ struct RawReq {
     int64_t z_off;                   // 16-bit words (even): zero-cell bits of (strip k, chunk c), lane l at z_off + (k * ncs + c) * 64 + l
     int64_t top_off;                 // float4 elements: the boundary row o[0][x], x = 0 .. L2 (+ PRALINE_RAWB_ROW_PAD); the same offset in `wrap`
     int64_t edge_off;                // float4 elements: o[L1][x], x = 0 .. L2, then o[y][L2], y = 0 .. L1
-    int64_t best_off;                // float4 elements [PRALINE_RAWB_WAVES * 64]: every lane's first maximum (local mode)
+    int64_t best_off;                // float4 elements [min(nstrips, PRALINE_RAWB_WAVES) * 64]: every lane's first maximum (local mode)
     int64_t path_off;                // path rows (int32 pairs): a slot of L1 + L2 + 2 rows
 };
 

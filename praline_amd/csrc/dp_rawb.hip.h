@@ -2,7 +2,8 @@
 // praline/util/cext.c:99-306): every request has its own m, g1, g2 and zero cells, so there is nothing for the lanes of a
 // wave to share ACROSS requests - the parallelism is inside one request.
 //
-// k_rawb_fill: one workgroup per request, one wave per strip of 64 ROWS.  Lane l owns row y0 + l and walks along it; at step
+// k_rawb_fill: one workgroup per request at a time (it walks every PRALINE_RAWB_GROUPS-th request of the size-sorted list), one
+// wave per strip of 64 ROWS.  Lane l owns row y0 + l and walks along it; at step
 // s it computes column x = s - l, the cells of one step form an anti-diagonal:
 //   - left neighbour (y, x - 1): the lane's own previous step;
 //   - up neighbour (y - 1, x): lane l - 1's previous step, one `v_mov_b32_dpp wave_shr:1`; the diagonal neighbour is the up
@@ -27,7 +28,7 @@
 
 #define RAWB_NEG_INF (-__builtin_inff())
 // measurement builds only (scripts/build_variant.sh, VARIANT_RAWB=1): bit 0 no tie flags, bit 1 no waiting for the neighbour
-// strips, bit 2 no zero-cell / boundary selects - wrong results, never in the product library
+// strips - wrong results, never in the product library
 #ifndef PRALINE_RAWB_ABLATE
 #define PRALINE_RAWB_ABLATE 0
 #endif

@@ -68,7 +68,7 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
     b->cells = m_off[(size_t)n];
     b->reqs.resize((size_t)n);
     b->place.resize((size_t)n);
-    int64_t n_blocks = 0, rows4 = 0, edge4 = 0, path_rows = 0;
+    int64_t n_blocks = 0, rows4 = 0, edge4 = 0, path_rows = 0, best4 = 0;
     std::vector<int64_t> block0((size_t)n);
     int max_strips = 1;
     for (int64_t q = 0; q < n; ++q) {
@@ -88,7 +88,7 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
         n_blocks += blocks;
         rq.top_off = rows4; rows4 += l2[r] + PRALINE_RAWB_ROW_PAD;
         rq.edge_off = edge4; edge4 += l1[r] + l2[r] + 2;
-        rq.best_off = q * (PRALINE_RAWB_WAVES * 64);
+        rq.best_off = best4; best4 += (int64_t)std::min(rq.nstrips, PRALINE_RAWB_WAVES) * 64;   // (a record per lane of the waves that take part)
         rq.path_off = path_rows; path_rows += l1[r] + l2[r] + 2;
         max_strips = std::max(max_strips, rq.nstrips);
     }
@@ -105,7 +105,7 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
     RC(b->d_top.alloc((size_t)rows4));
     RC(b->d_wrap.alloc(max_strips > PRALINE_RAWB_WAVES ? (size_t)rows4 : 1));
     RC(b->d_edge.alloc((size_t)edge4));
-    RC(b->d_best.alloc((size_t)n * PRALINE_RAWB_WAVES * 64));
+    RC(b->d_best.alloc((size_t)best4));
     RC(b->d_t.alloc((size_t)n_blocks * 1024));
     RC(b->d_paths.alloc((size_t)path_rows * 2));
     RC(b->d_info.alloc((size_t)n * 2));
