@@ -301,6 +301,9 @@ int praline_batch_scores(praline_arena *arena, int mode, float gap_open, float g
 typedef struct praline_raw_batch praline_raw_batch;
 int praline_raw_batch_create(int64_t n, const int32_t *l1, const int32_t *l2, const float *m, const float *g1, const float *g2,
                              const int64_t *zero_off, const int32_t *zero_idx, praline_raw_batch **out);
+/* The same with one pointer per request: m[r], g1[r], g2[r] (host or device memory each) - no concatenation on the caller's side. */
+int praline_raw_batch_create_v(int64_t n, const int32_t *l1, const int32_t *l2, const float *const *m, const float *const *g1,
+                               const float *const *g2, const int64_t *zero_off, const int32_t *zero_idx, praline_raw_batch **out);
 int praline_raw_batch_run(praline_raw_batch *batch, const int32_t *modes, int mode);
 int praline_raw_batch_results(praline_raw_batch *batch, float *scores, int64_t *path_rows);
 int praline_raw_batch_paths(praline_raw_batch *batch, int32_t *paths, int64_t cap_rows);

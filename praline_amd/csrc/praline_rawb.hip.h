@@ -40,12 +40,23 @@ struct praline_raw_batch {
     }
 };
 
-extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int32_t *l2, const float *m, const float *g1, const float *g2,
-                                        const int64_t *zero_off, const int32_t *zero_idx, praline_raw_batch **out)
+// the requests' arrays: one after the other (m, g1, g2) or one pointer per request (mv, g1v, g2v)
+struct RawSource {
+    const float *m = nullptr, *g1 = nullptr, *g2 = nullptr;
+    const float *const *mv = nullptr, *const *g1v = nullptr, *const *g2v = nullptr;
+};
+
+static int raw_batch_create_impl(int64_t n, const int32_t *l1, const int32_t *l2, const RawSource &src, const int64_t *zero_off,
+                                 const int32_t *zero_idx, praline_raw_batch **out)
 {
     if (!out) return fail(PRALINE_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (n <= 0 || n > (int64_t)INT32_MAX || !l1 || !l2 || !m || !g1 || !g2) return fail(PRALINE_ERR_ARG, "bad raw batch arguments");
+    const bool listed = src.mv != nullptr;
+    if (n <= 0 || n > (int64_t)INT32_MAX || !l1 || !l2 || (listed ? (!src.g1v || !src.g2v) : (!src.m || !src.g1 || !src.g2)))
+        return fail(PRALINE_ERR_ARG, "bad raw batch arguments");
+    if (listed)
+        for (int64_t r = 0; r < n; ++r)
+            if (!src.mv[r] || !src.g1v[r] || !src.g2v[r]) return fail(PRALINE_ERR_ARG, "request %lld: NULL array", (long long)r);
     if ((zero_off != nullptr) != (zero_idx != nullptr) && zero_off && zero_off[n] > 0) return fail(PRALINE_ERR_ARG, "zero_off given without zero_idx");
     for (int64_t r = 0; r < n; ++r) {
         if (l1[r] < 1 || l2[r] < 1) return fail(PRALINE_ERR_ARG, "request %lld: m has shape %d x %d (both must be >= 1)", (long long)r, l1[r], l2[r]);
@@ -116,8 +127,15 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
     // used: it only has to exist - it is cleared once so that no run reads uninitialised memory.
     HIPCHK(hipMemsetAsync(b->d_g1.p + g1_off[(size_t)n], 0, PRALINE_RAWB_ROW_PAD * sizeof(float2), st));
     HIPCHK(hipMemsetAsync(b->d_g2.p + g2_off[(size_t)n], 0, PRALINE_RAWB_ROW_PAD * sizeof(float2), st));
-    HIPCHK(hipMemcpyAsync(b->d_g1.p, g1, (size_t)g1_off[(size_t)n] * sizeof(float2), hipMemcpyDefault, st));
-    HIPCHK(hipMemcpyAsync(b->d_g2.p, g2, (size_t)g2_off[(size_t)n] * sizeof(float2), hipMemcpyDefault, st));
+    if (listed) {
+        for (int64_t r = 0; r < n; ++r) {
+            HIPCHK(hipMemcpyAsync(b->d_g1.p + g1_off[(size_t)r], src.g1v[r], (size_t)l1[r] * sizeof(float2), hipMemcpyDefault, st));
+            HIPCHK(hipMemcpyAsync(b->d_g2.p + g2_off[(size_t)r], src.g2v[r], (size_t)l2[r] * sizeof(float2), hipMemcpyDefault, st));
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(b->d_g1.p, src.g1, (size_t)g1_off[(size_t)n] * sizeof(float2), hipMemcpyDefault, st));
+        HIPCHK(hipMemcpyAsync(b->d_g2.p, src.g2, (size_t)g2_off[(size_t)n] * sizeof(float2), hipMemcpyDefault, st));
+    }
     HIPCHK(hipMemsetAsync(b->d_error.p, 0, sizeof(int32_t), st));
     HIPCHK(hipMemcpyAsync(b->d_reqs.p, b->reqs.data(), (size_t)n * sizeof(RawReq), hipMemcpyHostToDevice, st));
     {   // m: the caller's rows into the arena's aligned rows (dp_rawb.h)
@@ -125,7 +143,12 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
         DevBuf<int64_t> d_block0;
         RC(tmp.alloc((size_t)b->cells));
         RC(d_block0.upload(block0, st));
-        HIPCHK(hipMemcpyAsync(tmp.p, m, (size_t)b->cells * sizeof(float), hipMemcpyDefault, st));
+        if (listed) {
+            for (int64_t r = 0; r < n; ++r)
+                HIPCHK(hipMemcpyAsync(tmp.p + m_off[(size_t)r], src.mv[r], (size_t)l1[r] * l2[r] * sizeof(float), hipMemcpyDefault, st));
+        } else {
+            HIPCHK(hipMemcpyAsync(tmp.p, src.m, (size_t)b->cells * sizeof(float), hipMemcpyDefault, st));
+        }
         praline_launch_rawb_stage(b->view(), tmp.p, b->d_m.p, d_block0.p, n_blocks, st);
         HIPCHK(hipGetLastError());
     }
@@ -146,6 +169,24 @@ extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int3
     HIPCHK(hipStreamSynchronize(st));   // (the caller's buffers and the staging vectors above are free again)
     *out = b.release();
     return PRALINE_OK;
+}
+
+extern "C" int praline_raw_batch_create(int64_t n, const int32_t *l1, const int32_t *l2, const float *m, const float *g1, const float *g2,
+                                        const int64_t *zero_off, const int32_t *zero_idx, praline_raw_batch **out)
+{
+    RawSource src;
+    src.m = m; src.g1 = g1; src.g2 = g2;
+    return raw_batch_create_impl(n, l1, l2, src, zero_off, zero_idx, out);
+}
+
+// the same with one pointer per request (m[r], g1[r], g2[r]: host or device memory each): no concatenation on the caller's side
+extern "C" int praline_raw_batch_create_v(int64_t n, const int32_t *l1, const int32_t *l2, const float *const *m, const float *const *g1,
+                                          const float *const *g2, const int64_t *zero_off, const int32_t *zero_idx, praline_raw_batch **out)
+{
+    if (!m) return fail(PRALINE_ERR_ARG, "bad raw batch arguments");
+    RawSource src;
+    src.mv = m; src.g1v = g1; src.g2v = g2;
+    return raw_batch_create_impl(n, l1, l2, src, zero_off, zero_idx, out);
 }
 
 // One run of every request: `modes` [n] per request (PRALINE_MODE_*), or NULL and `mode` for all.  Asynchronous on the library

@@ -116,6 +116,7 @@ def lib():
     L.praline_merge_order.argtypes = [i64, vp, i32, vp]
     L.praline_plan_kernel_name.argtypes = [vp, ctypes.c_char_p, i64]
     L.praline_raw_batch_create.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.praline_raw_batch_create_v.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
     L.praline_raw_batch_run.argtypes = [vp, vp, i32]
     L.praline_raw_batch_results.argtypes = [vp, vp, vp]
     L.praline_raw_batch_paths.argtypes = [vp, vp, i64]
@@ -304,7 +305,7 @@ class RawBatch(object):
         n = len(requests)
         if n == 0:
             raise ValueError("empty request list")
-        ms, g1s, g2s, zs = [], [], [], []
+        ms, g1s, g2s, zs = [], [], [], []       # (the arrays themselves: they are handed over by pointer, one per request)
         l1 = np.zeros(n, np.int32)
         l2 = np.zeros(n, np.int32)
         zoff = np.zeros(n + 1, np.int64)
@@ -315,7 +316,7 @@ class RawBatch(object):
             if m.ndim != 2 or g1.shape != (m.shape[0], 2) or g2.shape != (m.shape[1], 2):
                 raise ValueError("request %d: m %s, g1 %s, g2 %s do not fit" % (r, m.shape, g1.shape, g2.shape))
             l1[r], l2[r] = m.shape
-            ms.append(m.reshape(-1)); g1s.append(g1.reshape(-1)); g2s.append(g2.reshape(-1))
+            ms.append(m); g1s.append(g1); g2s.append(g2)
             if zero_idxs is not None and len(zero_idxs):
                 z = np.asarray(zero_idxs, dtype=np.int64).reshape(-1, 2)
                 # (the reference indexes a numpy array with these tuples: negative indices count from the end)
@@ -327,12 +328,15 @@ class RawBatch(object):
             else:
                 zoff[r + 1] = zoff[r]
         self.n, self.l1, self.l2 = n, l1, l2
-        m_all, g1_all, g2_all = np.concatenate(ms), np.concatenate(g1s), np.concatenate(g2s)
+        pm = np.array([a.ctypes.data for a in ms], dtype=np.uint64)
+        pg1 = np.array([a.ctypes.data for a in g1s], dtype=np.uint64)
+        pg2 = np.array([a.ctypes.data for a in g2s], dtype=np.uint64)
         z_all = np.ascontiguousarray(np.concatenate(zs)) if zs else None
         h = ctypes.c_void_p()
-        _check(lib().praline_raw_batch_create(n, l1.ctypes.data, l2.ctypes.data, m_all.ctypes.data, g1_all.ctypes.data,
-                                              g2_all.ctypes.data, zoff.ctypes.data if z_all is not None else None,
-                                              z_all.ctypes.data if z_all is not None else None, ctypes.byref(h)))
+        _check(lib().praline_raw_batch_create_v(n, l1.ctypes.data, l2.ctypes.data, pm.ctypes.data, pg1.ctypes.data,
+                                                pg2.ctypes.data, zoff.ctypes.data if z_all is not None else None,
+                                                z_all.ctypes.data if z_all is not None else None, ctypes.byref(h)))
+        del ms, g1s, g2s                        # (copied: praline_raw_batch_create_v returns after its uploads)
         self._h = h
 
     @classmethod
