@@ -216,6 +216,12 @@ def test_raw_batch_rejects_misuse(nat):
         assert L.praline_raw_batch_cells(h) == 23
     finally:
         L.praline_raw_batch_destroy(h)
+    ptrs = np.array([m.ctypes.data, 0], dtype=np.uint64)      # (one pointer per request: a NULL among them)
+    good = np.array([g1.ctypes.data, g1.ctypes.data], dtype=np.uint64)
+    assert L.praline_raw_batch_create_v(2, l1.ctypes.data, l2.ctypes.data, ptrs.ctypes.data, good.ctypes.data, good.ctypes.data, None, None,
+                                        ctypes.byref(h)) == nat.ERR_ARG
+    assert L.praline_raw_batch_create_v(2, l1.ctypes.data, l2.ctypes.data, None, good.ctypes.data, good.ctypes.data, None, None,
+                                        ctypes.byref(h)) == nat.ERR_ARG
     with pytest.raises(ValueError):
         nat.RawBatch([(np.zeros((3, 4), np.float32), np.zeros((3, 2), np.float32), np.zeros((5, 2), np.float32), None)])
     with pytest.raises(IndexError):
