@@ -17,6 +17,7 @@
 #include <chrono>
 #include <mutex>
 #include <atomic>
+#include <pthread.h>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -114,7 +115,13 @@ int sched_threads(int64_t n_pairs)
 // pass's thread count without doing work), so the job description is never replaced while a worker may still read it.
 class SchedPool {
 public:
-    static SchedPool &get() { static SchedPool p; return p; }
+    static SchedPool &get()
+    {
+        static SchedPool p;
+        static const bool once = (pthread_atfork(nullptr, nullptr, [] { SchedPool::get().after_fork(); }), true);
+        (void)once;
+        return p;
+    }
     void warm(int nt)
     {
         std::lock_guard<std::mutex> whole(one_caller_);
@@ -140,6 +147,22 @@ public:
         job_ = nullptr;
     }
 private:
+    // In a forked child the pool's threads do not exist (praline_init starts them, so a host program that forks workers after
+    // it would otherwise wait for their acknowledgements for ever): forget them - the thread objects are leaked, they
+    // cannot be joined - and start new ones on demand.
+    void after_fork()
+    {
+        new std::vector<std::thread>(std::move(th_));   // (leaked on purpose)
+        th_.clear();
+        pending_.store(0, std::memory_order_relaxed);
+        job_ = nullptr;
+        // (the condition variables count waiters that do not exist here - a broadcast would wait for them to leave -, and a
+        // mutex may have been held by one of them: fresh ones in place)
+        new (&cv_) std::condition_variable();
+        new (&done_) std::condition_variable();
+        new (&m_) std::mutex();
+        new (&one_caller_) std::mutex();
+    }
     static constexpr int kSpins = 20000;   // ~100-200 us of polling
     static void cpu_relax()
     {

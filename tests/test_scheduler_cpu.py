@@ -307,3 +307,39 @@ def test_thread_pool_back_to_back_with_changing_thread_counts(pipe_sched, monkey
         if k % 20 == 19:
             time.sleep(0.02)
     monkeypatch.delenv("PRALINE_SCHED_THREADS")
+
+
+def test_scheduler_threads_survive_a_fork():
+    """praline_init starts the scheduler's threads; a host program that forks afterwards has none of them in the child. The
+    pool forgets them there (pthread_atfork) and starts new ones: a forked child schedules a large list like its parent.
+    (In a subprocess with a time limit: the failure mode is a child that waits for ever.)"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import ctypes, os, numpy as np
+        lib = ctypes.CDLL(%r)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        lib.praline_sched_pipe_test.argtypes = [vp, i64, i64, vp, ctypes.c_int, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+        def run(lens, pairs):
+            cap = len(pairs) + 4096
+            n_i, n_t, n_s = i64(0), i64(0), i64(0)
+            items = np.zeros((cap, 6), np.int32); tasks = np.zeros((cap, 3), np.int32)
+            lp = np.zeros((cap, 32), np.int32); so = np.zeros((cap, 32), np.int32)
+            rc = lib.praline_sched_pipe_test(lens.ctypes.data, len(lens), len(pairs), pairs.ctypes.data, 0, 0, cap, cap, cap, ctypes.byref(n_i),
+                                             ctypes.byref(n_t), ctypes.byref(n_s), items.ctypes.data, tasks.ctypes.data, lp.ctypes.data, so.ctypes.data)
+            return rc, items[:n_i.value].copy()
+        rng = np.random.default_rng(1); n = 400
+        lens = rng.integers(50, 400, n).astype(np.int32)
+        pairs = np.array([(i, j) for i in range(n) for j in range(i + 1, n)], dtype=np.int32)
+        os.environ["PRALINE_SCHED_THREADS"] = "6"
+        a = run(lens, pairs)
+        pid = os.fork()
+        if pid == 0:
+            b = run(lens, pairs)
+            os._exit(0 if (b[0] == a[0] and np.array_equal(a[1], b[1])) else 3)
+        _, status = os.waitpid(pid, 0)
+        b = run(lens, pairs)
+        raise SystemExit(0 if (os.WEXITSTATUS(status) == 0 and np.array_equal(a[1], b[1])) else 4)
+    ''') % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "praline_amd", "libpraline_sched_test.so")
+    done = subprocess.run([sys.executable, "-c", code], timeout=120, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                          start_new_session=True)
+    assert done.returncode == 0
