@@ -728,3 +728,28 @@ def test_all_pairs_scores_with_the_schedule_prepared_beside_the_arena(env):
     finally:
         native.prepare_schedule_async = real
     assert calls == [len(ii), len(ii)]
+
+
+def test_adhoc_join_order_on_a_near_tie(env):
+    """A case scripts/stress_msa.py found (tests/golden/adhoc_tie_case.json: nine short sequences, two track sets): two cluster
+    pairs whose scores differ by ~1e-7.  The batching manager scores cluster pairs with scores-only plans (f16 hi/lo split),
+    the serial one with single alignments (fp32 chain) - in the default match-score mode the two may join the clusters in a
+    different order; in the reference-order mode (bit-identical scores on every path) they must give the same alignment."""
+    import json, os
+    from praline_amd import native
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "adhoc_tie_case.json")))
+    seqs = []
+    for i, tracks in enumerate(d["tracks"]):
+        seqs.append(ct.Sequence("q%02d" % i, [(tid, ct.PlainTrack(None, ct.ALPHABET_AA if tid == ct.TRACK_ID_INPUT else ct.ALPHABET_RNA,
+                                                               raw_indices=np.array(vals))) for tid, vals in tracks]))
+    ss = ct.ScoreMatrix(None, [ct.ALPHABET_RNA, ct.ALPHABET_RNA], matrix=(np.eye(4, dtype=np.float32) * 3 - 1).astype(np.float32))
+    native.set_match_mode("ref")
+    try:
+        outs = []
+        for name in ("batch", "serial"):
+            outs.append(run_one(env[name], comp.AdHocMultipleSequenceAligner, {"merge_mode": d["merge_mode"], "dist_mode": d["dist_mode"]},
+                                sequences=seqs, track_id_sets=[[ct.TRACK_ID_INPUT], ["ss"]], score_matrices=[env["blosum"], ss])['alignment'])
+    finally:
+        native.set_match_mode(None)
+    assert [x.name for x in outs[0].items] == [x.name for x in outs[1].items]
+    assert np.array_equal(np.asarray(outs[0].path), np.asarray(outs[1].path))
